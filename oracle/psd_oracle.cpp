@@ -1,0 +1,116 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see psd_oracle_real.hpp for the rules).
+// C ABI over the CPU restatement so that tests/ and bench.py's cpu_baseline leg can drive it with
+// ctypes.  All matrix arguments are packed [p][n][n], each n x n block column-major (ld = n),
+// factor j (1-based, user order) at offset (j-1)*n*n.
+#include "psd_oracle_real.hpp"
+
+#include <chrono>
+
+using namespace psdo;
+
+extern "C" {
+double psdo_dbg_maxdust(int reset) { double v = dbg_maxdust; if (reset) dbg_maxdust = 0; return v; }
+int psdo_dbg_dustpos() { return dbg_dustpos; }
+
+// PSD.jl:213-259 phessenberg!(A): A overwritten LAPACK-style, tau is [p][n].
+int psdo_d_phessenberg(int n, int p, double* A, double* tau) {
+    std::vector<MatD> Av(p + 1);
+    for (int j = 1; j <= p; ++j) Av[j] = MatD{A + (size_t)(j - 1) * n * n, n};
+    std::vector<std::vector<double>> t;
+    phessenberg(n, p, Av, t);
+    for (int j = 1; j <= p; ++j)
+        for (int i = 1; i <= n; ++i) tau[(size_t)(j - 1) * n + (i - 1)] = t[j][i];
+    return 0;
+}
+
+// Explicit Q factors of a phessenberg! result (what PSD.jl:136-143 builds).  Q is [p][n][n].
+int psdo_d_hessenberg_q(int n, int p, const double* A, const double* tau, double* Q) {
+    for (int j = 1; j <= p; ++j) {
+        std::vector<double> tj(n + 1, 0.0);
+        for (int i = 1; i <= n; ++i) tj[i] = tau[(size_t)(j - 1) * n + (i - 1)];
+        MatD Aj{const_cast<double*>(A) + (size_t)(j - 1) * n * n, n};
+        MatD Qj{Q + (size_t)(j - 1) * n * n, n};
+        materializeQ(n, j, Aj, tj, Qj);
+    }
+    return 0;
+}
+
+// PSD.jl:322-1096 pschur!(H1, Hs; wantT, wantZ, Q): H is [p][n][n] with H[0] Hessenberg, the rest
+// upper triangular (internal order, no orientation handling); Z in/out (Q on entry or identity).
+// sweeplog: optional [3*maxlog] int32 (kind,l,i per inner iteration); nlog receives the count.
+// Returns info: 0 ok, >0 level at which convergence failed.
+int psdo_d_pschur_hess(int n, int p, double* H, double* Z, int wantT, int wantZ, int maxitfac,
+                       double* wr, double* wi, int64_t* niter, int32_t* sweeplog, int64_t maxlog,
+                       int64_t* nlog) {
+    std::vector<MatD> Hv(p + 1), Zv(p + 1);
+    for (int j = 1; j <= p; ++j) {
+        Hv[j] = MatD{H + (size_t)(j - 1) * n * n, n};
+        Zv[j] = MatD{Z ? Z + (size_t)(j - 1) * n * n : nullptr, n};
+    }
+    std::vector<std::complex<double>> lam(n);
+    SweepLog log;
+    int info = pschur_hess(n, p, Hv, Zv, wantT != 0, wantZ != 0 && Z, maxitfac, lam.data(), niter,
+                           &log);
+    for (int q = 0; q < n; ++q) {
+        wr[q] = lam[q].real();
+        wi[q] = lam[q].imag();
+    }
+    int64_t cnt = (int64_t)log.rec.size() / 3;
+    if (nlog) *nlog = cnt;
+    if (sweeplog)
+        for (int64_t q = 0; q < std::min(cnt, maxlog) * 3; ++q) sweeplog[q] = log.rec[q];
+    return info;
+}
+
+// PSD.jl:120-152 pschur!(A, lr; wantZ, wantT, maxitfac), real.
+// A [p][n][n] in user order: on exit slot s holds the user-order factor T_s; the quasi-triangular
+// factor sits in slot *schurindex (1 for 'R', p for 'L' — PSD.jl:1092-1094).  Z [p][n][n] in user
+// order (ignored if !wantZ).  phase_ms: optional [3] = {hessenberg, q formation, iteration} wall ms.
+int psdo_d_pschur(int n, int p, double* A, char orient, int wantT, int wantZ, int maxitfac, double* Z,
+                  double* wr, double* wi, int* schurindex, int64_t* niter, int32_t* sweeplog,
+                  int64_t maxlog, int64_t* nlog, double* phase_ms) {
+    if (orient != 'R' && orient != 'L') return -4;  // PSD.jl:175-177 ArgumentError
+    const bool left = orient == 'L';
+    auto slotA = [&](int j) { return left ? (p + 1 - j) : j; };           // PSD.jl:127-131
+    auto slotZ = [&](int j) { return (!left || j == 1) ? j : (p + 2 - j); };  // PSD.jl:1079-1084
+    std::vector<MatD> Av(p + 1), Zv(p + 1);
+    for (int j = 1; j <= p; ++j) {
+        Av[j] = MatD{A + (size_t)(slotA(j) - 1) * n * n, n};
+        Zv[j] = MatD{(wantZ && Z) ? Z + (size_t)(slotZ(j) - 1) * n * n : nullptr, n};
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::vector<double>> tau;
+    phessenberg(n, p, Av, tau);
+    auto t1 = std::chrono::steady_clock::now();
+    if (wantZ && Z)
+        for (int j = 1; j <= p; ++j) materializeQ(n, j, Av[j], tau[j], Zv[j]);
+    // PSD.jl:147,149: Hs = R factors (triu), H1 = triu(H1,-1)
+    for (int j = 1; j <= p; ++j) {
+        const int sub = (j == 1) ? 1 : 0;
+        for (int c = 1; c <= n; ++c)
+            for (int r = c + sub + 1; r <= n; ++r) Av[j](r, c) = 0.0;
+    }
+    auto t2 = std::chrono::steady_clock::now();
+    std::vector<std::complex<double>> lam(n);
+    SweepLog log;
+    int info = pschur_hess(n, p, Av, Zv, wantT != 0, wantZ != 0 && Z, maxitfac, lam.data(), niter, &log);
+    auto t3 = std::chrono::steady_clock::now();
+    for (int q = 0; q < n; ++q) {
+        wr[q] = lam[q].real();
+        wi[q] = lam[q].imag();
+    }
+    if (schurindex) *schurindex = left ? p : 1;
+    int64_t cnt = (int64_t)log.rec.size() / 3;
+    if (nlog) *nlog = cnt;
+    if (sweeplog)
+        for (int64_t q = 0; q < std::min(cnt, maxlog) * 3; ++q) sweeplog[q] = log.rec[q];
+    if (phase_ms) {
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        phase_ms[0] = ms(t0, t1);
+        phase_ms[1] = ms(t1, t2);
+        phase_ms[2] = ms(t2, t3);
+    }
+    return info;
+}
+
+}  // extern "C"

@@ -1,0 +1,292 @@
+"""Shared test infrastructure (NOT product code).
+
+* ctypes loader for the CPU oracle (oracle/libpsd_oracle.so),
+* the counter-based synthetic input generator of SURVEY.md §8(d) (splitmix64 -> Box-Muller),
+* numpy restatements of the reference's own checkers:
+    compare_reigvals   /root/reference/test/testfuncs.jl:28-52
+    pschur_check       /root/reference/test/testfuncs.jl:56-145
+    checkpsd           /root/reference/src/diagnostics.jl:190-263
+  (the decomposition is non-unique, so parity is judged on these invariants, never element-wise).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+EPS = np.finfo(np.float64).eps
+
+
+# --------------------------------------------------------------------------------------------
+# synthetic inputs (identical on every machine; no dependence on numpy's RNG implementation)
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def randn_counter(seed, stream, count):
+    """`count` N(0,1) doubles from a counter-based generator: splitmix64(seed, stream, index) -> Box-Muller."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(count, dtype=np.uint64)
+        base = _splitmix64(np.uint64(seed) * np.uint64(0x100000001B3) + np.uint64(stream))
+        u1 = _splitmix64(base + np.uint64(2) * idx)
+        u2 = _splitmix64(base + np.uint64(2) * idx + np.uint64(1))
+    f1 = ((u1 >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
+    f2 = ((u2 >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
+    return np.sqrt(-2.0 * np.log(f1)) * np.cos(2.0 * np.pi * f2)
+
+
+def synth_factors(n, p, seed, dtype=np.float64):
+    """p factors n x n with i.i.d. N(0, 1/n) entries (complex: re, im ~ N(0, 1/(2n))): spectral radius ~ 1
+    per factor, so the period-p product neither overflows nor underflows."""
+    out = []
+    for j in range(p):
+        if np.issubdtype(dtype, np.complexfloating):
+            g = randn_counter(seed, j, 2 * n * n)
+            a = (g[: n * n] + 1j * g[n * n:]) / np.sqrt(2.0 * n)
+        else:
+            a = randn_counter(seed, j, n * n) / np.sqrt(float(n))
+        out.append(np.asfortranarray(a.reshape(n, n).astype(dtype)))
+    return out
+
+
+def rand_uniform_factors(n, p, seed):
+    """U(0,1) entries like the reference's own tests (`rand(T,n,n)`, test/runtests.jl:20,93)."""
+    out = []
+    for j in range(p):
+        with np.errstate(over="ignore"):
+            u = _splitmix64(_splitmix64(np.uint64(seed) * np.uint64(7919) + np.uint64(j)) + np.arange(n * n, dtype=np.uint64))
+        f = (u >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+        out.append(np.asfortranarray(f.reshape(n, n)))
+    return out
+
+
+def expsplit(p):
+    """Kressner's exponentially split example, /root/reference/test/testfuncs.jl:412-421 (literal data)."""
+    fac = 0.1
+    A1 = np.array([[9, 4, 1, 4, 3, 4], [6, 8, 2, 4, 0, 2], [0, 7, 4, 4, 6, 6], [0, 0, 8, 4, 6, 7],
+                   [0, 0, 0, 8, 9, 3], [0, 0, 0, 0, 5, 0]], dtype=np.float64)
+    Aj = np.diag([fac, fac ** 2, fac ** 3, 1, 1, 1]).astype(np.float64)
+    A = [np.asfortranarray(A1)] + [np.asfortranarray(Aj.copy()) for _ in range(p - 1)]
+    lam = [15.6284, -1.31418 - 3.51424j, -1.31418 + 3.51424j, 90 * fac ** p, (1600 / 3) * fac ** (2 * p),
+           -(71750 / 11) * fac ** (3 * p)]
+    return A, lam
+
+
+# --------------------------------------------------------------------------------------------
+# packing helpers: list of n x n matrices <-> [p][n][n] with column-major blocks
+def pack(As, dtype=np.float64):
+    p = len(As)
+    n = As[0].shape[0]
+    out = np.empty((p, n, n), dtype=dtype)
+    for j, a in enumerate(As):
+        out[j] = np.asarray(a, dtype=dtype).T  # C-order block holding the transpose == column-major matrix
+    return out
+
+
+def unpack(P):
+    return [np.asfortranarray(P[j].T.copy()) for j in range(P.shape[0])]
+
+
+# --------------------------------------------------------------------------------------------
+_oracle = None
+
+
+def oracle_lib():
+    """Load (building if needed) the CPU oracle."""
+    global _oracle
+    if _oracle is not None:
+        return _oracle
+    so = os.path.join(ORACLE_DIR, "libpsd_oracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    lib = C.CDLL(so)
+    dp = C.POINTER(C.c_double)
+    lib.psdo_d_phessenberg.argtypes = [C.c_int, C.c_int, dp, dp]
+    lib.psdo_d_hessenberg_q.argtypes = [C.c_int, C.c_int, dp, dp, dp]
+    lib.psdo_d_pschur_hess.argtypes = [C.c_int, C.c_int, dp, dp, C.c_int, C.c_int, C.c_int, dp, dp,
+                                       C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64)]
+    lib.psdo_d_pschur.argtypes = [C.c_int, C.c_int, dp, C.c_char, C.c_int, C.c_int, C.c_int, dp, dp, dp,
+                                  C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int64,
+                                  C.POINTER(C.c_int64), dp]
+    _oracle = lib
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class PSD:
+    """Result record mirroring the reference's PeriodicSchur (PSD.jl:59-92), with the full user-order T list."""
+
+    def __init__(self, Ts, Zs, values, orientation, schurindex, info=0, niter=0, sweeplog=None, phase_ms=None):
+        self.Ts = Ts
+        self.Z = Zs
+        self.values = values
+        self.orientation = orientation
+        self.schurindex = schurindex
+        self.info = info
+        self.niter = niter
+        self.sweeplog = sweeplog
+        self.phase_ms = phase_ms
+
+    @property
+    def T1(self):
+        return self.Ts[self.schurindex - 1]
+
+    @property
+    def T(self):
+        return [t for j, t in enumerate(self.Ts) if j != self.schurindex - 1]
+
+    @property
+    def period(self):
+        return len(self.Ts)
+
+
+def oracle_pschur(As, lr="R", wantZ=True, wantT=True, maxitfac=30):
+    """CPU restatement of pschur!(A, lr; wantZ, wantT, maxitfac) (PSD.jl:120-152) for Float64."""
+    lib = oracle_lib()
+    p = len(As)
+    n = As[0].shape[0]
+    A = pack(As)
+    Z = np.zeros((p, n, n))
+    wr = np.zeros(n)
+    wi = np.zeros(n)
+    si = C.c_int(0)
+    niter = C.c_int64(0)
+    maxlog = 3 * maxitfac * n + 16
+    log = np.zeros(3 * maxlog, dtype=np.int32)
+    nlog = C.c_int64(0)
+    ph = np.zeros(3)
+    info = lib.psdo_d_pschur(n, p, _dp(A), lr.encode()[0:1], int(wantT), int(wantZ), maxitfac, _dp(Z), _dp(wr),
+                             _dp(wi), C.byref(si), C.byref(niter), log.ctypes.data_as(C.POINTER(C.c_int32)),
+                             maxlog, C.byref(nlog), _dp(ph))
+    return PSD(unpack(A), unpack(Z) if wantZ else [], wr + 1j * wi, lr, si.value, info, niter.value,
+               log[: 3 * nlog.value].reshape(-1, 3).copy(), ph)
+
+
+def oracle_phessenberg(As):
+    lib = oracle_lib()
+    p = len(As)
+    n = As[0].shape[0]
+    A = pack(As)
+    tau = np.zeros((p, n))
+    lib.psdo_d_phessenberg(n, p, _dp(A), _dp(tau))
+    Q = np.zeros((p, n, n))
+    lib.psdo_d_hessenberg_q(n, p, _dp(A), _dp(tau), _dp(Q))
+    packed = unpack(A)
+    Hs = [np.triu(a, -1 if j == 0 else 0) for j, a in enumerate(packed)]
+    return Hs, unpack(Q), packed, tau
+
+
+# --------------------------------------------------------------------------------------------
+# checkers
+def product(As, left=False):
+    P = np.eye(As[0].shape[0], dtype=As[0].dtype)
+    for a in As:
+        P = a @ P if left else P @ a
+    return P
+
+
+def compare_reigvals(lam, lamx, ltol):
+    """test/testfuncs.jl:28-52: sort by modulus, real / conjugate-pair aware; returns max scaled error.
+    Raises AssertionError on a real/complex mismatch or |dlam| >= ltol * |lam|max."""
+    lam = np.asarray(lam, dtype=complex)
+    lamx = np.asarray(lamx, dtype=complex)
+    n = len(lam)
+    idx = np.argsort(np.abs(lam), kind="stable")
+    idxx = np.argsort(np.abs(lamx), kind="stable")
+    scale = abs(lam[idx[-1]])
+    worst = 0.0
+    i = 0
+    while i < n:
+        l1, l1x = lam[idx[i]], lamx[idxx[i]]
+        if l1.imag == 0:
+            assert l1x.imag == 0, f"eigenvalue {i}: reference real {l1}, got complex {l1x}"
+            worst = max(worst, abs(l1 - l1x))
+            i += 1
+        else:
+            l2, l2x = lam[idx[i + 1]], lamx[idxx[i + 1]]
+            if l1.imag * l1x.imag < 0:
+                l1x, l2x = l2x, l1x
+            worst = max(worst, abs(l1 - l1x), abs(l2 - l2x))
+            i += 2
+    assert worst < ltol * scale, f"eigenvalue mismatch {worst:.3e} >= {ltol:.3e} * {scale:.3e}"
+    return worst / scale if scale > 0 else 0.0
+
+
+def match_eigs(lam, lamx):
+    """Greedy multiset match (robust to near-equal moduli); returns max |dlam|."""
+    lam = list(np.asarray(lam, dtype=complex))
+    lamx = list(np.asarray(lamx, dtype=complex))
+    worst = 0.0
+    for l in lam:
+        d = [abs(l - x) for x in lamx]
+        k = int(np.argmin(d))
+        worst = max(worst, d[k])
+        lamx.pop(k)
+    return worst
+
+
+def pschur_check(As, ps, qtol=10, tol=32, ltol=1000, check_lam=True, lam=None, real=True):
+    """test/testfuncs.jl:56-145 (non-developing branch). Returns dict of measured quantities."""
+    p = len(As)
+    n = As[0].shape[0]
+    left = ps.orientation == "L"
+    js = ps.schurindex
+    Ts, Zs = ps.Ts, ps.Z
+    out = {"resid": [], "orth": []}
+    for j in range(p):
+        jn = (j + 1) % p
+        Ax = Zs[jn] @ Ts[j] @ Zs[j].conj().T if left else Zs[j] @ Ts[j] @ Zs[jn].conj().T
+        k = -1 if (j == js - 1) else 0
+        assert np.all(np.tril(Ts[j], k - 1) == 0), f"T[{j+1}] not (quasi-)triangular"
+        if j == js - 1 and real:
+            for i in range(n - 1):
+                if ps.values[i].imag == 0:
+                    assert Ts[j][i + 1, i] == 0, f"subdiagonal junk at {i+1} for real eigenvalue"
+        orth = np.linalg.norm(Zs[j] @ Zs[j].conj().T - np.eye(n))
+        assert orth < qtol * EPS * n, f"Z[{j+1}] orthogonality {orth:.3e}"
+        res = np.linalg.norm(As[j] - Ax)
+        bound = tol * EPS * np.linalg.norm(As[j], 1)
+        assert res < bound, f"residual[{j+1}] {res:.3e} >= {bound:.3e}"
+        out["orth"].append(orth / (EPS * n))
+        out["resid"].append(res / (EPS * np.linalg.norm(As[j], 1)))
+    if check_lam:
+        if lam is None:
+            lam = np.linalg.eigvals(product(As, left))
+        out["lam_err"] = compare_reigvals(lam, ps.values, ltol * EPS)
+    return out
+
+
+def checkpsd(ps, As, thresh=100, strict=True, S=None):
+    """src/diagnostics.jl:190-263: returns (ok, err[]) with err = ||Z T Z' - A|| / eps / ||A||_1."""
+    p = len(As)
+    n = As[0].shape[0]
+    S = [True] * p if S is None else S
+    ok = True
+    err = np.zeros(p)
+    real = not np.iscomplexobj(ps.Ts[0])
+    for l in range(p):
+        l1 = (l + 1) % p
+        Tl = ps.Ts[l]
+        cmp_ = 0 if strict else 10 * EPS * n
+        tval = np.tril(Tl, -2) if (real and l == ps.schurindex - 1) else np.tril(Tl, -1)
+        if np.linalg.norm(tval) > cmp_:
+            ok = False
+        if np.linalg.norm(ps.Z[l] @ ps.Z[l].conj().T - np.eye(n)) > 10 * EPS * n:
+            ok = False
+        if S[l] != (ps.orientation == "L"):
+            Hx = ps.Z[l] @ Tl @ ps.Z[l1].conj().T
+        else:
+            Hx = ps.Z[l1] @ Tl @ ps.Z[l].conj().T
+        err[l] = np.linalg.norm(Hx - As[l]) / EPS / np.linalg.norm(As[l], 1)
+        if err[l] > thresh:
+            ok = False
+    return ok, err
