@@ -1,0 +1,99 @@
+/* libpsd_mi355x — C ABI of the MI355X-native periodic Schur engine.
+ *
+ * The reference (RalphAS/PeriodicSchurDecompositions.jl v0.1.6) has no FFI layer: its operator API
+ * is a set of Julia methods.  Each entry point below is what a thin Julia `ccall` wrapper binds
+ * to replace one of those methods (file:line under /root/reference/src); INTEGRATION.md shows the
+ * wrapper.  Plain pointers and sizes only; no exceptions cross the boundary.
+ *
+ * Conventions
+ *   - matrices are column-major, ld = n, Float64;
+ *   - host entry points take an array of p pointers (Julia's Vector{Matrix{Float64}}); the caller
+ *     owns every buffer, results are written back into the same buffers (the reference's
+ *     in-place contract, PeriodicSchurDecompositions.jl:120-152);
+ *   - `_dev` entry points take one device allocation [p][n][n] (factor-major) already resident
+ *     in HBM and leave the result there;
+ *   - return value == *info: 0 ok; <0 argument -k invalid; >0 algorithmic:
+ *       PSD_INFO_NOCONV + level  convergence failed at level i  (PSD.jl:892 ErrorException)
+ *       PSD_INFO_NOTIMPL         not implemented                 (PSD.jl:30 NotImplemented)
+ *       PSD_INFO_RUNTIME         HIP runtime failure / no device
+ */
+#ifndef PSD_MI355X_H
+#define PSD_MI355X_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSD_INFO_NOCONV 1000000
+#define PSD_INFO_NOTIMPL 2000000
+#define PSD_INFO_RUNTIME 3000000
+
+typedef struct psd_ctx psd_ctx;
+
+/* per-call statistics: what bench.py needs to turn time into sweeps/s and algorithmic GB/s */
+typedef struct psd_stats {
+    int64_t niter;        /* sum of `its` over deflation levels (PSD.jl:1060 `niter`)            */
+    int32_t maxits;       /* PSD.jl:1059                                                         */
+    int32_t nsweeps;      /* double-shift QR sweeps performed (PSD.jl:806-887)                   */
+    int32_t nrqpass;      /* RQ clean-up passes (PSD.jl:602-635)                                 */
+    int32_t ndefl1;       /* 1x1 deflations                                                      */
+    int32_t ndefl2;       /* 2x2 deflations                                                      */
+    int32_t nwindows;     /* diagonal windows chased (= step-kernel launches that did work)      */
+    int32_t nlaunch_step; /* step-kernel launches issued                                         */
+    int32_t window;       /* window width W used by the chase kernel                             */
+    int32_t nlog;         /* entries in the sweep log                                            */
+    double ms_hess;       /* periodic Hessenberg-triangular reduction                            */
+    double ms_formq;      /* Q formation                                                         */
+    double ms_iter;       /* periodic QR iteration                                               */
+    double ms_total;      /* device time of the whole call (excludes host<->device copies)       */
+    double ms_copy;       /* host<->device copies (host entry points only)                       */
+    double bytes_sweeps;  /* algorithmic bytes of all sweeps: sum 2*8*p*w*(2n+1) (wantZ) etc.    */
+    double bytes_hess;    /* algorithmic bytes of the reduction: 2*8*p*(5/6)*n^3                 */
+    double bytes_formq;   /* 2*8*p*n^3/3                                                         */
+    double step_kernel_ms_avg; /* sampled HIP-event duration of the chase kernel (profile mode)  */
+    int32_t step_kernel_samples;
+    int32_t reserved;
+} psd_stats;
+
+/* context: device selection, stream, workspace cache. One call at a time per context. */
+int psd_create(psd_ctx** ctx, int device);
+int psd_destroy(psd_ctx* ctx);
+/* profile != 0: sample the chase kernel's duration with HIP events (every 4th launch) */
+int psd_set_profile(psd_ctx* ctx, int profile);
+const char* psd_version(void);
+
+/* phessenberg!(A)  — PeriodicSchurDecompositions.jl:213-259.
+ * A[j] overwritten LAPACK-style (H_j in the upper part, reflectors below), tau is [p][n]
+ * (tau[0][n-1] unused, tau[j>=1][n-1] = 0) exactly as the Hessenberg / QR objects the reference
+ * returns are laid out. */
+int psd_d_phessenberg(psd_ctx* ctx, int n, int p, double* const* A, double* tau, psd_stats* stats, int* info);
+
+/* pschur!(A, lr; wantZ, wantT, maxitfac), Float64 — PeriodicSchurDecompositions.jl:120-152.
+ * S must be NULL or all-true in this build (signed/generalized case: PSD_INFO_NOTIMPL).
+ * On exit A[s] holds the user-order factor T_s; the quasi-triangular one is A[*schurindex - 1]
+ * (schurindex = 1 for 'R', p for 'L').  Z[s] (p pointers, may be NULL when !wantZ) receive Z_s.
+ * wr/wi: n eigenvalues of the product.  sweeplog: optional [3*maxlog] (kind,l,i) per iteration. */
+int psd_d_pschur(psd_ctx* ctx, int n, int p, double* const* A, const uint8_t* S, char orient, int wantT, int wantZ,
+                 int maxitfac, double* const* Z, double* wr, double* wi, int* schurindex, psd_stats* stats,
+                 int32_t* sweeplog, int64_t maxlog, int* info);
+
+/* pschur!(H1, Hs; wantT, wantZ, Q, maxitfac, rev) — PeriodicSchurDecompositions.jl:322-330.
+ * H[0] upper Hessenberg, H[1..p-1] upper triangular (internal order).  Q: p pointers holding Q_j
+ * on entry (post-multiplied in place and returned as Z_j), or NULL for Z_j = accumulated
+ * transformations only (then Zout receives them if wantZ).  With rev != 0 the caller permutes the
+ * result as the reference does at :1078-1092 (the kernel work is identical). */
+int psd_d_pschur_hess(psd_ctx* ctx, int n, int p, double* const* H, double* const* Q, int wantT, int wantZ,
+                      int maxitfac, double* wr, double* wi, psd_stats* stats, int32_t* sweeplog, int64_t maxlog,
+                      int* info);
+
+/* Device-resident variant of psd_d_pschur: dA, dZ are device pointers to [p][n][n] blocks in user
+ * order (dZ may be NULL when !wantZ).  wr/wi/sweeplog are host buffers. */
+int psd_d_pschur_dev(psd_ctx* ctx, int n, int p, double* dA, char orient, int wantT, int wantZ, int maxitfac,
+                     double* dZ, double* wr, double* wi, int* schurindex, psd_stats* stats, int32_t* sweeplog,
+                     int64_t maxlog, int* info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

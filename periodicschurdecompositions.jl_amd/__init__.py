@@ -1,0 +1,303 @@
+"""periodicschurdecompositions.jl_amd — MI355X-native periodic Schur engine, host-side mirror.
+
+The reference (RalphAS/PeriodicSchurDecompositions.jl) exposes `pschur`, `pschur!`, `phessenberg!`
+and the `PeriodicSchur` result type as Julia methods (src/PeriodicSchurDecompositions.jl:11,59-152).
+No Julia toolchain exists in the build/GPU images, so this module mirrors that interface — same
+names (`!` spelled `_`), argument meaning and error behaviour — in Python over the C ABI of
+`libpsd_mi355x.so` (include/psd_mi355x.h).  The Julia `ccall` wrapper a maintainer would add is in
+INTEGRATION.md.
+
+All numerical work happens in the HIP library.  There is no CPU fallback: if the library is
+missing or no GPU is visible, `Engine()` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpsd_mi355x.so")
+
+INFO_NOCONV = 1000000
+INFO_NOTIMPL = 2000000
+INFO_RUNTIME = 3000000
+
+
+class NotImplementedPSD(Exception):
+    """PeriodicSchurDecompositions.NotImplemented (src/PeriodicSchurDecompositions.jl:30)."""
+
+
+class ConvergenceError(Exception):
+    """ErrorException("convergence failed at level i") (src/PeriodicSchurDecompositions.jl:892)."""
+
+    def __init__(self, level):
+        super().__init__(f"convergence failed at level {level}")
+        self.level = level
+
+
+class DimensionMismatch(ValueError):
+    """DimensionMismatch (src/PeriodicSchurDecompositions.jl:216-222)."""
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("niter", C.c_int64), ("maxits", C.c_int32), ("nsweeps", C.c_int32), ("nrqpass", C.c_int32),
+        ("ndefl1", C.c_int32), ("ndefl2", C.c_int32), ("nwindows", C.c_int32), ("nlaunch_step", C.c_int32),
+        ("window", C.c_int32), ("nlog", C.c_int32), ("ms_hess", C.c_double), ("ms_formq", C.c_double),
+        ("ms_iter", C.c_double), ("ms_total", C.c_double), ("ms_copy", C.c_double), ("bytes_sweeps", C.c_double),
+        ("bytes_hess", C.c_double), ("bytes_formq", C.c_double), ("step_kernel_ms_avg", C.c_double),
+        ("step_kernel_samples", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class PeriodicSchur:
+    """Mirror of the reference's `PeriodicSchur` (src/PeriodicSchurDecompositions.jl:59-92).
+
+    `T1` is the quasi-triangular factor (position `schurindex` in the user's sequence), `T` the
+    remaining p-1 upper-triangular factors in order, `Z` the p orthogonal factors (empty if
+    wantZ=False), `values` the eigenvalues of the product, `orientation` 'R' or 'L'.
+    """
+
+    def __init__(self, Ts, Z, values, orientation, schurindex, stats=None, sweeplog=None):
+        self.Ts = Ts  # all p factors in user order (T1 included)
+        self.Z = Z
+        self.values = values
+        self.orientation = orientation
+        self.schurindex = schurindex
+        self.stats = stats
+        self.sweeplog = sweeplog
+
+    @property
+    def T1(self):
+        return self.Ts[self.schurindex - 1]
+
+    @property
+    def T(self):
+        return [t for j, t in enumerate(self.Ts) if j != self.schurindex - 1]
+
+    @property
+    def period(self):  # src/PeriodicSchurDecompositions.jl:85-91
+        return len(self.Ts)
+
+
+def char_lr(lr):
+    """src/PeriodicSchurDecompositions.jl:155-163,175-177."""
+    if lr in ("R", ":R"):
+        return "R"
+    if lr in ("L", ":L"):
+        return "L"
+    raise ValueError("orientation argument must be either :R (right) or :L (left)")
+
+
+def _check_square(A):
+    """src/PeriodicSchurDecompositions.jl:214-222."""
+    if len(A) == 0:
+        raise DimensionMismatch("empty sequence")
+    n = A[0].shape[0]
+    for a in A:
+        if a.ndim != 2 or a.shape[0] != a.shape[1]:
+            raise DimensionMismatch("matrices must be square")
+        if a.shape[0] != n:
+            raise DimensionMismatch("matrices must have equal order")
+    return n
+
+
+class Engine:
+    """One device context (stream + workspace). One call at a time per Engine."""
+
+    def __init__(self, device=0, libpath=None):
+        path = libpath or LIB_PATH
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        self.lib = lib = C.CDLL(path)
+        dp, dpp = C.POINTER(C.c_double), C.POINTER(C.c_void_p)
+        ip = C.POINTER(C.c_int)
+        lib.psd_version.restype = C.c_char_p
+        lib.psd_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        lib.psd_destroy.argtypes = [C.c_void_p]
+        lib.psd_set_profile.argtypes = [C.c_void_p, C.c_int]
+        lib.psd_d_phessenberg.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, dp, C.POINTER(Stats), ip]
+        lib.psd_d_pschur.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, C.POINTER(C.c_uint8), C.c_char, C.c_int,
+                                     C.c_int, C.c_int, dpp, dp, dp, ip, C.POINTER(Stats), C.POINTER(C.c_int32),
+                                     C.c_int64, ip]
+        lib.psd_d_pschur_hess.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, dpp, C.c_int, C.c_int, C.c_int, dp, dp,
+                                          C.POINTER(Stats), C.POINTER(C.c_int32), C.c_int64, ip]
+        lib.psd_d_pschur_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p, dp, dp, ip, C.POINTER(Stats), C.POINTER(C.c_int32), C.c_int64, ip]
+        self.ctx = C.c_void_p()
+        rc = lib.psd_create(C.byref(self.ctx), device)
+        if rc != 0:
+            raise RuntimeError(f"psd_create failed (info={rc}): no usable HIP device; there is no CPU fallback")
+
+    def version(self):
+        return self.lib.psd_version().decode()
+
+    def set_profile(self, on):
+        self.lib.psd_set_profile(self.ctx, int(on))
+
+    def close(self):
+        if self.ctx:
+            self.lib.psd_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------------------------------
+    @staticmethod
+    def _ptrs(mats):
+        arr = (C.c_void_p * len(mats))()
+        for j, a in enumerate(mats):
+            arr[j] = a.ctypes.data
+        return arr
+
+    @staticmethod
+    def _raise(info):
+        if info == 0:
+            return
+        if info < 0:
+            raise ValueError(f"argument {-info} invalid")
+        if info >= INFO_RUNTIME:
+            raise RuntimeError(f"HIP runtime failure (code {info - INFO_RUNTIME})")
+        if info >= INFO_NOTIMPL:
+            raise NotImplementedPSD("not implemented in this build")
+        if info >= INFO_NOCONV:
+            raise ConvergenceError(info - INFO_NOCONV)
+        raise RuntimeError(f"info={info}")
+
+    @staticmethod
+    def _as_work(A):
+        """In-place contract: every A[j] must be a Fortran-contiguous float64 matrix we may overwrite."""
+        for a in A:
+            if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.f_contiguous and a.flags.writeable):
+                raise TypeError("pschur_ needs writable Fortran-ordered float64 matrices (use pschur for a copy)")
+
+    def phessenberg_(self, A):
+        """phessenberg!(A) — src/PeriodicSchurDecompositions.jl:213-259.
+        Overwrites A LAPACK-style; returns (H list, tau[p][n]) where H[0] = triu(A[0],-1), H[j] = triu(A[j])."""
+        n = _check_square(A)
+        self._as_work(A)
+        p = len(A)
+        tau = np.zeros((p, n))
+        st = Stats()
+        info = C.c_int(0)
+        self.lib.psd_d_phessenberg(self.ctx, n, p, self._ptrs(A), tau.ctypes.data_as(C.POINTER(C.c_double)),
+                                   C.byref(st), C.byref(info))
+        self._raise(info.value)
+        Hs = [np.triu(a, -1 if j == 0 else 0) for j, a in enumerate(A)]
+        return Hs, tau, st
+
+    def pschur_(self, A, lr="R", S=None, wantZ=True, wantT=True, maxitfac=30):
+        """pschur!(A, lr; wantZ, wantT, maxitfac) — src/PeriodicSchurDecompositions.jl:120-152.
+        `A` is workspace and is overwritten with the T factors."""
+        orient = char_lr(lr)
+        n = _check_square(A)
+        self._as_work(A)
+        p = len(A)
+        Z = [np.zeros((n, n), order="F") for _ in range(p)] if wantZ else []
+        wr = np.zeros(n)
+        wi = np.zeros(n)
+        si = C.c_int(0)
+        st = Stats()
+        maxlog = 2 * maxitfac * n + n + 16
+        log = np.zeros(3 * maxlog, dtype=np.int32)
+        info = C.c_int(0)
+        Sarr = None
+        if S is not None:
+            if len(S) != p:
+                raise DimensionMismatch("length of S must match the period")
+            Sarr = (C.c_uint8 * p)(*[1 if s else 0 for s in S])
+        dp = C.POINTER(C.c_double)
+        self.lib.psd_d_pschur(self.ctx, n, p, self._ptrs(A), Sarr, orient.encode(), int(wantT), int(wantZ), int(maxitfac),
+                              self._ptrs(Z) if wantZ else None, wr.ctypes.data_as(dp), wi.ctypes.data_as(dp),
+                              C.byref(si), C.byref(st), log.ctypes.data_as(C.POINTER(C.c_int32)), maxlog,
+                              C.byref(info))
+        self._raise(info.value)
+        nl = min(st.nlog, maxlog)
+        return PeriodicSchur(list(A), Z, wr + 1j * wi, orient, si.value, st, log[: 3 * nl].reshape(-1, 3).copy())
+
+    def pschur(self, A, lr="R", **kw):
+        """pschur(A, lr; kwargs...) — copying variant, src/PeriodicSchurDecompositions.jl:108-113."""
+        Atmp = [np.array(a, dtype=np.float64, order="F", copy=True) for a in A]
+        return self.pschur_(Atmp, lr, **kw)
+
+    def pschur_hess_(self, H1, Hs, Q=None, wantT=True, wantZ=True, maxitfac=30, rev=False):
+        """pschur!(H1, Hs; wantT, wantZ, Q, maxitfac, rev) — src/PeriodicSchurDecompositions.jl:322-330."""
+        H = [H1] + list(Hs)
+        n = _check_square(H)
+        self._as_work(H)
+        p = len(H)
+        if wantZ:
+            if Q is None:
+                Q = [np.asfortranarray(np.eye(n)) for _ in range(p)]
+            self._as_work(Q)
+        wr = np.zeros(n)
+        wi = np.zeros(n)
+        st = Stats()
+        maxlog = 2 * maxitfac * n + n + 16
+        log = np.zeros(3 * maxlog, dtype=np.int32)
+        info = C.c_int(0)
+        dp = C.POINTER(C.c_double)
+        self.lib.psd_d_pschur_hess(self.ctx, n, p, self._ptrs(H), self._ptrs(Q) if wantZ else None, int(wantT),
+                                   int(wantZ), int(maxitfac), wr.ctypes.data_as(dp), wi.ctypes.data_as(dp),
+                                   C.byref(st), log.ctypes.data_as(C.POINTER(C.c_int32)), maxlog, C.byref(info))
+        self._raise(info.value)
+        nl = min(st.nlog, maxlog)
+        lam = wr + 1j * wi
+        Z = list(Q) if wantZ else []
+        slog = log[: 3 * nl].reshape(-1, 3).copy()
+        if rev:  # src/PeriodicSchurDecompositions.jl:1078-1092
+            Zr = ([Z[0]] + [Z[p + 1 - l] for l in range(2, p + 1)]) if wantZ else Z
+            Ts = [H[p - l] for l in range(1, p)] + [H[0]]
+            return PeriodicSchur(Ts, Zr, lam, "L", p, st, slog)
+        return PeriodicSchur(H, Z, lam, "R", 1, st, slog)
+
+    def pschur_dev(self, dA_ptr, n, p, lr="R", dZ_ptr=None, wantT=True, maxitfac=30):
+        """Device-resident pschur!: dA_ptr / dZ_ptr are device addresses of [p][n][n] column-major blocks."""
+        orient = char_lr(lr)
+        wantZ = dZ_ptr is not None
+        wr = np.zeros(n)
+        wi = np.zeros(n)
+        si = C.c_int(0)
+        st = Stats()
+        maxlog = 2 * maxitfac * n + n + 16
+        log = np.zeros(3 * maxlog, dtype=np.int32)
+        info = C.c_int(0)
+        dp = C.POINTER(C.c_double)
+        self.lib.psd_d_pschur_dev(self.ctx, n, p, C.c_void_p(dA_ptr), orient.encode(), int(wantT), int(wantZ),
+                                  int(maxitfac), C.c_void_p(dZ_ptr) if wantZ else None, wr.ctypes.data_as(dp),
+                                  wi.ctypes.data_as(dp), C.byref(si), C.byref(st),
+                                  log.ctypes.data_as(C.POINTER(C.c_int32)), maxlog, C.byref(info))
+        self._raise(info.value)
+        nl = min(st.nlog, maxlog)
+        return wr + 1j * wi, si.value, st, log[: 3 * nl].reshape(-1, 3).copy()
+
+
+_default_engine = None
+
+
+def default_engine():
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = Engine()
+    return _default_engine
+
+
+def pschur(A, lr="R", **kw):
+    return default_engine().pschur(A, lr, **kw)
+
+
+def pschur_(A, lr="R", **kw):
+    return default_engine().pschur_(A, lr, **kw)
+
+
+def phessenberg_(A):
+    return default_engine().phessenberg_(A)

@@ -1,0 +1,539 @@
+// Host side of libpsd_mi355x: launch sequencing and the C ABI (include/psd_mi355x.h).
+// Built by hipcc (-x hip, gfx950).  tests/hostsim builds the same file with g++ -DPSD_HOSTSIM as a
+// serial simulation for the CPU-only test tier; the package never loads that build.
+#include "psd_hess.h"
+#include "psd_real_qr.h"
+
+#include "../../include/psd_mi355x.h"
+
+#include <chrono>
+#include <new>
+#include <vector>
+
+#ifdef PSD_HOSTSIM
+psd_simctx psd_sim;
+#define PSD_LIB_FLAVOUR "hostsim"
+#else
+#define PSD_LIB_FLAVOUR "hip-gfx950"
+#endif
+
+#define PSD_CHECK(expr)                                  \
+    do {                                                 \
+        int _e = (int)(expr);                            \
+        if (_e != 0) return PSD_INFO_RUNTIME + (_e & 0xffff); \
+    } while (0)
+
+namespace {
+
+struct Timer {
+#ifdef PSD_HOSTSIM
+    std::chrono::steady_clock::time_point t0;
+    void start(psd_stream_t) { t0 = std::chrono::steady_clock::now(); }
+    double stop(psd_stream_t) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+#else
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    Timer() {
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+    }
+    ~Timer() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+    void start(psd_stream_t s) { (void)hipEventRecord(e0, s); }
+    double stop(psd_stream_t s) {
+        (void)hipEventRecord(e1, s);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        return (double)ms;
+    }
+#endif
+};
+
+int choose_window(int p) {
+    // largest W with p blocks of W x (W+1) doubles (+ scratch) inside the 160 KiB LDS of one CU
+    const size_t budget = 150 * 1024;
+    const int cand[] = {32, 24, 16, 12, 8};
+    for (int W : cand) {
+        size_t need = (size_t)p * W * (W + 1) * 8 + PSD_STEP_NT * 8 + 2 * PSD_STEP_NT * 4 + (size_t)p * 4 + 64;
+        if (need <= budget) return W;
+    }
+    return 0;
+}
+size_t step_lds_bytes(int p, int W) {
+    size_t b = ((size_t)p * W * (W + 1) + PSD_STEP_NT) * 8 + (2 * PSD_STEP_NT + (size_t)p) * 4;
+    return (b + 15) & ~(size_t)15;
+}
+size_t apply_lds_bytes() { return sizeof(psd_tr) * PSD_TR_CAP + (size_t)32 * (PSD_APPLY_NT + 1) * 8; }
+
+}  // namespace
+
+struct psd_ctx {
+    int device = 0;
+    psd_stream_t stream = 0;
+    int profile = 0;
+    // workspace (grown on demand)
+    int cap_n = 0, cap_p = 0;
+    bool cap_mats = false;
+    double *dH = nullptr, *dZ = nullptr;  // staging for the host entry points
+    double *tau = nullptr, *vbuf = nullptr;
+    double *hdiag = nullptr, *hsub = nullptr, *hsup = nullptr, *Pd = nullptr, *Pe = nullptr, *Pf = nullptr;
+    double *hnorms = nullptr, *wr = nullptr, *wi = nullptr;
+    psd_rstate* st = nullptr;
+    psd_apply_desc* desc = nullptr;
+    psd_tr* tr = nullptr;
+    int* cnt = nullptr;
+    int* log = nullptr;
+    int logcap = 0;
+    size_t step_lds_set = 0;
+
+    void release() {
+        void* ptrs[] = {dH, dZ, tau, vbuf, hdiag, hsub, hsup, Pd, Pe, Pf, hnorms, wr, wi, st, desc, tr, cnt, log};
+        for (void* q : ptrs)
+            if (q) psd_rt_free(q);
+        dH = dZ = tau = vbuf = hdiag = hsub = hsup = Pd = Pe = Pf = hnorms = wr = wi = nullptr;
+        st = nullptr; desc = nullptr; tr = nullptr; cnt = nullptr; log = nullptr;
+        cap_n = cap_p = 0;
+        cap_mats = false;
+        logcap = 0;
+    }
+
+    int reserve(int n, int p, bool mats, int maxlog) {
+        if (n <= cap_n && p <= cap_p && (!mats || cap_mats) && maxlog <= logcap) return 0;
+        const bool keep_mats = mats || cap_mats;
+        release();
+        const size_t nn = (size_t)n * n;
+#define PSD_ALLOC(ptr, type, count) PSD_CHECK(psd_rt_malloc((void**)&ptr, sizeof(type) * (size_t)(count)))
+        if (keep_mats) {
+            PSD_ALLOC(dH, double, nn * p);
+            PSD_ALLOC(dZ, double, nn * p);
+        }
+        PSD_ALLOC(tau, double, (size_t)n * p);
+        PSD_ALLOC(vbuf, double, n + 8);
+        PSD_ALLOC(hdiag, double, n + 8);
+        PSD_ALLOC(hsub, double, n + 8);
+        PSD_ALLOC(hsup, double, n + 8);
+        PSD_ALLOC(Pd, double, n + 8);
+        PSD_ALLOC(Pe, double, n + 8);
+        PSD_ALLOC(Pf, double, n + 8);
+        PSD_ALLOC(hnorms, double, p + 8);
+        PSD_ALLOC(wr, double, n + 8);
+        PSD_ALLOC(wi, double, n + 8);
+        PSD_ALLOC(st, psd_rstate, 1);
+        PSD_ALLOC(desc, psd_apply_desc, 1);
+        PSD_ALLOC(tr, psd_tr, (size_t)p * PSD_TR_CAP);
+        PSD_ALLOC(cnt, int, p + 8);
+        PSD_ALLOC(log, int, 3 * (size_t)maxlog + 8);
+#undef PSD_ALLOC
+        cap_n = n;
+        cap_p = p;
+        cap_mats = keep_mats;
+        logcap = maxlog;
+        return 0;
+    }
+};
+
+namespace {
+
+void fill_bytes(psd_stats* s, int n, int p, int wantT, int wantZ, const std::vector<int>& log) {
+    if (!s) return;
+    double b = 0.0;
+    const double E = 8.0;
+    for (size_t q = 0; q + 2 < log.size(); q += 3) {
+        if (log[q] != 0) continue;
+        const double w = log[q + 2] - log[q + 1] + 1;
+        if (!wantT) b += 2 * E * p * w * w + (wantZ ? 2 * E * p * w * n : 0.0);
+        else b += 2 * E * p * w * (wantZ ? (2.0 * n + 1) : (n + 1.0));
+    }
+    s->bytes_sweeps = b;
+}
+
+// PSD.jl:213-259 on device: dH [p][n][n] internal order, overwritten LAPACK-style; tau [p][n]
+int hessenberg_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
+    const size_t nn = (size_t)n * n;
+    PSD_CHECK(psd_rt_memset(dtau, 0, sizeof(double) * (size_t)n * p, c->stream));
+    const size_t lds_refl = PSD_HESS_NT * 8;
+    const size_t lds_apply = (PSD_HESS_NT + (size_t)n + 8) * 8;
+    for (int i = 1; i <= n - 1; ++i) {
+        for (int j = p; j >= 1; --j) {
+            const int r0 = (j == 1) ? (i + 1) : i;  // first row of the reflector
+            if (n - r0 + 1 < 2) continue;
+            double* Aj = dH + (size_t)(j - 1) * nn;
+            double* Ajm1 = dH + (size_t)((j == 1 ? p : j - 1) - 1) * nn;
+            PSD_LAUNCH(psd_hess_refl, psd_dim3(1), PSD_HESS_NT, lds_refl, c->stream, Aj, n, r0, i, c->vbuf,
+                       dtau + (size_t)(j - 1) * n + (i - 1));
+            const int lc0 = i + 1;
+            const int nL = (n - lc0 + 1 + 3) / 4;
+            const int nR = (n + 31) / 32;
+            if (Aj != Ajm1) {
+                PSD_LAUNCH(psd_hess_apply, psd_dim3(nL + nR), PSD_HESS_NT, lds_apply, c->stream, Aj, Ajm1, n, r0, lc0,
+                           (const double*)c->vbuf, nL);
+            } else {  // p == 1: same matrix, left then right (PSD.jl:245-246)
+                PSD_LAUNCH(psd_hess_apply, psd_dim3(nL), PSD_HESS_NT, lds_apply, c->stream, Aj, (double*)nullptr, n, r0,
+                           lc0, (const double*)c->vbuf, nL);
+                PSD_LAUNCH(psd_hess_apply, psd_dim3(nR), PSD_HESS_NT, lds_apply, c->stream, (double*)nullptr, Ajm1, n, r0,
+                           lc0, (const double*)c->vbuf, 0);
+            }
+        }
+    }
+    return 0;
+}
+
+int formq_dev(psd_ctx* c, int n, int p, const double* dH, const double* dtau, double* dQ) {
+    PSD_LAUNCH(psd_set_identity, psd_dim3(n, p), 64, 0, c->stream, dQ, n);
+    const size_t lds = PSD_HESS_NT * 8;
+    for (int i = n - 1; i >= 1; --i) {
+        const int tiles = (n - i + 1 + 3) / 4;
+        PSD_LAUNCH(psd_formq_step, psd_dim3(tiles, p), PSD_HESS_NT, lds, c->stream, dH, dtau, dQ, n, i);
+    }
+    return 0;
+}
+
+// PSD.jl:322-1096 on device.  dH: H_1 Hessenberg, H_j triangular; dZ: Q_j (or identity) or null.
+int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int wantZ, int maxitfac,
+                psd_rstate* st_out, psd_stats* stats, int maxlog) {
+    const int W = choose_window(p);
+    if (W == 0) return PSD_INFO_NOTIMPL;
+    psd_rparams P;
+    P.H = dH;
+    P.Z = wantZ ? dZ : nullptr;
+    P.st = c->st;
+    P.desc = c->desc;
+    P.tr = c->tr;
+    P.cnt = c->cnt;
+    P.hdiag = c->hdiag;
+    P.hsub = c->hsub;
+    P.hsup = c->hsup;
+    P.Pd = c->Pd;
+    P.Pe = c->Pe;
+    P.Pf = c->Pf;
+    P.hnorms = c->hnorms;
+    P.wr = c->wr;
+    P.wi = c->wi;
+    P.log = c->log;
+    const size_t lds_step = step_lds_bytes(p, W);
+#ifndef PSD_HOSTSIM
+    if (lds_step > c->step_lds_set) {
+        PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_rq_step),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
+        c->step_lds_set = lds_step;
+    }
+#endif
+    PSD_LAUNCH(psd_rq_init, psd_dim3(p), 256, 256 * 8, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog);
+    const size_t lds_apply = apply_lds_bytes();
+    const int tiles = (n + PSD_APPLY_NT - 1) / PSD_APPLY_NT;
+    const int batch = 32;
+    psd_rstate hst;
+    memset(&hst, 0, sizeof(hst));
+    long long launched = 0;
+    // every window advances the chase by >= 1 position; generous cap against a runaway loop
+    const long long cap = (long long)maxitfac * n * ((long long)n / (W - 4) + 4) + 4LL * n + 1024;
+    double sample_ms = 0.0;
+    int samples = 0;
+#ifndef PSD_HOSTSIM
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pend;
+#endif
+    for (;;) {
+        for (int b = 0; b < batch; ++b) {
+#ifndef PSD_HOSTSIM
+            const bool sample = c->profile && ((launched & 3) == 0);
+            if (sample) {
+                (void)hipEventCreate(&ev0);
+                (void)hipEventCreate(&ev1);
+                (void)hipEventRecord(ev0, c->stream);
+            }
+#endif
+            PSD_LAUNCH(psd_rq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
+#ifndef PSD_HOSTSIM
+            if (sample) {
+                (void)hipEventRecord(ev1, c->stream);
+                pend.emplace_back(ev0, ev1);
+            }
+#endif
+            PSD_LAUNCH(psd_rq_apply, psd_dim3(tiles, p, 3), PSD_APPLY_NT, lds_apply, c->stream, P, n, p);
+            ++launched;
+        }
+        PSD_CHECK(psd_rt_d2h(&hst, c->st, sizeof(hst), c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+#ifndef PSD_HOSTSIM
+        for (auto& pr : pend) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                sample_ms += ms;
+                ++samples;
+            }
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        pend.clear();
+#endif
+        if (hst.phase == PSD_PH_DONE) break;
+        if (launched > cap) {
+            *st_out = hst;
+            return PSD_INFO_RUNTIME + 0xfffe;
+        }
+    }
+    PSD_CHECK(psd_rt_last_error());
+    *st_out = hst;
+    if (stats) {
+        stats->nlaunch_step = (int32_t)launched;
+        stats->window = W;
+        stats->step_kernel_ms_avg = samples ? sample_ms / samples : 0.0;
+        stats->step_kernel_samples = samples;
+    }
+    return 0;
+}
+
+void stats_from_state(psd_stats* s, const psd_rstate& st) {
+    if (!s) return;
+    s->niter = st.niter;
+    s->maxits = st.maxits;
+    s->nsweeps = st.nsweeps;
+    s->nrqpass = st.nrqpass;
+    s->ndefl1 = st.ndefl1;
+    s->ndefl2 = st.ndefl2;
+    s->nwindows = st.nwindows;
+    s->nlog = st.nlog;
+}
+
+// shared tail: run the iteration, fetch eigenvalues / log
+int run_iteration(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int wantZ, int maxitfac, double* wr,
+                  double* wi, psd_stats* stats, int32_t* sweeplog, int64_t maxlog_user, int* info) {
+    const int maxlog = 2 * maxitfac * n + n + 16;
+    if (n == 1) {  // PSD.jl:333-352
+        PSD_LAUNCH(psd_scalar_product, psd_dim3(1), 64, 0, c->stream, (const double*)dH, p, c->wr, c->wi);
+        if (wantZ && dZ) PSD_LAUNCH(psd_set_identity, psd_dim3(1, p), 64, 0, c->stream, dZ, 1);
+        PSD_CHECK(psd_rt_d2h(wr, c->wr, sizeof(double), c->stream));
+        PSD_CHECK(psd_rt_d2h(wi, c->wi, sizeof(double), c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+        *info = 0;
+        return 0;
+    }
+    psd_rstate st;
+    int rc = iterate_dev(c, n, p, dH, dZ, wantT, wantZ, maxitfac, &st, stats, maxlog);
+    if (rc != 0) {
+        *info = rc;
+        return rc;
+    }
+    stats_from_state(stats, st);
+    PSD_CHECK(psd_rt_d2h(wr, c->wr, sizeof(double) * n, c->stream));
+    PSD_CHECK(psd_rt_d2h(wi, c->wi, sizeof(double) * n, c->stream));
+    const int nl = st.nlog < maxlog ? st.nlog : maxlog;
+    std::vector<int> hlog((size_t)3 * nl + 3, 0);
+    if (nl > 0) PSD_CHECK(psd_rt_d2h(hlog.data(), c->log, sizeof(int) * 3 * (size_t)nl, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    hlog.resize((size_t)3 * nl);
+    fill_bytes(stats, n, p, wantT, wantZ, hlog);
+    if (sweeplog) {
+        const int64_t m = nl < maxlog_user ? nl : maxlog_user;
+        for (int64_t q = 0; q < 3 * m; ++q) sweeplog[q] = hlog[q];
+    }
+    *info = (st.info != 0) ? (PSD_INFO_NOCONV + st.info) : 0;
+    return *info;
+}
+
+int check_dims(int n, int p) {
+    if (n < 1) return -2;
+    if (p < 1) return -3;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* psd_version(void) { return "psd_mi355x 0.1 (" PSD_LIB_FLAVOUR ")"; }
+
+int psd_create(psd_ctx** ctx, int device) {
+    if (!ctx) return -1;
+    *ctx = nullptr;
+#ifndef PSD_HOSTSIM
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PSD_INFO_RUNTIME + 1;
+    if (device < 0 || device >= ndev) return -2;
+    if (hipSetDevice(device) != hipSuccess) return PSD_INFO_RUNTIME + 2;
+#endif
+    psd_ctx* c = new (std::nothrow) psd_ctx();
+    if (!c) return PSD_INFO_RUNTIME + 3;
+    c->device = device;
+#ifndef PSD_HOSTSIM
+    if (hipStreamCreate(&c->stream) != hipSuccess) {
+        delete c;
+        return PSD_INFO_RUNTIME + 4;
+    }
+#endif
+    *ctx = c;
+    return 0;
+}
+
+int psd_destroy(psd_ctx* c) {
+    if (!c) return 0;
+    c->release();
+#ifndef PSD_HOSTSIM
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+#endif
+    delete c;
+    return 0;
+}
+
+int psd_set_profile(psd_ctx* c, int profile) {
+    if (!c) return -1;
+    c->profile = profile;
+    return 0;
+}
+
+int psd_d_phessenberg(psd_ctx* c, int n, int p, double* const* A, double* tau, psd_stats* stats, int* info) {
+    int dummy;
+    if (!info) info = &dummy;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!c) return *info = -1;
+    if ((*info = check_dims(n, p)) != 0) return *info;
+    if (!A || !tau) return *info = -4;
+    const int maxlog = 16;
+    if ((*info = c->reserve(n, p, true, maxlog)) != 0) return *info;
+    const size_t nn = (size_t)n * n;
+    Timer tc, tk;
+    tc.start(c->stream);
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->dH + j * nn, A[j], nn * 8, c->stream));
+    double ms_copy = tc.stop(c->stream);
+    tk.start(c->stream);
+    if ((*info = hessenberg_dev(c, n, p, c->dH, c->tau)) != 0) return *info;
+    double ms = tk.stop(c->stream);
+    tc.start(c->stream);
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(A[j], c->dH + j * nn, nn * 8, c->stream));
+    PSD_CHECK(psd_rt_d2h(tau, c->tau, sizeof(double) * (size_t)n * p, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    ms_copy += tc.stop(c->stream);
+    PSD_CHECK(psd_rt_last_error());
+    if (stats) {
+        stats->ms_hess = ms;
+        stats->ms_total = ms;
+        stats->ms_copy = ms_copy;
+        stats->bytes_hess = 2.0 * 8.0 * p * (5.0 / 6.0) * (double)n * n * n;
+    }
+    return *info = 0;
+}
+
+int psd_d_pschur_dev(psd_ctx* c, int n, int p, double* dA, char orient, int wantT, int wantZ, int maxitfac, double* dZ,
+                     double* wr, double* wi, int* schurindex, psd_stats* stats, int32_t* sweeplog, int64_t maxlog,
+                     int* info) {
+    int dummy;
+    if (!info) info = &dummy;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!c) return *info = -1;
+    if ((*info = check_dims(n, p)) != 0) return *info;
+    if (!dA) return *info = -4;
+    if (orient != 'R' && orient != 'L') return *info = -5;  // PSD.jl:175-177
+    if (maxitfac < 1) return *info = -8;
+    if (wantZ && !dZ) return *info = -9;
+    if (!wr || !wi) return *info = -10;
+    const bool left = orient == 'L';
+    const int mlog = 2 * maxitfac * n + n + 16;
+    if ((*info = c->reserve(n, p, false, mlog)) != 0) return *info;
+    Timer tall, tph;
+    tall.start(c->stream);
+    // PSD.jl:127-131: 'L' works on the reversed sequence
+    if (left && p > 1) PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, p / 2), 64, 0, c->stream, dA, n, 0, p);
+    tph.start(c->stream);
+    if ((*info = hessenberg_dev(c, n, p, dA, c->tau)) != 0) return *info;
+    const double ms_hess = tph.stop(c->stream);
+    tph.start(c->stream);
+    if (wantZ) {
+        if ((*info = formq_dev(c, n, p, dA, c->tau, dZ)) != 0) return *info;
+    }
+    PSD_LAUNCH(psd_triu, psd_dim3(n, p), 64, 0, c->stream, dA, n);
+    const double ms_formq = tph.stop(c->stream);
+    tph.start(c->stream);
+    psd_stats local;
+    memset(&local, 0, sizeof(local));
+    psd_stats* s = stats ? stats : &local;
+    int rc = run_iteration(c, n, p, dA, dZ, wantT, wantZ, maxitfac, wr, wi, s, sweeplog, maxlog, info);
+    const double ms_iter = tph.stop(c->stream);
+    // PSD.jl:1078-1092: undo the reversal; Z_1 stays, Z_2..Z_p reverse
+    if (left && p > 1) {
+        PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, p / 2), 64, 0, c->stream, dA, n, 0, p);
+        if (wantZ && p > 2) PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, (p - 1) / 2), 64, 0, c->stream, dZ, n, 1, p - 1);
+    }
+    s->ms_hess = ms_hess;
+    s->ms_formq = ms_formq;
+    s->ms_iter = ms_iter;
+    s->ms_total = tall.stop(c->stream);
+    s->bytes_hess = 2.0 * 8.0 * p * (5.0 / 6.0) * (double)n * n * n;
+    s->bytes_formq = wantZ ? 2.0 * 8.0 * p * (double)n * n * n / 3.0 : 0.0;
+    if (schurindex) *schurindex = left ? p : 1;
+    return rc;
+}
+
+int psd_d_pschur(psd_ctx* c, int n, int p, double* const* A, const uint8_t* S, char orient, int wantT, int wantZ,
+                 int maxitfac, double* const* Z, double* wr, double* wi, int* schurindex, psd_stats* stats,
+                 int32_t* sweeplog, int64_t maxlog, int* info) {
+    int dummy;
+    if (!info) info = &dummy;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!c) return *info = -1;
+    if ((*info = check_dims(n, p)) != 0) return *info;
+    if (!A) return *info = -4;
+    if (S)
+        for (int j = 0; j < p; ++j)
+            if (!S[j]) return *info = PSD_INFO_NOTIMPL;  // signed case: src/rgeneralized.jl (not in this build)
+    if (orient != 'R' && orient != 'L') return *info = -6;
+    if (wantZ && !Z) return *info = -10;
+    const int mlog = 2 * (maxitfac > 0 ? maxitfac : 1) * n + n + 16;
+    if ((*info = c->reserve(n, p, true, mlog)) != 0) return *info;
+    const size_t nn = (size_t)n * n;
+    Timer tc;
+    tc.start(c->stream);
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->dH + j * nn, A[j], nn * 8, c->stream));
+    double ms_copy = tc.stop(c->stream);
+    psd_stats local;
+    psd_stats* s = stats ? stats : &local;
+    int rc = psd_d_pschur_dev(c, n, p, c->dH, orient, wantT, wantZ, maxitfac, wantZ ? c->dZ : nullptr, wr, wi,
+                              schurindex, s, sweeplog, maxlog, info);
+    if (rc < 0 || rc >= PSD_INFO_NOTIMPL) return rc;
+    tc.start(c->stream);
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(A[j], c->dH + j * nn, nn * 8, c->stream));
+    if (wantZ)
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(Z[j], c->dZ + j * nn, nn * 8, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    ms_copy += tc.stop(c->stream);
+    s->ms_copy = ms_copy;
+    return rc;
+}
+
+int psd_d_pschur_hess(psd_ctx* c, int n, int p, double* const* H, double* const* Q, int wantT, int wantZ, int maxitfac,
+                      double* wr, double* wi, psd_stats* stats, int32_t* sweeplog, int64_t maxlog, int* info) {
+    int dummy;
+    if (!info) info = &dummy;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!c) return *info = -1;
+    if ((*info = check_dims(n, p)) != 0) return *info;
+    if (!H) return *info = -4;
+    if (wantZ && !Q) return *info = -5;
+    if (maxitfac < 1) return *info = -8;
+    const int mlog = 2 * maxitfac * n + n + 16;
+    if ((*info = c->reserve(n, p, true, mlog)) != 0) return *info;
+    const size_t nn = (size_t)n * n;
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->dH + j * nn, H[j], nn * 8, c->stream));
+    if (wantZ)
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->dZ + j * nn, Q[j], nn * 8, c->stream));
+    psd_stats local;
+    memset(&local, 0, sizeof(local));
+    psd_stats* s = stats ? stats : &local;
+    Timer t;
+    t.start(c->stream);
+    int rc = run_iteration(c, n, p, c->dH, wantZ ? c->dZ : nullptr, wantT, wantZ, maxitfac, wr, wi, s, sweeplog, maxlog,
+                           info);
+    s->ms_iter = s->ms_total = t.stop(c->stream);
+    if (rc < 0 || rc >= PSD_INFO_NOTIMPL) return rc;
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(H[j], c->dH + j * nn, nn * 8, c->stream));
+    if (wantZ)
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(Q[j], c->dZ + j * nn, nn * 8, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,975 @@
+// Real periodic QR iteration on the GPU: device-resident state machine.
+//
+// Replaces pschur!(H1, Hs; wantT, wantZ, Q, maxitfac) — /root/reference/src/
+// PeriodicSchurDecompositions.jl:322-1096 (MB03WD-type double-shift periodic QR).
+//
+// MI355X design (not a translation of the reference's loop nest):
+//   * The reference applies every 2-/3-wide reflector immediately to full rows/columns.  Here the
+//     serial dependency chain (w*p reflector generations per sweep) runs inside ONE wavefront on
+//     LDS-resident *diagonal window blocks* of all p factors (`psd_rq_step`), emitting the
+//     reflectors as per-factor transform lists; the O(n) off-window updates of H_m (rows),
+//     H_{m-1} (columns) and Z_m (columns) are applied afterwards at bandwidth by a wide kernel
+//     (`psd_rq_apply`), every element read once and written once per window.
+//   * All control (deflation tests, shifts, window bookkeeping) lives in device memory, so the
+//     host only enqueues {step, apply} pairs and polls a flag every few dozen launches.
+//   * Ownership convention for a transform generated "at factor m": left on rows of H_m, right on
+//     columns of H_{m-1 (cyclic)} and of Z_m.
+#pragma once
+#include "psd_scalar.h"
+
+enum {
+    PSD_PH_DECIDE = 0,
+    PSD_PH_RQ = 1,
+    PSD_PH_SHIFT = 2,
+    PSD_PH_QR = 3,
+    PSD_PH_DEFLATE = 4,
+    PSD_PH_NEXT = 5,
+    PSD_PH_FINAL = 6,
+    PSD_PH_DONE = 7
+};
+enum { PSD_TR_R3 = 3, PSD_TR_H2 = 2, PSD_TR_R2 = 4, PSD_TR_G = 5 };
+
+#define PSD_TR_CAP 64     // transform-list capacity per owner and window
+#define PSD_STEP_NT 64    // the chase runs in one wavefront
+#define PSD_APPLY_NT 128  // threads (= tile rows / tile columns) of the bulk-apply kernel
+
+struct psd_tr {
+    int pos;   // first row/column index (1-based) the transform acts on
+    int kind;  // PSD_TR_*
+    double c0, c1, c2;
+};
+
+// transform acting on up to three values (identical formula from the left on a column and from
+// the right on a row, because everything is real)
+PSD_HD void psd_tr_apply(const psd_tr& t, double& a1, double& a2, double& a3) {
+    if (t.kind == PSD_TR_R3) {  // householder.jl:207-237 with v = (1, c0, c1), tau = c2
+        const double x = t.c2 * (a1 + t.c0 * a2 + t.c1 * a3);
+        a1 -= x;
+        a2 -= x * t.c0;
+        a3 -= x * t.c1;
+    } else if (t.kind == PSD_TR_H2) {  // v = (1, c0), tau = c2
+        const double x = t.c2 * (a1 + t.c0 * a2);
+        a1 -= x;
+        a2 -= x * t.c0;
+    } else if (t.kind == PSD_TR_R2) {  // householder.jl:281-304 HH2(v1 = c0, v2 = c1, tau = c2)
+        const double s = a1 * t.c0 + a2 * t.c1;
+        a1 -= s * (t.c2 * t.c0);
+        a2 -= s * (t.c2 * t.c1);
+    } else {  // Givens: lmul!(G, .) on rows == rmul!(., G') on columns
+        const double b1 = t.c0 * a1 + t.c1 * a2;
+        const double b2 = -t.c1 * a1 + t.c0 * a2;
+        a1 = b1;
+        a2 = b2;
+    }
+}
+PSD_HD int psd_tr_len(const psd_tr& t) { return t.kind == PSD_TR_R3 ? 3 : 2; }
+
+struct psd_apply_desc {
+    int active;
+    int plo, phi;  // span of positions touched by the lists
+    int lc0, lc1;  // left role: columns of H_m
+    int rr0, rr1;  // right role: rows of H_{m-1}
+    int zr0, zr1;  // Z role: rows of Z_m (empty when !wantZ)
+};
+
+struct psd_rstate {
+    int n, p, wantT, wantZ, W;
+    int phase, info;
+    int i, l, its, maxitleft;
+    int i1, i2;
+    int kcur;
+    int maxits;
+    long long niter;
+    int nsweeps, nrqpass, ndefl1, ndefl2, nwindows, nlog, maxlog;
+    double v[3];
+    double smlnum, ulp, ulpx;
+};
+
+struct psd_rparams {
+    double* H;  // [p][n][n] column-major blocks, internal order (H_1 Hessenberg)
+    double* Z;  // [p][n][n] or nullptr
+    psd_rstate* st;
+    psd_apply_desc* desc;
+    psd_tr* tr;     // [p][PSD_TR_CAP]
+    int* cnt;       // [p]
+    double* hdiag;  // [n+2], 1-based
+    double* hsub;
+    double* hsup;
+    double* Pd;     // [n+3] band of prod_{j>=2} H_j: diagonal, first and second superdiagonal
+    double* Pe;
+    double* Pf;
+    double* hnorms;  // [p+1], 1-based
+    double* wr;      // [n] eigenvalues (0-based)
+    double* wi;
+    int* log;  // [3*maxlog]
+};
+
+PSD_HD psd_mat<double> psd_fac(const psd_rparams& P, int n, int j) {
+    return psd_mat<double>{P.H + (size_t)(j - 1) * n * n, n};
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS window: blocks [bs..be]^2 of all p factors, column-major with leading dimension W+1
+struct psd_win {
+    double* b;
+    int W, ld, bsz, bs, be;
+    PSD_HD double& at(int j, int r, int c) const { return b[(size_t)(j - 1) * bsz + (c - bs) * ld + (r - bs)]; }
+};
+
+PSD_D void psd_win_load(const psd_rparams& P, const psd_win& w, int n, int p) {
+    const int m = w.be - w.bs + 1;
+    for (int j = 1; j <= p; ++j) {
+        const psd_mat<double> Hj = psd_fac(P, n, j);
+        PSD_PAR_FOR(t, m * m) {
+            const int r = w.bs + t % m, c = w.bs + t / m;
+            w.at(j, r, c) = Hj(r, c);
+        }
+    }
+    PSD_SYNC();
+}
+PSD_D void psd_win_store(const psd_rparams& P, const psd_win& w, int n, int p) {
+    const int m = w.be - w.bs + 1;
+    PSD_SYNC();
+    for (int j = 1; j <= p; ++j) {
+        const psd_mat<double> Hj = psd_fac(P, n, j);
+        PSD_PAR_FOR(t, m * m) {
+            const int r = w.bs + t % m, c = w.bs + t / m;
+            Hj(r, c) = w.at(j, r, c);
+        }
+    }
+    PSD_SYNC();
+}
+
+// in-window application: from the left to rows tr.pos.. of factor jl over columns [c0,c1], and
+// from the right to columns tr.pos.. of factor jr over rows [r0,r1] (ranges clipped to the window)
+PSD_D void psd_win_apply(const psd_win& w, int jl, int jr, const psd_tr& tr, int c0, int c1, int r0, int r1) {
+    if (c0 < w.bs) c0 = w.bs;
+    if (c1 > w.be) c1 = w.be;
+    if (r0 < w.bs) r0 = w.bs;
+    if (r1 > w.be) r1 = w.be;
+    const int nl = (jl > 0 && c1 >= c0) ? (c1 - c0 + 1) : 0;
+    const int nr = (jr > 0 && r1 >= r0) ? (r1 - r0 + 1) : 0;
+    const int len = psd_tr_len(tr);
+    const int q = tr.pos;
+    if (jl == jr) {  // p == 1: same matrix, left then right
+        PSD_PAR_FOR(t, nl) {
+            const int c = c0 + t;
+            double a1 = w.at(jl, q, c), a2 = w.at(jl, q + 1, c), a3 = (len == 3) ? w.at(jl, q + 2, c) : 0.0;
+            psd_tr_apply(tr, a1, a2, a3);
+            w.at(jl, q, c) = a1;
+            w.at(jl, q + 1, c) = a2;
+            if (len == 3) w.at(jl, q + 2, c) = a3;
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(t, nr) {
+            const int r = r0 + t;
+            double a1 = w.at(jr, r, q), a2 = w.at(jr, r, q + 1), a3 = (len == 3) ? w.at(jr, r, q + 2) : 0.0;
+            psd_tr_apply(tr, a1, a2, a3);
+            w.at(jr, r, q) = a1;
+            w.at(jr, r, q + 1) = a2;
+            if (len == 3) w.at(jr, r, q + 2) = a3;
+        }
+        PSD_SYNC();
+    } else {
+        PSD_PAR_FOR(t, nl + nr) {
+            if (t < nl) {
+                const int c = c0 + t;
+                double a1 = w.at(jl, q, c), a2 = w.at(jl, q + 1, c), a3 = (len == 3) ? w.at(jl, q + 2, c) : 0.0;
+                psd_tr_apply(tr, a1, a2, a3);
+                w.at(jl, q, c) = a1;
+                w.at(jl, q + 1, c) = a2;
+                if (len == 3) w.at(jl, q + 2, c) = a3;
+            } else {
+                const int r = r0 + (t - nl);
+                double a1 = w.at(jr, r, q), a2 = w.at(jr, r, q + 1), a3 = (len == 3) ? w.at(jr, r, q + 2) : 0.0;
+                psd_tr_apply(tr, a1, a2, a3);
+                w.at(jr, r, q) = a1;
+                w.at(jr, r, q + 1) = a2;
+                if (len == 3) w.at(jr, r, q + 2) = a3;
+            }
+        }
+        PSD_SYNC();
+    }
+}
+
+// append a transform to owner m's list (LDS counters, global list)
+PSD_D void psd_record(const psd_rparams& P, int* lcnt, int m, const psd_tr& tr) {
+    PSD_ONE {
+        const int q = lcnt[m - 1];
+        if (q < PSD_TR_CAP) P.tr[(size_t)(m - 1) * PSD_TR_CAP + q] = tr;
+        lcnt[m - 1] = q + 1;
+    }
+}
+
+PSD_D void psd_log(const psd_rparams& P, psd_rstate& st, int kind, int l, int i) {
+    PSD_ONE {
+        if (st.nlog < st.maxlog) {
+            P.log[3 * st.nlog + 0] = kind;
+            P.log[3 * st.nlog + 1] = l;
+            P.log[3 * st.nlog + 2] = i;
+        }
+    }
+    st.nlog += 1;
+}
+
+// opnorm(view(H1, lo:hi, lo:hi), 1) — PSD.jl:537,596 fallback when a diagonal pair is exactly zero
+PSD_D double psd_h1_opnorm(const psd_rparams& P, const psd_rstate& st, double* red, int lo, int hi) {
+    const psd_mat<double> H1 = psd_fac(P, st.n, 1);
+    const int NT = PSD_NTHREADS;
+    PSD_PAR_FOR(t, NT) {
+        double best = 0.0;
+        for (int c = lo + t; c <= hi; c += NT) {
+            double s = 0.0;
+            const int rmax = (c + 1 < hi) ? (c + 1) : hi;
+            for (int r = lo; r <= rmax; ++r) s += fabs(H1(r, c));
+            if (s > best) best = s;
+        }
+        red[t] = best;
+    }
+    PSD_SYNC();
+    double best = 0.0;
+    for (int t = 0; t < NT; ++t)
+        if (red[t] > best) best = red[t];
+    PSD_SYNC();
+    return best;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PSD.jl:471-672: product band, deflation search, RQ decision
+PSD_D void psd_rq_decide(const psd_rparams& P, psd_rstate& st, double* red, int* redi) {
+    const int n = st.n, p = st.p, i = st.i, lo = st.l;
+    const int NT = PSD_NTHREADS;
+    if (!(st.its < st.maxitleft)) {  // PSD.jl:471,891-893
+        st.info = i;
+        st.phase = PSD_PH_DONE;
+        return;
+    }
+    const psd_mat<double> H1 = psd_fac(P, n, 1);
+    // band of P = H_2 H_3 ... H_p on rows lo..i (PSD.jl:475-495,507-516, evaluated per row)
+    PSD_PAR_FOR(t, i - lo + 1) {
+        const int a = lo + t;
+        double d = 1.0, e = 0.0, f = 0.0;
+        for (int j = 2; j <= p; ++j) {
+            const psd_mat<double> Hj = psd_fac(P, n, j);
+            if (a + 2 <= i) f = d * Hj(a, a + 2) + e * Hj(a + 1, a + 2) + f * Hj(a + 2, a + 2);
+            if (a + 1 <= i) e = d * Hj(a, a + 1) + e * Hj(a + 1, a + 1);
+            d *= Hj(a, a);
+        }
+        P.Pd[a] = d;
+        P.Pe[a] = e;
+        P.Pf[a] = f;
+    }
+    PSD_SYNC();
+    // tridiagonal band of the product (PSD.jl:485-488,517-528)
+    PSD_PAR_FOR(t, i - lo + 1) {
+        const int r = lo + t;
+        if (i == lo) {
+            P.hdiag[i] = H1(i, i) * P.Pd[i];
+        } else if (r == i) {
+            P.hsub[i] = H1(i, i - 1) * P.Pd[i - 1];
+            P.hdiag[i] = H1(i, i - 1) * P.Pe[i - 1] + H1(i, i) * P.Pd[i];
+        } else if (r > lo) {
+            P.hsub[r] = H1(r, r - 1) * P.Pd[r - 1];
+            P.hdiag[r] = H1(r, r - 1) * P.Pe[r - 1] + H1(r, r) * P.Pd[r];
+            P.hsup[n - i + r] = H1(r, r - 1) * P.Pf[r - 1] + H1(r, r) * P.Pe[r] + H1(r, r + 1) * P.Pd[r + 1];
+        } else {
+            P.hdiag[r] = H1(r, r) * P.Pd[r];
+            P.hsup[n - i + r] = H1(r, r) * P.Pe[r] + H1(r, r + 1) * P.Pd[r + 1];
+        }
+    }
+    PSD_SYNC();
+    // search for a negligible subdiagonal from the bottom (PSD.jl:504-576)
+    int klast = 0;
+    double h1norm = -1.0;
+    for (int pass = 0; pass < 2; ++pass) {
+        PSD_PAR_FOR(t, NT) {
+            int best = 0, need = 0;
+            for (int k = i - t; k >= lo + 1; k -= NT) {
+                const double hh21 = P.hsub[k], hh22 = P.hdiag[k], hh11 = P.hdiag[k - 1], hh12 = P.hsup[n - i + k - 1];
+                double tst1 = fabs(hh11) + fabs(hh22);
+                if (tst1 == 0) {
+                    if (h1norm < 0) {
+                        need = 1;
+                        continue;
+                    }
+                    tst1 = h1norm;
+                }
+                bool found = false;
+                if (fabs(hh21) <= st.smlnum) {
+                    found = true;
+                } else if (fabs(hh21) <= st.ulp * tst1) {  // LAPACK + Ahues-Tisseur, PSD.jl:548-555
+                    const double ab = fmax(fabs(hh21), fabs(hh12));
+                    const double ba = fmin(fabs(hh21), fabs(hh12));
+                    const double aa = fmax(fabs(hh22), fabs(hh11 - hh22));
+                    const double bb = fmin(fabs(hh22), fabs(hh11 - hh22));
+                    const double stmp = aa + ab;
+                    found = ba * (ab / stmp) <= fmax(st.smlnum, st.ulpx * (bb * (aa / stmp)));
+                }
+                if (found) {
+                    best = k;
+                    break;
+                }
+            }
+            redi[t] = best;
+            redi[NT + t] = need;
+        }
+        PSD_SYNC();
+        int need = 0;
+        klast = 0;
+        for (int t = 0; t < NT; ++t) {
+            if (redi[t] > klast) klast = redi[t];
+            need |= redi[NT + t];
+        }
+        PSD_SYNC();
+        if (!need) break;
+        h1norm = psd_h1_opnorm(P, st, red, lo, i);
+    }
+    const bool found = klast > 0;
+    const int l = (i > lo) ? (found ? klast : lo) : i;  // PSD.jl:585
+    st.l = l;
+    st.phase = PSD_PH_SHIFT;
+    if (l > 1 && st.wantT) {  // PSD.jl:589-665
+        double tst1 = fabs(H1(l - 1, l - 1)) + fabs(H1(l, l));
+        if (tst1 == 0) tst1 = psd_h1_opnorm(P, st, red, l, i);
+        if (fabs(H1(l, l - 1)) > fmax(st.ulp * tst1, st.smlnum)) {
+            st.phase = PSD_PH_RQ;
+            st.kcur = i;
+            st.nrqpass += 1;
+            psd_log(P, st, 1, l, i);
+        } else {
+            PSD_SYNC();
+            PSD_ONE { H1(l, l - 1) = 0.0; }
+            PSD_SYNC();
+        }
+    }
+}
+
+// PSD.jl:668-803: split test, shifts, first column of the shifted product
+PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st) {
+    const int n = st.n, i = st.i, l = st.l;
+    if (l >= i - 1) {
+        st.phase = PSD_PH_DEFLATE;
+        return;
+    }
+    if (!st.wantT) {
+        st.i1 = l;
+        st.i2 = i;
+    }
+    psd_log(P, st, 0, l, i);
+    st.nsweeps += 1;
+    const double dat1 = 0.75, dat2 = -0.4375;
+    const double* hdiag = P.hdiag;
+    const double* hsub = P.hsub;
+    const double* hsup = P.hsup;
+    double h33 = 0, h44 = 0, h43h34 = 0;
+    double rt1r = 0, rt2r = 0, rt1i = 0, rt2i = 0;
+    bool exc = false;
+    if (st.its == 10) {  // PSD.jl:680-689
+        exc = true;
+        const double s = fabs(hsub[l + 1]) + fabs(hsub[l + 2]);
+        h44 = dat1 * s + hdiag[l];
+        h33 = h44;
+        h43h34 = dat2 * s * s;
+    } else if (st.its % 10 == 0) {  // PSD.jl:690-699
+        exc = true;
+        const double s = fabs(hsub[i]) + fabs(hsub[i - 1]);
+        h44 = dat1 * s + hdiag[i];
+        h33 = h44;
+        h43h34 = dat2 * s * s;
+    } else {  // PSD.jl:729-762 (dlahqr shifts; _slicot_shifts[] is false by default)
+        h44 = hdiag[i];
+        h33 = hdiag[i - 1];
+        double h43 = hsub[i], h34 = hsup[n - 1];
+        const double s = fabs(h33) + fabs(h34) + fabs(h43) + fabs(h44);
+        if (s != 0) {
+            h33 /= s; h44 /= s; h34 /= s; h43 /= s;
+            const double trc = (h33 + h44) * 0.5;
+            const double disc = (h33 - trc) * (h44 - trc) - h34 * h43;
+            const double rtdisc = sqrt(fabs(disc));
+            if (disc >= 0) {
+                rt1r = trc * s;
+                rt2r = rt1r;
+                rt1i = rtdisc * s;
+                rt2i = -rt1i;
+            } else {
+                rt1r = trc + rtdisc;
+                rt2r = trc - rtdisc;
+                rt1r = (fabs(rt1r - h44) <= fabs(rt2r - h44)) ? (rt1r * s) : (rt2r * s);
+                rt2r = rt1r;
+                rt1i = rt2i = 0.0;
+            }
+        }
+    }
+    {  // PSD.jl:768-803 with mmax = l (_allow_early_QR[] is false by default)
+        const int m = l;
+        const double h11 = hdiag[m], h12 = hsup[n - i + m], h21 = hsub[m + 1], h22 = hdiag[m + 1];
+        double v1, v2, v3;
+        if (exc) {
+            const double h44s = h44 - h11, h33s = h33 - h11;
+            v1 = (h33s * h44s - h43h34) / h21 + h12;
+            v2 = h22 - h11 - h33s - h44s;
+            v3 = hsub[m + 2];
+        } else {
+            const double s = fabs(h11 - rt2r) + fabs(rt2i) + fabs(h21);
+            const double h21s = h21 / s;
+            v1 = h21s * h12 + (h11 - rt1r) * ((h11 - rt2r) / s) - rt1i * (rt2i / s);
+            v2 = h21s * (h11 + h22 - rt1r - rt2r);
+            v3 = h21s * hsub[m + 2];
+        }
+        const double s = fabs(v1) + fabs(v2) + fabs(v3);
+        st.v[0] = v1 / s;
+        st.v[1] = v2 / s;
+        st.v[2] = v3 / s;
+    }
+    st.phase = PSD_PH_QR;
+    st.kcur = l;
+}
+
+PSD_D void psd_desc_write(const psd_rparams& P, const psd_rstate& st, const int* lcnt, int plo, int phi, int lc0,
+                          int lc1, int rr0, int rr1) {
+    PSD_SYNC();
+    PSD_PAR_FOR(m, st.p) { P.cnt[m] = lcnt[m]; }
+    PSD_ONE {
+        psd_apply_desc d;
+        d.active = 1;
+        d.plo = plo;
+        d.phi = phi;
+        d.lc0 = lc0;
+        d.lc1 = lc1;
+        d.rr0 = rr0;
+        d.rr1 = rr1;
+        d.zr0 = 1;
+        d.zr1 = st.wantZ ? st.n : 0;
+        *P.desc = d;
+    }
+    PSD_SYNC();
+}
+
+// PSD.jl:806-886: one window (steps kcur .. kcur+nb-1) of the double-shift periodic QR sweep
+PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, int* lcnt) {
+    const int n = st.n, p = st.p, i = st.i, l = st.l, i1 = st.i1, i2 = st.i2;
+    const int nb = st.W - 4;
+    const int ks = st.kcur;
+    const int ke = (ks + nb - 1 < i - 1) ? (ks + nb - 1) : (i - 1);
+    psd_win w;
+    w.b = ldsd;
+    w.W = st.W;
+    w.ld = st.W + 1;
+    w.bsz = st.W * (st.W + 1);
+    w.bs = (ks > l) ? (ks - 1) : l;
+    w.be = (ke + 3 < i) ? (ke + 3) : i;
+    PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
+    psd_win_load(P, w, n, p);
+    for (int k = ks; k <= ke; ++k) {
+        const int nr = (3 < i - k + 1) ? 3 : (i - k + 1);
+        const int rlim = (k + nr < i) ? (k + nr) : i;
+        double x[3];
+        if (k > l) {
+            for (int q = 0; q < nr; ++q) x[q] = w.at(1, k + q, k - 1);
+        } else {
+            x[0] = st.v[0]; x[1] = st.v[1]; x[2] = st.v[2];
+        }
+        PSD_SYNC();
+        double tau = psd_reflector_small(x, nr);
+        if (k > l) {
+            PSD_ONE {
+                w.at(1, k, k - 1) = x[0];
+                w.at(1, k + 1, k - 1) = 0.0;
+                if (k < i - 1) w.at(1, k + 2, k - 1) = 0.0;
+            }
+            PSD_SYNC();
+        }
+        psd_tr tr;
+        tr.pos = k;
+        tr.kind = (nr == 3) ? PSD_TR_R3 : PSD_TR_H2;
+        tr.c0 = x[1];
+        tr.c1 = (nr == 3) ? x[2] : 0.0;
+        tr.c2 = tau;
+        psd_win_apply(w, 1, p, tr, k, i2, i1, rlim);
+        psd_record(P, lcnt, 1, tr);
+        for (int j = p; j >= 2; --j) {
+            for (int q = 0; q < nr; ++q) x[q] = w.at(j, k + q, k);
+            PSD_SYNC();
+            tau = psd_reflector_small(x, nr);
+            PSD_ONE {
+                w.at(j, k, k) = x[0];
+                w.at(j, k + 1, k) = 0.0;
+                if (nr == 3) w.at(j, k + 2, k) = 0.0;
+            }
+            PSD_SYNC();
+            tr.pos = k;
+            tr.kind = (nr == 3) ? PSD_TR_R3 : PSD_TR_H2;
+            tr.c0 = x[1];
+            tr.c1 = (nr == 3) ? x[2] : 0.0;
+            tr.c2 = tau;
+            psd_win_apply(w, j, j - 1, tr, k + 1, i2, i1, rlim);
+            psd_record(P, lcnt, j, tr);
+            if (nr == 3) {
+                x[0] = w.at(j, k + 1, k + 1);
+                x[1] = w.at(j, k + 2, k + 1);
+                PSD_SYNC();
+                tau = psd_reflector_small(x, 2);
+                PSD_ONE {
+                    w.at(j, k + 1, k + 1) = x[0];
+                    w.at(j, k + 2, k + 1) = 0.0;
+                }
+                PSD_SYNC();
+                tr.pos = k + 1;
+                tr.kind = PSD_TR_H2;
+                tr.c0 = x[1];
+                tr.c1 = 0.0;
+                tr.c2 = tau;
+                psd_win_apply(w, j, j - 1, tr, k + 2, i2, i1, rlim);
+                psd_record(P, lcnt, j, tr);
+            }
+        }
+    }
+    psd_win_store(P, w, n, p);
+    const int phi = (ke + 2 < i) ? (ke + 2) : i;
+    psd_desc_write(P, st, lcnt, ks, phi, w.be + 1, i2, i1, w.bs - 1);
+    st.nwindows += 1;
+    st.kcur = ke + 1;
+    if (ke >= i - 1) {  // sweep complete (PSD.jl:887)
+        st.its += 1;
+        st.phase = PSD_PH_DECIDE;
+    }
+}
+
+// PSD.jl:602-663: one window of the RQ clean-up pass (k descending from kcur)
+PSD_D void psd_rq_rq_window(const psd_rparams& P, psd_rstate& st, double* ldsd, int* lcnt) {
+    const int n = st.n, p = st.p, i = st.i, l = st.l, i1 = st.i1, i2 = st.i2;
+    const int nb = st.W - 3;
+    const int ks = st.kcur;
+    const int ke = (ks - nb + 1 > l) ? (ks - nb + 1) : l;
+    psd_win w;
+    w.b = ldsd;
+    w.W = st.W;
+    w.ld = st.W + 1;
+    w.bsz = st.W * (st.W + 1);
+    w.bs = ke - 1;
+    w.be = (ks + 1 < i) ? (ks + 1) : i;
+    PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
+    psd_win_load(P, w, n, p);
+    for (int k = ks; k >= ke; --k) {
+        for (int j = 1; j <= p - 1; ++j) {
+            double x[2] = {w.at(j, k, k), w.at(j, k, k - 1)};
+            PSD_SYNC();
+            const double t = psd_reflector_small(x, 2);
+            PSD_ONE {
+                w.at(j, k, k - 1) = 0.0;
+                w.at(j, k, k) = x[0];
+            }
+            PSD_SYNC();
+            psd_tr tr;
+            tr.pos = k - 1;
+            tr.kind = PSD_TR_R2;
+            tr.c0 = x[1];
+            tr.c1 = 1.0;
+            tr.c2 = t;
+            psd_win_apply(w, j + 1, j, tr, k - 1, i2, i1, k - 1);
+            psd_record(P, lcnt, j + 1, tr);
+        }
+        if (k < i) {
+            double x[2] = {w.at(p, k + 1, k + 1), w.at(p, k + 1, k)};
+            PSD_SYNC();
+            const double t = psd_reflector_small(x, 2);
+            PSD_ONE {
+                w.at(p, k + 1, k) = 0.0;
+                w.at(p, k + 1, k + 1) = x[0];
+            }
+            PSD_SYNC();
+            psd_tr tr;
+            tr.pos = k;
+            tr.kind = PSD_TR_R2;
+            tr.c0 = x[1];
+            tr.c1 = 1.0;
+            tr.c2 = t;
+            if (p == 1) {
+                // same matrix: the reference applies rmul! (rows i1:k) first, then lmul! (PSD.jl:627-629)
+                psd_win_apply(w, 0, 1, tr, 0, -1, i1, k);
+                psd_win_apply(w, 1, 0, tr, k, i2, 0, -1);
+            } else {
+                psd_win_apply(w, 1, p, tr, k, i2, i1, k);
+            }
+            psd_record(P, lcnt, 1, tr);
+        }
+    }
+    psd_win_store(P, w, n, p);
+    psd_desc_write(P, st, lcnt, w.bs, w.be, w.be + 1, i2, i1, w.bs - 1);
+    st.nwindows += 1;
+    st.kcur = ke - 1;
+    if (ke <= l) {  // pass complete: PSD.jl:653-663
+        const psd_mat<double> H1 = psd_fac(P, n, 1);
+        const psd_mat<double> Hp = psd_fac(P, n, p);
+        PSD_ONE {
+            Hp(l, l - 1) = 0.0;
+            H1(l, l - 1) = 0.0;
+        }
+        PSD_SYNC();
+        st.phase = PSD_PH_SHIFT;
+    }
+}
+
+// PSD.jl:896-1054: deflation of a 1x1 or 2x2 block at the bottom of the active window.
+// Returns true if an apply descriptor was emitted.
+PSD_D bool psd_rq_deflate(const psd_rparams& P, psd_rstate& st, double* ldsd, int* lcnt) {
+    const int n = st.n, p = st.p, i = st.i, l = st.l, i1 = st.i1, i2 = st.i2;
+    st.phase = PSD_PH_NEXT;
+    if (l == i) {  // PSD.jl:896-899
+        PSD_ONE {
+            P.wr[i - 1] = P.hdiag[i];
+            P.wi[i - 1] = 0.0;
+        }
+        st.ndefl1 += 1;
+        return false;
+    }
+    st.ndefl2 += 1;
+    psd_win w;
+    w.b = ldsd;
+    w.W = st.W;
+    w.ld = st.W + 1;
+    w.bsz = st.W * (st.W + 1);
+    w.bs = i - 1;
+    w.be = i;
+    double hh11, hh12, hh21, hh22;
+    if (st.wantT) {
+        PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
+        psd_win_load(P, w, n, p);
+        double hp22 = 1.0, hp12 = 0.0, hp11 = 1.0;  // PSD.jl:908-920
+        for (int j = 2; j <= p; ++j) {
+            hp22 *= w.at(j, i, i);
+            hp12 = hp11 * w.at(j, i - 1, i) + hp12 * w.at(j, i, i);
+            hp11 *= w.at(j, i - 1, i - 1);
+        }
+        hh21 = w.at(1, i, i - 1) * hp11;
+        hh22 = w.at(1, i, i - 1) * hp12 + w.at(1, i, i) * hp22;
+        hh11 = w.at(1, i - 1, i - 1) * hp11;
+        hh12 = w.at(1, i - 1, i - 1) * hp12 + w.at(1, i - 1, i) * hp22;
+    } else {  // PSD.jl:921-926
+        hh11 = P.hdiag[i - 1];
+        hh12 = P.hsup[n - 1];
+        hh21 = P.hsub[i];
+        hh22 = P.hdiag[i];
+    }
+    PSD_SYNC();
+    double a = hh11, b = hh12, c = hh21, d = hh22, gcs, gsn, w1r, w1i, w2r, w2i;
+    psd_gs2x2(a, b, c, d, gcs, gsn, w1r, w1i, w2r, w2i);  // PSD.jl:930
+    const double hsub_im1 = w1i;                           // PSD.jl:934
+    if (!st.wantT) {
+        PSD_ONE {
+            P.wr[i - 2] = w1r; P.wi[i - 2] = w1i;
+            P.wr[i - 1] = w2r; P.wi[i - 1] = w2i;
+        }
+        return false;
+    }
+    // negligible diagonal entries of H_j, j > 1 (PSD.jl:937-958)
+    int jmin = 0, jmax = 0;
+    for (int j = 2; j <= p; ++j) {
+        const double hn = P.hnorms[j];
+        if (jmin == 0 && fabs(w.at(j, i - 1, i - 1)) <= hn) jmin = j;
+        if (fabs(w.at(j, i, i)) <= hn) jmax = j;
+    }
+    if (jmin != 0 && jmax != 0) {
+        if (jmin - 1 <= p - jmax + 1) jmax = 0;
+        else jmin = 0;
+    }
+    if (jmin != 0) {  // PSD.jl:959-977 (with beta written back; the reference writes xi[2] — defect)
+        for (int j = 1; j <= jmin - 1; ++j) {
+            double x[2] = {w.at(j, i, i), w.at(j, i, i - 1)};
+            PSD_SYNC();
+            const double t = psd_reflector_small(x, 2);
+            psd_tr tr;
+            tr.pos = i - 1;
+            tr.kind = PSD_TR_R2;
+            tr.c0 = x[1];
+            tr.c1 = 1.0;
+            tr.c2 = t;
+            PSD_ONE {
+                w.at(j, i, i - 1) = 0.0;
+                w.at(j, i, i) = x[0];
+            }
+            PSD_SYNC();
+            psd_win_apply(w, j + 1, j, tr, i - 1, i2, i1, i - 1);
+            psd_record(P, lcnt, j + 1, tr);
+        }
+    } else {  // PSD.jl:978-1052
+        bool replaceG = (jmax > 0) && (hsub_im1 == 0);
+        const double a1 = hypot(w1r, w1i), a2 = hypot(w2r, w2i);
+        const double prr = w2r * w1r - w2i * w1i, pri = w2r * w1i + w2i * w1r;
+        if (prr == 0 && pri == 0) {
+            replaceG = true;
+        } else if (hsub_im1 == 0) {
+            if (fmin(a1, a2) / fmax(a1, a2) < PSD_DBL_EPS) replaceG = true;
+        }
+        for (int its2 = 1; its2 <= 20; ++its2) {
+            if (replaceG) {
+                double rr;
+                psd_givens(w.at(1, i - 1, i - 1), w.at(1, i, i - 1), gcs, gsn, rr);
+            }
+            PSD_SYNC();
+            psd_tr tr;
+            tr.pos = i - 1;
+            tr.kind = PSD_TR_G;
+            tr.c0 = gcs;
+            tr.c1 = gsn;
+            tr.c2 = 0.0;
+            if (p == 1) {
+                psd_win_apply(w, 1, 0, tr, i - 1, i2, 0, -1);
+                psd_win_apply(w, 0, 1, tr, 0, -1, i1, i);
+            } else {
+                psd_win_apply(w, 1, p, tr, i - 1, i2, i1, i);
+            }
+            psd_record(P, lcnt, 1, tr);
+            const int jstop = (2 > jmax + 1) ? 2 : (jmax + 1);
+            for (int j = p; j >= jstop; --j) {
+                double x[2] = {w.at(j, i - 1, i - 1), w.at(j, i, i - 1)};
+                PSD_SYNC();
+                const double t = psd_reflector_small(x, 2);
+                PSD_ONE {
+                    w.at(j, i - 1, i - 1) = x[0];
+                    w.at(j, i, i - 1) = 0.0;
+                }
+                PSD_SYNC();
+                tr.pos = i - 1;
+                tr.kind = PSD_TR_H2;
+                tr.c0 = x[1];
+                tr.c1 = 0.0;
+                tr.c2 = t;
+                psd_win_apply(w, j, j - 1, tr, i, i2, i1, i);
+                psd_record(P, lcnt, j, tr);
+            }
+            const double h21 = w.at(1, i, i - 1);
+            PSD_SYNC();
+            if (!replaceG || (fabs(h21) < fmax(st.smlnum, st.ulp * fmax(a1, a2)))) break;
+            replaceG = true;
+        }
+        PSD_ONE {
+            if (jmax > 0) {
+                w.at(1, i, i - 1) = 0.0;
+                if (jmax > 1) w.at(jmax, i, i - 1) = 0.0;
+            } else if (hh21 == 0) {
+                w.at(1, i, i - 1) = 0.0;
+            }
+        }
+        PSD_SYNC();
+        if (replaceG) {  // PSD.jl:1039-1051 (indices i-1, i; the reference's [1],[2] is a defect)
+            double l1 = w.at(1, i - 1, i - 1);
+            for (int j = 2; j <= p; ++j) l1 *= w.at(j, i - 1, i - 1);
+            const double d1 = hypot(l1 - w1r, w1i), d2 = hypot(l1 - w2r, w2i);
+            if (d1 > d2) {
+                double tr_ = w1r, ti_ = w1i;
+                w1r = w2r; w1i = w2i;
+                w2r = tr_; w2i = ti_;
+            }
+        }
+    }
+    PSD_ONE {
+        P.wr[i - 2] = w1r; P.wi[i - 2] = w1i;
+        P.wr[i - 1] = w2r; P.wi[i - 1] = w2i;
+    }
+    psd_win_store(P, w, n, p);
+    psd_desc_write(P, st, lcnt, i - 1, i, i + 1, i2, i1, i - 2);
+    return true;
+}
+
+// One launch = state transitions until a window's worth of transforms has been emitted.
+PSD_KERNEL psd_rq_step(psd_rparams P) {
+    PSD_LDS_DECL;
+    psd_rstate st = *P.st;
+    if (st.phase == PSD_PH_DONE) {
+        PSD_ONE { P.desc->active = 0; }
+        return;
+    }
+    const int NT = PSD_NTHREADS;
+    double* ldsd = (double*)psd_lds;
+    const size_t winb = (size_t)st.p * st.W * (st.W + 1);
+    double* red = ldsd + winb;
+    int* redi = (int*)(red + NT);
+    int* lcnt = redi + 2 * NT;
+    PSD_ONE { P.desc->active = 0; }
+    bool emitted = false;
+    int guard = 0;
+    while (!emitted && st.phase != PSD_PH_DONE && guard < 4 * st.n + 16) {
+        ++guard;
+        switch (st.phase) {
+            case PSD_PH_DECIDE:
+                psd_rq_decide(P, st, red, redi);
+                break;
+            case PSD_PH_RQ:
+                psd_rq_rq_window(P, st, ldsd, lcnt);
+                emitted = true;
+                break;
+            case PSD_PH_SHIFT:
+                psd_rq_shift(P, st);
+                break;
+            case PSD_PH_QR:
+                psd_rq_qr_window(P, st, ldsd, lcnt);
+                emitted = true;
+                break;
+            case PSD_PH_DEFLATE:
+                emitted = psd_rq_deflate(P, st, ldsd, lcnt);
+                break;
+            case PSD_PH_NEXT:  // PSD.jl:1057-1060
+                st.maxitleft -= st.its;
+                st.niter += st.its;
+                if (st.its > st.maxits) st.maxits = st.its;
+                st.i = st.l - 1;
+                st.l = 1;
+                st.its = 1;
+                st.phase = (st.i >= 1) ? PSD_PH_DECIDE : PSD_PH_FINAL;
+                break;
+            case PSD_PH_FINAL: {  // PSD.jl:1066-1073
+                const psd_mat<double> H1 = psd_fac(P, st.n, 1);
+                PSD_SYNC();
+                PSD_PAR_FOR(q, st.n - 1) {
+                    if (P.wi[q] == 0.0) H1(q + 2, q + 1) = 0.0;
+                }
+                PSD_SYNC();
+                st.phase = PSD_PH_DONE;
+                break;
+            }
+            default:
+                st.phase = PSD_PH_DONE;
+                break;
+        }
+    }
+    PSD_SYNC();
+    PSD_ONE { *P.st = st; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bulk application of one window's transform lists.  grid = (tiles, p owners, 3 roles).
+//   role 0: left on H_m,  rows [plo,phi] x columns [lc0,lc1]
+//   role 1: right on H_{m-1}, rows [rr0,rr1] x columns [plo,phi]
+//   role 2: right on Z_m, rows [zr0,zr1] x columns [plo,phi]
+// Every element of the panel is read once and written once; the sequence runs out of LDS.
+PSD_KERNEL psd_rq_apply(psd_rparams P, int n, int p) {
+    PSD_LDS_DECL;
+    const psd_apply_desc d = *P.desc;
+    if (!d.active) return;
+    const int m = PSD_BLOCK_Y + 1;
+    const int role = PSD_BLOCK_Z;
+    const int cnt = P.cnt[m - 1] < PSD_TR_CAP ? P.cnt[m - 1] : PSD_TR_CAP;
+    if (cnt <= 0) return;
+    const int T = PSD_APPLY_NT;
+    const int S = d.phi - d.plo + 1;
+    psd_tr* ltr = (psd_tr*)psd_lds;
+    double* tile = (double*)(psd_lds + sizeof(psd_tr) * PSD_TR_CAP);
+    if (role == 0) {
+        const int c0 = d.lc0 + PSD_BLOCK_X * T;
+        if (c0 > d.lc1) return;
+        const int nc = (d.lc1 - c0 + 1 < T) ? (d.lc1 - c0 + 1) : T;
+        const psd_mat<double> M = psd_mat<double>{P.H + (size_t)(m - 1) * n * n, n};
+        const int ldt = T + 1;
+        PSD_PAR_FOR(e, cnt) { ltr[e] = P.tr[(size_t)(m - 1) * PSD_TR_CAP + e]; }
+        PSD_PAR_FOR(t, S * nc) {
+            const int r = t % S, c = t / S;
+            tile[r * ldt + c] = M(d.plo + r, c0 + c);
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(c, nc) {
+            for (int e = 0; e < cnt; ++e) {
+                const psd_tr tr = ltr[e];
+                const int r = tr.pos - d.plo;
+                const int len = psd_tr_len(tr);
+                double a1 = tile[r * ldt + c], a2 = tile[(r + 1) * ldt + c], a3 = (len == 3) ? tile[(r + 2) * ldt + c] : 0.0;
+                psd_tr_apply(tr, a1, a2, a3);
+                tile[r * ldt + c] = a1;
+                tile[(r + 1) * ldt + c] = a2;
+                if (len == 3) tile[(r + 2) * ldt + c] = a3;
+            }
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(t, S * nc) {
+            const int r = t % S, c = t / S;
+            M(d.plo + r, c0 + c) = tile[r * ldt + c];
+        }
+    } else {
+        const int lo = (role == 1) ? d.rr0 : d.zr0;
+        const int hi = (role == 1) ? d.rr1 : d.zr1;
+        const int r0 = lo + PSD_BLOCK_X * T;
+        if (r0 > hi) return;
+        const int nr = (hi - r0 + 1 < T) ? (hi - r0 + 1) : T;
+        const int jm = (role == 1) ? ((m == 1) ? p : (m - 1)) : m;
+        double* base = (role == 1) ? P.H : P.Z;
+        const psd_mat<double> M = psd_mat<double>{base + (size_t)(jm - 1) * n * n, n};
+        PSD_PAR_FOR(e, cnt) { ltr[e] = P.tr[(size_t)(m - 1) * PSD_TR_CAP + e]; }
+        PSD_PAR_FOR(t, S * nr) {
+            const int r = t % nr, c = t / nr;
+            tile[c * T + r] = M(r0 + r, d.plo + c);
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(r, nr) {
+            for (int e = 0; e < cnt; ++e) {
+                const psd_tr tr = ltr[e];
+                const int c = tr.pos - d.plo;
+                const int len = psd_tr_len(tr);
+                double a1 = tile[c * T + r], a2 = tile[(c + 1) * T + r], a3 = (len == 3) ? tile[(c + 2) * T + r] : 0.0;
+                psd_tr_apply(tr, a1, a2, a3);
+                tile[c * T + r] = a1;
+                tile[(c + 1) * T + r] = a2;
+                if (len == 3) tile[(c + 2) * T + r] = a3;
+            }
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(t, S * nr) {
+            const int r = t % nr, c = t / nr;
+            M(r0 + r, d.plo + c) = tile[c * T + r];
+        }
+    }
+}
+
+// hnorms[j] = ulp*n*opnorm(H_j, 1), column-1 / sub-Hessenberg clean-up (PSD.jl:379-388,406), and
+// state initialisation.  grid = p blocks.
+PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W, int maxitfac, int maxlog) {
+    PSD_LDS_DECL;
+    double* red = (double*)psd_lds;
+    const int j = PSD_BLOCK_X + 1;
+    const int NT = PSD_NTHREADS;
+    const psd_mat<double> Hj = psd_mat<double>{P.H + (size_t)(j - 1) * n * n, n};
+    if (j == 1) {
+        // _gethess!: zero below the first subdiagonal
+        PSD_PAR_FOR(c, n) {
+            for (int r = c + 3; r <= n; ++r) Hj(r, c + 1) = 0.0;
+        }
+        PSD_ONE {
+            psd_rstate st;
+            st.n = n; st.p = p; st.wantT = wantT; st.wantZ = wantZ; st.W = W;
+            st.phase = PSD_PH_DECIDE; st.info = 0;
+            st.i = n; st.l = 1; st.its = 1; st.maxitleft = maxitfac * n;
+            st.i1 = 1; st.i2 = n; st.kcur = 0; st.maxits = 0; st.niter = 0;
+            st.nsweeps = st.nrqpass = st.ndefl1 = st.ndefl2 = st.nwindows = st.nlog = 0;
+            st.maxlog = maxlog;
+            st.v[0] = st.v[1] = st.v[2] = 0.0;
+            st.ulp = PSD_DBL_EPS;
+            st.smlnum = PSD_DBL_MIN * ((double)n / PSD_DBL_EPS);
+            // PSD.jl:366-375 with _AT_pwr16[] = 4: ulpx = ulp^(1 + 4/16)
+            double s = PSD_DBL_EPS, ulpx = PSD_DBL_EPS;
+            s = sqrt(s);          // iu = 8
+            s = sqrt(s);          // iu = 4 -> selected
+            ulpx *= s;
+            st.ulpx = ulpx;
+            *P.st = st;
+            P.desc->active = 0;
+        }
+    } else {
+        PSD_PAR_FOR(r, n - 1) { Hj(r + 2, 1) = 0.0; }
+        PSD_SYNC();
+        PSD_PAR_FOR(t, NT) {
+            double best = 0.0;
+            for (int c = 1 + t; c <= n; c += NT) {
+                double s = 0.0;
+                for (int r = 1; r <= n; ++r) s += fabs(Hj(r, c));
+                if (s > best) best = s;
+            }
+            red[t] = best;
+        }
+        PSD_SYNC();
+        PSD_ONE {
+            double best = 0.0;
+            for (int t = 0; t < NT; ++t)
+                if (red[t] > best) best = red[t];
+            P.hnorms[j] = PSD_DBL_EPS * n * best;
+        }
+    }
+}

@@ -55,6 +55,18 @@ def synth_factors(n, p, seed, dtype=np.float64):
     return out
 
 
+def bench_factors(n, p, seed, dtype=np.float64, eps=0.5):
+    """Benchmark / parity ensemble: A_j = I + eps * G_j / sqrt(n), G_j i.i.d. standard normal.
+
+    SURVEY.md §8(d) proposed plain N(0, 1/n) factors, but the period-p product of those has real eigenvalue
+    pairs of modulus 1e-16..1e-46 for p >= 16, and on such pairs the reference's own 2x2 standardisation
+    (PeriodicSchurDecompositions.jl:900-1054, rotation taken from the explicitly formed product block) leaves a
+    sub-diagonal of 1e-11..1e-6 in T1 that is then zeroed (:1066-1073): the reference algorithm fails its own
+    `checkpsd` there (measured with the oracle; DESIGN.md "Inputs").  Shifting by I keeps every factor well
+    conditioned, so the reference's invariants hold and can be demanded of the GPU path."""
+    return [np.asfortranarray(np.eye(n, dtype=dtype) + eps * a) for a in synth_factors(n, p, seed, dtype)]
+
+
 def rand_uniform_factors(n, p, seed):
     """U(0,1) entries like the reference's own tests (`rand(T,n,n)`, test/runtests.jl:20,93)."""
     out = []
