@@ -1,0 +1,175 @@
+"""Parity cases shared by the simulated-device tier (CPU, tests/hostsim) and the GPU tier: every case drives the
+engine through the C ABI (via the Python mirror) and judges it with the reference's own checkers against the
+oracle / goldens."""
+import numpy as np
+
+import psdtest as pt
+
+
+def case_phessenberg(eng, p):
+    # test/runtests.jl:14-50
+    n, tol, qtol = 5, 20, 10
+    A = pt.rand_uniform_factors(n, p, seed=40 + p)
+    W = [a.copy(order="F") for a in A]
+    Hs, tau, _ = eng.phessenberg_(W)
+    Ho, Qo, packed, tauo = pt.oracle_phessenberg(A)
+    assert np.all(np.tril(Hs[0], -2) == 0)
+    for j in range(p):
+        if j > 0:
+            assert np.all(np.tril(Hs[j], -1) == 0)
+        # same reflector convention as the oracle => same packed storage up to rounding
+        assert np.allclose(W[j], packed[j], rtol=0, atol=200 * pt.EPS * n * np.abs(packed[j]).max())
+        assert np.allclose(tau[j], tauo[j], rtol=0, atol=100 * pt.EPS)
+        Ax = Qo[j] @ Hs[j] @ Qo[(j + 1) % p].T
+        assert np.linalg.norm(A[j] - Ax) < tol * pt.EPS * n * max(1.0, np.linalg.norm(A[j], 1))
+
+
+def case_hess_ut(eng, p):
+    n = 5
+    A = [np.asfortranarray(np.triu(a)) for a in pt.rand_uniform_factors(n, p, seed=7 + p)]
+    A[0] = np.asfortranarray(np.triu(pt.rand_uniform_factors(n, 1, seed=77 + p)[0], -1))
+    pt.pschur_check(A, eng.pschur(A, "R"))
+    if p > 1:
+        A[0], A[p - 1] = A[p - 1], A[0]
+    pt.pschur_check(A, eng.pschur(A, "L"))
+
+
+def case_expsplit(eng, golden, p):
+    A, lam = pt.expsplit(p)
+    ps = eng.pschur(A, "R")
+    pt.pschur_check(A, ps, check_lam=False, tol=128)
+    for lj in lam:
+        d = np.abs(ps.values - lj)
+        k = int(np.argmin(d))
+        assert d[k] < 1e-3 * abs(lj) or max(abs(lj), abs(ps.values[k])) < pt.EPS ** 2
+    for lj in golden[f"expsplit_p{p}_lam"]:
+        d = np.abs(ps.values - lj)
+        k = int(np.argmin(d))
+        assert d[k] < 1e-9 * abs(lj) or max(abs(lj), abs(ps.values[k])) < pt.EPS ** 2
+    A[0], A[p - 1] = A[p - 1], A[0]
+    pt.pschur_check(A, eng.pschur(A, "L"), check_lam=False, tol=128)
+
+
+def case_full_small(eng, golden, p):
+    A = pt.rand_uniform_factors(5, p, seed=500 + p)
+    pt.pschur_check(A, eng.pschur(A, "R"), lam=golden[f"rand5_p{p}_lam"])
+    pt.pschur_check(A, eng.pschur(A, "L"), lam=golden[f"rand5_p{p}_lamL"])
+
+
+def case_fast_paths(eng, p):
+    n, tol = 5, 20
+    A = pt.rand_uniform_factors(n, p, seed=9 + p)
+    p2 = eng.pschur(A, wantZ=True)
+    p0 = eng.pschur(A, wantT=False, wantZ=False)
+    assert len(p0.Z) == 0
+    pt.compare_reigvals(p2.values, p0.values, 1000 * pt.EPS)
+    p1 = eng.pschur(A, wantT=True, wantZ=False)
+    assert len(p1.Z) == 0
+    assert np.linalg.norm(p1.T1 - p2.T1) < tol * pt.EPS * n
+    for j in range(1, p - 1):
+        assert np.linalg.norm(p1.T[j] - p2.T[j]) < tol * pt.EPS * n
+    pt.compare_reigvals(p2.values, p1.values, 1000 * pt.EPS)
+
+
+def case_config1(eng, golden):
+    As = pt.bench_factors(32, 4, seed=int(golden["cfg1_seed"][0]))
+    ps = eng.pschur(As, "R")
+    pt.pschur_check(As, ps, lam=golden["cfg1_lam"])
+    ok, err = pt.checkpsd(ps, As)
+    assert ok, err
+    po = pt.oracle_pschur(As, "R")
+    assert pt.match_eigs(po.values, ps.values) < 1000 * pt.EPS * abs(po.values).max()
+    As = pt.rand_uniform_factors(32, 4, seed=532)
+    pt.pschur_check(As, eng.pschur(As, "R"), lam=golden["rand32_p4_lam"])
+    pt.pschur_check(As, eng.pschur(As, "L"))
+
+
+def case_rq_cleanup(eng):
+    n, p = 8, 3
+    A = [np.asfortranarray(np.triu(a) + np.eye(n)) for a in pt.rand_uniform_factors(n, p, seed=321)]
+    A[0] = np.asfortranarray(np.triu(pt.rand_uniform_factors(n, 1, seed=322)[0], -1) + np.eye(n))
+    A[1][3, 3] = 1e-19
+    ps = eng.pschur(A, "R")
+    assert ps.stats.nrqpass >= 1
+    pt.pschur_check(A, ps, check_lam=False)
+    lam = np.linalg.eigvals(pt.product(A))
+    assert pt.match_eigs(lam, ps.values) < 1e-12 * abs(lam).max()
+    po = pt.oracle_pschur(A, "R")
+    assert pt.match_eigs(po.values, ps.values) < 1e-12 * abs(lam).max()
+
+
+def case_rq_cleanup_windows(eng):
+    """RQ clean-up pass long enough to span several diagonal windows, for every window width."""
+    for (n, p) in [(80, 3), (60, 20), (50, 40), (40, 80)]:
+        A = [np.asfortranarray(np.triu(a) + 2 * np.eye(n)) for a in pt.bench_factors(n, p, seed=n + p)]
+        A[0] = np.asfortranarray(np.triu(pt.bench_factors(n, 1, seed=n + p + 1)[0], -1))
+        A[p - 1][4, 4] = 1e-19
+        ps = eng.pschur(A, "R")
+        assert ps.stats.nrqpass >= 1
+        ok, err = pt.checkpsd(ps, A, thresh=100 * np.sqrt(max(n / 32, 1)))
+        assert ok, (n, p, err)
+        po = pt.oracle_pschur(A, "R")
+        scale = abs(po.values).max()
+        assert pt.match_eigs(po.values, ps.values) < 1e-10 * scale
+
+
+def case_edge(eng):
+    import psd_amd
+
+    A = [np.asfortranarray(np.array([[2.0]])), np.asfortranarray(np.array([[-3.0]]))]
+    ps = eng.pschur(A, "R")
+    assert ps.values[0] == -6.0 and ps.Z[0][0, 0] == 1.0
+    for n, p in [(2, 1), (2, 3), (3, 2), (4, 1)]:
+        A = pt.rand_uniform_factors(n, p, seed=n * 10 + p)
+        pt.pschur_check(A, eng.pschur(A, "R"))
+        pt.pschur_check(A, eng.pschur(A, "L"))
+    try:
+        eng.pschur(A, "X")
+        raise AssertionError("orientation must be rejected")
+    except ValueError:
+        pass
+    try:
+        eng.pschur([np.zeros((3, 3)), np.zeros((4, 4))])
+        raise AssertionError("ragged input must be rejected")
+    except psd_amd.DimensionMismatch:
+        pass
+    try:
+        eng.pschur([np.eye(3), np.eye(3)], S=[True, False])
+        raise AssertionError("signed case is not in this build")
+    except psd_amd.NotImplementedPSD:
+        pass
+    # non-convergence is reported, not hidden: maxitfac=1 cannot converge a 12x12 problem
+    A = pt.rand_uniform_factors(12, 3, seed=99)
+    try:
+        eng.pschur(A, maxitfac=1)
+        raise AssertionError("expected ConvergenceError")
+    except psd_amd.ConvergenceError as e:
+        assert 1 <= e.level <= 12
+
+
+def case_window_widths(eng, sizes):
+    """Multi-window sweeps for each LDS window width W in {32, 24, 16, 12} (chosen from p)."""
+    for (n, p, W) in sizes:
+        for lr in "RL":
+            As = pt.bench_factors(n, p, seed=n + p)
+            ps = eng.pschur(As, lr)
+            assert ps.stats.window == W
+            ok, err = pt.checkpsd(ps, As, thresh=100 * np.sqrt(max(n / 32, 1)))
+            assert ok, (n, p, lr, err)
+            po = pt.oracle_pschur(As, lr)
+            Pn = np.linalg.norm(pt.product(As, lr == "L"), 2)
+            assert pt.match_eigs(po.values, ps.values) < 1e-10 * Pn
+
+
+def case_pschur_hess(eng):
+    """pre-reduced entry pschur!(H1, Hs; Q) (PeriodicSchurDecompositions.jl:322-330) incl. rev=true."""
+    n, p = 24, 4
+    A = pt.bench_factors(n, p, seed=77)
+    Hs, Qs, _, _ = pt.oracle_phessenberg(A)
+    H = [np.asfortranarray(h.copy()) for h in Hs]
+    Q = [np.asfortranarray(q.copy()) for q in Qs]
+    ps = eng.pschur_hess_(H[0], H[1:], Q=Q)
+    pt.pschur_check(A, ps)
+    H = [np.asfortranarray(h.copy()) for h in Hs]
+    ps = eng.pschur_hess_(H[0], H[1:], Q=None)  # Z = accumulated transformations only
+    pt.pschur_check(Hs, ps)

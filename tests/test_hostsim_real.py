@@ -1,0 +1,52 @@
+"""CPU tier: the device state machines (window chase, bulk apply, Hessenberg kernels) executed by the TEST-ONLY
+serial simulation build of the same sources (tests/hostsim).  This is not the product path: the product is the
+HIP build, covered by tests/test_gpu_real.py with the same cases."""
+import pytest
+
+import engine_cases as ec
+
+
+@pytest.mark.parametrize("p", [1, 2, 5])
+def test_phessenberg(sim_engine, p):
+    ec.case_phessenberg(sim_engine, p)
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 5])
+def test_hess_ut(sim_engine, p):
+    ec.case_hess_ut(sim_engine, p)
+
+
+@pytest.mark.parametrize("p", [5, 20])
+def test_expsplit(sim_engine, golden, p):
+    ec.case_expsplit(sim_engine, golden, p)
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 5])
+def test_full_small(sim_engine, golden, p):
+    ec.case_full_small(sim_engine, golden, p)
+
+
+@pytest.mark.parametrize("p", [1, 5])
+def test_fast_paths(sim_engine, p):
+    ec.case_fast_paths(sim_engine, p)
+
+
+def test_config1(sim_engine, golden):
+    ec.case_config1(sim_engine, golden)
+
+
+def test_rq_cleanup(sim_engine):
+    ec.case_rq_cleanup(sim_engine)
+    ec.case_rq_cleanup_windows(sim_engine)
+
+
+def test_edge(sim_engine):
+    ec.case_edge(sim_engine)
+
+
+def test_window_widths(sim_engine):
+    ec.case_window_widths(sim_engine, [(72, 6, 32), (60, 20, 24), (48, 40, 16), (40, 80, 12)])
+
+
+def test_pschur_hess(sim_engine):
+    ec.case_pschur_hess(sim_engine)
