@@ -54,6 +54,9 @@ typedef struct psd_stats {
     double step_kernel_ms_avg; /* sampled HIP-event duration of the chase kernel (profile mode)  */
     int32_t step_kernel_samples;
     int32_t reserved;
+    /* in-kernel cycle accounting of the chase kernel (s_memtime ticks): decide, window load, chase, window
+     * store, total; [5] = total in 100 MHz s_memrealtime ticks (shader clock = cyc[4]/cyc[5]*100 MHz) */
+    int64_t step_cycles[6];
 } psd_stats;
 
 /* context: device selection, stream, workspace cache. One call at a time per context. */

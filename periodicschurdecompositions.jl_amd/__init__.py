@@ -46,11 +46,13 @@ class Stats(C.Structure):
         ("window", C.c_int32), ("nlog", C.c_int32), ("ms_hess", C.c_double), ("ms_formq", C.c_double),
         ("ms_iter", C.c_double), ("ms_total", C.c_double), ("ms_copy", C.c_double), ("bytes_sweeps", C.c_double),
         ("bytes_hess", C.c_double), ("bytes_formq", C.c_double), ("step_kernel_ms_avg", C.c_double),
-        ("step_kernel_samples", C.c_int32), ("reserved", C.c_int32),
+        ("step_kernel_samples", C.c_int32), ("reserved", C.c_int32), ("step_cycles", C.c_int64 * 6),
     ]
 
     def asdict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["step_cycles"] = list(self.step_cycles)
+        return d
 
 
 class PeriodicSchur:

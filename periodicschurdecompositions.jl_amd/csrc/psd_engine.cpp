@@ -298,6 +298,7 @@ void stats_from_state(psd_stats* s, const psd_rstate& st) {
     s->ndefl2 = st.ndefl2;
     s->nwindows = st.nwindows;
     s->nlog = st.nlog;
+    for (int q = 0; q < 6; ++q) s->step_cycles[q] = st.cyc[q];
 }
 
 // shared tail: run the iteration, fetch eigenvalues / log

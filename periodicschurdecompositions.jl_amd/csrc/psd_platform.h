@@ -29,6 +29,7 @@ struct psd_simctx {
 };
 extern psd_simctx psd_sim;  // the block currently being simulated (serial)
 #define PSD_KERNEL static void
+#define PSD_KERNEL_B(nt) static void
 #define PSD_BLOCK_X (psd_sim.block.x)
 #define PSD_BLOCK_Y (psd_sim.block.y)
 #define PSD_BLOCK_Z (psd_sim.block.z)
@@ -36,9 +37,26 @@ extern psd_simctx psd_sim;  // the block currently being simulated (serial)
 #define PSD_NTHREADS (psd_sim.nthreads)
 #define PSD_LDS_DECL char* psd_lds = psd_sim.lds
 #define PSD_SYNC() ((void)0)
+#define PSD_WAVE_SYNC() ((void)0)
 // data-parallel loop over [0,count): iterations must be independent of each other
 #define PSD_PAR_FOR(t, count) for (int t = 0; t < (int)(count); ++t)
 #define PSD_ONE if (true)
+// Single-pass data-parallel region (count <= PSD_NTHREADS) with per-lane variables that live across
+// regions and can be broadcast from a given lane (v_readlane on the GPU, array slot here).
+#define PSD_MAXLANES 64
+#define PSD_PAR_ONCE(t, count) for (int t = 0; t < (int)(count); ++t)
+#define PSD_LANEVAR(type, name) type name[PSD_MAXLANES]
+#define PSD_LANEVAR_REF(type, name) type* name
+#define PSD_LV(name) name[t]
+#define PSD_BCAST(name, lane) (name[lane])
+// 1/x and (sqrt(s), 1/sqrt(s)) for arguments known to be normal and far from the range limits
+static inline double psd_rcp_fast(double x) { return 1.0 / x; }
+static inline void psd_sqrt_pair_fast(double s, double& g, double& rg) {
+    g = sqrt(s);
+    rg = 1.0 / g;
+}
+static inline long long psd_clock() { return 0; }
+static inline long long psd_wallclock() { return 0; }
 typedef int psd_stream_t;
 #define PSD_LAUNCH(kern, grid_, nthreads_, ldsbytes_, stream_, ...)                  \
     do {                                                                              \
@@ -86,6 +104,7 @@ static inline int psd_rt_last_error() { return 0; }
 #define PSD_D __device__ __forceinline__
 typedef dim3 psd_dim3;
 #define PSD_KERNEL __global__ void
+#define PSD_KERNEL_B(nt) __global__ void __launch_bounds__(nt)
 #define PSD_BLOCK_X ((int)blockIdx.x)
 #define PSD_BLOCK_Y ((int)blockIdx.y)
 #define PSD_BLOCK_Z ((int)blockIdx.z)
@@ -93,8 +112,51 @@ typedef dim3 psd_dim3;
 #define PSD_NTHREADS ((int)blockDim.x)
 #define PSD_LDS_DECL extern __shared__ __attribute__((aligned(16))) char psd_lds[]
 #define PSD_SYNC() __syncthreads()
+// LDS hand-off between lanes of ONE wavefront (only valid in single-wave workgroups): DS operations
+// of a wave execute in order, so only the compiler has to be fenced; unlike __syncthreads() this does
+// not drain outstanding global stores (vmcnt), which would put their acknowledge latency on the chain.
+#define PSD_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define PSD_PAR_FOR(t, count) for (int t = (int)threadIdx.x; t < (int)(count); t += (int)blockDim.x)
 #define PSD_ONE if (threadIdx.x == 0)
+#define PSD_MAXLANES 64
+#define PSD_PAR_ONCE(t, count) if (const int t = (int)threadIdx.x; t < (int)(count))
+#define PSD_LANEVAR(type, name) type name = type()
+#define PSD_LANEVAR_REF(type, name) type name
+#define PSD_LV(name) name
+#define PSD_BCAST(name, lane) psd_readlane_f64(name, lane)
+__device__ __forceinline__ double psd_readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+// 1/x and (sqrt(s), 1/sqrt(s)) for arguments known to be normal and far from the range limits:
+// hardware seed (v_rcp_f64 / v_rsq_f64) + two Newton steps, without the scale/fixup wrapper the
+// IEEE division and sqrt expansions carry (that wrapper is most of their latency).
+__device__ __forceinline__ double psd_rcp_fast(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+__device__ __forceinline__ void psd_sqrt_pair_fast(double s, double& g, double& rg) {
+    const double y = __builtin_amdgcn_rsq(s);
+    double gg = s * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, gg, 0.5);
+    gg = __builtin_fma(gg, r, gg);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, gg, 0.5);
+    gg = __builtin_fma(gg, r, gg);
+    h = __builtin_fma(h, r, h);
+    // final correction of the root: g += (s - g*g) * h
+    const double d = __builtin_fma(-gg, gg, s);
+    gg = __builtin_fma(d, h, gg);
+    g = gg;
+    rg = h + h;
+}
+__device__ __forceinline__ long long psd_clock() { return (long long)__builtin_amdgcn_s_memtime(); }
+__device__ __forceinline__ long long psd_wallclock() { return (long long)__builtin_amdgcn_s_memrealtime(); }
 typedef hipStream_t psd_stream_t;
 #define PSD_LAUNCH(kern, grid_, nthreads_, ldsbytes_, stream_, ...) \
     hipLaunchKernelGGL(kern, (grid_), dim3(nthreads_), (ldsbytes_), (stream_), __VA_ARGS__)

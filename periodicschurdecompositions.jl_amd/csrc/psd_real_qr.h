@@ -83,6 +83,9 @@ struct psd_rstate {
     int nsweeps, nrqpass, ndefl1, ndefl2, nwindows, nlog, maxlog;
     double v[3];
     double smlnum, ulp, ulpx;
+    // in-kernel cycle accounting (s_memtime): 0 decide, 1 window load, 2 chase, 3 window store, 4 total; 5 = total in
+    // 100 MHz wall ticks (s_memrealtime) so that the shader clock can be derived
+    long long cyc[6];
 };
 
 struct psd_rparams {
@@ -113,28 +116,55 @@ PSD_HD psd_mat<double> psd_fac(const psd_rparams& P, int n, int j) {
 struct psd_win {
     double* b;
     int W, ld, bsz, bs, be;
-    PSD_HD double& at(int j, int r, int c) const { return b[(size_t)(j - 1) * bsz + (c - bs) * ld + (r - bs)]; }
+    PSD_HD double& at(int j, int r, int c) const { return b[(j - 1) * bsz + (c - bs) * ld + (r - bs)]; }
 };
 
+// Window <-> HBM: 64 lanes, lane = (row, column group); 16 independent 8-byte accesses in flight per
+// lane and batch, column segments contiguous in memory.
 PSD_D void psd_win_load(const psd_rparams& P, const psd_win& w, int n, int p) {
     const int m = w.be - w.bs + 1;
-    for (int j = 1; j <= p; ++j) {
-        const psd_mat<double> Hj = psd_fac(P, n, j);
-        PSD_PAR_FOR(t, m * m) {
-            const int r = w.bs + t % m, c = w.bs + t / m;
-            w.at(j, r, c) = Hj(r, c);
+    const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
+    const int total = p * m;  // columns over all factors
+    PSD_PAR_FOR(t, PSD_STEP_NT) {
+        const int r = t & (RW - 1), g = t >> sh;
+        if (r < m) {
+            for (int q0 = g; q0 < total; q0 += 16 * ncg) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int q = q0 + u * ncg;
+                    if (q < total) {
+                        const int j = q / m, c = q - j * m;
+                        v[u] = P.H[(size_t)j * n * n + (size_t)(w.bs - 1 + c) * n + (w.bs - 1 + r)];
+                    } else {
+                        v[u] = 0.0;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int q = q0 + u * ncg;
+                    if (q < total) {
+                        const int j = q / m, c = q - j * m;
+                        w.b[j * w.bsz + c * w.ld + r] = v[u];
+                    }
+                }
+            }
         }
     }
     PSD_SYNC();
 }
 PSD_D void psd_win_store(const psd_rparams& P, const psd_win& w, int n, int p) {
     const int m = w.be - w.bs + 1;
+    const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
+    const int total = p * m;
     PSD_SYNC();
-    for (int j = 1; j <= p; ++j) {
-        const psd_mat<double> Hj = psd_fac(P, n, j);
-        PSD_PAR_FOR(t, m * m) {
-            const int r = w.bs + t % m, c = w.bs + t / m;
-            Hj(r, c) = w.at(j, r, c);
+    PSD_PAR_FOR(t, PSD_STEP_NT) {
+        const int r = t & (RW - 1), g = t >> sh;
+        if (r < m) {
+            for (int q = g; q < total; q += ncg) {
+                const int j = q / m, c = q - j * m;
+                P.H[(size_t)j * n * n + (size_t)(w.bs - 1 + c) * n + (w.bs - 1 + r)] = w.b[j * w.bsz + c * w.ld + r];
+            }
         }
     }
     PSD_SYNC();
@@ -445,6 +475,211 @@ PSD_D void psd_desc_write(const psd_rparams& P, const psd_rstate& st, const int*
     PSD_SYNC();
 }
 
+// Hot micro-step of the sweep, (k, factor j >= 2), 3-wide case (PSD.jl:844-883): 3-reflector from
+// column k of H_j, then the 2-reflector from column k+1, both applied to rows of H_j (lanes =
+// columns k+1..c1max) and to columns of H_{j-1} (lanes = rows r0..rlim) inside the window.
+//   * one wave, ONE code path: a lane addresses its three operands as base + {0,1,2}*stride
+//     (column lanes: stride 1 in H_j; row lanes: stride ld in H_{j-1}; the extra lane that writes
+//     the annihilated column (beta,0,0) is folded in with selects) — no divergence, because with
+//     a single resident wave every extra VALU instruction is ~8 issue cycles on the serial chain;
+//   * operands are loaded from LDS once, BEFORE the reflector arithmetic (latency hidden), stay
+//     in registers across both reflectors and are stored once;
+//   * the values the chain needs next (column k+1 of H_j for the 2-reflector, column k of H_{j-1}
+//     for the next factor) travel by v_readlane, not through LDS.
+// (x0,x1,x2) in: H_j[k..k+2,k]; out: H_{j-1}[k..k+2,k].  lane_off/lane_str: per-lane operand
+// offset inside a factor block / stride, lane_adj: 0 for column lanes, bsz for row lanes.
+PSD_D void psd_qr_micro3(const psd_rparams& P, const psd_win& w, int j, int nl, int cnt, int lk, int k,
+                         PSD_LANEVAR_REF(int, lane_off), PSD_LANEVAR_REF(int, lane_str),
+                         PSD_LANEVAR_REF(int, lane_adj), double& x0, double& x1, double& x2, int slot) {
+    PSD_LANEVAR(double, a1);
+    PSD_LANEVAR(double, a2);
+    PSD_LANEVAR(double, a3);
+    const int boff = (j - 1) * w.bsz;
+    PSD_PAR_ONCE(t, cnt) {
+        const double* q = w.b + (boff - PSD_LV(lane_adj) + PSD_LV(lane_off));
+        const int sd = PSD_LV(lane_str);
+        PSD_LV(a1) = q[0];
+        PSD_LV(a2) = q[sd];
+        PSD_LV(a3) = q[2 * sd];
+    }
+    const double tau = psd_refl3(x0, x1, x2);
+    const double beta = x0, v2 = x1, v3 = x2;
+    PSD_PAR_ONCE(t, cnt) {
+        const double x = tau * (PSD_LV(a1) + v2 * PSD_LV(a2) + v3 * PSD_LV(a3));
+        PSD_LV(a1) -= x;
+        PSD_LV(a2) -= x * v2;
+        PSD_LV(a3) -= x * v3;
+    }
+    double y0 = PSD_BCAST(a2, 0), y1 = PSD_BCAST(a3, 0);  // H_j[k+1..k+2, k+1]
+    x0 = PSD_BCAST(a1, lk);                               // H_{j-1}[k..k+2, k] for the next factor
+    x1 = PSD_BCAST(a1, lk + 1);
+    x2 = PSD_BCAST(a1, lk + 2);
+    const double tau2 = psd_refl2(y0, y1);
+    const double beta2 = y0, w2 = y1;
+    PSD_PAR_ONCE(t, cnt) {
+        const double x = tau2 * (PSD_LV(a2) + w2 * PSD_LV(a3));
+        double b1 = PSD_LV(a1), b2 = PSD_LV(a2) - x, b3 = PSD_LV(a3) - x * w2;
+        if (t == 0) {  // column k+1 of H_j: annihilated by the 2-reflector
+            b2 = beta2;
+            b3 = 0.0;
+        }
+        if (t == cnt - 1) {  // column k of H_j: annihilated by the 3-reflector
+            b1 = beta;
+            b2 = 0.0;
+            b3 = 0.0;
+        }
+        double* q = w.b + (boff - PSD_LV(lane_adj) + PSD_LV(lane_off));
+        const int sd = PSD_LV(lane_str);
+        q[0] = b1;
+        q[sd] = b2;
+        q[2 * sd] = b3;
+        if (t == cnt - 1) {
+            psd_tr tr;
+            tr.pos = k;
+            tr.kind = PSD_TR_R3;
+            tr.c0 = v2;
+            tr.c1 = v3;
+            tr.c2 = tau;
+            if (slot < PSD_TR_CAP) P.tr[(size_t)(j - 1) * PSD_TR_CAP + slot] = tr;
+            tr.pos = k + 1;
+            tr.kind = PSD_TR_H2;
+            tr.c0 = w2;
+            tr.c1 = 0.0;
+            tr.c2 = tau2;
+            if (slot + 1 < PSD_TR_CAP) P.tr[(size_t)(j - 1) * PSD_TR_CAP + slot + 1] = tr;
+        }
+    }
+    PSD_WAVE_SYNC();
+}
+
+// H_1's 3-reflector at step k (PSD.jl:812-842), p > 1: rows of H_1 (columns k..c1max), columns of
+// H_p (rows r0..rlim).  (x0,x1,x2) in: the vector to reflect; out: H_p[k..k+2, k].
+PSD_D void psd_qr_micro_h1(const psd_rparams& P, const psd_win& w, int p, int k, int c1max, int r0, int rlim,
+                           double& x0, double& x1, double& x2, bool fix, int slot) {
+    const int nl = c1max - k + 1;  // columns k..c1max
+    const int nrw = rlim - r0 + 1;
+    const int cnt = nl + nrw + 1;
+    PSD_LANEVAR(double, a1);
+    PSD_LANEVAR(double, a2);
+    PSD_LANEVAR(double, a3);
+    PSD_PAR_ONCE(t, cnt) {
+        if (t < nl) {
+            const int c = k + t;
+            PSD_LV(a1) = w.at(1, k, c);
+            PSD_LV(a2) = w.at(1, k + 1, c);
+            PSD_LV(a3) = w.at(1, k + 2, c);
+        } else if (t < nl + nrw) {
+            const int r = r0 + (t - nl);
+            PSD_LV(a1) = w.at(p, r, k);
+            PSD_LV(a2) = w.at(p, r, k + 1);
+            PSD_LV(a3) = w.at(p, r, k + 2);
+        } else {
+            PSD_LV(a1) = 0.0;
+            PSD_LV(a2) = 0.0;
+            PSD_LV(a3) = 0.0;
+        }
+    }
+    const double tau = psd_refl3(x0, x1, x2);
+    const double beta = x0, v2 = x1, v3 = x2;
+    PSD_PAR_ONCE(t, cnt) {
+        if (t < nl + nrw) {
+            const double x = tau * (PSD_LV(a1) + v2 * PSD_LV(a2) + v3 * PSD_LV(a3));
+            PSD_LV(a1) -= x;
+            PSD_LV(a2) -= x * v2;
+            PSD_LV(a3) -= x * v3;
+            if (t < nl) {
+                const int c = k + t;
+                w.at(1, k, c) = PSD_LV(a1);
+                w.at(1, k + 1, c) = PSD_LV(a2);
+                w.at(1, k + 2, c) = PSD_LV(a3);
+            } else {
+                const int r = r0 + (t - nl);
+                w.at(p, r, k) = PSD_LV(a1);
+                w.at(p, r, k + 1) = PSD_LV(a2);
+                w.at(p, r, k + 2) = PSD_LV(a3);
+            }
+        } else {
+            if (fix) {
+                w.at(1, k, k - 1) = beta;
+                w.at(1, k + 1, k - 1) = 0.0;
+                w.at(1, k + 2, k - 1) = 0.0;
+            }
+            psd_tr tr;
+            tr.pos = k;
+            tr.kind = PSD_TR_R3;
+            tr.c0 = v2;
+            tr.c1 = v3;
+            tr.c2 = tau;
+            if (slot < PSD_TR_CAP) P.tr[slot] = tr;
+        }
+    }
+    const int lk = nl + (k - r0);
+    x0 = PSD_BCAST(a1, lk);
+    x1 = PSD_BCAST(a1, lk + 1);
+    x2 = PSD_BCAST(a1, lk + 2);
+    PSD_WAVE_SYNC();
+}
+
+// In-window application of a 3- or 2-reflector with v = (1, v2, v3) (general, slower form used for
+// the last step of a sweep and for p == 1): from the left to rows q.. of factor jl over columns
+// [c0,c1], from the right to columns q.. of factor jr (!= jl) over rows [r0,r1]; one extra lane
+// writes the annihilated column (beta, 0, 0) at (q.., fc) of factor jf and appends the transform
+// to owner `own`'s list.
+PSD_D void psd_win_reflect(const psd_rparams& P, const psd_win& w, int jl, int jr, int len, int q, double v2,
+                           double v3, double tau, int c0, int c1, int r0, int r1, int jf, int fc, double beta,
+                           bool fix, int own, int slot) {
+    if (c1 > w.be) c1 = w.be;
+    if (r0 < w.bs) r0 = w.bs;
+    if (r1 > w.be) r1 = w.be;
+    const int nl = (c1 >= c0) ? (c1 - c0 + 1) : 0;
+    const int nr = (r1 >= r0) ? (r1 - r0 + 1) : 0;
+    PSD_PAR_FOR(t, nl + nr + 1) {
+        if (t < nl) {
+            const int c = c0 + t;
+            if (len == 3) {
+                double a1 = w.at(jl, q, c), a2 = w.at(jl, q + 1, c), a3 = w.at(jl, q + 2, c);
+                const double x = tau * (a1 + v2 * a2 + v3 * a3);
+                w.at(jl, q, c) = a1 - x;
+                w.at(jl, q + 1, c) = a2 - x * v2;
+                w.at(jl, q + 2, c) = a3 - x * v3;
+            } else {
+                double a1 = w.at(jl, q, c), a2 = w.at(jl, q + 1, c);
+                const double x = tau * (a1 + v2 * a2);
+                w.at(jl, q, c) = a1 - x;
+                w.at(jl, q + 1, c) = a2 - x * v2;
+            }
+        } else if (t < nl + nr) {
+            const int r = r0 + (t - nl);
+            if (len == 3) {
+                double a1 = w.at(jr, r, q), a2 = w.at(jr, r, q + 1), a3 = w.at(jr, r, q + 2);
+                const double x = tau * (a1 + v2 * a2 + v3 * a3);
+                w.at(jr, r, q) = a1 - x;
+                w.at(jr, r, q + 1) = a2 - x * v2;
+                w.at(jr, r, q + 2) = a3 - x * v3;
+            } else {
+                double a1 = w.at(jr, r, q), a2 = w.at(jr, r, q + 1);
+                const double x = tau * (a1 + v2 * a2);
+                w.at(jr, r, q) = a1 - x;
+                w.at(jr, r, q + 1) = a2 - x * v2;
+            }
+        } else {
+            if (fix) {
+                w.at(jf, q, fc) = beta;
+                w.at(jf, q + 1, fc) = 0.0;
+                if (len == 3) w.at(jf, q + 2, fc) = 0.0;
+            }
+            psd_tr tr;
+            tr.pos = q;
+            tr.kind = (len == 3) ? PSD_TR_R3 : PSD_TR_H2;
+            tr.c0 = v2;
+            tr.c1 = v3;
+            tr.c2 = tau;
+            if (slot < PSD_TR_CAP) P.tr[(size_t)(own - 1) * PSD_TR_CAP + slot] = tr;
+        }
+    }
+    PSD_SYNC();
+}
+
 // PSD.jl:806-886: one window (steps kcur .. kcur+nb-1) of the double-shift periodic QR sweep
 PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, int* lcnt) {
     const int n = st.n, p = st.p, i = st.i, l = st.l, i1 = st.i1, i2 = st.i2;
@@ -458,73 +693,83 @@ PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
     w.bsz = st.W * (st.W + 1);
     w.bs = (ks > l) ? (ks - 1) : l;
     w.be = (ke + 3 < i) ? (ke + 3) : i;
-    PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
+    const long long tc0 = psd_clock();
     psd_win_load(P, w, n, p);
+    const long long tc1 = psd_clock();
+    const int c1max = (w.be < i2) ? w.be : i2;
+    const int r0 = (w.bs > i1) ? w.bs : i1;
+    int n1 = 0, nj = 0;  // list lengths: owner 1, owners 2..p
     for (int k = ks; k <= ke; ++k) {
         const int nr = (3 < i - k + 1) ? 3 : (i - k + 1);
         const int rlim = (k + nr < i) ? (k + nr) : i;
-        double x[3];
+        double x0, x1, x2 = 0.0;
         if (k > l) {
-            for (int q = 0; q < nr; ++q) x[q] = w.at(1, k + q, k - 1);
+            x0 = w.at(1, k, k - 1);
+            x1 = w.at(1, k + 1, k - 1);
+            if (nr == 3) x2 = w.at(1, k + 2, k - 1);
         } else {
-            x[0] = st.v[0]; x[1] = st.v[1]; x[2] = st.v[2];
+            x0 = st.v[0];
+            x1 = st.v[1];
+            x2 = (nr == 3) ? st.v[2] : 0.0;
         }
-        PSD_SYNC();
-        double tau = psd_reflector_small(x, nr);
-        if (k > l) {
-            PSD_ONE {
-                w.at(1, k, k - 1) = x[0];
-                w.at(1, k + 1, k - 1) = 0.0;
-                if (k < i - 1) w.at(1, k + 2, k - 1) = 0.0;
-            }
-            PSD_SYNC();
-        }
-        psd_tr tr;
-        tr.pos = k;
-        tr.kind = (nr == 3) ? PSD_TR_R3 : PSD_TR_H2;
-        tr.c0 = x[1];
-        tr.c1 = (nr == 3) ? x[2] : 0.0;
-        tr.c2 = tau;
-        psd_win_apply(w, 1, p, tr, k, i2, i1, rlim);
-        psd_record(P, lcnt, 1, tr);
-        for (int j = p; j >= 2; --j) {
-            for (int q = 0; q < nr; ++q) x[q] = w.at(j, k + q, k);
-            PSD_SYNC();
-            tau = psd_reflector_small(x, nr);
-            PSD_ONE {
-                w.at(j, k, k) = x[0];
-                w.at(j, k + 1, k) = 0.0;
-                if (nr == 3) w.at(j, k + 2, k) = 0.0;
-            }
-            PSD_SYNC();
-            tr.pos = k;
-            tr.kind = (nr == 3) ? PSD_TR_R3 : PSD_TR_H2;
-            tr.c0 = x[1];
-            tr.c1 = (nr == 3) ? x[2] : 0.0;
-            tr.c2 = tau;
-            psd_win_apply(w, j, j - 1, tr, k + 1, i2, i1, rlim);
-            psd_record(P, lcnt, j, tr);
-            if (nr == 3) {
-                x[0] = w.at(j, k + 1, k + 1);
-                x[1] = w.at(j, k + 2, k + 1);
-                PSD_SYNC();
-                tau = psd_reflector_small(x, 2);
-                PSD_ONE {
-                    w.at(j, k + 1, k + 1) = x[0];
-                    w.at(j, k + 2, k + 1) = 0.0;
+        if (nr == 3 && p > 1) {
+            psd_qr_micro_h1(P, w, p, k, c1max, r0, rlim, x0, x1, x2, k > l, n1);
+            // lane roles for the factors j = p..2 at this k: [0,nl) columns k+1.. of H_j, [nl,nl+nrw) rows
+            // r0..rlim of H_{j-1}, last lane = annihilated column k of H_j
+            const int nl = c1max - k, nrw = rlim - r0 + 1, cnt = nl + nrw + 1;
+            PSD_LANEVAR(int, lane_off);
+            PSD_LANEVAR(int, lane_str);
+            PSD_LANEVAR(int, lane_adj);
+            PSD_PAR_ONCE(t, cnt) {
+                if (t < nl) {
+                    PSD_LV(lane_off) = (k + 1 + t - w.bs) * w.ld + (k - w.bs);
+                    PSD_LV(lane_str) = 1;
+                    PSD_LV(lane_adj) = 0;
+                } else if (t < nl + nrw) {
+                    PSD_LV(lane_off) = (k - w.bs) * w.ld + (r0 + (t - nl) - w.bs);
+                    PSD_LV(lane_str) = w.ld;
+                    PSD_LV(lane_adj) = w.bsz;
+                } else {
+                    PSD_LV(lane_off) = (k - w.bs) * w.ld + (k - w.bs);
+                    PSD_LV(lane_str) = 1;
+                    PSD_LV(lane_adj) = 0;
                 }
-                PSD_SYNC();
-                tr.pos = k + 1;
-                tr.kind = PSD_TR_H2;
-                tr.c0 = x[1];
-                tr.c1 = 0.0;
-                tr.c2 = tau;
-                psd_win_apply(w, j, j - 1, tr, k + 2, i2, i1, rlim);
-                psd_record(P, lcnt, j, tr);
+            }
+            const int lk = nl + (k - r0);
+            for (int j = p; j >= 2; --j)
+                psd_qr_micro3(P, w, j, nl, cnt, lk, k, lane_off, lane_str, lane_adj, x0, x1, x2, nj);
+        } else {
+            double tau = (nr == 3) ? psd_refl3(x0, x1, x2) : psd_refl2(x0, x1);
+            if (p > 1) {
+                psd_win_reflect(P, w, 1, p, nr, k, x1, x2, tau, k, i2, i1, rlim, 1, k - 1, x0, k > l, 1, n1);
+            } else {  // same matrix: left, then right (PSD.jl:834-837)
+                psd_win_reflect(P, w, 1, 1, nr, k, x1, x2, tau, k, i2, 1, 0, 1, k - 1, x0, k > l, 1, n1);
+                psd_win_reflect(P, w, 1, 1, nr, k, x1, x2, tau, 1, 0, i1, rlim, 1, k - 1, x0, false, 1, n1);
+            }
+            for (int j = p; j >= 2; --j) {
+                x0 = w.at(j, k, k);
+                x1 = w.at(j, k + 1, k);
+                x2 = (nr == 3) ? w.at(j, k + 2, k) : 0.0;
+                tau = (nr == 3) ? psd_refl3(x0, x1, x2) : psd_refl2(x0, x1);
+                psd_win_reflect(P, w, j, j - 1, nr, k, x1, x2, tau, k + 1, i2, i1, rlim, j, k, x0, true, j, nj);
+                if (nr == 3) {
+                    double y0 = w.at(j, k + 1, k + 1), y1 = w.at(j, k + 2, k + 1);
+                    const double tau2 = psd_refl2(y0, y1);
+                    psd_win_reflect(P, w, j, j - 1, 2, k + 1, y1, 0.0, tau2, k + 2, i2, i1, rlim, j, k + 1, y0, true,
+                                    j, nj + 1);
+                }
             }
         }
+        n1 += 1;
+        nj += (nr == 3) ? 2 : 1;
     }
+    PSD_PAR_FOR(m, p) { lcnt[m] = (m == 0) ? n1 : nj; }
+    const long long tc2 = psd_clock();
     psd_win_store(P, w, n, p);
+    const long long tc3 = psd_clock();
+    st.cyc[1] += tc1 - tc0;
+    st.cyc[2] += tc2 - tc1;
+    st.cyc[3] += tc3 - tc2;
     const int phi = (ke + 2 < i) ? (ke + 2) : i;
     psd_desc_write(P, st, lcnt, ks, phi, w.be + 1, i2, i1, w.bs - 1);
     st.nwindows += 1;
@@ -773,7 +1018,7 @@ PSD_D bool psd_rq_deflate(const psd_rparams& P, psd_rstate& st, double* ldsd, in
 }
 
 // One launch = state transitions until a window's worth of transforms has been emitted.
-PSD_KERNEL psd_rq_step(psd_rparams P) {
+PSD_KERNEL_B(PSD_STEP_NT) psd_rq_step(psd_rparams P) {
     PSD_LDS_DECL;
     psd_rstate st = *P.st;
     if (st.phase == PSD_PH_DONE) {
@@ -787,14 +1032,18 @@ PSD_KERNEL psd_rq_step(psd_rparams P) {
     int* redi = (int*)(red + NT);
     int* lcnt = redi + 2 * NT;
     PSD_ONE { P.desc->active = 0; }
+    const long long tk0 = psd_clock(), tw0 = psd_wallclock();
     bool emitted = false;
     int guard = 0;
     while (!emitted && st.phase != PSD_PH_DONE && guard < 4 * st.n + 16) {
         ++guard;
         switch (st.phase) {
-            case PSD_PH_DECIDE:
+            case PSD_PH_DECIDE: {
+                const long long td0 = psd_clock();
                 psd_rq_decide(P, st, red, redi);
+                st.cyc[0] += psd_clock() - td0;
                 break;
+            }
             case PSD_PH_RQ:
                 psd_rq_rq_window(P, st, ldsd, lcnt);
                 emitted = true;
@@ -833,6 +1082,8 @@ PSD_KERNEL psd_rq_step(psd_rparams P) {
                 break;
         }
     }
+    st.cyc[4] += psd_clock() - tk0;
+    st.cyc[5] += psd_wallclock() - tw0;
     PSD_SYNC();
     PSD_ONE { *P.st = st; }
 }
@@ -843,7 +1094,7 @@ PSD_KERNEL psd_rq_step(psd_rparams P) {
 //   role 1: right on H_{m-1}, rows [rr0,rr1] x columns [plo,phi]
 //   role 2: right on Z_m, rows [zr0,zr1] x columns [plo,phi]
 // Every element of the panel is read once and written once; the sequence runs out of LDS.
-PSD_KERNEL psd_rq_apply(psd_rparams P, int n, int p) {
+PSD_KERNEL_B(PSD_APPLY_NT) psd_rq_apply(psd_rparams P, int n, int p) {
     PSD_LDS_DECL;
     const psd_apply_desc d = *P.desc;
     if (!d.active) return;
@@ -941,6 +1192,7 @@ PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W,
             st.nsweeps = st.nrqpass = st.ndefl1 = st.ndefl2 = st.nwindows = st.nlog = 0;
             st.maxlog = maxlog;
             st.v[0] = st.v[1] = st.v[2] = 0.0;
+            for (int q = 0; q < 6; ++q) st.cyc[q] = 0;
             st.ulp = PSD_DBL_EPS;
             st.smlnum = PSD_DBL_MIN * ((double)n / PSD_DBL_EPS);
             // PSD.jl:366-375 with _AT_pwr16[] = 4: ulpx = ulp^(1 + 4/16)

@@ -60,6 +60,54 @@ PSD_HD double psd_reflector_small(double* x, int n) {
     return tau;
 }
 
+// Register-only forms of the same reflector for the sweep's 3- and 2-vectors.  When no square can
+// overflow or underflow (the common case) the norm is formed directly — one sqrt and two
+// independent divisions on the dependency chain instead of the scaled-sum-of-squares recurrence;
+// otherwise the dlarfg path above runs.  (x0, x1, x2) <- (beta, v2, v3); returns tau.
+PSD_HD double psd_refl3(double& x0, double& x1, double& x2) {
+    const double tmax = fmax(fabs(x1), fabs(x2));
+    if (tmax == 0.0) return 0.0;
+    const double big = fmax(tmax, fabs(x0));
+    if (big < 1e140 && tmax > 1e-140) {
+        // beta = -sign(x0) nrm;  tau = (beta - x0)/beta = 1 + |x0|/nrm;  v = x / (x0 - beta)
+        double nrm, rn;
+        psd_sqrt_pair_fast(x0 * x0 + (x1 * x1 + x2 * x2), nrm, rn);
+        const double ax0 = fabs(x0);
+        const double tau = 1.0 + ax0 * rn;
+        const double t = psd_rcp_fast(copysign(ax0 + nrm, x0));
+        x1 *= t;
+        x2 *= t;
+        x0 = -copysign(nrm, x0);
+        return tau;
+    }
+    double x[3] = {x0, x1, x2};
+    const double tau = psd_reflector_small(x, 3);
+    x0 = x[0];
+    x1 = x[1];
+    x2 = x[2];
+    return tau;
+}
+PSD_HD double psd_refl2(double& x0, double& x1) {
+    const double tmax = fabs(x1);
+    if (tmax == 0.0) return 0.0;
+    const double big = fmax(tmax, fabs(x0));
+    if (big < 1e140 && tmax > 1e-140) {
+        double nrm, rn;
+        psd_sqrt_pair_fast(x0 * x0 + x1 * x1, nrm, rn);
+        const double ax0 = fabs(x0);
+        const double tau = 1.0 + ax0 * rn;
+        const double t = psd_rcp_fast(copysign(ax0 + nrm, x0));
+        x1 *= t;
+        x0 = -copysign(nrm, x0);
+        return tau;
+    }
+    double x[2] = {x0, x1};
+    const double tau = psd_reflector_small(x, 2);
+    x0 = x[0];
+    x1 = x[1];
+    return tau;
+}
+
 // stdlib LinearAlgebra.givensAlgorithm(f::Float64, g::Float64) (imported by the reference at
 // PSD.jl:9): (c, s, r) with [c s; -s c][f; g] = [r; 0].
 PSD_HD void psd_givens(double f, double g, double& cs, double& sn, double& r) {

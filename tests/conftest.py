@@ -40,6 +40,11 @@ def sim_engine(built):
 
 @pytest.fixture(scope="session")
 def gpu_engine():
+    # torch bundles its own HIP runtime: when torch is used in the same process (device-resident test), it has to
+    # initialise first, otherwise it reports "No HIP GPUs are available" ("Mixing with PyTorch").
+    import torch
+
+    torch.cuda.init()
     import psd_amd
 
     return psd_amd.Engine(device=0)
