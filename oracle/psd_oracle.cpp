@@ -2,7 +2,7 @@
 // C ABI over the CPU restatement so that tests/ and bench.py's cpu_baseline leg can drive it with
 // ctypes.  All matrix arguments are packed [p][n][n], each n x n block column-major (ld = n),
 // factor j (1-based, user order) at offset (j-1)*n*n.
-#include "psd_oracle_real.hpp"
+#include "psd_oracle_complex.hpp"
 
 #include <chrono>
 
@@ -104,6 +104,96 @@ int psdo_d_pschur(int n, int p, double* A, char orient, int wantT, int wantZ, in
     if (nlog) *nlog = cnt;
     if (sweeplog)
         for (int64_t q = 0; q < std::min(cnt, maxlog) * 3; ++q) sweeplog[q] = log.rec[q];
+    if (phase_ms) {
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        phase_ms[0] = ms(t0, t1);
+        phase_ms[1] = ms(t1, t2);
+        phase_ms[2] = ms(t2, t3);
+    }
+    return info;
+}
+
+// ---------------------------------------------------------------------------------------------
+// complex path.  Matrices are interleaved (re, im) doubles, [p][n][n] column-major blocks.
+
+// generalized.jl:166-931 pschur!(H1, Hs, S; wantT, wantZ, Q): internal order, general signatures.
+// alpha [n] interleaved, beta [n], ascale [n]: values = alpha/beta*2^ascale (generalized.jl:74-76).
+int psdo_z_pschur_hess(int n, int p, double* H, const uint8_t* S, double* Z, int wantT, int wantZ, int maxitfac,
+                       double* alpha, double* beta, int32_t* ascale, int64_t* niter, int32_t* zlog, int64_t maxlog,
+                       int64_t* nlog) {
+    std::vector<MatZ> Hv(p + 1), Zv(p + 1);
+    std::vector<char> Sv(p + 1, 1);
+    for (int j = 1; j <= p; ++j) {
+        Hv[j] = MatZ{reinterpret_cast<cplx*>(H) + (size_t)(j - 1) * n * n, n};
+        Zv[j] = MatZ{Z ? reinterpret_cast<cplx*>(Z) + (size_t)(j - 1) * n * n : nullptr, n};
+        if (S) Sv[j] = S[j - 1] ? 1 : 0;
+    }
+    if (!Sv[1]) return -5;  // generalized.jl:182
+    std::vector<int> sc(n, 0);
+    ZLog log;
+    int info = pschur_hess_z(n, p, Hv, Sv, Zv, wantT != 0, wantZ != 0 && Z, maxitfac, reinterpret_cast<cplx*>(alpha),
+                             beta, sc.data(), niter, &log);
+    for (int q = 0; q < n; ++q) ascale[q] = sc[q];
+    int64_t cnt = (int64_t)log.rec.size() / 3;
+    if (nlog) *nlog = cnt;
+    if (zlog)
+        for (int64_t q = 0; q < std::min(cnt, maxlog) * 3; ++q) zlog[q] = log.rec[q];
+    return info;
+}
+
+// PSD.jl:213-259 for ComplexF64: packed reflectors + tau [p][n] (interleaved)
+int psdo_z_phessenberg(int n, int p, double* A, double* tau, double* Q) {
+    std::vector<MatZ> Av(p + 1);
+    for (int j = 1; j <= p; ++j) Av[j] = MatZ{reinterpret_cast<cplx*>(A) + (size_t)(j - 1) * n * n, n};
+    std::vector<std::vector<cplx>> t;
+    phessenbergz(n, p, Av, t);
+    cplx* tz = reinterpret_cast<cplx*>(tau);
+    for (int j = 1; j <= p; ++j)
+        for (int i = 1; i <= n; ++i) tz[(size_t)(j - 1) * n + (i - 1)] = t[j][i];
+    if (Q)
+        for (int j = 1; j <= p; ++j)
+            materializeQz(n, j, Av[j], t[j], MatZ{reinterpret_cast<cplx*>(Q) + (size_t)(j - 1) * n * n, n});
+    return 0;
+}
+
+// PSD.jl:1106-1111 -> generalized.jl:108-148 with all(S): pschur!(A::Vector{Matrix{ComplexF64}}, lr).
+// User-order in/out as in psdo_d_pschur.
+int psdo_z_pschur(int n, int p, double* A, char orient, int wantT, int wantZ, int maxitfac, double* Z, double* alpha,
+                  double* beta, int32_t* ascale, int* schurindex, int64_t* niter, int32_t* zlog, int64_t maxlog,
+                  int64_t* nlog, double* phase_ms) {
+    if (orient != 'R' && orient != 'L') return -4;
+    const bool left = orient == 'L';
+    auto slotA = [&](int j) { return left ? (p + 1 - j) : j; };
+    auto slotZ = [&](int j) { return (!left || j == 1) ? j : (p + 2 - j); };
+    std::vector<MatZ> Av(p + 1), Zv(p + 1);
+    std::vector<char> Sv(p + 1, 1);
+    for (int j = 1; j <= p; ++j) {
+        Av[j] = MatZ{reinterpret_cast<cplx*>(A) + (size_t)(slotA(j) - 1) * n * n, n};
+        Zv[j] = MatZ{(wantZ && Z) ? reinterpret_cast<cplx*>(Z) + (size_t)(slotZ(j) - 1) * n * n : nullptr, n};
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::vector<cplx>> tau;
+    phessenbergz(n, p, Av, tau);
+    auto t1 = std::chrono::steady_clock::now();
+    if (wantZ && Z)
+        for (int j = 1; j <= p; ++j) materializeQz(n, j, Av[j], tau[j], Zv[j]);
+    for (int j = 1; j <= p; ++j) {
+        const int sub = (j == 1) ? 1 : 0;
+        for (int c = 1; c <= n; ++c)
+            for (int r = c + sub + 1; r <= n; ++r) Av[j](r, c) = cplx(0.0);
+    }
+    auto t2 = std::chrono::steady_clock::now();
+    std::vector<int> sc(n, 0);
+    ZLog log;
+    int info = pschur_hess_z(n, p, Av, Sv, Zv, wantT != 0, wantZ != 0 && Z, maxitfac, reinterpret_cast<cplx*>(alpha),
+                             beta, sc.data(), niter, &log);
+    auto t3 = std::chrono::steady_clock::now();
+    for (int q = 0; q < n; ++q) ascale[q] = sc[q];
+    if (schurindex) *schurindex = left ? p : 1;
+    int64_t cnt = (int64_t)log.rec.size() / 3;
+    if (nlog) *nlog = cnt;
+    if (zlog)
+        for (int64_t q = 0; q < std::min(cnt, maxlog) * 3; ++q) zlog[q] = log.rec[q];
     if (phase_ms) {
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         phase_ms[0] = ms(t0, t1);

@@ -1,0 +1,816 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (rules in psd_oracle_real.hpp).
+//
+// CPU restatement of the reference's complex path: complex reflectors (householder.jl:26-56,
+// 110-156, 190-266), complex periodic Hessenberg reduction (PSD.jl:213-259), and the complex
+// single-shift periodic QZ iteration with signatures (generalized.jl:166-931, SLICOT MB03BZ type),
+// `_safeprod` (generalized.jl:939-976).  The one non-deterministic step of the reference — the
+// `rand` exceptional shift at generalized.jl:782 — is replaced by a fixed pair.
+#pragma once
+#include "psd_oracle_real.hpp"
+
+namespace psdo {
+
+typedef std::complex<double> cplx;
+
+struct MatZ {
+    cplx* a;
+    int ld;
+    inline cplx& operator()(int r, int c) const { return a[(size_t)(c - 1) * ld + (r - 1)]; }
+};
+
+// householder.jl:26-56 _norm2 (complex)
+inline double norm2z(const cplx* x, int n, int inc) {
+    if (n < 1) return 0.0;
+    if (n == 1) return std::abs(x[0]);
+    double scale = 0.0, ssq = 0.0;
+    auto acc = [&](double v) {
+        if (v != 0.0) {
+            double a = std::fabs(v);
+            if (scale < a) {
+                double q = scale / a;
+                ssq = 1.0 + ssq * q * q;
+                scale = a;
+            } else {
+                double q = a / scale;
+                ssq += q * q;
+            }
+        }
+    };
+    for (int k = 0; k < n; ++k) {
+        acc(x[(size_t)k * inc].real());
+        acc(x[(size_t)k * inc].imag());
+    }
+    return scale * std::sqrt(ssq);
+}
+
+// householder.jl:161-169 _hypot3
+inline double hypot3(double x, double y, double z) {
+    double xa = std::fabs(x), ya = std::fabs(y), za = std::fabs(z);
+    double w = std::max(xa, std::max(ya, za));
+    double rw = 1.0 / w;
+    return w * std::sqrt((rw * xa) * (rw * xa) + (rw * ya) * (rw * ya) + (rw * za) * (rw * za));
+}
+
+// householder.jl:110-156 _xreflector! (complex, zlarfg): beta real even for n = 1
+inline cplx xreflectorz(cplx* x, int n, int inc) {
+    if (n < 1) return cplx(0.0);
+    const double sfmin = std::numeric_limits<double>::min() / std::numeric_limits<double>::epsilon();
+    cplx alpha = x[0];
+    double ar = alpha.real(), ai = alpha.imag();
+    double xnorm = norm2z(x + inc, n - 1, inc);
+    if (xnorm == 0.0 && ai == 0.0) return cplx(0.0);
+    double beta = -std::copysign(hypot3(ar, ai, xnorm), ar);
+    int kount = 0;
+    bool smallb = std::fabs(beta) < sfmin;
+    if (smallb) {
+        const double rsfmin = 1.0 / sfmin;
+        while (smallb) {
+            kount += 1;
+            for (int j = 1; j < n; ++j) x[(size_t)j * inc] *= rsfmin;
+            beta *= rsfmin;
+            ar *= rsfmin;
+            ai *= rsfmin;
+            smallb = (std::fabs(beta) < sfmin) && (kount < 20);
+        }
+        xnorm = norm2z(x + inc, n - 1, inc);
+        alpha = cplx(ar, ai);
+        beta = -std::copysign(hypot3(ar, ai, xnorm), ar);
+    }
+    cplx tau((beta - ar) / beta, -ai / beta);
+    cplx t = cplx(1.0) / (alpha - beta);
+    for (int j = 1; j < n; ++j) x[(size_t)j * inc] *= t;
+    for (int j = 0; j < kount; ++j) beta *= sfmin;
+    x[0] = beta;
+    return tau;
+}
+
+// householder.jl:222-237 lmul!(H', A) / :190-205 lmul!(H, A): `adj` selects conj(tau)
+inline void lmul_Hz(const cplx* v, cplx tau, bool adj, const MatZ& A, int r0, int c0, int m, int ncols) {
+    const cplx t = adj ? std::conj(tau) : tau;
+    for (int j = 0; j < ncols; ++j) {
+        cplx va = A(r0, c0 + j);
+        for (int r = 1; r < m; ++r) va += std::conj(v[r - 1]) * A(r0 + r, c0 + j);
+        va = t * va;
+        A(r0, c0 + j) -= va;
+        for (int r = 1; r < m; ++r) A(r0 + r, c0 + j) -= va * v[r - 1];
+    }
+}
+// householder.jl:207-220,256-266 rmul!(A, H)
+inline void rmul_Hz(const MatZ& A, int r0, int c0, int nrows, int m, const cplx* v, cplx tau) {
+    for (int r = 0; r < nrows; ++r) {
+        cplx x = A(r0 + r, c0);
+        for (int c = 1; c < m; ++c) x += A(r0 + r, c0 + c) * v[c - 1];
+        A(r0 + r, c0) -= tau * x;
+        for (int c = 1; c < m; ++c) A(r0 + r, c0 + c) -= x * tau * std::conj(v[c - 1]);
+    }
+}
+
+// PSD.jl:213-259 for complex eltype
+inline void phessenbergz(int n, int p, std::vector<MatZ>& A, std::vector<std::vector<cplx>>& tau) {
+    tau.assign(p + 1, std::vector<cplx>(n + 1, cplx(0.0)));
+    for (int i = 1; i <= n - 1; ++i) {
+        const int i1 = i + 1;
+        for (int j = p; j >= 2; --j) {
+            cplx* xi = &A[j](i, i);
+            cplx t = xreflectorz(xi, n - i + 1, 1);
+            tau[j][i] = t;
+            lmul_Hz(xi + 1, t, true, A[j], i, i1, n - i + 1, n - i);
+            rmul_Hz(A[j - 1], 1, i, n, n - i + 1, xi + 1, t);
+        }
+        cplx* xi = &A[1](i1, i);
+        cplx t = xreflectorz(xi, n - i, 1);
+        tau[1][i] = t;
+        lmul_Hz(xi + 1, t, true, A[1], i1, i1, n - i, n - i);
+        rmul_Hz(A[p], 1, i1, n, n - i, xi + 1, t);
+    }
+}
+
+// Q_j = prod_i H_{j,i}
+inline void materializeQz(int n, int j, const MatZ& Aj, const std::vector<cplx>& tauj, const MatZ& Q) {
+    for (int c = 1; c <= n; ++c)
+        for (int r = 1; r <= n; ++r) Q(r, c) = (r == c) ? cplx(1.0) : cplx(0.0);
+    const int off = (j == 1) ? 1 : 0;
+    for (int i = n - 1; i >= 1; --i) {
+        const int r0 = i + off;
+        const int m = n - r0 + 1;
+        if (m < 1) continue;
+        const cplx* v = &Aj.a[(size_t)(i - 1) * Aj.ld + (r0 - 1)] + 1;
+        lmul_Hz(v, tauj[i], false, Q, r0, r0, m, n - r0 + 1);
+    }
+}
+
+// stdlib LinearAlgebra.givensAlgorithm(f::ComplexF64, g::ComplexF64) (LAPACK zlartg port):
+// c real, [c s; -conj(s) c][f; g] = [r; 0]
+inline void givens_algorithm_z(cplx f, cplx g, double& cs, cplx& sn, cplx& r) {
+    const double eps = std::numeric_limits<double>::epsilon();
+    const double safmin = std::numeric_limits<double>::min();
+    const double safmn2 = std::pow(2.0, std::trunc(std::log(safmin / eps) / std::log(2.0) / 2.0));
+    const double safmx2 = 1.0 / safmn2;
+    auto abs1 = [](cplx z) { return std::max(std::fabs(z.real()), std::fabs(z.imag())); };
+    double scale = std::max(abs1(f), abs1(g));
+    cplx fs = f, gs = g;
+    int count = 0;
+    if (scale >= safmx2) {
+        while (true) {
+            count += 1;
+            fs *= safmn2; gs *= safmn2; scale *= safmn2;
+            if (scale < safmx2 || count >= 20) break;
+        }
+    } else if (scale <= safmn2) {
+        if (g == cplx(0.0)) {
+            cs = 1.0; sn = cplx(0.0); r = f;
+            return;
+        }
+        while (true) {
+            count -= 1;
+            fs *= safmx2; gs *= safmx2; scale *= safmx2;
+            if (scale > safmn2) break;
+        }
+    }
+    const double f2 = std::norm(fs), g2 = std::norm(gs);
+    if (f2 <= std::max(g2, 1.0) * safmin) {
+        if (f == cplx(0.0)) {
+            cs = 0.0;
+            r = cplx(std::hypot(g.real(), g.imag()));
+            double d = std::hypot(gs.real(), gs.imag());
+            sn = cplx(gs.real() / d, -gs.imag() / d);
+            return;
+        }
+        double f2s = std::hypot(fs.real(), fs.imag());
+        double g2s = std::sqrt(g2);
+        cs = f2s / g2s;
+        cplx ff;
+        if (abs1(f) > 1) {
+            double d = std::hypot(f.real(), f.imag());
+            ff = cplx(f.real() / d, f.imag() / d);
+        } else {
+            double dr = safmx2 * f.real(), di = safmx2 * f.imag();
+            double d = std::hypot(dr, di);
+            ff = cplx(dr / d, di / d);
+        }
+        sn = ff * cplx(gs.real() / g2s, -gs.imag() / g2s);
+        r = cs * f + sn * g;
+    } else {
+        double f2s = std::sqrt(1.0 + g2 / f2);
+        r = cplx(f2s * fs.real(), f2s * fs.imag());
+        cs = 1.0 / f2s;
+        double d = f2 + g2;
+        sn = cplx(r.real() / d, r.imag() / d);
+        sn *= std::conj(gs);
+        if (count != 0) {
+            if (count > 0)
+                for (int i = 0; i < count; ++i) r *= safmx2;
+            else
+                for (int i = 0; i < -count; ++i) r *= safmn2;
+        }
+    }
+}
+
+// stdlib Givens{ComplexF64}: indices may be "backwards" (i1 > i2), as the reference uses them
+struct GivZ {
+    int i1, i2;
+    double c;
+    cplx s;
+    GivZ adj() const { return GivZ{i1, i2, c, -s}; }
+};
+inline void lmulG(const GivZ& G, const MatZ& A, int c0, int c1) {
+    for (int c = c0; c <= c1; ++c) {
+        cplx a1 = A(G.i1, c), a2 = A(G.i2, c);
+        A(G.i1, c) = G.c * a1 + G.s * a2;
+        A(G.i2, c) = -std::conj(G.s) * a1 + G.c * a2;
+    }
+}
+inline void rmulG(const MatZ& A, int r0, int r1, const GivZ& G) {
+    for (int r = r0; r <= r1; ++r) {
+        cplx a1 = A(r, G.i1), a2 = A(r, G.i2);
+        A(r, G.i1) = a1 * G.c - a2 * std::conj(G.s);
+        A(r, G.i2) = a1 * G.s + a2 * G.c;
+    }
+}
+
+// generalized.jl:939-976 _safeprod
+inline void safeprod(const std::vector<char>& S /*1-based*/, int p, cplx x0, const cplx* v /*p-1*/, cplx& alpha,
+                     double& beta, int& scale) {
+    alpha = cplx(1.0);
+    beta = 1.0;
+    scale = 0;
+    for (int i = 1; i <= p; ++i) {
+        cplx xi = (i == 1) ? x0 : v[i - 2];
+        if (S[i]) {
+            alpha *= xi;
+        } else {
+            if (xi == cplx(0.0)) beta = 0.0;
+            else alpha /= xi;
+        }
+        if (std::abs(alpha) == 0) {
+            alpha = cplx(0.0);
+            scale = 0;
+            if (beta == 0.0) return;
+        } else {
+            while (std::abs(alpha) < 1.0) {
+                alpha *= 2.0;
+                scale -= 1;
+            }
+            while (std::abs(alpha) >= 2.0) {
+                alpha /= 2.0;
+                scale += 1;
+            }
+        }
+    }
+}
+
+inline double opnorm1z(const MatZ& M, int r0, int r1, int c0, int c1, bool upper) {
+    double best = 0.0;
+    for (int c = c0; c <= c1; ++c) {
+        double s = 0.0;
+        for (int r = r0; r <= r1; ++r) {
+            if (upper && (r - r0) > (c - c0)) break;
+            s += std::abs(M(r, c));
+        }
+        if (s > best) best = s;
+    }
+    return best;
+}
+
+struct ZLog {
+    std::vector<int32_t> rec;  // kind (0 sweep, 2 case II, 3 case III, 4 zero shift), ifirst/jlo, ilast
+    void add(int kind, int lo, int hi) {
+        rec.push_back(kind); rec.push_back(lo); rec.push_back(hi);
+    }
+};
+
+// generalized.jl:166-931.  H[1] Hessenberg, H[2..p] upper triangular; S[1..p] (S[1] true);
+// Z[1..p] preset (Q or identity) when wantZ.  Returns 0 or the level at which convergence failed.
+inline int pschur_hess_z(int n, int p, std::vector<MatZ>& H, const std::vector<char>& S, std::vector<MatZ>& Z,
+                         bool wantT, bool wantZ, int maxitfac, cplx* alpha, double* beta, int* ascale,
+                         int64_t* niter_out, ZLog* log) {
+    const double unfl = std::numeric_limits<double>::min();
+    const double safmin = unfl;
+    const double ulp = std::numeric_limits<double>::epsilon();
+    const double smlnum = unfl * (n / ulp);
+    MatZ& H1 = H[1];
+    for (int c = 1; c <= n; ++c)
+        for (int r = c + 2; r <= n; ++r) H1(r, c) = cplx(0.0);  // _gethess!
+    // generalized.jl:199
+    int ziter = (p >= std::log2(unfl) / std::log2(ulp)) ? -1 : 0;
+    std::vector<GivZ> Gtmp(n + 2);
+    std::vector<cplx> v4ev(p > 1 ? p - 1 : 1);
+    int ilast = n, ifirst = -1, ifirstm = 1, ilastm = n, iiter = 1;
+    const int maxit = maxitfac * n;
+    if (niter_out) *niter_out = 0;
+
+    auto check_deflate_hess = [&](int ilo, int il, int& jlo) -> bool {  // :260-278
+        jlo = ilo;
+        for (int j = il; j >= ilo + 1; --j) {
+            double tol = std::abs(H1(j - 1, j - 1)) + std::abs(H1(j, j));
+            if (tol == 0) tol = opnorm1z(H1, ilo, j, ilo, j, false);
+            tol = std::max(ulp * tol, smlnum);
+            if (std::abs(H1(j, j - 1)) <= tol) {
+                H1(j, j - 1) = cplx(0.0);
+                jlo = j;
+                if (j == il) return true;
+                break;
+            }
+        }
+        return false;
+    };
+    auto check_deflate_tr = [&](MatZ& Hl, int jlo, int il, int& jx) -> bool {  // :280-299
+        for (int j = il; j >= jlo; --j) {
+            double tol;
+            if (j == il) tol = std::abs(Hl(j - 1, j));
+            else if (j == jlo) tol = std::abs(Hl(j, j + 1));
+            else tol = std::abs(Hl(j - 1, j)) + std::abs(Hl(j, j + 1));
+            if (tol == 0) tol = opnorm1z(Hl, jlo, j, jlo, j, true);
+            tol = std::max(ulp * tol, smlnum);
+            if (std::abs(Hl(j, j)) <= tol) {
+                Hl(j, j) = cplx(0.0);
+                jx = j;
+                return true;
+            }
+        }
+        jx = 0;
+        return false;
+    };
+    auto giv = [&](cplx f, cplx g, double& c, cplx& s, cplx& r) { givens_algorithm_z(f, g, c, s, r); };
+
+    bool done = false;
+    int64_t jiter_done = 0;
+    for (int jiter = 1; jiter <= maxit; ++jiter) {
+        jiter_done = jiter;
+        bool split1block = false, deflate_pos = false, deflate_neg = false, doqziter = true;
+        int ldeflate = -1, jdeflate = -1, jlo = 1;
+        do {  // generalized.jl:313-449
+            if (ilast == 1) {
+                split1block = true;
+                break;
+            }
+            split1block = check_deflate_hess(1, ilast, jlo);
+            if (split1block) break;
+            for (int l = 2; l <= p; ++l) {
+                if (S[l]) {
+                    int jx;
+                    deflate_pos = check_deflate_tr(H[l], jlo, ilast, jx);
+                    if (deflate_pos) {
+                        ldeflate = l;
+                        jdeflate = jx;
+                        break;
+                    }
+                }
+            }
+            for (int l = 2; l <= p; ++l) {
+                if (!S[l]) {
+                    int jx;
+                    deflate_neg = check_deflate_tr(H[l], jlo, ilast, jx);
+                    if (deflate_neg) {
+                        ldeflate = l;
+                        jdeflate = jx;
+                        break;
+                    }
+                }
+            }
+            // Test 4: controlled zero shift (:356-448)
+            if (ziter >= 7 || ziter < 0) {
+                if (log) log->add(4, jlo, ilast);
+                for (int j = jlo; j <= ilast - 1; ++j) {
+                    double c; cplx s, r;
+                    giv(H1(j, j), H1(j + 1, j), c, s, r);
+                    H1(j, j) = r;
+                    H1(j + 1, j) = cplx(0.0);
+                    GivZ G{j, j + 1, c, s};
+                    lmulG(G, H1, j + 1, ilastm);
+                    Gtmp[j] = G;
+                }
+                if (wantZ)
+                    for (int j = jlo; j <= ilast - 1; ++j) rmulG(Z[1], 1, n, Gtmp[j].adj());
+                for (int l = p; l >= 2; --l) {
+                    MatZ& Hl = H[l];
+                    if (S[l]) {
+                        for (int j = jlo; j <= ilast - 1; ++j) {
+                            GivZ G = Gtmp[j];
+                            if (G.s != cplx(0.0)) {
+                                rmulG(Hl, ifirstm, j + 1, Gtmp[j].adj());
+                                double tol = std::abs(Hl(j, j)) + std::abs(Hl(j + 1, j + 1));
+                                if (tol == 0) tol = opnorm1z(Hl, jlo, j + 1, jlo, j + 1, false);
+                                tol = std::max(ulp * tol, smlnum);
+                                if (std::abs(Hl(j + 1, j)) <= tol) {
+                                    Hl(j + 1, j) = cplx(0.0);
+                                    Gtmp[j] = GivZ{j, j + 1, 1.0, cplx(0.0)};
+                                } else {
+                                    double c; cplx s, r;
+                                    giv(Hl(j, j), Hl(j + 1, j), c, s, r);
+                                    Hl(j, j) = r;
+                                    Hl(j + 1, j) = cplx(0.0);
+                                    G = GivZ{j, j + 1, c, s};
+                                    lmulG(G, Hl, j + 1, ilastm);
+                                    Gtmp[j] = G;
+                                }
+                            }
+                        }
+                    } else {
+                        for (int j = jlo; j <= ilast - 1; ++j) {
+                            GivZ G = Gtmp[j];
+                            if (G.s != cplx(0.0)) {
+                                lmulG(G, Hl, j, ilastm);
+                                double tol = std::abs(Hl(j, j)) + std::abs(Hl(j + 1, j + 1));
+                                if (tol == 0) tol = opnorm1z(Hl, jlo, j + 1, jlo, j + 1, false);
+                                tol = std::max(ulp * tol, smlnum);
+                                if (std::abs(Hl(j + 1, j)) <= tol) {
+                                    Hl(j + 1, j) = cplx(0.0);
+                                    Gtmp[j] = GivZ{j, j + 1, 1.0, cplx(-0.0)};
+                                } else {
+                                    double c; cplx s, r;
+                                    giv(Hl(j + 1, j + 1), Hl(j + 1, j), c, s, r);
+                                    Hl(j + 1, j + 1) = r;
+                                    Hl(j + 1, j) = cplx(0.0);
+                                    G = GivZ{j + 1, j, c, std::conj(s)};
+                                    rmulG(Hl, ifirstm, j, G.adj());
+                                    Gtmp[j] = GivZ{j, j + 1, c, -s};
+                                }
+                            }
+                        }
+                    }
+                    if (wantZ)
+                        for (int j = jlo; j <= ilast - 1; ++j) rmulG(Z[l], 1, n, Gtmp[j].adj());
+                }
+                ziter = 0;
+                for (int j = jlo; j <= ilast - 1; ++j) {
+                    GivZ G = Gtmp[j];
+                    rmulG(H1, ifirstm, j + 1, G.adj());
+                    if (G.s == cplx(0.0)) ziter = 1;
+                }
+                doqziter = false;
+                break;
+            }
+        } while (false);
+
+        if (deflate_pos && !split1block && doqziter) {  // Case II (:453-566)
+            if (log) log->add(2, jlo, ilast);
+            for (int j = jlo; j <= jdeflate - 1; ++j) {
+                double c; cplx s, r;
+                giv(H1(j, j), H1(j + 1, j), c, s, r);
+                H1(j, j) = r;
+                H1(j + 1, j) = cplx(0.0);
+                GivZ G{j, j + 1, c, s};
+                lmulG(G, H1, j + 1, ilastm);
+                Gtmp[j] = G;
+            }
+            if (wantZ)
+                for (int j = jlo; j <= jdeflate - 1; ++j) rmulG(Z[1], 1, n, Gtmp[j].adj());
+            for (int l = p; l >= 2; --l) {
+                const int ntra = (l < ldeflate) ? (jdeflate - 2) : (jdeflate - 1);
+                MatZ& Hl = H[l];
+                if (S[l]) {
+                    for (int j = jlo; j <= ntra; ++j) {
+                        rmulG(Hl, ifirstm, j + 1, Gtmp[j].adj());
+                        double c; cplx s, r;
+                        giv(Hl(j, j), Hl(j + 1, j), c, s, r);
+                        Hl(j, j) = r;
+                        Hl(j + 1, j) = cplx(0.0);
+                        GivZ G{j, j + 1, c, s};
+                        lmulG(G, Hl, j + 1, ilastm);
+                        Gtmp[j] = G;
+                    }
+                } else {
+                    for (int j = jlo; j <= ntra; ++j) {
+                        lmulG(Gtmp[j], Hl, j, ilastm);
+                        double c; cplx s, r;
+                        giv(Hl(j + 1, j + 1), Hl(j + 1, j), c, s, r);
+                        Hl(j + 1, j + 1) = r;
+                        Hl(j + 1, j) = cplx(0.0);
+                        GivZ G{j + 1, j, c, std::conj(s)};
+                        rmulG(Hl, ifirstm, j, G.adj());
+                        Gtmp[j] = GivZ{j, j + 1, c, -s};
+                    }
+                }
+                if (wantZ)
+                    for (int j = jlo; j <= ntra; ++j) rmulG(Z[l], 1, n, Gtmp[j].adj());
+            }
+            for (int j = jlo; j <= jdeflate - 2; ++j) rmulG(H1, ifirstm, j + 1, Gtmp[j].adj());
+            // second unshifted step from the bottom (:512-564)
+            for (int j = ilast; j >= jdeflate + 1; --j) {
+                double c; cplx s, r;
+                giv(H1(j, j), H1(j, j - 1), c, s, r);
+                H1(j, j) = r;
+                H1(j, j - 1) = cplx(0.0);
+                GivZ G{j, j - 1, c, std::conj(s)};
+                rmulG(H1, ifirstm, j - 1, G.adj());
+                Gtmp[j] = GivZ{j - 1, j, c, -s};
+            }
+            if (wantZ)
+                for (int j = ilast; j >= jdeflate + 1; --j) rmulG(Z[p >= 2 ? 2 : 1], 1, n, Gtmp[j].adj());
+            for (int l = 2; l <= p; ++l) {
+                const int ntra = (l > ldeflate) ? (jdeflate + 2) : (jdeflate + 1);
+                MatZ& Hl = H[l];
+                if (!S[l]) {
+                    for (int j = ilast; j >= ntra; --j) {
+                        rmulG(Hl, ifirstm, j, Gtmp[j].adj());
+                        double c; cplx s, r;
+                        giv(Hl(j - 1, j - 1), Hl(j, j - 1), c, s, r);
+                        Hl(j - 1, j - 1) = r;
+                        Hl(j, j - 1) = cplx(0.0);
+                        GivZ G{j - 1, j, c, s};
+                        lmulG(G, Hl, j, ilastm);
+                        Gtmp[j] = G;
+                    }
+                } else {
+                    for (int j = ilast; j >= ntra; --j) {
+                        lmulG(Gtmp[j], Hl, j - 1, ilastm);
+                        double c; cplx s, r;
+                        giv(Hl(j, j), Hl(j, j - 1), c, s, r);
+                        Hl(j, j) = r;
+                        Hl(j, j - 1) = cplx(0.0);
+                        GivZ G{j, j - 1, c, std::conj(s)};
+                        rmulG(Hl, ifirstm, j - 1, G.adj());
+                        Gtmp[j] = GivZ{j - 1, j, c, -s};
+                    }
+                }
+                if (wantZ) {
+                    const int ln = (l % p) + 1;
+                    for (int j = ilast; j >= ntra; --j) rmulG(Z[ln], 1, n, Gtmp[j].adj());
+                }
+            }
+            for (int j = ilast; j >= jdeflate + 2; --j) lmulG(Gtmp[j], H1, j - 1, ilastm);
+            doqziter = false;
+        } else if (deflate_neg && !split1block && doqziter) {  // Case III (:568-740)
+            if (log) log->add(3, jlo, ilast);
+            if (jdeflate > (ilast - jlo + 1) / 2.0) {  // chase the zero down
+                for (int j1 = jdeflate; j1 <= ilast - 1; ++j1) {
+                    int j = j1;
+                    MatZ& Hl = H[ldeflate];
+                    double c; cplx s, r;
+                    giv(Hl(j, j + 1), Hl(j + 1, j + 1), c, s, r);
+                    Hl(j, j + 1) = r;
+                    Hl(j + 1, j + 1) = cplx(0.0);
+                    GivZ G{j, j + 1, c, s};
+                    lmulG(G, Hl, j + 2, ilastm);
+                    int ln = (ldeflate % p) + 1;
+                    if (wantZ) rmulG(Z[ln], 1, n, G.adj());
+                    for (int l = 1; l <= p - 1; ++l) {
+                        if (ln == 1) {
+                            lmulG(G, H1, j - 1, ilastm);
+                            giv(H1(j + 1, j), H1(j + 1, j - 1), c, s, r);
+                            H1(j + 1, j) = r;
+                            H1(j + 1, j - 1) = cplx(0.0);
+                            G = GivZ{j, j - 1, c, std::conj(s)};
+                            rmulG(H1, ifirstm, j, G.adj());
+                            G = GivZ{j - 1, j, c, -s};
+                            j -= 1;
+                        } else if (S[ln]) {
+                            MatZ& Hln = H[ln];
+                            lmulG(G, Hln, j, ilastm);
+                            giv(Hln(j + 1, j + 1), Hln(j + 1, j), c, s, r);
+                            Hln(j + 1, j + 1) = r;
+                            Hln(j + 1, j) = cplx(0.0);
+                            G = GivZ{j + 1, j, c, std::conj(s)};
+                            rmulG(Hln, ifirstm, j, G.adj());
+                            G = GivZ{j, j + 1, c, -s};
+                        } else {
+                            MatZ& Hln = H[ln];
+                            rmulG(Hln, ifirstm, j + 1, G.adj());
+                            giv(Hln(j, j), Hln(j + 1, j), c, s, r);
+                            Hln(j, j) = r;
+                            Hln(j + 1, j) = cplx(0.0);
+                            G = GivZ{j, j + 1, c, s};
+                            lmulG(G, Hln, j + 1, ilastm);
+                        }
+                        ln = (ln % p) + 1;
+                        if (wantZ) rmulG(Z[ln], 1, n, G.adj());
+                    }
+                    rmulG(H[ldeflate], ifirstm, j, G.adj());
+                }
+                {  // deflate last element in Hessenberg (:620-655)
+                    int j = ilast;
+                    double c; cplx s, r;
+                    giv(H1(j, j), H1(j, j - 1), c, s, r);
+                    H1(j, j) = r;
+                    H1(j, j - 1) = cplx(0.0);
+                    GivZ G{j, j - 1, c, std::conj(s)};
+                    rmulG(H1, ifirstm, j - 1, G.adj());
+                    G = GivZ{j - 1, j, c, -s};
+                    if (wantZ) rmulG(Z[2], 1, n, G.adj());
+                    for (int l = 2; l <= ldeflate - 1; ++l) {
+                        MatZ& Hl = H[l];
+                        if (!S[l]) {
+                            rmulG(Hl, ifirstm, j, G.adj());
+                            giv(Hl(j - 1, j - 1), Hl(j, j - 1), c, s, r);
+                            Hl(j - 1, j - 1) = r;
+                            Hl(j, j - 1) = cplx(0.0);
+                            G = GivZ{j - 1, j, c, s};
+                            lmulG(G, Hl, j, ilastm);
+                        } else {
+                            lmulG(G, Hl, j - 1, ilastm);
+                            giv(Hl(j, j), Hl(j, j - 1), c, s, r);
+                            Hl(j, j) = r;
+                            Hl(j, j - 1) = cplx(0.0);
+                            G = GivZ{j, j - 1, c, std::conj(s)};
+                            rmulG(Hl, ifirstm, j - 1, G.adj());
+                            G = GivZ{j - 1, j, c, -s};
+                        }
+                        if (wantZ) {
+                            const int ln = (l % p) + 1;
+                            rmulG(Z[ln], 1, n, G.adj());
+                        }
+                    }
+                    rmulG(H[ldeflate], ifirstm, j, G.adj());
+                }
+            } else {  // chase the zero up (:656-739)
+                for (int j1 = jdeflate; j1 >= jlo + 1; --j1) {
+                    int j = j1;
+                    MatZ& Hl = H[ldeflate];
+                    double c; cplx s, r;
+                    giv(Hl(j - 1, j), Hl(j - 1, j - 1), c, s, r);
+                    Hl(j - 1, j) = r;
+                    Hl(j - 1, j - 1) = cplx(0.0);
+                    GivZ G{j, j - 1, c, std::conj(s)};
+                    rmulG(Hl, ifirstm, j - 2, G.adj());
+                    G = GivZ{j - 1, j, c, -s};
+                    if (wantZ) rmulG(Z[ldeflate], 1, n, G.adj());
+                    int ln = ldeflate - 1;
+                    for (int l = 1; l <= p - 1; ++l) {
+                        MatZ& Hln = H[ln];
+                        if (ln == 1) {
+                            rmulG(Hln, ifirstm, j + 1, G.adj());
+                            giv(Hln(j, j - 1), Hln(j + 1, j - 1), c, s, r);
+                            Hln(j, j - 1) = r;
+                            Hln(j + 1, j - 1) = cplx(0.0);
+                            G = GivZ{j, j + 1, c, s};
+                            lmulG(G, Hln, j, ilastm);
+                            j += 1;
+                        } else if (!S[ln]) {
+                            lmulG(G, Hln, j - 1, ilastm);
+                            giv(Hln(j, j), Hln(j, j - 1), c, s, r);
+                            Hln(j, j) = r;
+                            Hln(j, j - 1) = cplx(0.0);
+                            G = GivZ{j, j - 1, c, std::conj(s)};
+                            rmulG(Hln, ifirstm, j - 1, G.adj());
+                            G = GivZ{j - 1, j, c, -s};
+                        } else {
+                            rmulG(Hln, ifirstm, j, G.adj());
+                            giv(Hln(j - 1, j - 1), Hln(j, j - 1), c, s, r);
+                            Hln(j - 1, j - 1) = r;
+                            Hln(j, j - 1) = cplx(0.0);
+                            G = GivZ{j - 1, j, c, s};
+                            lmulG(G, Hln, j, ilastm);
+                        }
+                        if (wantZ) rmulG(Z[ln], 1, n, G.adj());
+                        ln = (ln == 1) ? p : (ln - 1);
+                    }
+                    lmulG(G, H[ldeflate], j, ilastm);
+                }
+                {  // deflate the first element in Hessenberg (:705-738)
+                    int j = jlo;
+                    double c; cplx s, r;
+                    giv(H1(j, j), H1(j + 1, j), c, s, r);
+                    H1(j, j) = r;
+                    H1(j + 1, j) = cplx(0.0);
+                    GivZ G{j, j + 1, c, s};
+                    lmulG(G, H1, j + 1, ilastm);
+                    if (wantZ) rmulG(Z[1], 1, n, G.adj());
+                    for (int l = p; l >= ldeflate + 1; --l) {
+                        MatZ& Hl = H[l];
+                        if (S[l]) {
+                            rmulG(Hl, ifirstm, j + 1, G.adj());
+                            giv(Hl(j, j), Hl(j + 1, j), c, s, r);
+                            Hl(j, j) = r;
+                            Hl(j + 1, j) = cplx(0.0);
+                            G = GivZ{j, j + 1, c, s};
+                            lmulG(G, Hl, j + 1, ilastm);
+                        } else {
+                            lmulG(G, Hl, j, ilastm);
+                            giv(Hl(j + 1, j + 1), Hl(j + 1, j), c, s, r);
+                            Hl(j + 1, j + 1) = r;
+                            Hl(j + 1, j) = cplx(0.0);
+                            G = GivZ{j + 1, j, c, std::conj(s)};
+                            rmulG(Hl, ifirstm, j, G.adj());
+                            G = GivZ{j, j + 1, c, -s};
+                        }
+                        if (wantZ) rmulG(Z[l], 1, n, G.adj());
+                    }
+                    lmulG(G, H[ldeflate], j + 1, ilastm);
+                }
+            }
+            doqziter = false;
+        } else if (split1block) {  // (:741-762)
+            for (int l = 1; l <= p - 1; ++l) v4ev[l - 1] = H[l + 1](ilast, ilast);
+            safeprod(S, p, H1(ilast, ilast), v4ev.data(), alpha[ilast - 1], beta[ilast - 1], ascale[ilast - 1]);
+            ilast -= 1;
+            if (ilast < 1) {
+                done = true;
+                break;
+            }
+            iiter = 0;
+            if (ziter != -1) ziter = 0;
+            if (!wantT) {
+                ilastm = ilast;
+                if (ifirstm > ilast) ifirstm = 1;
+            }
+            doqziter = false;
+        } else if (doqziter) {
+            ifirst = jlo;
+        }
+
+        if (doqziter) {  // (:770-854)
+            iiter += 1;
+            ziter += 1;
+            if (!wantT) ifirstm = ifirst;
+            if (log) log->add(0, ifirst, ilast);
+            double c; cplx s, r;
+            if (iiter % 10 == 0) {
+                // exceptional shift: the reference draws rand(T,2) here; fixed pair instead
+                giv(cplx(0.35, 0.62), cplx(0.81, 0.27), c, s, r);
+            } else {
+                giv(cplx(1.0), cplx(1.0), c, s, r);
+                for (int l = p; l >= 2; --l) {
+                    MatZ& Hl = H[l];
+                    if (S[l]) {
+                        giv(Hl(ifirst, ifirst) * c, Hl(ilast, ilast) * std::conj(s), c, s, r);
+                    } else {
+                        giv(Hl(ilast, ilast) * c, -Hl(ifirst, ifirst) * std::conj(s), c, s, r);
+                        s = -s;
+                    }
+                }
+                giv(H1(ifirst, ifirst) * c - H1(ilast, ilast) * std::conj(s), H1(ifirst + 1, ifirst) * c, c, s, r);
+            }
+            for (int j1 = ifirst - 1; j1 <= ilast - 2; ++j1) {
+                const int j = j1 + 1;
+                if (j1 >= ifirst) {
+                    giv(H1(j, j - 1), H1(j + 1, j - 1), c, s, r);
+                    H1(j, j - 1) = r;
+                    H1(j + 1, j - 1) = cplx(0.0);
+                }
+                GivZ G{j, j + 1, c, s};
+                lmulG(G, H1, j, ilastm);
+                if (wantZ) rmulG(Z[1], 1, n, G.adj());
+                for (int l = p; l >= 2; --l) {
+                    MatZ& Hl = H[l];
+                    if (S[l]) {
+                        rmulG(Hl, ifirstm, j + 1, G.adj());
+                        giv(Hl(j, j), Hl(j + 1, j), c, s, r);
+                        Hl(j, j) = r;
+                        Hl(j + 1, j) = cplx(0.0);
+                        G = GivZ{j, j + 1, c, s};
+                        lmulG(G, Hl, j + 1, ilastm);
+                    } else {
+                        lmulG(G, Hl, j, ilastm);
+                        giv(Hl(j + 1, j + 1), Hl(j + 1, j), c, s, r);
+                        Hl(j + 1, j + 1) = r;
+                        Hl(j + 1, j) = cplx(0.0);
+                        G = GivZ{j + 1, j, c, std::conj(s)};
+                        rmulG(Hl, ifirstm, j, G.adj());
+                        s = -s;
+                        G = GivZ{j, j + 1, c, s};
+                    }
+                    if (wantZ) rmulG(Z[l], 1, n, G.adj());
+                }
+                const int itmp = std::min(j + 2, ilastm);
+                rmulG(H1, ifirstm, itmp, G.adj());
+            }
+        }
+    }
+    if (niter_out) *niter_out = jiter_done;
+    if (!done) return ilast;
+
+    if (wantT) {  // generalized.jl:860-908: diag(T_l) real >= 0 for l >= 2
+        std::vector<cplx> sf(n + 1);
+        for (int l = p; l >= 2; --l) {
+            MatZ& Hl = H[l];
+            if (S[l]) {
+                for (int j = 1; j <= n; ++j) {
+                    double abst = std::abs(Hl(j, j));
+                    cplx z(1.0);
+                    if (abst > safmin) {
+                        z = std::conj(Hl(j, j) / abst);
+                        Hl(j, j) = cplx(abst);
+                        for (int c = j + 1; c <= n; ++c) Hl(j, c) *= z;
+                    }
+                    sf[j] = z;
+                }
+            } else {
+                for (int j = 1; j <= n; ++j) {
+                    double abst = std::abs(Hl(j, j));
+                    cplx z(1.0);
+                    if (abst > safmin) {
+                        z = std::conj(Hl(j, j) / abst);
+                        Hl(j, j) = cplx(abst);
+                        for (int r = 1; r <= j - 1; ++r) Hl(r, j) *= z;
+                    }
+                    sf[j] = std::conj(z);
+                }
+            }
+            if (wantZ)
+                for (int j = 1; j <= n; ++j)
+                    for (int r = 1; r <= n; ++r) Z[l](r, j) *= std::conj(sf[j]);
+            MatZ& Hm = H[l - 1];
+            if (S[l - 1]) {
+                for (int j = 1; j <= n; ++j)
+                    for (int r = 1; r <= j; ++r) Hm(r, j) *= std::conj(sf[j]);
+            } else {
+                for (int j = 1; j <= n; ++j)
+                    for (int c = j; c <= n; ++c) Hm(j, c) *= sf[j];
+            }
+        }
+    }
+    return 0;
+}
+
+}  // namespace psdo

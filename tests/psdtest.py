@@ -126,6 +126,12 @@ def oracle_lib():
     lib.psdo_d_pschur.argtypes = [C.c_int, C.c_int, dp, C.c_char, C.c_int, C.c_int, C.c_int, dp, dp, dp,
                                   C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int64,
                                   C.POINTER(C.c_int64), dp]
+    i32p, i64p, u8p = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8)
+    lib.psdo_z_pschur_hess.argtypes = [C.c_int, C.c_int, dp, u8p, dp, C.c_int, C.c_int, C.c_int, dp, dp, i32p, i64p,
+                                       i32p, C.c_int64, i64p]
+    lib.psdo_z_phessenberg.argtypes = [C.c_int, C.c_int, dp, dp, dp]
+    lib.psdo_z_pschur.argtypes = [C.c_int, C.c_int, dp, C.c_char, C.c_int, C.c_int, C.c_int, dp, dp, dp, i32p,
+                                  C.POINTER(C.c_int), i64p, i32p, C.c_int64, i64p, dp]
     _oracle = lib
     return lib
 
@@ -181,6 +187,131 @@ def oracle_pschur(As, lr="R", wantZ=True, wantT=True, maxitfac=30):
                              maxlog, C.byref(nlog), _dp(ph))
     return PSD(unpack(A), unpack(Z) if wantZ else [], wr + 1j * wi, lr, si.value, info, niter.value,
                log[: 3 * nlog.value].reshape(-1, 3).copy(), ph)
+
+
+def gvalues(alpha, beta, ascale):
+    """GeneralizedPeriodicSchur.values (generalized.jl:74-76): alpha ./ beta .* 2 .^ ascale."""
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        return alpha / beta * np.exp2(ascale.astype(np.float64))
+
+
+class GPSD(PSD):
+    """Mirror of GeneralizedPeriodicSchur (generalized.jl:31-85)."""
+
+    def __init__(self, S, Ts, Zs, alpha, beta, ascale, orientation, schurindex, info=0, niter=0, sweeplog=None,
+                 phase_ms=None):
+        super().__init__(Ts, Zs, gvalues(alpha, beta, ascale), orientation, schurindex, info, niter, sweeplog, phase_ms)
+        self.S = list(S)
+        self.alpha, self.beta, self.ascale = alpha, beta, ascale
+
+
+def _zp(a):
+    return a.view(np.float64).ctypes.data_as(C.POINTER(C.c_double))
+
+
+def oracle_zpschur(As, lr="R", wantZ=True, wantT=True, maxitfac=30):
+    """CPU restatement of pschur!(A::Vector{Matrix{ComplexF64}}, lr) (PSD.jl:1106-1111 -> generalized.jl:108-148)."""
+    lib = oracle_lib()
+    p = len(As)
+    n = As[0].shape[0]
+    A = pack(As, np.complex128)
+    Z = np.zeros((p, n, n), dtype=np.complex128)
+    alpha = np.zeros(n, dtype=np.complex128)
+    beta = np.zeros(n)
+    sc = np.zeros(n, dtype=np.int32)
+    si = C.c_int(0)
+    niter = C.c_int64(0)
+    maxlog = 3 * maxitfac * n + 16
+    log = np.zeros(3 * maxlog, dtype=np.int32)
+    nlog = C.c_int64(0)
+    ph = np.zeros(3)
+    info = lib.psdo_z_pschur(n, p, _zp(A), lr.encode()[0:1], int(wantT), int(wantZ), maxitfac, _zp(Z), _zp(alpha),
+                             _dp(beta), sc.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(si), C.byref(niter),
+                             log.ctypes.data_as(C.POINTER(C.c_int32)), maxlog, C.byref(nlog), _dp(ph))
+    return GPSD([True] * p, unpack(A), unpack(Z) if wantZ else [], alpha, beta, sc, lr, si.value, info, niter.value,
+                log[: 3 * nlog.value].reshape(-1, 3).copy(), ph)
+
+
+def oracle_zpschur_hess(H1, Hs, S=None, Q=None, wantZ=True, wantT=True, maxitfac=30, rev=False):
+    """CPU restatement of pschur!(H1, Hs, S; wantT, wantZ, Q, rev) for ComplexF64 (generalized.jl:166-931)."""
+    lib = oracle_lib()
+    Hl = [H1] + list(Hs)
+    p = len(Hl)
+    n = H1.shape[0]
+    S = [True] * p if S is None else list(S)
+    H = pack(Hl, np.complex128)
+    Z = pack(Q if Q is not None else [np.eye(n)] * p, np.complex128)
+    alpha = np.zeros(n, dtype=np.complex128)
+    beta = np.zeros(n)
+    sc = np.zeros(n, dtype=np.int32)
+    niter = C.c_int64(0)
+    maxlog = 3 * maxitfac * n + 16
+    log = np.zeros(3 * maxlog, dtype=np.int32)
+    nlog = C.c_int64(0)
+    Sarr = (C.c_uint8 * p)(*[1 if x else 0 for x in S])
+    info = lib.psdo_z_pschur_hess(n, p, _zp(H), Sarr, _zp(Z), int(wantT), int(wantZ), maxitfac, _zp(alpha), _dp(beta),
+                                  sc.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(niter),
+                                  log.ctypes.data_as(C.POINTER(C.c_int32)), maxlog, C.byref(nlog))
+    Ts, Zs = unpack(H), (unpack(Z) if wantZ else [])
+    slog = log[: 3 * nlog.value].reshape(-1, 3).copy()
+    if rev:  # generalized.jl:910-927
+        Zr = ([Zs[0]] + [Zs[p + 1 - l] for l in range(2, p + 1)]) if wantZ else Zs
+        Tr = [Ts[p - l] for l in range(1, p)] + [Ts[0]]
+        return GPSD(S[::-1], Tr, Zr, alpha, beta, sc, "L", p, info, niter.value, slog)
+    return GPSD(S, Ts, Zs, alpha, beta, sc, "R", 1, info, niter.value, slog)
+
+
+def oracle_zphessenberg(As):
+    lib = oracle_lib()
+    p = len(As)
+    n = As[0].shape[0]
+    A = pack(As, np.complex128)
+    tau = np.zeros((p, n), dtype=np.complex128)
+    Q = np.zeros((p, n, n), dtype=np.complex128)
+    lib.psdo_z_phessenberg(n, p, _zp(A), _zp(tau), _zp(Q))
+    packed = unpack(A)
+    Hs = [np.triu(a, -1 if j == 0 else 0) for j, a in enumerate(packed)]
+    return Hs, unpack(Q), packed, tau
+
+
+def gpschur_check(As, S, ps, qtol=10, tol=100):
+    """test/testfuncs.jl:155-235 (complex, non-developing branch)."""
+    p = len(S)
+    n = As[0].shape[0]
+    left = ps.orientation == "L"
+    Ts, Zs = ps.Ts, ps.Z
+    out = {"resid": [], "orth": []}
+    for l in range(p):
+        ln = (l + 1) % p
+        if bool(S[l]) != left:
+            Ax = Zs[l] @ Ts[l] @ Zs[ln].conj().T
+        else:
+            Ax = Zs[ln] @ Ts[l] @ Zs[l].conj().T
+        assert np.all(np.tril(Ts[l], -2) == 0)  # istriu(Ts[l], -1)
+        orth = np.linalg.norm(Zs[l] @ Zs[l].conj().T - np.eye(n))
+        assert orth < qtol * EPS * n, f"Z[{l+1}] orthogonality {orth:.3e}"
+        res = np.linalg.norm(As[l] - Ax)
+        assert res < tol * EPS * n * max(1.0, np.linalg.norm(As[l], 1) / n), f"residual[{l+1}] {res:.3e}"
+        out["orth"].append(orth / (EPS * n))
+        out["resid"].append(res / (EPS * n))
+    # eigenvalues consistent with the diagonals of the Schur factors (testfuncs.jl:211-234)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        lam_s = np.ones(n, dtype=complex)
+        for l in range(p):
+            d = np.diag(Ts[l])
+            lam_s = lam_s * (d if ps.S[l] else 1.0 / d)
+    for j in range(n):
+        if np.isfinite(lam_s[j]):
+            assert np.isclose(ps.values[j], lam_s[j], rtol=1e-8, atol=0), (j, ps.values[j], lam_s[j])
+        else:
+            assert not np.isfinite(ps.values[j])
+    return out
+
+
+def rand_uniform_zfactors(n, p, seed):
+    re = rand_uniform_factors(n, p, seed)
+    im = rand_uniform_factors(n, p, seed + 100003)
+    return [np.asfortranarray(a + 1j * b) for a, b in zip(re, im)]
 
 
 def oracle_phessenberg(As):
