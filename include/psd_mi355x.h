@@ -96,6 +96,30 @@ int psd_d_pschur_dev(psd_ctx* ctx, int n, int p, double* dA, char orient, int wa
                      double* dZ, double* wr, double* wi, int* schurindex, psd_stats* stats, int32_t* sweeplog,
                      int64_t maxlog, int* info);
 
+/* ---- ComplexF64 (interleaved re,im; same conventions) ---------------------------------------------
+ * Eigenvalues are returned in the reference's scaled form (generalized.jl:40-42,74-76):
+ * values[k] = alpha[k] / beta[k] * 2^ascale[k], alpha interleaved complex. */
+
+/* phessenberg!(A) for ComplexF64 — PeriodicSchurDecompositions.jl:213-259; tau is [p][n] complex */
+int psd_z_phessenberg(psd_ctx* ctx, int n, int p, double* const* A, double* tau, psd_stats* stats, int* info);
+
+/* pschur!(A::Vector{Matrix{ComplexF64}}, lr; wantZ, wantT) — PeriodicSchurDecompositions.jl:1106-1111, which runs
+ * generalized.jl:108-137 with S = trues.  A non-true S (generalized.jl:138-146) returns PSD_INFO_NOTIMPL in this
+ * build, as does a zero on the diagonal of a triangular factor (deflation Case II, generalized.jl:453-566). */
+int psd_z_pschur(psd_ctx* ctx, int n, int p, double* const* A, const uint8_t* S, char orient, int wantT, int wantZ,
+                 int maxitfac, double* const* Z, double* alpha, double* beta, int32_t* ascale, int* schurindex,
+                 psd_stats* stats, int32_t* sweeplog, int64_t maxlog, int* info);
+
+/* pschur!(H1, Hs, S; wantT, wantZ, Q, maxitfac, rev) for ComplexF64 — generalized.jl:166-175 */
+int psd_z_pschur_hess(psd_ctx* ctx, int n, int p, double* const* H, const uint8_t* S, double* const* Q, int wantT,
+                      int wantZ, int maxitfac, double* alpha, double* beta, int32_t* ascale, psd_stats* stats,
+                      int32_t* sweeplog, int64_t maxlog, int* info);
+
+/* device-resident variant of psd_z_pschur */
+int psd_z_pschur_dev(psd_ctx* ctx, int n, int p, double* dA, char orient, int wantT, int wantZ, int maxitfac,
+                     double* dZ, double* alpha, double* beta, int32_t* ascale, int* schurindex, psd_stats* stats,
+                     int32_t* sweeplog, int64_t maxlog, int* info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,6 +85,18 @@ class PeriodicSchur:
         return len(self.Ts)
 
 
+class GeneralizedPeriodicSchur(PeriodicSchur):
+    """Mirror of `GeneralizedPeriodicSchur` (src/generalized.jl:31-85): eigenvalues in scaled form
+    `values = alpha ./ beta .* 2 .^ alphascale`."""
+
+    def __init__(self, S, Ts, Z, alpha, beta, alphascale, orientation, schurindex, stats=None, sweeplog=None):
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            values = alpha / beta * np.exp2(alphascale.astype(np.float64))
+        super().__init__(Ts, Z, values, orientation, schurindex, stats, sweeplog)
+        self.S = list(S)
+        self.alpha, self.beta, self.alphascale = alpha, beta, alphascale
+
+
 def char_lr(lr):
     """src/PeriodicSchurDecompositions.jl:155-163,175-177."""
     if lr in ("R", ":R"):
@@ -131,6 +143,14 @@ class Engine:
                                           C.POINTER(Stats), C.POINTER(C.c_int32), C.c_int64, ip]
         lib.psd_d_pschur_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p, dp, dp, ip, C.POINTER(Stats), C.POINTER(C.c_int32), C.c_int64, ip]
+        i32p = C.POINTER(C.c_int32)
+        lib.psd_z_phessenberg.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, dp, C.POINTER(Stats), ip]
+        lib.psd_z_pschur.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, C.POINTER(C.c_uint8), C.c_char, C.c_int,
+                                     C.c_int, C.c_int, dpp, dp, dp, i32p, ip, C.POINTER(Stats), i32p, C.c_int64, ip]
+        lib.psd_z_pschur_hess.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, C.POINTER(C.c_uint8), dpp, C.c_int,
+                                          C.c_int, C.c_int, dp, dp, i32p, C.POINTER(Stats), i32p, C.c_int64, ip]
+        lib.psd_z_pschur_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p, dp, dp, i32p, ip, C.POINTER(Stats), i32p, C.c_int64, ip]
         self.ctx = C.c_void_p()
         rc = lib.psd_create(C.byref(self.ctx), device)
         if rc != 0:
@@ -176,16 +196,30 @@ class Engine:
         raise RuntimeError(f"info={info}")
 
     @staticmethod
-    def _as_work(A):
-        """In-place contract: every A[j] must be a Fortran-contiguous float64 matrix we may overwrite."""
+    def _as_work(A, dtype=np.float64):
+        """In-place contract: every A[j] must be a Fortran-contiguous matrix of `dtype` we may overwrite."""
         for a in A:
-            if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.f_contiguous and a.flags.writeable):
-                raise TypeError("pschur_ needs writable Fortran-ordered float64 matrices (use pschur for a copy)")
+            if not (isinstance(a, np.ndarray) and a.dtype == dtype and a.flags.f_contiguous and a.flags.writeable):
+                raise TypeError(f"needs writable Fortran-ordered {np.dtype(dtype).name} matrices (use pschur for a copy)")
+
+    @staticmethod
+    def _is_complex(A):
+        return any(np.iscomplexobj(a) for a in A)
 
     def phessenberg_(self, A):
         """phessenberg!(A) — src/PeriodicSchurDecompositions.jl:213-259.
         Overwrites A LAPACK-style; returns (H list, tau[p][n]) where H[0] = triu(A[0],-1), H[j] = triu(A[j])."""
         n = _check_square(A)
+        if self._is_complex(A):
+            self._as_work(A, np.complex128)
+            p = len(A)
+            tau = np.zeros((p, n), dtype=np.complex128)
+            st = Stats()
+            info = C.c_int(0)
+            self.lib.psd_z_phessenberg(self.ctx, n, p, self._ptrs(A), tau.view(np.float64).ctypes.data_as(
+                C.POINTER(C.c_double)), C.byref(st), C.byref(info))
+            self._raise(info.value)
+            return [np.triu(a, -1 if j == 0 else 0) for j, a in enumerate(A)], tau, st
         self._as_work(A)
         p = len(A)
         tau = np.zeros((p, n))
@@ -202,6 +236,8 @@ class Engine:
         `A` is workspace and is overwritten with the T factors."""
         orient = char_lr(lr)
         n = _check_square(A)
+        if self._is_complex(A):
+            return self._zpschur_(A, orient, S, wantZ, wantT, maxitfac)
         self._as_work(A)
         p = len(A)
         Z = [np.zeros((n, n), order="F") for _ in range(p)] if wantZ else []
@@ -226,10 +262,85 @@ class Engine:
         nl = min(st.nlog, maxlog)
         return PeriodicSchur(list(A), Z, wr + 1j * wi, orient, si.value, st, log[: 3 * nl].reshape(-1, 3).copy())
 
+    def _zpschur_(self, A, orient, S, wantZ, wantT, maxitfac):
+        """pschur!(A::Vector{Matrix{ComplexF64}}[, S], lr) — src/PeriodicSchurDecompositions.jl:1106-1111,
+        src/generalized.jl:108-148.  Without S the result is a PeriodicSchur (as at :1110)."""
+        n = A[0].shape[0]
+        self._as_work(A, np.complex128)
+        p = len(A)
+        Z = [np.zeros((n, n), dtype=np.complex128, order="F") for _ in range(p)] if wantZ else []
+        alpha = np.zeros(n, dtype=np.complex128)
+        beta = np.zeros(n)
+        sc = np.zeros(n, dtype=np.int32)
+        si = C.c_int(0)
+        st = Stats()
+        maxlog = 2 * maxitfac * n + n + 16
+        log = np.zeros(3 * maxlog, dtype=np.int32)
+        info = C.c_int(0)
+        Sarr = None
+        if S is not None:
+            if len(S) != p:
+                raise DimensionMismatch("length of S must match the period")
+            first = S[p - 1] if orient == "L" else S[0]
+            if not first:
+                raise ValueError("The leftmost entry in S must be true")  # src/generalized.jl:140
+            Sarr = (C.c_uint8 * p)(*[1 if x else 0 for x in S])
+        dp = C.POINTER(C.c_double)
+        self.lib.psd_z_pschur(self.ctx, n, p, self._ptrs(A), Sarr, orient.encode(), int(wantT), int(wantZ),
+                              int(maxitfac), self._ptrs(Z) if wantZ else None,
+                              alpha.view(np.float64).ctypes.data_as(dp), beta.ctypes.data_as(dp),
+                              sc.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(si), C.byref(st),
+                              log.ctypes.data_as(C.POINTER(C.c_int32)), maxlog, C.byref(info))
+        self._raise(info.value)
+        nl = min(st.nlog, maxlog)
+        slog = log[: 3 * nl].reshape(-1, 3).copy()
+        g = GeneralizedPeriodicSchur([True] * p if S is None else S, list(A), Z, alpha, beta, sc, orient, si.value, st,
+                                     slog)
+        if S is None:
+            return PeriodicSchur(g.Ts, g.Z, g.values, g.orientation, g.schurindex, st, slog)
+        return g
+
     def pschur(self, A, lr="R", **kw):
         """pschur(A, lr; kwargs...) — copying variant, src/PeriodicSchurDecompositions.jl:108-113."""
-        Atmp = [np.array(a, dtype=np.float64, order="F", copy=True) for a in A]
+        dt = np.complex128 if self._is_complex(A) else np.float64
+        Atmp = [np.array(a, dtype=dt, order="F", copy=True) for a in A]
         return self.pschur_(Atmp, lr, **kw)
+
+    def zpschur_hess_(self, H1, Hs, S=None, Q=None, wantT=True, wantZ=True, maxitfac=30, rev=False):
+        """pschur!(H1, Hs, S; wantT, wantZ, Q, maxitfac, rev) for ComplexF64 — src/generalized.jl:166-175."""
+        H = [H1] + list(Hs)
+        n = _check_square(H)
+        self._as_work(H, np.complex128)
+        p = len(H)
+        S = [True] * p if S is None else list(S)
+        if not S[0]:
+            raise ValueError("Signature entry S[1] must be true")  # src/generalized.jl:182
+        if wantZ:
+            if Q is None:
+                Q = [np.asfortranarray(np.eye(n, dtype=np.complex128)) for _ in range(p)]
+            self._as_work(Q, np.complex128)
+        alpha = np.zeros(n, dtype=np.complex128)
+        beta = np.zeros(n)
+        sc = np.zeros(n, dtype=np.int32)
+        st = Stats()
+        maxlog = 2 * maxitfac * n + n + 16
+        log = np.zeros(3 * maxlog, dtype=np.int32)
+        info = C.c_int(0)
+        Sarr = (C.c_uint8 * p)(*[1 if x else 0 for x in S])
+        dp = C.POINTER(C.c_double)
+        self.lib.psd_z_pschur_hess(self.ctx, n, p, self._ptrs(H), Sarr, self._ptrs(Q) if wantZ else None, int(wantT),
+                                   int(wantZ), int(maxitfac), alpha.view(np.float64).ctypes.data_as(dp),
+                                   beta.ctypes.data_as(dp), sc.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(st),
+                                   log.ctypes.data_as(C.POINTER(C.c_int32)), maxlog, C.byref(info))
+        self._raise(info.value)
+        nl = min(st.nlog, maxlog)
+        slog = log[: 3 * nl].reshape(-1, 3).copy()
+        Z = list(Q) if wantZ else []
+        if rev:  # src/generalized.jl:910-927
+            Zr = ([Z[0]] + [Z[p + 1 - l] for l in range(2, p + 1)]) if wantZ else Z
+            Ts = [H[p - l] for l in range(1, p)] + [H[0]]
+            return GeneralizedPeriodicSchur(S[::-1], Ts, Zr, alpha, beta, sc, "L", p, st, slog)
+        return GeneralizedPeriodicSchur(S, H, Z, alpha, beta, sc, "R", 1, st, slog)
 
     def pschur_hess_(self, H1, Hs, Q=None, wantT=True, wantZ=True, maxitfac=30, rev=False):
         """pschur!(H1, Hs; wantT, wantZ, Q, maxitfac, rev) — src/PeriodicSchurDecompositions.jl:322-330."""

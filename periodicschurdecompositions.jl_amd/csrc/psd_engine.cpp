@@ -3,6 +3,8 @@
 // serial simulation for the CPU-only test tier; the package never loads that build.
 #include "psd_hess.h"
 #include "psd_real_qr.h"
+#include "psd_zhess.h"
+#include "psd_zqz.h"
 
 #include "../../include/psd_mi355x.h"
 
@@ -53,18 +55,18 @@ struct Timer {
 #endif
 };
 
-int choose_window(int p) {
-    // largest W with p blocks of W x (W+1) doubles (+ scratch) inside the 160 KiB LDS of one CU
+int choose_window(int p, int esize = 8) {
+    // largest W with p blocks of W x (W+1) elements (+ scratch) inside the 160 KiB LDS of one CU
     const size_t budget = 150 * 1024;
-    const int cand[] = {32, 24, 16, 12, 8};
+    const int cand[] = {32, 24, 20, 16, 12, 10, 8, 6};
     for (int W : cand) {
-        size_t need = (size_t)p * W * (W + 1) * 8 + PSD_STEP_NT * 8 + 2 * PSD_STEP_NT * 4 + (size_t)p * 4 + 64;
+        size_t need = (size_t)p * W * (W + 1) * esize + PSD_STEP_NT * 8 + 2 * PSD_STEP_NT * 4 + (size_t)p * 4 + 64;
         if (need <= budget) return W;
     }
     return 0;
 }
-size_t step_lds_bytes(int p, int W) {
-    size_t b = ((size_t)p * W * (W + 1) + PSD_STEP_NT) * 8 + (2 * PSD_STEP_NT + (size_t)p) * 4;
+size_t step_lds_bytes(int p, int W, int esize = 8) {
+    size_t b = (size_t)p * W * (W + 1) * esize + PSD_STEP_NT * 8 + (2 * PSD_STEP_NT + (size_t)p) * 4;
     return (b + 15) & ~(size_t)15;
 }
 size_t apply_lds_bytes() { return sizeof(psd_tr) * PSD_TR_CAP + (size_t)32 * (PSD_APPLY_NT + 1) * 8; }
@@ -88,7 +90,16 @@ struct psd_ctx {
     int* cnt = nullptr;
     int* log = nullptr;
     int logcap = 0;
-    size_t step_lds_set = 0;
+    size_t step_lds_set = 0, zstep_lds_set = 0;
+    // complex path
+    int zcap_n = 0, zcap_p = 0, zlogcap = 0;
+    bool zcap_mats = false;
+    psd_z *zH = nullptr, *zZ = nullptr, *ztau = nullptr, *zvbuf = nullptr, *zalpha = nullptr;
+    double* zbeta = nullptr;
+    int *zascale = nullptr, *zcnt = nullptr, *zlog = nullptr;
+    psd_zstate* zst = nullptr;
+    psd_zapply_desc* zdesc = nullptr;
+    psd_ztr *ztr = nullptr, *zdG = nullptr;
 
     void release() {
         void* ptrs[] = {dH, dZ, tau, vbuf, hdiag, hsub, hsup, Pd, Pe, Pf, hnorms, wr, wi, st, desc, tr, cnt, log};
@@ -99,6 +110,47 @@ struct psd_ctx {
         cap_n = cap_p = 0;
         cap_mats = false;
         logcap = 0;
+    }
+
+    void zrelease() {
+        void* ptrs[] = {zH, zZ, ztau, zvbuf, zalpha, zbeta, zascale, zcnt, zlog, zst, zdesc, ztr, zdG};
+        for (void* q : ptrs)
+            if (q) psd_rt_free(q);
+        zH = zZ = ztau = zvbuf = zalpha = nullptr;
+        zbeta = nullptr;
+        zascale = zcnt = zlog = nullptr;
+        zst = nullptr; zdesc = nullptr; ztr = zdG = nullptr;
+        zcap_n = zcap_p = zlogcap = 0;
+        zcap_mats = false;
+    }
+
+    int zreserve(int n, int p, bool mats, int maxlog) {
+        if (n <= zcap_n && p <= zcap_p && (!mats || zcap_mats) && maxlog <= zlogcap) return 0;
+        const bool keep = mats || zcap_mats;
+        zrelease();
+        const size_t nn = (size_t)n * n;
+#define PSD_ALLOC(ptr, type, count) PSD_CHECK(psd_rt_malloc((void**)&ptr, sizeof(type) * (size_t)(count)))
+        if (keep) {
+            PSD_ALLOC(zH, psd_z, nn * p);
+            PSD_ALLOC(zZ, psd_z, nn * p);
+        }
+        PSD_ALLOC(ztau, psd_z, (size_t)n * p);
+        PSD_ALLOC(zvbuf, psd_z, n + 8);
+        PSD_ALLOC(zalpha, psd_z, n + 8);
+        PSD_ALLOC(zbeta, double, n + 8);
+        PSD_ALLOC(zascale, int, n + 8);
+        PSD_ALLOC(zcnt, int, p + 8);
+        PSD_ALLOC(zlog, int, 3 * (size_t)maxlog + 8);
+        PSD_ALLOC(zst, psd_zstate, 1);
+        PSD_ALLOC(zdesc, psd_zapply_desc, 1);
+        PSD_ALLOC(ztr, psd_ztr, (size_t)p * PSD_ZTR_CAP);
+        PSD_ALLOC(zdG, psd_ztr, n + 8);
+#undef PSD_ALLOC
+        zcap_n = n;
+        zcap_p = p;
+        zcap_mats = keep;
+        zlogcap = maxlog;
+        return 0;
     }
 
     int reserve(int n, int p, bool mats, int maxlog) {
@@ -374,6 +426,7 @@ int psd_create(psd_ctx** ctx, int device) {
 int psd_destroy(psd_ctx* c) {
     if (!c) return 0;
     c->release();
+    c->zrelease();
 #ifndef PSD_HOSTSIM
     if (c->stream) (void)hipStreamDestroy(c->stream);
 #endif
@@ -438,7 +491,7 @@ int psd_d_pschur_dev(psd_ctx* c, int n, int p, double* dA, char orient, int want
     Timer tall, tph;
     tall.start(c->stream);
     // PSD.jl:127-131: 'L' works on the reversed sequence
-    if (left && p > 1) PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, p / 2), 64, 0, c->stream, dA, n, 0, p);
+    if (left && p > 1) PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, p / 2), 64, 0, c->stream, dA, n, n, 0, p);
     tph.start(c->stream);
     if ((*info = hessenberg_dev(c, n, p, dA, c->tau)) != 0) return *info;
     const double ms_hess = tph.stop(c->stream);
@@ -456,8 +509,8 @@ int psd_d_pschur_dev(psd_ctx* c, int n, int p, double* dA, char orient, int want
     const double ms_iter = tph.stop(c->stream);
     // PSD.jl:1078-1092: undo the reversal; Z_1 stays, Z_2..Z_p reverse
     if (left && p > 1) {
-        PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, p / 2), 64, 0, c->stream, dA, n, 0, p);
-        if (wantZ && p > 2) PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, (p - 1) / 2), 64, 0, c->stream, dZ, n, 1, p - 1);
+        PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, p / 2), 64, 0, c->stream, dA, n, n, 0, p);
+        if (wantZ && p > 2) PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, (p - 1) / 2), 64, 0, c->stream, dZ, n, n, 1, p - 1);
     }
     s->ms_hess = ms_hess;
     s->ms_formq = ms_formq;
@@ -533,6 +586,350 @@ int psd_d_pschur_hess(psd_ctx* c, int n, int p, double* const* H, double* const*
     for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(H[j], c->dH + j * nn, nn * 8, c->stream));
     if (wantZ)
         for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(Q[j], c->dZ + j * nn, nn * 8, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    return rc;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// complex path
+namespace {
+
+int zhessenberg_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dtau) {
+    const size_t nn = (size_t)n * n;
+    PSD_CHECK(psd_rt_memset(dtau, 0, sizeof(psd_z) * (size_t)n * p, c->stream));
+    const size_t lds_refl = PSD_HESS_NT * 8;
+    const size_t lds_apply = (PSD_HESS_NT + (size_t)n + 8) * sizeof(psd_z);
+    for (int i = 1; i <= n - 1; ++i) {
+        for (int j = p; j >= 1; --j) {
+            const int r0 = (j == 1) ? (i + 1) : i;
+            if (n - r0 + 1 < 1) continue;
+            psd_z* Aj = dH + (size_t)(j - 1) * nn;
+            psd_z* Ajm1 = dH + (size_t)((j == 1 ? p : j - 1) - 1) * nn;
+            PSD_LAUNCH(psd_zhess_refl, psd_dim3(1), PSD_HESS_NT, lds_refl, c->stream, Aj, n, r0, i, c->zvbuf,
+                       dtau + (size_t)(j - 1) * n + (i - 1));
+            const int lc0 = i + 1;
+            const int nL = (n - lc0 + 1 + 3) / 4;
+            const int nR = (n + 31) / 32;
+            if (Aj != Ajm1) {
+                PSD_LAUNCH(psd_zhess_apply, psd_dim3(nL + nR), PSD_HESS_NT, lds_apply, c->stream, Aj, Ajm1, n, r0, lc0,
+                           (const psd_z*)c->zvbuf, nL);
+            } else {
+                PSD_LAUNCH(psd_zhess_apply, psd_dim3(nL), PSD_HESS_NT, lds_apply, c->stream, Aj, (psd_z*)nullptr, n, r0,
+                           lc0, (const psd_z*)c->zvbuf, nL);
+                PSD_LAUNCH(psd_zhess_apply, psd_dim3(nR), PSD_HESS_NT, lds_apply, c->stream, (psd_z*)nullptr, Ajm1, n, r0,
+                           lc0, (const psd_z*)c->zvbuf, 0);
+            }
+        }
+    }
+    return 0;
+}
+
+int zformq_dev(psd_ctx* c, int n, int p, const psd_z* dH, const psd_z* dtau, psd_z* dQ) {
+    PSD_LAUNCH(psd_zset_identity, psd_dim3(n, p), 64, 0, c->stream, dQ, n);
+    const size_t lds = PSD_HESS_NT * sizeof(psd_z);
+    for (int i = n - 1; i >= 1; --i) {
+        const int tiles = (n - i + 1 + 3) / 4;
+        PSD_LAUNCH(psd_zformq_step, psd_dim3(tiles, p), PSD_HESS_NT, lds, c->stream, dH, dtau, dQ, n, i);
+    }
+    return 0;
+}
+
+// generalized.jl:166-931 on device (all signatures true)
+int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int wantZ, int maxitfac, psd_zstate* st_out,
+                 psd_stats* stats, int maxlog) {
+    const int W = choose_window(p, 16);
+    if (W == 0) return PSD_INFO_NOTIMPL;
+    psd_zparams P;
+    P.H = dH;
+    P.Z = wantZ ? dZ : nullptr;
+    P.st = c->zst;
+    P.desc = c->zdesc;
+    P.tr = c->ztr;
+    P.cnt = c->zcnt;
+    P.dG = c->zdG;
+    P.alpha = c->zalpha;
+    P.beta = c->zbeta;
+    P.ascale = c->zascale;
+    P.log = c->zlog;
+    const size_t lds_step = step_lds_bytes(p, W, 16);
+#ifndef PSD_HOSTSIM
+    if (lds_step > c->zstep_lds_set) {
+        PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_zq_step),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
+        c->zstep_lds_set = lds_step;
+    }
+#endif
+    PSD_LAUNCH(psd_zq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog);
+    const size_t lds_apply = sizeof(psd_ztr) * PSD_ZTR_CAP + (size_t)32 * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
+    const int tiles = (n + PSD_ZAPPLY_NT - 1) / PSD_ZAPPLY_NT;
+    const int dtiles = (n + 255) / 256;
+    const int batch = 32;
+    psd_zstate hst;
+    memset(&hst, 0, sizeof(hst));
+    long long launched = 0;
+    const int nbmin = (W - 3 > 0) ? (W - 3) : 1;
+    const long long cap = (long long)maxitfac * n * ((long long)n / nbmin + 4) + 4LL * n + 1024;
+    double sample_ms = 0.0;
+    int samples = 0;
+#ifndef PSD_HOSTSIM
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pend;
+#endif
+    for (;;) {
+        for (int b = 0; b < batch; ++b) {
+#ifndef PSD_HOSTSIM
+            const bool sample = c->profile && ((launched & 3) == 0);
+            if (sample) {
+                (void)hipEventCreate(&ev0);
+                (void)hipEventCreate(&ev1);
+                (void)hipEventRecord(ev0, c->stream);
+            }
+#endif
+            PSD_LAUNCH(psd_zq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
+#ifndef PSD_HOSTSIM
+            if (sample) {
+                (void)hipEventRecord(ev1, c->stream);
+                pend.emplace_back(ev0, ev1);
+            }
+#endif
+            PSD_LAUNCH(psd_zq_apply, psd_dim3(tiles, p, 3), PSD_ZAPPLY_NT, lds_apply, c->stream, P, n, p);
+            PSD_LAUNCH(psd_zq_defer, psd_dim3(dtiles), 256, 0, c->stream, P, n);
+            ++launched;
+        }
+        PSD_CHECK(psd_rt_d2h(&hst, c->zst, sizeof(hst), c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+#ifndef PSD_HOSTSIM
+        for (auto& pr : pend) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                sample_ms += ms;
+                ++samples;
+            }
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        pend.clear();
+#endif
+        if (hst.phase == PSD_ZPH_DONE) break;
+        if (launched > cap) {
+            *st_out = hst;
+            return PSD_INFO_RUNTIME + 0xfffe;
+        }
+    }
+    if (hst.info == 0 && wantT) {  // generalized.jl:860-908
+        for (int l = p; l >= 2; --l)
+            PSD_LAUNCH(psd_zq_phase, psd_dim3(n), 64, 64, c->stream, P, n, l, wantZ);
+    }
+    PSD_CHECK(psd_rt_last_error());
+    *st_out = hst;
+    if (stats) {
+        stats->nlaunch_step = (int32_t)launched;
+        stats->window = W;
+        stats->step_kernel_ms_avg = samples ? sample_ms / samples : 0.0;
+        stats->step_kernel_samples = samples;
+    }
+    return 0;
+}
+
+int zrun_iteration(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int wantZ, int maxitfac, double* alpha,
+                   double* beta, int32_t* ascale, psd_stats* stats, int32_t* sweeplog, int64_t maxlog_user, int* info) {
+    const int maxlog = 2 * maxitfac * n + n + 16;
+    psd_zstate st;
+    int rc = ziterate_dev(c, n, p, dH, dZ, wantT, wantZ, maxitfac, &st, stats, maxlog);
+    if (rc != 0) {
+        *info = rc;
+        return rc;
+    }
+    if (stats) {
+        stats->niter = st.jiter;
+        stats->nsweeps = st.nsweeps;
+        stats->nrqpass = st.nzshift;
+        stats->ndefl1 = st.nsplit;
+        stats->nwindows = st.nwindows;
+        stats->nlog = st.nlog;
+        for (int q = 0; q < 6; ++q) stats->step_cycles[q] = st.cyc[q];
+    }
+    PSD_CHECK(psd_rt_d2h(alpha, c->zalpha, sizeof(psd_z) * n, c->stream));
+    PSD_CHECK(psd_rt_d2h(beta, c->zbeta, sizeof(double) * n, c->stream));
+    std::vector<int> hsc(n, 0);
+    PSD_CHECK(psd_rt_d2h(hsc.data(), c->zascale, sizeof(int) * n, c->stream));
+    const int nl = st.nlog < maxlog ? st.nlog : maxlog;
+    std::vector<int> hlog((size_t)3 * nl + 3, 0);
+    if (nl > 0) PSD_CHECK(psd_rt_d2h(hlog.data(), c->zlog, sizeof(int) * 3 * (size_t)nl, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    for (int q = 0; q < n; ++q) ascale[q] = hsc[q];
+    if (stats) {  // algorithmic bytes of the sweeps, E = 16
+        double b = 0.0;
+        for (int q = 0; q < nl; ++q)
+            if (hlog[3 * q] == 0 || hlog[3 * q] == 4) {
+                const double w = hlog[3 * q + 2] - hlog[3 * q + 1] + 1;
+                if (!wantT) b += 2 * 16.0 * p * w * w + (wantZ ? 2 * 16.0 * p * w * n : 0.0);
+                else b += 2 * 16.0 * p * w * (wantZ ? (2.0 * n + 1) : (n + 1.0));
+            }
+        stats->bytes_sweeps = b;
+    }
+    if (sweeplog) {
+        const int64_t m = nl < maxlog_user ? nl : maxlog_user;
+        for (int64_t q = 0; q < 3 * m; ++q) sweeplog[q] = hlog[q];
+    }
+    if (st.info == -1000) *info = PSD_INFO_NOTIMPL;  // Case II
+    else *info = (st.info != 0) ? (PSD_INFO_NOCONV + st.info) : 0;
+    return *info;
+}
+
+}  // namespace
+
+extern "C" {
+
+int psd_z_phessenberg(psd_ctx* c, int n, int p, double* const* A, double* tau, psd_stats* stats, int* info) {
+    int dummy;
+    if (!info) info = &dummy;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!c) return *info = -1;
+    if ((*info = check_dims(n, p)) != 0) return *info;
+    if (!A || !tau) return *info = -4;
+    if ((*info = c->zreserve(n, p, true, 16)) != 0) return *info;
+    const size_t nn = (size_t)n * n;
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->zH + j * nn, A[j], nn * 16, c->stream));
+    Timer tk;
+    tk.start(c->stream);
+    if ((*info = zhessenberg_dev(c, n, p, c->zH, c->ztau)) != 0) return *info;
+    const double ms = tk.stop(c->stream);
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(A[j], c->zH + j * nn, nn * 16, c->stream));
+    PSD_CHECK(psd_rt_d2h(tau, c->ztau, sizeof(psd_z) * (size_t)n * p, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    PSD_CHECK(psd_rt_last_error());
+    if (stats) {
+        stats->ms_hess = stats->ms_total = ms;
+        stats->bytes_hess = 2.0 * 16.0 * p * (5.0 / 6.0) * (double)n * n * n;
+    }
+    return *info = 0;
+}
+
+int psd_z_pschur_dev(psd_ctx* c, int n, int p, double* dA_, char orient, int wantT, int wantZ, int maxitfac, double* dZ_,
+                     double* alpha, double* beta, int32_t* ascale, int* schurindex, psd_stats* stats,
+                     int32_t* sweeplog, int64_t maxlog, int* info) {
+    int dummy;
+    if (!info) info = &dummy;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!c) return *info = -1;
+    if ((*info = check_dims(n, p)) != 0) return *info;
+    if (!dA_) return *info = -4;
+    if (orient != 'R' && orient != 'L') return *info = -5;
+    if (maxitfac < 1) return *info = -8;
+    if (wantZ && !dZ_) return *info = -9;
+    if (!alpha || !beta || !ascale) return *info = -10;
+    psd_z* dA = reinterpret_cast<psd_z*>(dA_);
+    psd_z* dZ = reinterpret_cast<psd_z*>(dZ_);
+    const bool left = orient == 'L';
+    const int mlog = 2 * maxitfac * n + n + 16;
+    if ((*info = c->zreserve(n, p, false, mlog)) != 0) return *info;
+    Timer tall, tph;
+    tall.start(c->stream);
+    if (left && p > 1) PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, p / 2), 64, 0, c->stream, dA_, 2 * n, n, 0, p);
+    tph.start(c->stream);
+    if ((*info = zhessenberg_dev(c, n, p, dA, c->ztau)) != 0) return *info;
+    const double ms_hess = tph.stop(c->stream);
+    tph.start(c->stream);
+    if (wantZ) {
+        if ((*info = zformq_dev(c, n, p, dA, c->ztau, dZ)) != 0) return *info;
+    }
+    PSD_LAUNCH(psd_ztriu, psd_dim3(n, p), 64, 0, c->stream, dA, n);
+    const double ms_formq = tph.stop(c->stream);
+    tph.start(c->stream);
+    psd_stats local;
+    memset(&local, 0, sizeof(local));
+    psd_stats* s = stats ? stats : &local;
+    int rc = zrun_iteration(c, n, p, dA, dZ, wantT, wantZ, maxitfac, alpha, beta, ascale, s, sweeplog, maxlog, info);
+    const double ms_iter = tph.stop(c->stream);
+    if (left && p > 1) {
+        PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, p / 2), 64, 0, c->stream, dA_, 2 * n, n, 0, p);
+        if (wantZ && p > 2)
+            PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, (p - 1) / 2), 64, 0, c->stream, dZ_, 2 * n, n, 1, p - 1);
+    }
+    s->ms_hess = ms_hess;
+    s->ms_formq = ms_formq;
+    s->ms_iter = ms_iter;
+    s->ms_total = tall.stop(c->stream);
+    s->bytes_hess = 2.0 * 16.0 * p * (5.0 / 6.0) * (double)n * n * n;
+    s->bytes_formq = wantZ ? 2.0 * 16.0 * p * (double)n * n * n / 3.0 : 0.0;
+    if (schurindex) *schurindex = left ? p : 1;
+    return rc;
+}
+
+int psd_z_pschur(psd_ctx* c, int n, int p, double* const* A, const uint8_t* S, char orient, int wantT, int wantZ,
+                 int maxitfac, double* const* Z, double* alpha, double* beta, int32_t* ascale, int* schurindex,
+                 psd_stats* stats, int32_t* sweeplog, int64_t maxlog, int* info) {
+    int dummy;
+    if (!info) info = &dummy;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!c) return *info = -1;
+    if ((*info = check_dims(n, p)) != 0) return *info;
+    if (!A) return *info = -4;
+    if (S)
+        for (int j = 0; j < p; ++j)
+            if (!S[j]) return *info = PSD_INFO_NOTIMPL;  // signed complex case (generalized.jl:138-146): next rounds
+    if (orient != 'R' && orient != 'L') return *info = -6;
+    if (wantZ && !Z) return *info = -10;
+    const int mlog = 2 * (maxitfac > 0 ? maxitfac : 1) * n + n + 16;
+    if ((*info = c->zreserve(n, p, true, mlog)) != 0) return *info;
+    const size_t nn = (size_t)n * n;
+    Timer tc;
+    tc.start(c->stream);
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->zH + j * nn, A[j], nn * 16, c->stream));
+    double ms_copy = tc.stop(c->stream);
+    psd_stats local;
+    psd_stats* s = stats ? stats : &local;
+    int rc = psd_z_pschur_dev(c, n, p, reinterpret_cast<double*>(c->zH), orient, wantT, wantZ, maxitfac,
+                              wantZ ? reinterpret_cast<double*>(c->zZ) : nullptr, alpha, beta, ascale, schurindex, s,
+                              sweeplog, maxlog, info);
+    if (rc < 0 || rc >= PSD_INFO_NOTIMPL) return rc;
+    tc.start(c->stream);
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(A[j], c->zH + j * nn, nn * 16, c->stream));
+    if (wantZ)
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(Z[j], c->zZ + j * nn, nn * 16, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    ms_copy += tc.stop(c->stream);
+    s->ms_copy = ms_copy;
+    return rc;
+}
+
+int psd_z_pschur_hess(psd_ctx* c, int n, int p, double* const* H, const uint8_t* S, double* const* Q, int wantT,
+                      int wantZ, int maxitfac, double* alpha, double* beta, int32_t* ascale, psd_stats* stats,
+                      int32_t* sweeplog, int64_t maxlog, int* info) {
+    int dummy;
+    if (!info) info = &dummy;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!c) return *info = -1;
+    if ((*info = check_dims(n, p)) != 0) return *info;
+    if (!H) return *info = -4;
+    if (S) {
+        if (!S[0]) return *info = -5;  // generalized.jl:182
+        for (int j = 0; j < p; ++j)
+            if (!S[j]) return *info = PSD_INFO_NOTIMPL;
+    }
+    if (wantZ && !Q) return *info = -6;
+    if (maxitfac < 1) return *info = -9;
+    const int mlog = 2 * maxitfac * n + n + 16;
+    if ((*info = c->zreserve(n, p, true, mlog)) != 0) return *info;
+    const size_t nn = (size_t)n * n;
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->zH + j * nn, H[j], nn * 16, c->stream));
+    if (wantZ)
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->zZ + j * nn, Q[j], nn * 16, c->stream));
+    psd_stats local;
+    memset(&local, 0, sizeof(local));
+    psd_stats* s = stats ? stats : &local;
+    Timer t;
+    t.start(c->stream);
+    int rc = zrun_iteration(c, n, p, c->zH, wantZ ? c->zZ : nullptr, wantT, wantZ, maxitfac, alpha, beta, ascale, s,
+                            sweeplog, maxlog, info);
+    s->ms_iter = s->ms_total = t.stop(c->stream);
+    if (rc < 0 || rc >= PSD_INFO_NOTIMPL) return rc;
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(H[j], c->zH + j * nn, nn * 16, c->stream));
+    if (wantZ)
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(Q[j], c->zZ + j * nn, nn * 16, c->stream));
     PSD_CHECK(psd_rt_sync(c->stream));
     return rc;
 }

@@ -244,13 +244,14 @@ PSD_KERNEL psd_triu(double* H, int n) {
     }
 }
 
-// reverse the order of `cnt` consecutive n x n blocks starting at block `first` (orientation 'L',
-// PSD.jl:127-131,1078-1092).  grid = (n, cnt/2)
-PSD_KERNEL psd_reverse_blocks(double* X, int n, int first, int cnt) {
+// reverse the order of `cnt` consecutive blocks (each `ncols` columns of `collen` doubles) starting at
+// block `first` (orientation 'L', PSD.jl:127-131,1078-1092).  grid = (ncols, cnt/2)
+PSD_KERNEL psd_reverse_blocks(double* X, int collen, int ncols, int first, int cnt) {
     const int c = PSD_BLOCK_X, s = PSD_BLOCK_Y;
-    double* a = X + (size_t)(first + s) * n * n + (size_t)c * n;
-    double* b = X + (size_t)(first + cnt - 1 - s) * n * n + (size_t)c * n;
-    PSD_PAR_FOR(r, n) {
+    const size_t blk = (size_t)collen * ncols;
+    double* a = X + (size_t)(first + s) * blk + (size_t)c * collen;
+    double* b = X + (size_t)(first + cnt - 1 - s) * blk + (size_t)c * collen;
+    PSD_PAR_FOR(r, collen) {
         const double t = a[r];
         a[r] = b[r];
         b[r] = t;

@@ -1,0 +1,37 @@
+"""CPU tier: complex device path executed by the TEST-ONLY simulation build (see test_hostsim_real.py)."""
+import pytest
+
+import engine_cases as ec
+
+
+@pytest.mark.parametrize("p", [1, 2, 5])
+def test_zphessenberg(sim_engine, p):
+    ec.case_zphessenberg(sim_engine, p)
+
+
+@pytest.mark.parametrize("lr", ["R", "L"])
+def test_zfull(sim_engine, lr):
+    ec.case_zfull(sim_engine, lr)
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 5])
+def test_zhess_ut(sim_engine, p):
+    ec.case_zhess_ut(sim_engine, p)
+
+
+@pytest.mark.parametrize("p", [1, 5])
+def test_zfast_paths(sim_engine, p):
+    ec.case_zfast_paths(sim_engine, p)
+
+
+@pytest.mark.parametrize("p", [5, 20])
+def test_zexpsplit(sim_engine, p):
+    ec.case_zexpsplit(sim_engine, p)
+
+
+def test_zedge(sim_engine):
+    ec.case_zedge(sim_engine)
+
+
+def test_zwindow_widths(sim_engine):
+    ec.case_zwindow_widths(sim_engine, [(40, 4, 32), (36, 12, 24), (30, 22, 20), (28, 34, 16), (26, 70, 10)])
