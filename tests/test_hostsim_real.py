@@ -45,7 +45,7 @@ def test_edge(sim_engine):
 
 
 def test_window_widths(sim_engine):
-    ec.case_window_widths(sim_engine, [(72, 6, 32), (60, 20, 24), (48, 40, 16), (40, 80, 12)])
+    ec.case_window_widths(sim_engine, [(72, 6, 32), (60, 20, 24), (48, 40, 20), (44, 60, 16), (40, 80, 12)])
 
 
 def test_pschur_hess(sim_engine):
