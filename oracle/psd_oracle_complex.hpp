@@ -5,6 +5,14 @@
 // single-shift periodic QZ iteration with signatures (generalized.jl:166-931, SLICOT MB03BZ type),
 // `_safeprod` (generalized.jl:939-976).  The one non-deterministic step of the reference — the
 // `rand` exceptional shift at generalized.jl:782 — is replaced by a fixed pair.
+//
+// Deliberate deviation (reference defect, measured with this restatement): when test 2/3 flags a
+// zero diagonal entry AND test 4 runs a controlled zero shift in the same iteration
+// (generalized.jl:328-448), the reference goes on to execute Case II/III (:453-740) with the
+// position found BEFORE the zero-shift pass moved the matrices; the result is an invalid
+// decomposition (O(1) residual; e.g. n=60, p=20, T_7[30,30]=0).  The reference's tests never reach
+// it (it needs p >= 20 or seven stalled iterations together with an exact zero).  Here Case II/III
+// is skipped in an iteration in which the zero shift ran; the zero is re-detected next iteration.
 #pragma once
 #include "psd_oracle_real.hpp"
 
@@ -443,7 +451,7 @@ inline int pschur_hess_z(int n, int p, std::vector<MatZ>& H, const std::vector<c
             }
         } while (false);
 
-        if (deflate_pos && !split1block && doqziter) {  // Case II (:453-566)
+        if (deflate_pos && doqziter) {  // Case II (:453-566); see the header for the doqziter guard
             if (log) log->add(2, jlo, ilast);
             for (int j = jlo; j <= jdeflate - 1; ++j) {
                 double c; cplx s, r;
@@ -531,7 +539,7 @@ inline int pschur_hess_z(int n, int p, std::vector<MatZ>& H, const std::vector<c
             }
             for (int j = ilast; j >= jdeflate + 2; --j) lmulG(Gtmp[j], H1, j - 1, ilastm);
             doqziter = false;
-        } else if (deflate_neg && !split1block && doqziter) {  // Case III (:568-740)
+        } else if (deflate_neg && doqziter) {  // Case III (:568-740)
             if (log) log->add(3, jlo, ilast);
             if (jdeflate > (ilast - jlo + 1) / 2.0) {  // chase the zero down
                 for (int j1 = jdeflate; j1 <= ilast - 1; ++j1) {

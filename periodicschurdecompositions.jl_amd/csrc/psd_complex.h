@@ -40,6 +40,20 @@ PSD_HD void psd_zgivens(psd_z f, psd_z g, double& cs, psd_z& sn, psd_z& r) {
     const double safmn2 = 1.0010415475915505e-146;
     const double safmx2 = 9.989595361011175e+145;
     double scale = fmax(zabs1(f), zabs1(g));
+    if (scale < safmx2 && scale > safmn2) {
+        // common case of zlartg (no rescaling, f not negligible against g), with the two square roots
+        // taken as independent rsqrt pairs: cs = |f|/N, r = f N/|f|, sn = f conj(g)/(|f| N), N^2 = |f|^2+|g|^2
+        const double f2 = zabs2(f), g2 = zabs2(g);
+        if (f2 > fmax(g2, 1.0) * safmin) {
+            double sd, rsd, sf, rsf;
+            psd_sqrt_pair_fast(f2 + g2, sd, rsd);
+            psd_sqrt_pair_fast(f2, sf, rsf);
+            cs = sf * rsd;
+            r = zscal(sd * rsf, f);
+            sn = zmul(zscal(rsf * rsd, f), zconj(g));
+            return;
+        }
+    }
     psd_z fs = f, gs = g;
     int count = 0;
     if (scale >= safmx2) {

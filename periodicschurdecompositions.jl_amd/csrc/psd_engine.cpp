@@ -747,6 +747,7 @@ int zrun_iteration(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, in
         stats->nsweeps = st.nsweeps;
         stats->nrqpass = st.nzshift;
         stats->ndefl1 = st.nsplit;
+        stats->ndefl2 = st.ncase2;
         stats->nwindows = st.nwindows;
         stats->nlog = st.nlog;
         for (int q = 0; q < 6; ++q) stats->step_cycles[q] = st.cyc[q];
@@ -774,8 +775,7 @@ int zrun_iteration(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, in
         const int64_t m = nl < maxlog_user ? nl : maxlog_user;
         for (int64_t q = 0; q < 3 * m; ++q) sweeplog[q] = hlog[q];
     }
-    if (st.info == -1000) *info = PSD_INFO_NOTIMPL;  // Case II
-    else *info = (st.info != 0) ? (PSD_INFO_NOCONV + st.info) : 0;
+    *info = (st.info != 0) ? (PSD_INFO_NOCONV + st.info) : 0;
     return *info;
 }
 

@@ -8,10 +8,10 @@
 // Same MI355X structure as the real path (psd_real_qr.h): one wavefront chases a diagonal window of
 // all p factors in LDS and emits per-factor rotation lists; a wide kernel applies them to the
 // off-window rows/columns of H_m, H_{m-1} and Z_m.  Implemented state: deflation tests 1 and 2
-// (:323-339), controlled zero shift (test 4, :356-448), 1x1 split with `_safeprod` (:741-762),
+// (:323-339), controlled zero shift (test 4, :356-448), Case II (a zero on the diagonal of a
+// triangular factor: two unshifted half-passes, :453-566), 1x1 split with `_safeprod` (:741-762),
 // single-shift sweep with the reference's shift chain (:770-852), final phase normalisation
-// (:860-908).  Case II (a zero on the diagonal of a triangular factor, :453-566) is detected and
-// reported as PSD_INFO_NOTIMPL in this round; Case III needs a negative signature.
+// (:860-908).  Case III needs a negative signature (not in this build).
 #pragma once
 #include "psd_complex.h"
 #include "psd_real_qr.h"
@@ -20,6 +20,8 @@ enum {
     PSD_ZPH_CHECK = 0,
     PSD_ZPH_SWEEP = 1,
     PSD_ZPH_ZSHIFT = 2,
+    PSD_ZPH_CASE2A = 3,
+    PSD_ZPH_CASE2B = 4,
     PSD_ZPH_DONE = 7
 };
 #define PSD_ZTR_CAP 32  // rotations per owner and window
@@ -36,9 +38,9 @@ struct psd_zapply_desc {
     int lc0, lc1;   // left role: columns of H_m
     int rr0, rr1;   // right role: rows of H_{m-1}
     int zr0, zr1;   // Z role
-    int defer_h1;   // zero-shift pass: right-updates of H_1 are deferred to psd_zq_defer
-    int defer_run;  // set with the last window of a zero-shift pass: run psd_zq_defer now
-    int djlo, djhi, drow0;  // deferred list covers positions djlo..djhi, rows drow0..
+    int defer_h1;   // 1: right-updates of H_1 are deferred (downward passes); 2: left-updates (upward pass)
+    int defer_run;  // set with the last window of such a pass: run psd_zq_defer now (1 right, 2 left)
+    int djlo, djhi, drow0;  // deferred list covers positions djlo..djhi; rows drow0.. / columns ..drow0
 };
 
 struct psd_zstate {
@@ -46,6 +48,7 @@ struct psd_zstate {
     int phase, info;
     int ilast, ifirst, ifirstm, ilastm, iiter, ziter, jiter, maxit;
     int jlo, kcur, zflag;
+    int ldeflate, jdeflate, ncase2, pend2;
     int nsweeps, nzshift, nsplit, nwindows, nlog, maxlog;
     double c0;
     psd_z s0;
@@ -255,6 +258,21 @@ PSD_D void psd_zsafeprod(const psd_zparams& P, const psd_zstate& st, int idx, ps
     }
 }
 
+PSD_D void psd_zq_start_case2(const psd_zparams& P, psd_zstate& st) {
+    st.pend2 = 0;
+    st.ncase2 += 1;
+    psd_zlog(P, st, 2, st.jlo, st.ilast);
+    if (st.jdeflate > st.jlo) {
+        st.phase = PSD_ZPH_CASE2A;
+        st.kcur = st.jlo;
+    } else if (st.jdeflate < st.ilast) {
+        st.phase = PSD_ZPH_CASE2B;
+        st.kcur = st.ilast;
+    } else {
+        st.phase = PSD_ZPH_CHECK;
+    }
+}
+
 // generalized.jl:302-449,741-806: deflation tests, split, zero-shift decision, shift chain
 PSD_D void psd_zq_check(const psd_zparams& P, psd_zstate& st, double* red, int* redi) {
     const int n = st.n, p = st.p;
@@ -338,40 +356,57 @@ PSD_D void psd_zq_check(const psd_zparams& P, psd_zstate& st, double* red, int* 
         }
         return;  // next jiter
     }
-    // Test 2 (:280-299,328-339): zero on the diagonal of a triangular factor -> Case II
+    // Test 2 (:280-299,328-339): zero on the diagonal of a triangular factor -> Case II.
+    // First factor l (ascending) with a hit, and for it the largest j.
+    st.jlo = jlo;
     {
+        const int wd = ilast - jlo + 1;
         PSD_PAR_FOR(t, NT) {
-            int hit = 0;
-            for (int q = t; q < (p - 1) * (ilast - jlo + 1); q += NT) {
-                const int l = 2 + q / (ilast - jlo + 1), j = jlo + q % (ilast - jlo + 1);
+            int key = 0x7fffffff;
+            for (int q = t; q < (p - 1) * wd; q += NT) {
+                const int l = 2 + q / wd, j = jlo + q % wd;
                 const psd_mat<psd_z> Hl = psd_zfac(P, n, l);
                 double tol;
                 if (j == ilast) tol = zabs(Hl(j - 1, j));
                 else if (j == jlo) tol = zabs(Hl(j, j + 1));
                 else tol = zabs(Hl(j - 1, j)) + zabs(Hl(j, j + 1));
-                tol = fmax(st.ulp * tol, st.smlnum);  // (tol == 0 fallback: smlnum)
-                if (zabs(Hl(j, j)) <= tol) hit = 1;
+                tol = fmax(st.ulp * tol, st.smlnum);  // (tol == 0 fallback of the reference: smlnum floor)
+                if (zabs(Hl(j, j)) <= tol) {
+                    const int k = l * (n + 2) + (n + 1 - j);
+                    if (k < key) key = k;
+                }
             }
-            redi[t] = hit;
+            redi[t] = key;
         }
         PSD_SYNC();
-        int hit = 0;
-        for (int t = 0; t < NT; ++t) hit |= redi[t];
+        int key = 0x7fffffff;
+        for (int t = 0; t < NT; ++t)
+            if (redi[t] < key) key = redi[t];
         PSD_SYNC();
-        if (hit) {  // Case II (:453-566) is not implemented in this round
-            st.info = -1000;
-            st.phase = PSD_ZPH_DONE;
-            return;
+        if (key != 0x7fffffff) {  // Case II (:453-566)
+            const int l = key / (n + 2), j = (n + 1) - key % (n + 2);
+            const psd_mat<psd_z> Hl = psd_zfac(P, n, l);
+            PSD_ONE { Hl(j, j) = zmk(0.0, 0.0); }
+            PSD_SYNC();
+            st.ldeflate = l;
+            st.jdeflate = j;
+            st.pend2 = 1;
         }
     }
-    st.jlo = jlo;
-    // Test 4 (:356): controlled zero shift
+    // Test 4 (:356): controlled zero shift.  The reference would still run Case II afterwards with the
+    // now stale position (:446-453) and produce an invalid decomposition; the zero is re-detected in
+    // the next iteration instead.
     if (st.ziter >= 7 || st.ziter < 0) {
+        st.pend2 = 0;
         st.phase = PSD_ZPH_ZSHIFT;
         st.kcur = jlo;
         st.zflag = 0;
         st.nzshift += 1;
         psd_zlog(P, st, 4, jlo, ilast);
+        return;
+    }
+    if (st.pend2) {
+        psd_zq_start_case2(P, st);
         return;
     }
     // QZ step (:763-806)
@@ -462,12 +497,16 @@ PSD_D void psd_zq_sweep_window(const psd_zparams& P, psd_zstate& st, psd_z* ldsz
     if (ke >= ilast - 1) st.phase = PSD_ZPH_CHECK;
 }
 
-// generalized.jl:356-448: one window of the controlled zero-shift pass (positions kcur..)
-PSD_D void psd_zq_zshift_window(const psd_zparams& P, psd_zstate& st, psd_z* ldsz, int* lcnt) {
+// One window of a downward unshifted pass (positions kcur..): the controlled zero shift
+// (generalized.jl:356-448, `plain` = false, positions jlo..ilast-1, with the in-pass deflation
+// test) or the first half of Case II (:460-510, `plain` = true, positions jlo..jdeflate-1; the
+// rotations past the zero diagonal entry are exact identities, so the full chain is run).
+PSD_D void psd_zq_zshift_window(const psd_zparams& P, psd_zstate& st, psd_z* ldsz, int* lcnt, bool plain) {
     const int n = st.n, p = st.p, jlo = st.jlo, ilast = st.ilast, ifirstm = st.ifirstm, ilastm = st.ilastm;
     const int nb = st.W - 2;
     const int ks = st.kcur;
-    const int ke = (ks + nb - 1 < ilast - 1) ? (ks + nb - 1) : (ilast - 1);
+    const int jend = plain ? (st.jdeflate - 1) : (ilast - 1);
+    const int ke = (ks + nb - 1 < jend) ? (ks + nb - 1) : jend;
     psd_zwin w;
     w.b = ldsz;
     w.W = st.W;
@@ -490,7 +529,7 @@ PSD_D void psd_zq_zshift_window(const psd_zparams& P, psd_zstate& st, psd_z* lds
         psd_zwin_left(w, 1, j, c, s, j + 1, ilastm);
         psd_zrecord(P, lcnt, 1, j, c, s);
         for (int l = p; l >= 2; --l) {
-            if (!ziszero(s)) {
+            if (plain || !ziszero(s)) {
                 psd_zwin_right(w, l, j, c, s, ifirstm, j + 1);
                 double tol = zabs(w.at(l, j, j)) + zabs(w.at(l, j + 1, j + 1));
                 if (tol == 0) {  // opnorm(view(Hl, jlo:j+1, jlo:j+1), 1) restricted to the window
@@ -502,7 +541,7 @@ PSD_D void psd_zq_zshift_window(const psd_zparams& P, psd_zstate& st, psd_z* lds
                 }
                 tol = fmax(st.ulp * tol, st.smlnum);
                 const psd_z sub = w.at(l, j + 1, j);
-                if (zabs(sub) <= tol) {
+                if (!plain && zabs(sub) <= tol) {
                     c = 1.0;
                     s = zmk(0.0, 0.0);
                     PSD_WAVE_SYNC();
@@ -533,14 +572,87 @@ PSD_D void psd_zq_zshift_window(const psd_zparams& P, psd_zstate& st, psd_z* lds
         if (ziszero(s)) st.zflag = 1;
     }
     psd_zwin_store(P, w, n, p);
-    const bool last = ke >= ilast - 1;
-    psd_zdesc_write(P, st, lcnt, ks, ke + 1, w.be + 1, ilastm, ifirstm, w.bs - 1, 1, last ? 1 : 0, jlo, ilast - 1);
+    const bool last = ke >= jend;
+    psd_zdesc_write(P, st, lcnt, ks, ke + 1, w.be + 1, ilastm, ifirstm, w.bs - 1, 1, last ? 1 : 0, jlo, jend);
     st.nwindows += 1;
     st.kcur = ke + 1;
     if (last) {
-        st.ziter = st.zflag ? 1 : 0;
-        st.phase = PSD_ZPH_CHECK;
+        if (plain) {
+            if (st.jdeflate < ilast) {
+                st.phase = PSD_ZPH_CASE2B;
+                st.kcur = ilast;
+            } else {
+                st.phase = PSD_ZPH_CHECK;
+            }
+        } else {
+            st.ziter = st.zflag ? 1 : 0;
+            st.phase = PSD_ZPH_CHECK;
+            if (st.pend2) psd_zq_start_case2(P, st);
+        }
     }
+}
+
+// generalized.jl:512-564: one window of the second (upward) half of Case II: positions j = kcur
+// downwards to jdeflate+1; rotations are generated by annihilating H[j,j-1] from the right, the chain
+// runs H_1 -> H_2 -> ... -> H_p, and the left side of H_1 is deferred to psd_zq_defer.
+// A rotation generated at H_l is owned by m = l+1 (cyclic): right on H_l = H_{m-1}, Z_m, left on H_m.
+PSD_D void psd_zq_case2b_window(const psd_zparams& P, psd_zstate& st, psd_z* ldsz, int* lcnt) {
+    const int n = st.n, p = st.p, ilast = st.ilast, ifirstm = st.ifirstm, ilastm = st.ilastm;
+    const int jend = st.jdeflate + 1;
+    const int nb = st.W - 2;
+    const int ks = st.kcur;
+    const int ke = (ks - nb + 1 > jend) ? (ks - nb + 1) : jend;
+    psd_zwin w;
+    w.b = ldsz;
+    w.W = st.W;
+    w.ld = st.W + 1;
+    w.bsz = st.W * (st.W + 1);
+    w.bs = ke - 1;
+    w.be = ks;
+    PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
+    psd_zwin_load(P, w, n, p);
+    for (int j = ks; j >= ke; --j) {
+        double c;
+        psd_z s, r;
+        psd_zgivens(w.at(1, j, j), w.at(1, j, j - 1), c, s, r);
+        PSD_WAVE_SYNC();
+        PSD_ONE {
+            w.at(1, j, j) = r;
+            w.at(1, j, j - 1) = zmk(0.0, 0.0);
+        }
+        PSD_WAVE_SYNC();
+        psd_z sr = zneg(s);  // Gtmp[j] = Givens(j-1, j, c, -s)
+        psd_zwin_right(w, 1, j - 1, c, sr, ifirstm, j - 1);
+        psd_zrecord(P, lcnt, (p >= 2) ? 2 : 1, j - 1, c, sr);
+        for (int l = 2; l <= p; ++l) {
+            psd_zwin_left(w, l, j - 1, c, sr, j - 1, ilastm);
+            psd_zgivens(w.at(l, j, j), w.at(l, j, j - 1), c, s, r);
+            PSD_WAVE_SYNC();
+            PSD_ONE {
+                w.at(l, j, j) = r;
+                w.at(l, j, j - 1) = zmk(0.0, 0.0);
+            }
+            PSD_WAVE_SYNC();
+            sr = zneg(s);
+            psd_zwin_right(w, l, j - 1, c, sr, ifirstm, j - 1);
+            psd_zrecord(P, lcnt, (l == p) ? 1 : (l + 1), j - 1, c, sr);
+        }
+        PSD_ONE {
+            psd_ztr tr;
+            tr.pos = j - 1;
+            tr.pad = 0;
+            tr.c = c;
+            tr.s = sr;
+            P.dG[j] = tr;
+        }
+    }
+    psd_zwin_store(P, w, n, p);
+    const bool last = ke <= jend;
+    // deferred left side of H_1 covers j = ilast..jdeflate+2 (:561-564)
+    psd_zdesc_write(P, st, lcnt, w.bs, w.be, w.be + 1, ilastm, ifirstm, w.bs - 1, 2, last ? 2 : 0, st.jdeflate + 2, ilast);
+    st.nwindows += 1;
+    st.kcur = ke - 1;
+    if (last) st.phase = PSD_ZPH_CHECK;
 }
 
 PSD_KERNEL_B(PSD_STEP_NT) psd_zq_step(psd_zparams P) {
@@ -570,7 +682,13 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_zq_step(psd_zparams P) {
             psd_zq_sweep_window(P, st, ldsz, lcnt);
             emitted = true;
         } else if (st.phase == PSD_ZPH_ZSHIFT) {
-            psd_zq_zshift_window(P, st, ldsz, lcnt);
+            psd_zq_zshift_window(P, st, ldsz, lcnt, false);
+            emitted = true;
+        } else if (st.phase == PSD_ZPH_CASE2A) {
+            psd_zq_zshift_window(P, st, ldsz, lcnt, true);
+            emitted = true;
+        } else if (st.phase == PSD_ZPH_CASE2B) {
+            psd_zq_case2b_window(P, st, ldsz, lcnt);
             emitted = true;
         } else {
             st.phase = PSD_ZPH_DONE;
@@ -598,6 +716,7 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply(psd_zparams P, int n, int p) {
     psd_ztr* ltr = (psd_ztr*)psd_lds;
     psd_z* tile = (psd_z*)(psd_lds + sizeof(psd_ztr) * PSD_ZTR_CAP);
     if (role == 0) {
+        if (d.defer_h1 == 2 && m == 1) return;  // H_1's left side is deferred (upward pass of Case II)
         const int c0 = d.lc0 + PSD_BLOCK_X * T;
         if (c0 > d.lc1) return;
         const int nc = (d.lc1 - c0 + 1 < T) ? (d.lc1 - c0 + 1) : T;
@@ -626,7 +745,7 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply(psd_zparams P, int n, int p) {
         }
     } else {
         const int jm = (role == 1) ? ((m == 1) ? p : (m - 1)) : m;
-        if (role == 1 && d.defer_h1 && jm == 1) return;  // H_1's right side is deferred (zero-shift pass)
+        if (role == 1 && d.defer_h1 == 1 && jm == 1) return;  // H_1's right side is deferred (downward passes)
         const int lo = (role == 1) ? d.rr0 : d.zr0;
         const int hi = (role == 1) ? d.rr1 : d.zr1;
         const int r0 = lo + PSD_BLOCK_X * T;
@@ -665,20 +784,43 @@ PSD_KERNEL psd_zq_defer(psd_zparams P, int n) {
     if (!d.active || !d.defer_run) return;
     const psd_mat<psd_z> H1 = psd_mat<psd_z>{P.H, n};
     const int NT = PSD_NTHREADS;
-    const int rbase = d.drow0 + PSD_BLOCK_X * NT;
-    PSD_PAR_FOR(t, NT) {
-        const int r = rbase + t;
-        if (r <= d.djhi + 1) {
-            int j = (r - 1 > d.djlo) ? (r - 1) : d.djlo;
-            psd_z a1 = H1(r, j);
-            for (; j <= d.djhi; ++j) {
-                const psd_ztr g = P.dG[j];
-                psd_z a2 = H1(r, j + 1);
-                psd_zrot_right_adj(g.c, g.s, a1, a2);
-                H1(r, j) = a1;
-                a1 = a2;
+    if (d.defer_run == 1) {
+        const int rbase = d.drow0 + PSD_BLOCK_X * NT;
+        PSD_PAR_FOR(t, NT) {
+            const int r = rbase + t;
+            if (r <= d.djhi + 1 && d.djhi >= d.djlo) {
+                int j = (r - 1 > d.djlo) ? (r - 1) : d.djlo;
+                psd_z a1 = H1(r, j);
+                for (; j <= d.djhi; ++j) {
+                    const psd_ztr g = P.dG[j];
+                    psd_z a2 = H1(r, j + 1);
+                    psd_zrot_right_adj(g.c, g.s, a1, a2);
+                    H1(r, j) = a1;
+                    a1 = a2;
+                }
+                H1(r, d.djhi + 1) = a1;
             }
-            H1(r, d.djhi + 1) = a1;
+        }
+    } else {
+        // generalized.jl:561-564: for j = djhi:-1:djlo  lmul!(G_j, view(H1, :, (j-1):ilastm)), rows (j-1, j);
+        // one thread per column c (>= djlo-1), rotations j <= c+1, streamed up the column
+        const int cbase = (d.djlo - 1) + PSD_BLOCK_X * NT;
+        PSD_PAR_FOR(t, NT) {
+            const int c = cbase + t;
+            if (c <= d.lc1 && d.djhi >= d.djlo) {
+                int j = (c + 1 < d.djhi) ? (c + 1) : d.djhi;
+                if (j >= d.djlo) {
+                    psd_z a2 = H1(j, c);
+                    for (; j >= d.djlo; --j) {
+                        const psd_ztr g = P.dG[j];
+                        psd_z a1 = H1(j - 1, c);
+                        psd_zrot_left(g.c, g.s, a1, a2);
+                        H1(j, c) = a2;
+                        a2 = a1;
+                    }
+                    H1(d.djlo - 1, c) = a2;
+                }
+            }
         }
     }
 }
@@ -697,6 +839,7 @@ PSD_KERNEL psd_zq_init(psd_zparams P, int n, int p, int wantT, int wantZ, int W,
         st.ziter = (p >= 20) ? -1 : 0;
         st.jiter = 0; st.maxit = maxitfac * n;
         st.jlo = 1; st.kcur = 0; st.zflag = 0;
+        st.ldeflate = st.jdeflate = -1; st.ncase2 = 0; st.pend2 = 0;
         st.nsweeps = st.nzshift = st.nsplit = st.nwindows = st.nlog = 0;
         st.maxlog = maxlog;
         st.c0 = 1.0; st.s0 = zmk(0.0, 0.0);

@@ -227,6 +227,27 @@ def case_zhess_ut(eng, p):
     pt.gpschur_check(Arev, [True] * p, pr)
 
 
+def case_zholes(eng):
+    """test/generalized.jl:235-244,154-163: exact zero on the diagonal of a triangular factor (deflation Case II),
+    literal positions from the reference's tests plus multi-window variants incl. p >= 20 (zero shift first,
+    generalized.jl:199)."""
+    cases = [(5, 2, 2, 3), (5, 3, 2, 3), (5, 5, 2, 3), (5, 5, 4, 3), (5, 5, 5, 1), (5, 5, 3, 5), (32, 4, 2, 3),
+             (60, 20, 7, 30), (60, 20, 20, 2), (60, 20, 2, 59), (70, 3, 3, 35)]
+    for (n, p, fac, idx) in cases:
+        A = zhess_ut(n, p, 80 + p + n)
+        if n > 32:
+            A = [np.asfortranarray(a + 2 * np.eye(n)) if k > 0 else a for k, a in enumerate(A)]
+        A[fac - 1][idx - 1, idx - 1] = 0
+        ps = eng.zpschur_hess_(A[0].copy(order="F"), [a.copy(order="F") for a in A[1:]], [True] * p)
+        pt.gpschur_check(A, [True] * p, ps, tol=100 * max(1, n / 32))
+        po = pt.oracle_zpschur_hess(A[0], A[1:], [True] * p)
+        assert (po.sweeplog[:, 0] == 2).sum() == ps.stats.ndefl2
+        if p < 20:
+            assert ps.stats.ndefl2 >= 1
+        fin = np.isfinite(po.values)
+        assert pt.match_eigs(po.values[fin], ps.values[fin]) < 1e-10 * abs(po.values[fin]).max()
+
+
 def case_zfast_paths(eng, p):
     # test/generalized.jl:268-303
     n, tol = 5, 20
@@ -254,11 +275,10 @@ def case_zexpsplit(eng, p):
 def case_zedge(eng):
     import psd_amd
 
-    A = zhess_ut(5, 3, 91)
-    A[1][2, 2] = 0  # hole -> deflation Case II: reported, not silently mishandled
     try:
-        eng.zpschur_hess_(A[0].copy(order="F"), [a.copy(order="F") for a in A[1:]], [True] * 3)
-        raise AssertionError("Case II must be reported as not implemented in this build")
+        A = zhess_ut(5, 3, 91)
+        eng.zpschur_hess_(A[0].copy(order="F"), [a.copy(order="F") for a in A[1:]], [True, False, True])
+        raise AssertionError("negative signatures are not in this build")
     except psd_amd.NotImplementedPSD:
         pass
     try:

@@ -34,6 +34,10 @@ def test_zexpsplit(gpu_engine, p):
     ec.case_zexpsplit(gpu_engine, p)
 
 
+def test_zholes(gpu_engine):
+    ec.case_zholes(gpu_engine)
+
+
 def test_zedge(gpu_engine):
     ec.case_zedge(gpu_engine)
 

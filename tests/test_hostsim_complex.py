@@ -29,6 +29,10 @@ def test_zexpsplit(sim_engine, p):
     ec.case_zexpsplit(sim_engine, p)
 
 
+def test_zholes(sim_engine):
+    ec.case_zholes(sim_engine)
+
+
 def test_zedge(sim_engine):
     ec.case_zedge(sim_engine)
 
