@@ -3,6 +3,7 @@
 // ctypes.  All matrix arguments are packed [p][n][n], each n x n block column-major (ld = n),
 // factor j (1-based, user order) at offset (j-1)*n*n.
 #include "psd_oracle_complex.hpp"
+#include "psd_oracle_ord.hpp"
 
 #include <chrono>
 
@@ -201,6 +202,53 @@ int psdo_z_pschur(int n, int p, double* A, char orient, int wantT, int wantZ, in
         phase_ms[2] = ms(t2, t3);
     }
     return info;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ordschur!(P, select) for ComplexF64 (ordschur.jl:11-73).  T/Z [p][n][n] in user order (T1 at `schurindex`),
+// mutated in place; values recomputed from the diagonals (ordschur.jl:97-120) as alpha/beta*2^scale.
+int psdo_z_ordschur(int n, int p, double* Tz, double* Zz, char orient, int schurindex, const uint8_t* select, int wantZ,
+                    double* alpha, double* beta, int32_t* ascale, int64_t* nswaps) {
+    std::vector<MatT<cplx>> Tu(p + 1), Zu(p + 1);
+    for (int l = 1; l <= p; ++l) {
+        Tu[l] = MatT<cplx>{reinterpret_cast<cplx*>(Tz) + (size_t)(l - 1) * n * n, n};
+        Zu[l] = MatT<cplx>{Zz ? reinterpret_cast<cplx*>(Zz) + (size_t)(l - 1) * n * n : nullptr, n};
+    }
+    int info = ordschur1x1<cplx>(n, p, Tu, Zu, wantZ != 0 && Zz, orient, schurindex, select, nswaps);
+    if (info != 0) return info;
+    std::vector<char> Sv(p + 1, 1);
+    std::vector<cplx> v(p);
+    cplx* al = reinterpret_cast<cplx*>(alpha);
+    for (int j = 1; j <= n; ++j) {  // T1 first, then the others in order (ordschur.jl:104-110)
+        int q = 0;
+        for (int l = 1; l <= p; ++l)
+            if (l != schurindex) v[q++] = Tu[l](j, j);
+        int sc;
+        safeprod(Sv, p, Tu[schurindex](j, j), v.data(), al[j - 1], beta[j - 1], sc);
+        ascale[j - 1] = sc;
+    }
+    return 0;
+}
+
+// real ordschur! restricted to decompositions whose T1 is triangular (all eigenvalues real; rordschur.jl:3-132
+// then reduces to 1x1 swaps): returns -77 if a 2x2 block is present.
+int psdo_d_ordschur_real1x1(int n, int p, double* Td, double* Zd, char orient, int schurindex, const uint8_t* select,
+                            int wantZ, double* wr, int64_t* nswaps) {
+    std::vector<MatT<double>> Tu(p + 1), Zu(p + 1);
+    for (int l = 1; l <= p; ++l) {
+        Tu[l] = MatT<double>{Td + (size_t)(l - 1) * n * n, n};
+        Zu[l] = MatT<double>{Zd ? Zd + (size_t)(l - 1) * n * n : nullptr, n};
+    }
+    for (int j = 1; j < n; ++j)
+        if (Tu[schurindex](j + 1, j) != 0.0) return -77;
+    int info = ordschur1x1<double>(n, p, Tu, Zu, wantZ != 0 && Zd, orient, schurindex, select, nswaps);
+    if (info != 0) return info;
+    for (int j = 1; j <= n; ++j) {
+        double v = 1.0;
+        for (int l = 1; l <= p; ++l) v *= Tu[l](j, j);
+        wr[j - 1] = v;
+    }
+    return 0;
 }
 
 }  // extern "C"

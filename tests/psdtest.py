@@ -132,6 +132,8 @@ def oracle_lib():
     lib.psdo_z_phessenberg.argtypes = [C.c_int, C.c_int, dp, dp, dp]
     lib.psdo_z_pschur.argtypes = [C.c_int, C.c_int, dp, C.c_char, C.c_int, C.c_int, C.c_int, dp, dp, dp, i32p,
                                   C.POINTER(C.c_int), i64p, i32p, C.c_int64, i64p, dp]
+    lib.psdo_z_ordschur.argtypes = [C.c_int, C.c_int, dp, dp, C.c_char, C.c_int, u8p, C.c_int, dp, dp, i32p, i64p]
+    lib.psdo_d_ordschur_real1x1.argtypes = [C.c_int, C.c_int, dp, dp, C.c_char, C.c_int, u8p, C.c_int, dp, i64p]
     _oracle = lib
     return lib
 
@@ -312,6 +314,58 @@ def rand_uniform_zfactors(n, p, seed):
     re = rand_uniform_factors(n, p, seed)
     im = rand_uniform_factors(n, p, seed + 100003)
     return [np.asfortranarray(a + 1j * b) for a, b in zip(re, im)]
+
+
+def oracle_ordschur(ps, select, wantZ=True):
+    """CPU restatement of ordschur!(P, select) (ordschur.jl:11-73; real: rordschur.jl:3-132 for 1x1 blocks only).
+    Returns a new PSD record (inputs are not modified) and the number of adjacent swaps."""
+    lib = oracle_lib()
+    p = len(ps.Ts)
+    n = ps.Ts[0].shape[0]
+    cplx = np.iscomplexobj(ps.Ts[0])
+    dt = np.complex128 if cplx else np.float64
+    T = pack(ps.Ts, dt)
+    Z = pack(ps.Z, dt) if wantZ else None
+    sel = (C.c_uint8 * n)(*[1 if x else 0 for x in select])
+    nsw = C.c_int64(0)
+    if cplx:
+        alpha = np.zeros(n, dtype=np.complex128)
+        beta = np.zeros(n)
+        sc = np.zeros(n, dtype=np.int32)
+        info = lib.psdo_z_ordschur(n, p, _zp(T), _zp(Z) if wantZ else None, ps.orientation.encode()[0:1], ps.schurindex,
+                                   sel, int(wantZ), _zp(alpha), _dp(beta), sc.ctypes.data_as(C.POINTER(C.c_int32)),
+                                   C.byref(nsw))
+        vals = gvalues(alpha, beta, sc)
+    else:
+        wr = np.zeros(n)
+        info = lib.psdo_d_ordschur_real1x1(n, p, _dp(T), _dp(Z) if wantZ else None, ps.orientation.encode()[0:1],
+                                           ps.schurindex, sel, int(wantZ), _dp(wr), C.byref(nsw))
+        vals = wr + 0j
+    out = PSD(unpack(T), unpack(Z) if wantZ else [], vals, ps.orientation, ps.schurindex, info)
+    out.nswaps = nsw.value
+    return out
+
+
+def ord_test_factors(n, p, seed, dtype=np.float64):
+    """test/ordschur.jl:4-20: constructed spectrum lambda_j = 4^j (diag mu_j = 2^(2j/p) in every factor, 0.01*U(0,1)
+    strict upper part), hidden by a cycle of orthogonal similarity transformations."""
+    cplx = np.issubdtype(dtype, np.complexfloating)
+    A = []
+    for l in range(p):
+        u = rand_uniform_zfactors(n, 1, seed + 11 * l)[0] if cplx else rand_uniform_factors(n, 1, seed + 11 * l)[0]
+        a = 0.01 * np.triu(u)
+        for j in range(n):
+            a[j, j] = 2.0 ** (2 * (j + 1) / p)
+        A.append(np.asfortranarray(a.astype(dtype)))
+    for l in range(p):
+        g = randn_counter(seed + 999, l, n * n).reshape(n, n)
+        if cplx:
+            g = g + 1j * randn_counter(seed + 998, l, n * n).reshape(n, n)
+        q, _ = np.linalg.qr(g)
+        A[l] = np.asfortranarray(q @ A[l])
+        l1 = (l + 1) % p
+        A[l1] = np.asfortranarray(A[l1] @ q.conj().T)
+    return A
 
 
 def oracle_phessenberg(As):
