@@ -120,6 +120,18 @@ int psd_z_pschur_dev(psd_ctx* ctx, int n, int p, double* dA, char orient, int wa
                      double* dZ, double* alpha, double* beta, int32_t* ascale, int* schurindex, psd_stats* stats,
                      int32_t* sweeplog, int64_t maxlog, int* info);
 
+/* LinearAlgebra.ordschur!(P::PeriodicSchur{ComplexF64}, select; wantZ) — ordschur.jl:11-73: move the selected
+ * eigenvalues (select[j] != 0) and their subspace to the top by adjacent swaps (sylswap.jl:542-635).
+ * T: p pointers, the full user-order factor list with T1 at position `schurindex`; Z: p pointers (or NULL with
+ * !wantZ); both updated in place.  Supported alignments: ('R', 1) and ('L', p) — what pschur! returns.
+ * Eigenvalues are recomputed from the diagonals (ordschur.jl:97-120) in scaled form.
+ * info: 0; PSD_INFO_ILLCOND + j  IllConditionedException(j) (ordschur.jl:61); PSD_INFO_SINGULAR (utils.jl:128). */
+#define PSD_INFO_ILLCOND 2000
+#define PSD_INFO_SINGULAR 3000
+int psd_z_ordschur(psd_ctx* ctx, int n, int p, double* const* T, double* const* Z, char orient, int schurindex,
+                   const uint8_t* select, int wantZ, double* alpha, double* beta, int32_t* ascale, psd_stats* stats,
+                   int* info);
+
 #ifdef __cplusplus
 }
 #endif

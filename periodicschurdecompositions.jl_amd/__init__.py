@@ -35,6 +35,18 @@ class ConvergenceError(Exception):
         self.level = level
 
 
+class IllConditionedException(Exception):
+    """IllConditionedException(info) (src/PeriodicSchurDecompositions.jl:26-28)."""
+
+    def __init__(self, info):
+        super().__init__(f"IllConditionedException({info})")
+        self.info = info
+
+
+class SingularException(Exception):
+    """LinearAlgebra.SingularException (src/utils.jl:123-131)."""
+
+
 class DimensionMismatch(ValueError):
     """DimensionMismatch (src/PeriodicSchurDecompositions.jl:216-222)."""
 
@@ -151,6 +163,8 @@ class Engine:
                                           C.c_int, C.c_int, dp, dp, i32p, C.POINTER(Stats), i32p, C.c_int64, ip]
         lib.psd_z_pschur_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p, dp, dp, i32p, ip, C.POINTER(Stats), i32p, C.c_int64, ip]
+        lib.psd_z_ordschur.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, dpp, C.c_char, C.c_int, C.POINTER(C.c_uint8),
+                                       C.c_int, dp, dp, i32p, C.POINTER(Stats), ip]
         self.ctx = C.c_void_p()
         rc = lib.psd_create(C.byref(self.ctx), device)
         if rc != 0:
@@ -372,6 +386,44 @@ class Engine:
             Ts = [H[p - l] for l in range(1, p)] + [H[0]]
             return PeriodicSchur(Ts, Zr, lam, "L", p, st, slog)
         return PeriodicSchur(H, Z, lam, "R", 1, st, slog)
+
+    def ordschur_(self, P, select, wantZ=True):
+        """LinearAlgebra.ordschur!(P, select; wantZ) — src/ordschur.jl:11-73 (ComplexF64).  Mutates and returns P."""
+        n = P.Ts[0].shape[0]
+        p = len(P.Ts)
+        if len(select) != n:
+            raise DimensionMismatch("select must have one entry per eigenvalue")
+        if not np.iscomplexobj(P.Ts[0]):
+            raise NotImplementedPSD("real ordschur! (src/rordschur.jl) is not in this build")
+        if P.schurindex not in (1, p):
+            raise ValueError("only implemented for schurindex in (1,p)")  # src/ordschur.jl:32
+        self._as_work(P.Ts, np.complex128)
+        wantZ = wantZ and len(P.Z) > 0
+        if wantZ:
+            self._as_work(P.Z, np.complex128)
+        sel = (C.c_uint8 * n)(*[1 if x else 0 for x in select])
+        alpha = np.zeros(n, dtype=np.complex128)
+        beta = np.zeros(n)
+        sc = np.zeros(n, dtype=np.int32)
+        st = Stats()
+        info = C.c_int(0)
+        dp = C.POINTER(C.c_double)
+        self.lib.psd_z_ordschur(self.ctx, n, p, self._ptrs(P.Ts), self._ptrs(P.Z) if wantZ else None,
+                                P.orientation.encode(), P.schurindex, sel, int(wantZ),
+                                alpha.view(np.float64).ctypes.data_as(dp), beta.ctypes.data_as(dp),
+                                sc.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(st), C.byref(info))
+        iv = info.value
+        if iv == 3000:
+            raise SingularException()
+        if 2000 <= iv < 3000:
+            raise IllConditionedException(iv - 2000)
+        self._raise(iv)
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            P.values = alpha / beta * np.exp2(sc.astype(np.float64))
+        if isinstance(P, GeneralizedPeriodicSchur):
+            P.alpha, P.beta, P.alphascale = alpha, beta, sc
+        P.stats = st
+        return P
 
     def pschur_dev(self, dA_ptr, n, p, lr="R", dZ_ptr=None, wantT=True, maxitfac=30):
         """Device-resident pschur!: dA_ptr / dZ_ptr are device addresses of [p][n][n] column-major blocks."""

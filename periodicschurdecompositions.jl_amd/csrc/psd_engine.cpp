@@ -5,6 +5,7 @@
 #include "psd_real_qr.h"
 #include "psd_zhess.h"
 #include "psd_zqz.h"
+#include "psd_zord.h"
 
 #include "../../include/psd_mi355x.h"
 
@@ -100,6 +101,9 @@ struct psd_ctx {
     psd_zstate* zst = nullptr;
     psd_zapply_desc* zdesc = nullptr;
     psd_ztr *ztr = nullptr, *zdG = nullptr;
+    psd_ostate* ost = nullptr;
+    unsigned char* osel = nullptr;
+    size_t ostep_lds_set = 0;
 
     void release() {
         void* ptrs[] = {dH, dZ, tau, vbuf, hdiag, hsub, hsup, Pd, Pe, Pf, hnorms, wr, wi, st, desc, tr, cnt, log};
@@ -113,7 +117,9 @@ struct psd_ctx {
     }
 
     void zrelease() {
-        void* ptrs[] = {zH, zZ, ztau, zvbuf, zalpha, zbeta, zascale, zcnt, zlog, zst, zdesc, ztr, zdG};
+        void* ptrs[] = {zH, zZ, ztau, zvbuf, zalpha, zbeta, zascale, zcnt, zlog, zst, zdesc, ztr, zdG, ost, osel};
+        ost = nullptr;
+        osel = nullptr;
         for (void* q : ptrs)
             if (q) psd_rt_free(q);
         zH = zZ = ztau = zvbuf = zalpha = nullptr;
@@ -145,6 +151,8 @@ struct psd_ctx {
         PSD_ALLOC(zdesc, psd_zapply_desc, 1);
         PSD_ALLOC(ztr, psd_ztr, (size_t)p * PSD_ZTR_CAP);
         PSD_ALLOC(zdG, psd_ztr, n + 8);
+        PSD_ALLOC(ost, psd_ostate, 1);
+        PSD_ALLOC(osel, unsigned char, n + 16);
 #undef PSD_ALLOC
         zcap_n = n;
         zcap_p = p;
@@ -930,6 +938,140 @@ int psd_z_pschur_hess(psd_ctx* c, int n, int p, double* const* H, const uint8_t*
     for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(H[j], c->zH + j * nn, nn * 16, c->stream));
     if (wantZ)
         for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(Q[j], c->zZ + j * nn, nn * 16, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    return rc;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// ordschur! (complex)
+namespace {
+
+size_t ord_lds_bytes(int p, int W) {
+    size_t b = (size_t)p * W * (W + 1) * 16 + (size_t)13 * p * 16 + ((size_t)p + 2) * 8 + (size_t)p * 4 + 64;
+    return (b + 15) & ~(size_t)15;
+}
+int choose_window_ord(int p) {
+    const int cand[] = {32, 24, 20, 16, 12, 10, 8, 6, 4};
+    for (int W : cand)
+        if (ord_lds_bytes(p, W) <= 155 * 1024) return W;
+    return 0;
+}
+
+// device arrays in internal right order; select on host
+int zordschur_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t* select, int wantZ, double* alpha,
+                  double* beta, int32_t* ascale, psd_stats* stats, int* info) {
+    const int W = choose_window_ord(p);
+    if (W == 0) return *info = PSD_INFO_NOTIMPL;
+    PSD_CHECK(psd_rt_h2d(c->osel, select, (size_t)n, c->stream));
+    psd_oparams O;
+    O.z.H = dH;
+    O.z.Z = wantZ ? dZ : nullptr;
+    O.z.st = c->zst;
+    O.z.desc = c->zdesc;
+    O.z.tr = c->ztr;
+    O.z.cnt = c->zcnt;
+    O.z.dG = c->zdG;
+    O.z.alpha = c->zalpha;
+    O.z.beta = c->zbeta;
+    O.z.ascale = c->zascale;
+    O.z.log = c->zlog;
+    O.st = c->ost;
+    O.select = c->osel;
+    const size_t lds_step = ord_lds_bytes(p, W);
+#ifndef PSD_HOSTSIM
+    if (lds_step > c->ostep_lds_set) {
+        PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_zord_step),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
+        c->ostep_lds_set = lds_step;
+    }
+#endif
+    PSD_LAUNCH(psd_zord_init, psd_dim3(1), 64, 0, c->stream, O, n, p, wantZ, W);
+    const size_t lds_apply = sizeof(psd_ztr) * PSD_ZTR_CAP + (size_t)32 * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
+    const int tiles = (n + PSD_ZAPPLY_NT - 1) / PSD_ZAPPLY_NT;
+    psd_ostate hst;
+    memset(&hst, 0, sizeof(hst));
+    long long launched = 0;
+    const long long cap = (long long)n * ((long long)n / (W > 1 ? W - 1 : 1) + 2) + 1024;
+    Timer t;
+    t.start(c->stream);
+    for (;;) {
+        for (int b = 0; b < 32; ++b) {
+            PSD_LAUNCH(psd_zord_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, O);
+            PSD_LAUNCH(psd_zq_apply, psd_dim3(tiles, p, 3), PSD_ZAPPLY_NT, lds_apply, c->stream, O.z, n, p);
+            ++launched;
+        }
+        PSD_CHECK(psd_rt_d2h(&hst, c->ost, sizeof(hst), c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+        if (hst.phase == PSD_OPH_DONE) break;
+        if (launched > cap) return *info = PSD_INFO_RUNTIME + 0xfffd;
+    }
+    if (hst.info == 0) {
+        PSD_LAUNCH(psd_zord_values, psd_dim3((n + 255) / 256), 256, 0, c->stream, O.z, n, p);
+        PSD_CHECK(psd_rt_d2h(alpha, c->zalpha, sizeof(psd_z) * n, c->stream));
+        PSD_CHECK(psd_rt_d2h(beta, c->zbeta, sizeof(double) * n, c->stream));
+        std::vector<int> hsc(n, 0);
+        PSD_CHECK(psd_rt_d2h(hsc.data(), c->zascale, sizeof(int) * n, c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+        for (int q = 0; q < n; ++q) ascale[q] = hsc[q];
+    }
+    const double ms = t.stop(c->stream);
+    PSD_CHECK(psd_rt_last_error());
+    if (stats) {
+        stats->ms_iter = stats->ms_total = ms;
+        stats->nsweeps = hst.nswaps;  // adjacent swaps performed
+        stats->nwindows = hst.nwindows;
+        stats->nlaunch_step = (int32_t)launched;
+        stats->window = W;
+    }
+    return *info = hst.info;  // 0, 2000+j (IllConditionedException(j)), 3000 (SingularException)
+}
+
+}  // namespace
+
+extern "C" {
+
+int psd_z_ordschur(psd_ctx* c, int n, int p, double* const* T, double* const* Z, char orient, int schurindex,
+                   const uint8_t* select, int wantZ, double* alpha, double* beta, int32_t* ascale, psd_stats* stats,
+                   int* info) {
+    int dummy;
+    if (!info) info = &dummy;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!c) return *info = -1;
+    if ((*info = check_dims(n, p)) != 0) return *info;
+    if (!T) return *info = -4;
+    if (wantZ && !Z) return *info = -5;
+    if (orient != 'R' && orient != 'L') return *info = -6;
+    if (!select) return *info = -8;
+    // alignments produced by pschur!: ('R', 1) and ('L', p); the reference also accepts ('R', p) and ('L', 1)
+    // (ordschur.jl:26-33) — not in this build
+    if (!((orient == 'R' && schurindex == 1) || (orient == 'L' && schurindex == p))) {
+        if (schurindex != 1 && schurindex != p) return *info = -7;  // ArgumentError, ordschur.jl:32
+        return *info = PSD_INFO_NOTIMPL;
+    }
+    if ((*info = c->zreserve(n, p, true, 16)) != 0) return *info;
+    const size_t nn = (size_t)n * n;
+    const bool left = orient == 'L';
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->zH + j * nn, T[j], nn * 16, c->stream));
+    if (wantZ)
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->zZ + j * nn, Z[j], nn * 16, c->stream));
+    double* dA_ = reinterpret_cast<double*>(c->zH);
+    double* dZ_ = reinterpret_cast<double*>(c->zZ);
+    auto flip = [&]() {  // user 'L' order <-> internal right order (as in psd_z_pschur_dev)
+        if (left && p > 1) {
+            PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, p / 2), 64, 0, c->stream, dA_, 2 * n, n, 0, p);
+            if (wantZ && p > 2)
+                PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, (p - 1) / 2), 64, 0, c->stream, dZ_, 2 * n, n, 1, p - 1);
+        }
+    };
+    flip();
+    int rc = zordschur_dev(c, n, p, c->zH, c->zZ, select, wantZ, alpha, beta, ascale, stats, info);
+    flip();
+    if (rc < 0 || rc >= PSD_INFO_NOTIMPL) return rc;
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(T[j], c->zH + j * nn, nn * 16, c->stream));
+    if (wantZ)
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(Z[j], c->zZ + j * nn, nn * 16, c->stream));
     PSD_CHECK(psd_rt_sync(c->stream));
     return rc;
 }

@@ -320,3 +320,98 @@ def case_zwindow_widths(eng, sizes):
                 assert ps.stats.nrqpass >= 1  # controlled zero shift (generalized.jl:199,356)
             for T in ps.Ts[:ps.schurindex - 1] + ps.Ts[ps.schurindex:]:
                 assert np.all(np.diag(T).imag == 0) and np.all(np.diag(T).real >= 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# ordschur! (complex): ordschur.jl:11-73, sylswap.jl:542-635
+def _clone(ps):
+    import psd_amd
+
+    return psd_amd.PeriodicSchur([t.copy(order="F") for t in ps.Ts], [z.copy(order="F") for z in ps.Z],
+                                 ps.values.copy(), ps.orientation, ps.schurindex)
+
+
+def case_zordschur_reference(eng, p, lr):
+    """test/ordschur.jl:1-55 for ComplexF64: constructed spectrum 4^j, select the 2 smallest / 2 largest."""
+    n, nsel = 7, 2
+    A = pt.ord_test_factors(n, p, seed=4000 + p, dtype=np.complex128)
+    if lr == "R":
+        A = A[::-1]
+    ps0 = eng.pschur(A, lr)
+    lam0 = ps0.values.copy()
+    assert np.allclose(np.sort(np.abs(lam0)), [4.0 ** (j + 1) for j in range(n)], rtol=1e-8)
+    for which in ("smallest", "largest"):
+        idx = np.argsort(np.abs(lam0))
+        if which == "largest":
+            idx = idx[::-1]
+        select = np.zeros(n, dtype=bool)
+        select[idx[:nsel]] = True
+        ps1 = eng.ordschur_(_clone(ps0), select)
+        pt.pschur_check(A, ps1, check_lam=False, real=False)
+        for j in range(nsel):
+            assert np.any(np.isclose(ps1.values[:nsel], lam0[idx[j]], rtol=1e-8))
+        po = pt.oracle_ordschur(pt.PSD(ps0.Ts, ps0.Z, lam0, ps0.orientation, ps0.schurindex), select)
+        assert ps1.stats.nsweeps == po.nswaps
+        assert np.allclose(ps1.values, po.values, rtol=1e-10, atol=0)
+
+
+def case_zordschur_windows(eng, sizes):
+    """Random selections that need many swaps spanning several windows, every window width, both orientations,
+    with and without Z."""
+    for (n, p) in sizes:
+        for lr in "RL":
+            A = pt.bench_factors(n, p, seed=70 + n + p, dtype=np.complex128)
+            ps0 = eng.pschur(A, lr)
+            lam0 = ps0.values.copy()
+            rng = pt.randn_counter(n + p, 5, n)
+            select = rng > 0.3
+            select[-1] = True
+            select[0] = False
+            ps1 = eng.ordschur_(_clone(ps0), select)
+            assert ps1.stats.nsweeps > 0
+            ok, err = pt.checkpsd(ps1, A, thresh=100 * np.sqrt(max(n / 32, 1)))
+            assert ok, (n, p, lr, err)
+            m = int(select.sum())
+            sc = abs(lam0).max()
+            assert pt.match_eigs(lam0[select], ps1.values[:m]) < 1e-9 * sc
+            assert pt.match_eigs(lam0[~select], ps1.values[m:]) < 1e-9 * sc
+            # order inside the selected / unselected groups is preserved (stable bubbling)
+            assert np.allclose(ps1.values[:m], lam0[select], rtol=1e-7, atol=1e-9 * sc)
+            assert np.allclose(ps1.values[m:], lam0[~select], rtol=1e-7, atol=1e-9 * sc)
+            po = pt.oracle_ordschur(pt.PSD(ps0.Ts, ps0.Z, lam0, ps0.orientation, ps0.schurindex), select)
+            assert ps1.stats.nsweeps == po.nswaps
+            # wantZ = false leaves Z untouched and gives the same T
+            ps2 = eng.ordschur_(_clone(ps0), select, wantZ=False)
+            assert all(np.array_equal(a, b) for a, b in zip(ps2.Z, ps0.Z))
+            assert max(np.abs(a - b).max() for a, b in zip(ps2.Ts, ps1.Ts)) < 1e-12 * sc
+
+
+def case_zordschur_edge(eng):
+    import psd_amd
+
+    A = pt.bench_factors(6, 3, seed=3, dtype=np.complex128)
+    ps0 = eng.pschur(A, "R")
+    same = eng.ordschur_(_clone(ps0), np.zeros(6, dtype=bool))  # nothing selected: no-op
+    assert same.stats.nsweeps == 0 and all(np.array_equal(a, b) for a, b in zip(same.Ts, ps0.Ts))
+    allsel = eng.ordschur_(_clone(ps0), np.ones(6, dtype=bool))
+    assert allsel.stats.nsweeps == 0
+    try:
+        eng.ordschur_(_clone(ps0), np.ones(5, dtype=bool))
+        raise AssertionError("wrong select length must be rejected")
+    except psd_amd.DimensionMismatch:
+        pass
+    try:
+        eng.ordschur_(eng.pschur(pt.bench_factors(6, 3, seed=3), "R"), np.ones(6, dtype=bool))
+        raise AssertionError("real ordschur! is not in this build")
+    except psd_amd.NotImplementedPSD:
+        pass
+    # two equal eigenvalues cannot be swapped: the periodic Sylvester system is singular / the swap is rejected
+    n, p = 4, 2
+    T = [np.asfortranarray(np.triu(np.ones((n, n))).astype(np.complex128)) for _ in range(p)]
+    Z = [np.asfortranarray(np.eye(n, dtype=np.complex128)) for _ in range(p)]
+    P = psd_amd.PeriodicSchur(T, Z, np.ones(n, dtype=complex), "R", 1)
+    try:
+        eng.ordschur_(P, np.array([False, True, False, False]))
+        raise AssertionError("expected SingularException / IllConditionedException")
+    except (psd_amd.SingularException, psd_amd.IllConditionedException):
+        pass

@@ -85,3 +85,17 @@ def test_zdevice_resident_entry(gpu_engine):
     Zs = pt.unpack(dZ.cpu().numpy())
     ps = pt.GPSD([True] * p, Ts, Zs, alpha, beta, sc, "R", si.value)
     pt.gpschur_check(As, [True] * p, ps)
+
+
+@pytest.mark.parametrize("p", [5, 1, 2])
+@pytest.mark.parametrize("lr", ["L", "R"])
+def test_zordschur_reference(gpu_engine, p, lr):
+    ec.case_zordschur_reference(gpu_engine, p, lr)
+
+
+def test_zordschur_windows(gpu_engine):
+    ec.case_zordschur_windows(gpu_engine, [(48, 3), (44, 12), (40, 22), (36, 34), (30, 70)])
+
+
+def test_zordschur_edge(gpu_engine):
+    ec.case_zordschur_edge(gpu_engine)

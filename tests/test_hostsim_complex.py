@@ -39,3 +39,17 @@ def test_zedge(sim_engine):
 
 def test_zwindow_widths(sim_engine):
     ec.case_zwindow_widths(sim_engine, [(40, 4, 32), (36, 12, 24), (30, 22, 20), (28, 34, 16), (26, 70, 10)])
+
+
+@pytest.mark.parametrize("p", [5, 1, 2])
+@pytest.mark.parametrize("lr", ["L", "R"])
+def test_zordschur_reference(sim_engine, p, lr):
+    ec.case_zordschur_reference(sim_engine, p, lr)
+
+
+def test_zordschur_windows(sim_engine):
+    ec.case_zordschur_windows(sim_engine, [(48, 3), (44, 12), (40, 22), (36, 34), (30, 70)])
+
+
+def test_zordschur_edge(sim_engine):
+    ec.case_zordschur_edge(sim_engine)
