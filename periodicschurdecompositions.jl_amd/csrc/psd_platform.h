@@ -49,6 +49,7 @@ extern psd_simctx psd_sim;  // the block currently being simulated (serial)
 #define PSD_LANEVAR_REF(type, name) type* name
 #define PSD_LV(name) name[t]
 #define PSD_BCAST(name, lane) (name[lane])
+#define PSD_BCASTZ(name, lane) (name[lane])
 // 1/x and (sqrt(s), 1/sqrt(s)) for arguments known to be normal and far from the range limits
 static inline double psd_rcp_fast(double x) { return 1.0 / x; }
 static inline void psd_sqrt_pair_fast(double s, double& g, double& rg) {
@@ -124,6 +125,7 @@ typedef dim3 psd_dim3;
 #define PSD_LANEVAR_REF(type, name) type name
 #define PSD_LV(name) name
 #define PSD_BCAST(name, lane) psd_readlane_f64(name, lane)
+#define PSD_BCASTZ(name, lane) zmk(psd_readlane_f64((name).re, lane), psd_readlane_f64((name).im, lane))
 __device__ __forceinline__ double psd_readlane_f64(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);

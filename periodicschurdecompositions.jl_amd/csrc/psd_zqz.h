@@ -437,6 +437,60 @@ PSD_D void psd_zq_check(const psd_zparams& P, psd_zstate& st, double* red, int* 
     psd_zlog(P, st, 0, st.ifirst, ilast);
 }
 
+// Hot micro-step of the complex sweep (generalized.jl:823-845, S[l] true), factor l >= 2 at position j:
+// incoming rotation G' from the right on columns (j, j+1) of H_l (lanes = rows r0..j+1), new rotation
+// from (H_l[j,j], H_l[j+1,j]), applied from the left to rows (j, j+1) (lanes = columns j+1..c1max).
+// One pass: operands loaded once, the chain values (f, g and the 2 corner entries of column j+1)
+// travel by v_readlane, one wave-level sync.  (c, s) in: incoming rotation; out: the new one.
+PSD_D void psd_zq_micro(const psd_zparams& P, const psd_zwin& w, int l, int j, int nr, int nl,
+                        PSD_LANEVAR_REF(int, lane_off), PSD_LANEVAR_REF(int, lane_str), double& c, psd_z& s,
+                        int slot) {
+    const int cnt = nr + nl;
+    const int boff = (l - 1) * w.bsz;
+    PSD_LANEVAR(psd_z, x1);
+    PSD_LANEVAR(psd_z, x2);
+    PSD_PAR_ONCE(t, cnt) {
+        const psd_z* q = w.b + (boff + PSD_LV(lane_off));
+        PSD_LV(x1) = q[0];
+        PSD_LV(x2) = q[PSD_LV(lane_str)];
+        if (t < nr) psd_zrot_right_adj(c, s, PSD_LV(x1), PSD_LV(x2));
+    }
+    // rows j and j+1 are the last two row-lanes
+    const psd_z f = PSD_BCASTZ(x1, nr - 2), g = PSD_BCASTZ(x1, nr - 1);
+    const psd_z top = PSD_BCASTZ(x2, nr - 2), bot = PSD_BCASTZ(x2, nr - 1);
+    psd_z r;
+    psd_zgivens(f, g, c, s, r);
+    PSD_PAR_ONCE(t, cnt) {
+        psd_z* q = w.b + (boff + PSD_LV(lane_off));
+        if (t < nr) {
+            if (t >= nr - 2) {  // rows j, j+1: column j becomes (r, 0); their column j+1 belongs to the left pass
+                q[0] = (t == nr - 2) ? r : zmk(0.0, 0.0);
+            } else {
+                q[0] = PSD_LV(x1);
+                q[PSD_LV(lane_str)] = PSD_LV(x2);
+            }
+        } else {
+            psd_z a1 = PSD_LV(x1), a2 = PSD_LV(x2);
+            if (t == nr) {  // column j+1: entries already touched by the right pass
+                a1 = top;
+                a2 = bot;
+            }
+            psd_zrot_left(c, s, a1, a2);
+            q[0] = a1;
+            q[PSD_LV(lane_str)] = a2;
+        }
+        if (t == 0) {
+            psd_ztr tr;
+            tr.pos = j;
+            tr.pad = 0;
+            tr.c = c;
+            tr.s = s;
+            if (slot < PSD_ZTR_CAP) P.tr[(size_t)(l - 1) * PSD_ZTR_CAP + slot] = tr;
+        }
+    }
+    PSD_WAVE_SYNC();
+}
+
 // generalized.jl:808-852: one window of the single-shift sweep (positions kcur..kcur+nb-1)
 PSD_D void psd_zq_sweep_window(const psd_zparams& P, psd_zstate& st, psd_z* ldsz, int* lcnt) {
     const int n = st.n, p = st.p, ifirst = st.ifirst, ilast = st.ilast, ifirstm = st.ifirstm, ilastm = st.ilastm;
@@ -471,20 +525,35 @@ PSD_D void psd_zq_sweep_window(const psd_zparams& P, psd_zstate& st, psd_z* ldsz
         }
         psd_zwin_left(w, 1, j, c, s, j, ilastm);
         psd_zrecord(P, lcnt, 1, j, c, s);
-        for (int l = p; l >= 2; --l) {
-            psd_zwin_right(w, l, j, c, s, ifirstm, j + 1);
-            psd_zgivens(w.at(l, j, j), w.at(l, j + 1, j), c, s, r);
-            PSD_WAVE_SYNC();
-            PSD_ONE {
-                w.at(l, j, j) = r;
-                w.at(l, j + 1, j) = zmk(0.0, 0.0);
+        if (p >= 2) {
+            // lane roles for the factors l = p..2 at this position: [0,nr) rows r0..j+1 (columns j, j+1),
+            // [nr,nr+nl) columns j+1..c1max (rows j, j+1)
+            const int r0 = (w.bs > ifirstm) ? w.bs : ifirstm;
+            const int c1max = (w.be < ilastm) ? w.be : ilastm;
+            const int nr = j + 1 - r0 + 1, nl = c1max - j;
+            PSD_LANEVAR(int, lane_off);
+            PSD_LANEVAR(int, lane_str);
+            PSD_PAR_ONCE(t, nr + nl) {
+                if (t < nr) {
+                    PSD_LV(lane_off) = (j - w.bs) * w.ld + (r0 + t - w.bs);
+                    PSD_LV(lane_str) = w.ld;
+                } else {
+                    PSD_LV(lane_off) = (j + 1 + (t - nr) - w.bs) * w.ld + (j - w.bs);
+                    PSD_LV(lane_str) = 1;
+                }
             }
-            PSD_WAVE_SYNC();
-            psd_zwin_left(w, l, j, c, s, j + 1, ilastm);
-            psd_zrecord(P, lcnt, l, j, c, s);
+            const int slot = j - ks;
+            for (int l = p; l >= 2; --l) psd_zq_micro(P, w, l, j, nr, nl, lane_off, lane_str, c, s, slot);
         }
         const int itmp = (j + 2 < ilastm) ? (j + 2) : ilastm;
         psd_zwin_right(w, 1, j, c, s, ifirstm, itmp);
+    }
+    if (p >= 2) {
+        PSD_WAVE_SYNC();
+        PSD_PAR_FOR(m, p) {
+            if (m >= 1) lcnt[m] = ke - ks + 1;
+        }
+        PSD_WAVE_SYNC();
     }
     const long long tc2 = psd_clock();
     psd_zwin_store(P, w, n, p);

@@ -1,0 +1,51 @@
+// Standalone driver for profiler runs (rocprofv3 --pmc crashes under the python/torch harness on this image).
+// Usage: psd_profile [n] [p] [repeat]  — solves pschur!(A,:R) on A_j = I + 0.5 G_j/sqrt(n) through the C ABI.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <dlfcn.h>
+#include <vector>
+
+#include "../include/psd_mi355x.h"
+
+static uint64_t sm64(uint64_t& s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static double gauss(uint64_t& s) {
+    const double u1 = ((sm64(s) >> 11) + 0.5) / 9007199254740992.0, u2 = ((sm64(s) >> 11) + 0.5) / 9007199254740992.0;
+    return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+}
+
+int main(int argc, char** argv) {
+    const int n = argc > 1 ? atoi(argv[1]) : 512, p = argc > 2 ? atoi(argv[2]) : 16, rep = argc > 3 ? atoi(argv[3]) : 1;
+    const char* path = getenv("LIBPSD_MI355X");
+    void* h = dlopen(path ? path : "periodicschurdecompositions.jl_amd/libpsd_mi355x.so", RTLD_NOW);
+    if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
+    auto create = (int (*)(psd_ctx**, int))dlsym(h, "psd_create");
+    auto destroy = (int (*)(psd_ctx*))dlsym(h, "psd_destroy");
+    auto pschur = (decltype(&psd_d_pschur))dlsym(h, "psd_d_pschur");
+    psd_ctx* ctx = nullptr;
+    if (create(&ctx, 0) != 0) { fprintf(stderr, "psd_create failed\n"); return 3; }
+    const size_t nn = (size_t)n * n;
+    std::vector<std::vector<double>> A0(p, std::vector<double>(nn)), A(p), Z(p, std::vector<double>(nn));
+    uint64_t s = 1236;
+    for (int j = 0; j < p; ++j)
+        for (size_t q = 0; q < nn; ++q) A0[j][q] = 0.5 * gauss(s) / std::sqrt((double)n) + ((q % (n + 1)) == 0 ? 1.0 : 0.0);
+    std::vector<double> wr(n), wi(n);
+    for (int r = 0; r < rep; ++r) {
+        std::vector<double*> Ap(p), Zp(p);
+        for (int j = 0; j < p; ++j) { A[j] = A0[j]; Ap[j] = A[j].data(); Zp[j] = Z[j].data(); }
+        psd_stats st; int si = 0, info = 0;
+        pschur(ctx, n, p, Ap.data(), nullptr, 'R', 1, 1, 30, Zp.data(), wr.data(), wi.data(), &si, &st, nullptr, 0, &info);
+        printf("{\"n\": %d, \"p\": %d, \"info\": %d, \"sweeps\": %d, \"windows\": %d, \"launches\": %d, \"ms_total\": %.3f, "
+               "\"ms_iter\": %.3f, \"ms_hess\": %.3f, \"bytes_sweeps\": %.0f, \"bytes_hess\": %.0f, \"bytes_formq\": %.0f}\n",
+               n, p, info, st.nsweeps, st.nwindows, st.nlaunch_step, st.ms_total, st.ms_iter, st.ms_hess, st.bytes_sweeps,
+               st.bytes_hess, st.bytes_formq);
+    }
+    destroy(ctx);
+    return 0;
+}
