@@ -4,6 +4,7 @@
 // factor j (1-based, user order) at offset (j-1)*n*n.
 #include "psd_oracle_complex.hpp"
 #include "psd_oracle_ord.hpp"
+#include "psd_oracle_rord.hpp"
 
 #include <chrono>
 
@@ -249,6 +250,23 @@ int psdo_d_ordschur_real1x1(int n, int p, double* Td, double* Zd, char orient, i
         wr[j - 1] = v;
     }
     return 0;
+}
+
+// ordschur!(P, select) for Float64 (rordschur.jl:3-132) with 1x1 and 2x2 blocks.
+int psdo_d_ordschur(int n, int p, double* Td, double* Zd, char orient, int schurindex, const uint8_t* select, int wantZ,
+                    double* wr, double* wi, int64_t* nswaps) {
+    std::vector<MatT<double>> Tu(p + 1), Zu(p + 1);
+    for (int l = 1; l <= p; ++l) {
+        Tu[l] = MatT<double>{Td + (size_t)(l - 1) * n * n, n};
+        Zu[l] = MatT<double>{Zd ? Zd + (size_t)(l - 1) * n * n : nullptr, n};
+    }
+    std::vector<cplx> lam(n);
+    int info = rordschur(n, p, Tu, Zu, wantZ != 0 && Zd, orient, schurindex, select, lam.data(), nswaps);
+    for (int q = 0; q < n; ++q) {
+        wr[q] = lam[q].real();
+        wi[q] = lam[q].imag();
+    }
+    return info;
 }
 
 }  // extern "C"

@@ -134,6 +134,7 @@ def oracle_lib():
                                   C.POINTER(C.c_int), i64p, i32p, C.c_int64, i64p, dp]
     lib.psdo_z_ordschur.argtypes = [C.c_int, C.c_int, dp, dp, C.c_char, C.c_int, u8p, C.c_int, dp, dp, i32p, i64p]
     lib.psdo_d_ordschur_real1x1.argtypes = [C.c_int, C.c_int, dp, dp, C.c_char, C.c_int, u8p, C.c_int, dp, i64p]
+    lib.psdo_d_ordschur.argtypes = [C.c_int, C.c_int, dp, dp, C.c_char, C.c_int, u8p, C.c_int, dp, dp, i64p]
     _oracle = lib
     return lib
 
@@ -338,9 +339,10 @@ def oracle_ordschur(ps, select, wantZ=True):
         vals = gvalues(alpha, beta, sc)
     else:
         wr = np.zeros(n)
-        info = lib.psdo_d_ordschur_real1x1(n, p, _dp(T), _dp(Z) if wantZ else None, ps.orientation.encode()[0:1],
-                                           ps.schurindex, sel, int(wantZ), _dp(wr), C.byref(nsw))
-        vals = wr + 0j
+        wi = np.zeros(n)
+        info = lib.psdo_d_ordschur(n, p, _dp(T), _dp(Z) if wantZ else None, ps.orientation.encode()[0:1],
+                                   ps.schurindex, sel, int(wantZ), _dp(wr), _dp(wi), C.byref(nsw))
+        vals = wr + 1j * wi
     out = PSD(unpack(T), unpack(Z) if wantZ else [], vals, ps.orientation, ps.schurindex, info)
     out.nswaps = nsw.value
     return out
@@ -366,6 +368,41 @@ def ord_test_factors(n, p, seed, dtype=np.float64):
         l1 = (l + 1) % p
         A[l1] = np.asfortranarray(A[l1] @ q.conj().T)
     return A
+
+
+def mkrps(n, p, jcs, seed, nnfac=1e-2):
+    """test/ordschur.jl:62-125 `mkrps` (alt = false, tri = false): a left-oriented real periodic Schur decomposition
+    with schurindex p and conjugate pairs 4^jj (1 +- i) in the (1-based) rows jcs, jcs+1.  Returns (PSD, As)."""
+    T1 = np.triu(nnfac * rand_uniform_factors(n, 1, seed)[0])
+    Ts = [np.triu(nnfac * rand_uniform_factors(n, 1, seed + 1 + l)[0]) for l in range(p - 1)]
+    lam = np.zeros(n, dtype=complex)
+    jj = 0
+    mu = 0.0
+    for j in range(1, n + 1):
+        if (j - 1) in jcs:
+            T1[j - 1, j - 2] = mu
+            T1[j - 2, j - 1] = -mu
+            lam[j - 1] = 2.0 ** (2 * jj) * (1 - 1j)
+            lam[j - 2] = 2.0 ** (2 * jj) * (1 + 1j)
+            for l in range(p - 1):
+                Ts[l][j - 2, j - 1] = 0
+        else:
+            jj += 1
+            mu = 2.0 ** (2 * jj / p)
+            lam[j - 1] = 2.0 ** (2 * jj)
+        T1[j - 1, j - 1] = mu
+        for l in range(p - 1):
+            Ts[l][j - 1, j - 1] = mu
+    q1, _ = np.linalg.qr(randn_counter(seed + 500, 0, n * n).reshape(n, n))
+    q2, _ = np.linalg.qr(randn_counter(seed + 500, 1, n * n).reshape(n, n))
+    Zs = [q1] + [q2.copy() for _ in range(p - 1)]
+    if p > 1:
+        As = [Zs[l + 1] @ Ts[l] @ Zs[l].T for l in range(p - 1)] + [Zs[0] @ T1 @ Zs[p - 1].T]
+    else:
+        As = [Zs[0] @ T1 @ Zs[0].T]
+    full = [np.asfortranarray(t) for t in Ts] + [np.asfortranarray(T1)]
+    ps = PSD(full, [np.asfortranarray(z) for z in Zs], lam, "L", p)
+    return ps, [np.asfortranarray(a) for a in As]
 
 
 def oracle_phessenberg(As):

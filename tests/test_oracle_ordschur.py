@@ -55,10 +55,38 @@ def test_ordschur_complex_random_select(built):
     assert pt.match_eigs(ps0.values[~select], ps1.values[m:]) < 1e-9 * abs(ps0.values).max()
 
 
-def test_ordschur_real_rejects_2x2(built):
-    A = pt.bench_factors(8, 3, seed=5)
-    ps0 = pt.oracle_pschur(A, "R")
-    if np.any(ps0.values.imag != 0):
-        sel = np.zeros(8, dtype=bool)
-        sel[-1] = True
-        assert pt.oracle_ordschur(ps0, sel).info == -77
+# test/ordschur.jl:127-164 "conjugate pair(s)": constructed real PSD with 2x2 blocks, literal selections
+@pytest.mark.parametrize("p", [5, 1])
+@pytest.mark.parametrize("selset", [[1, 2, 5], [1, 3, 4], [1, 2, 6, 7]])
+def test_ordschur_conjugate_pairs(built, p, selset):
+    n = 7
+    ps0, A = pt.mkrps(n, p, [3, 6], seed=900 + p)
+    pt.pschur_check(A, ps0, check_lam=False)
+    lam0 = ps0.values
+    select = np.zeros(n, dtype=bool)
+    select[[j - 1 for j in selset]] = True
+    ps1 = pt.oracle_ordschur(ps0, select)
+    assert ps1.info == 0
+    pt.pschur_check(A, ps1, check_lam=False, tol=20000 if p == 1 else 32)
+    nsel = len(selset)
+    for j in selset:
+        assert np.any(np.isclose(ps1.values[:nsel], lam0[j - 1], rtol=1e-8)), (lam0[j - 1], ps1.values[:nsel])
+    assert pt.match_eigs(lam0, ps1.values) < 1e-8 * abs(lam0).max()
+
+
+def test_ordschur_real_random(built):
+    """pschur! result with a generic mix of real eigenvalues and conjugate pairs; select by modulus (conjugates closed),
+    as BASELINE config 5 does."""
+    for (n, p, lr) in [(12, 3, "R"), (16, 4, "L"), (30, 2, "R")]:
+        A = pt.bench_factors(n, p, seed=n + p)
+        ps0 = pt.oracle_pschur(A, lr)
+        lam0 = ps0.values
+        thr = np.sort(np.abs(lam0))[n // 2]
+        select = np.abs(lam0) <= thr  # the smaller half sits at the bottom after pschur!
+        ps1 = pt.oracle_ordschur(ps0, select)
+        assert ps1.info == 0 and ps1.nswaps > 0
+        pt.pschur_check(A, ps1, check_lam=False, tol=64)
+        m = int(select.sum())
+        sc = abs(lam0).max()
+        assert pt.match_eigs(lam0[select], ps1.values[:m]) < 1e-8 * sc
+        assert pt.match_eigs(lam0[~select], ps1.values[m:]) < 1e-8 * sc
