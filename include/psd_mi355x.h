@@ -132,6 +132,12 @@ int psd_z_ordschur(psd_ctx* ctx, int n, int p, double* const* T, double* const* 
                    const uint8_t* select, int wantZ, double* alpha, double* beta, int32_t* ascale, psd_stats* stats,
                    int* info);
 
+/* LinearAlgebra.ordschur!(P::PeriodicSchur{Float64}, select; wantZ) — rordschur.jl:3-132 (1x1 and 2x2 blocks;
+ * a selected member of a conjugate pair takes its partner along, :46-75).  Same conventions as psd_z_ordschur;
+ * eigenvalues are returned as wr + i*wi (ordschur.jl:122-204). */
+int psd_d_ordschur(psd_ctx* ctx, int n, int p, double* const* T, double* const* Z, char orient, int schurindex,
+                   const uint8_t* select, int wantZ, double* wr, double* wi, psd_stats* stats, int* info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -165,6 +165,8 @@ class Engine:
                                          C.c_void_p, dp, dp, i32p, ip, C.POINTER(Stats), i32p, C.c_int64, ip]
         lib.psd_z_ordschur.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, dpp, C.c_char, C.c_int, C.POINTER(C.c_uint8),
                                        C.c_int, dp, dp, i32p, C.POINTER(Stats), ip]
+        lib.psd_d_ordschur.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, dpp, C.c_char, C.c_int, C.POINTER(C.c_uint8),
+                                       C.c_int, dp, dp, C.POINTER(Stats), ip]
         self.ctx = C.c_void_p()
         rc = lib.psd_create(C.byref(self.ctx), device)
         if rc != 0:
@@ -394,7 +396,7 @@ class Engine:
         if len(select) != n:
             raise DimensionMismatch("select must have one entry per eigenvalue")
         if not np.iscomplexobj(P.Ts[0]):
-            raise NotImplementedPSD("real ordschur! (src/rordschur.jl) is not in this build")
+            return self._rordschur_(P, select, wantZ)
         if P.schurindex not in (1, p):
             raise ValueError("only implemented for schurindex in (1,p)")  # src/ordschur.jl:32
         self._as_work(P.Ts, np.complex128)
@@ -422,6 +424,35 @@ class Engine:
             P.values = alpha / beta * np.exp2(sc.astype(np.float64))
         if isinstance(P, GeneralizedPeriodicSchur):
             P.alpha, P.beta, P.alphascale = alpha, beta, sc
+        P.stats = st
+        return P
+
+    def _rordschur_(self, P, select, wantZ):
+        """LinearAlgebra.ordschur!(P, select; wantZ) for Float64 — src/rordschur.jl:3-132."""
+        n = P.Ts[0].shape[0]
+        p = len(P.Ts)
+        if P.schurindex not in (1, p):
+            raise ValueError("only implemented for schurindex in (1,p)")  # src/rordschur.jl:25
+        self._as_work(P.Ts)
+        wantZ = wantZ and len(P.Z) > 0
+        if wantZ:
+            self._as_work(P.Z)
+        sel = (C.c_uint8 * n)(*[1 if x else 0 for x in select])
+        wr = np.zeros(n)
+        wi = np.zeros(n)
+        st = Stats()
+        info = C.c_int(0)
+        dp = C.POINTER(C.c_double)
+        self.lib.psd_d_ordschur(self.ctx, n, p, self._ptrs(P.Ts), self._ptrs(P.Z) if wantZ else None,
+                                P.orientation.encode(), P.schurindex, sel, int(wantZ), wr.ctypes.data_as(dp),
+                                wi.ctypes.data_as(dp), C.byref(st), C.byref(info))
+        iv = info.value
+        if iv == 3000:
+            raise SingularException()
+        if 2000 <= iv < 3000:
+            raise IllConditionedException(iv - 2000)
+        self._raise(iv)
+        P.values = wr + 1j * wi
         P.stats = st
         return P
 

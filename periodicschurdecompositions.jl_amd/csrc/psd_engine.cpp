@@ -6,6 +6,7 @@
 #include "psd_zhess.h"
 #include "psd_zqz.h"
 #include "psd_zord.h"
+#include "psd_rord.h"
 
 #include "../../include/psd_mi355x.h"
 
@@ -91,7 +92,12 @@ struct psd_ctx {
     int* cnt = nullptr;
     int* log = nullptr;
     int logcap = 0;
-    size_t step_lds_set = 0, zstep_lds_set = 0;
+    size_t step_lds_set = 0, zstep_lds_set = 0, rostep_lds_set = 0;
+    psd_rostate* rost = nullptr;
+    psd_tq* rotq = nullptr;
+    unsigned char* rosel = nullptr;
+    double* roxscr = nullptr;
+    int rocap_n = 0, rocap_p = 0;
     // complex path
     int zcap_n = 0, zcap_p = 0, zlogcap = 0;
     bool zcap_mats = false;
@@ -114,6 +120,25 @@ struct psd_ctx {
         cap_n = cap_p = 0;
         cap_mats = false;
         logcap = 0;
+    }
+
+    void rorelease() {
+        void* ptrs[] = {rost, rotq, rosel, roxscr};
+        for (void* q : ptrs)
+            if (q) psd_rt_free(q);
+        rost = nullptr; rotq = nullptr; rosel = nullptr; roxscr = nullptr;
+        rocap_n = rocap_p = 0;
+    }
+    int roreserve(int n, int p) {
+        if (n <= rocap_n && p <= rocap_p) return 0;
+        rorelease();
+        PSD_CHECK(psd_rt_malloc((void**)&rost, sizeof(psd_rostate)));
+        PSD_CHECK(psd_rt_malloc((void**)&rotq, sizeof(psd_tq) * (size_t)p * PSD_RORD_CAP));
+        PSD_CHECK(psd_rt_malloc((void**)&rosel, (size_t)n + 16));
+        PSD_CHECK(psd_rt_malloc((void**)&roxscr, sizeof(double) * (size_t)n * p * 8 + 64));
+        rocap_n = n;
+        rocap_p = p;
+        return 0;
     }
 
     void zrelease() {
@@ -435,6 +460,7 @@ int psd_destroy(psd_ctx* c) {
     if (!c) return 0;
     c->release();
     c->zrelease();
+    c->rorelease();
 #ifndef PSD_HOSTSIM
     if (c->stream) (void)hipStreamDestroy(c->stream);
 #endif
@@ -1072,6 +1098,130 @@ int psd_z_ordschur(psd_ctx* c, int n, int p, double* const* T, double* const* Z,
     for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(T[j], c->zH + j * nn, nn * 16, c->stream));
     if (wantZ)
         for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(Z[j], c->zZ + j * nn, nn * 16, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    return rc;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// ordschur! (real)
+namespace {
+
+size_t rord_lds_bytes(int p, int W) {
+    size_t b = ((size_t)p * W * (W + 1) + (size_t)p * (PSD_RORD_SCR + 52) + 4) * 8 + (size_t)p * 4 + 64;
+    return (b + 15) & ~(size_t)15;
+}
+int choose_window_rord(int p) {
+    const int cand[] = {32, 24, 20, 16, 12, 10, 8, 6};
+    for (int W : cand)
+        if (rord_lds_bytes(p, W) <= 155 * 1024) return W;
+    return 0;
+}
+
+int rordschur_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t* select, int wantZ, double* wr,
+                  double* wi, psd_stats* stats, int* info) {
+    const int W = choose_window_rord(p);
+    if (W == 0) return *info = PSD_INFO_NOTIMPL;
+    if ((*info = c->roreserve(n, p)) != 0) return *info;
+    PSD_CHECK(psd_rt_h2d(c->rosel, select, (size_t)n, c->stream));
+    psd_roparams P;
+    P.H = dH;
+    P.Z = wantZ ? dZ : nullptr;
+    P.st = c->rost;
+    P.desc = c->desc;
+    P.tq = c->rotq;
+    P.cnt = c->cnt;
+    P.select = c->rosel;
+    P.wr = c->wr;
+    P.wi = c->wi;
+    P.xscr = c->roxscr;
+    const size_t lds_step = rord_lds_bytes(p, W);
+#ifndef PSD_HOSTSIM
+    if (lds_step > c->rostep_lds_set) {
+        PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_rord_step),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
+        c->rostep_lds_set = lds_step;
+    }
+#endif
+    PSD_LAUNCH(psd_rord_init, psd_dim3(1), 64, 0, c->stream, P, n, p, wantZ, W);
+    const size_t lds_apply = sizeof(psd_tq) * PSD_RORD_CAP + (size_t)32 * (PSD_APPLY_NT + 1) * 8;
+    const int tiles = (n + PSD_APPLY_NT - 1) / PSD_APPLY_NT;
+    psd_rostate hst;
+    memset(&hst, 0, sizeof(hst));
+    long long launched = 0;
+    const long long cap = 2LL * n * ((long long)n / (W > 4 ? W - 4 : 1) + 2) + 1024;
+    Timer t;
+    t.start(c->stream);
+    for (;;) {
+        for (int b = 0; b < 32; ++b) {
+            PSD_LAUNCH(psd_rord_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
+            PSD_LAUNCH(psd_rord_apply, psd_dim3(tiles, p, 3), PSD_APPLY_NT, lds_apply, c->stream, P, n, p);
+            ++launched;
+        }
+        PSD_CHECK(psd_rt_d2h(&hst, c->rost, sizeof(hst), c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+        if (hst.phase == PSD_ROPH_DONE) break;
+        if (launched > cap) return *info = PSD_INFO_RUNTIME + 0xfffc;
+    }
+    if (hst.info == 0) {
+        PSD_LAUNCH(psd_rord_values, psd_dim3((n + 63) / 64), 64, 0, c->stream, P, n, p);
+        PSD_LAUNCH(psd_rord_cleanup, psd_dim3(n), 64, 0, c->stream, P, n);
+        PSD_CHECK(psd_rt_d2h(wr, c->wr, sizeof(double) * n, c->stream));
+        PSD_CHECK(psd_rt_d2h(wi, c->wi, sizeof(double) * n, c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+    }
+    const double ms = t.stop(c->stream);
+    PSD_CHECK(psd_rt_last_error());
+    if (stats) {
+        stats->ms_iter = stats->ms_total = ms;
+        stats->nsweeps = hst.nswaps;
+        stats->nwindows = hst.nwindows;
+        stats->nlaunch_step = (int32_t)launched;
+        stats->window = W;
+    }
+    return *info = hst.info;
+}
+
+}  // namespace
+
+extern "C" {
+
+int psd_d_ordschur(psd_ctx* c, int n, int p, double* const* T, double* const* Z, char orient, int schurindex,
+                   const uint8_t* select, int wantZ, double* wr, double* wi, psd_stats* stats, int* info) {
+    int dummy;
+    if (!info) info = &dummy;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!c) return *info = -1;
+    if ((*info = check_dims(n, p)) != 0) return *info;
+    if (!T) return *info = -4;
+    if (wantZ && !Z) return *info = -5;
+    if (orient != 'R' && orient != 'L') return *info = -6;
+    if (!select) return *info = -8;
+    if (!((orient == 'R' && schurindex == 1) || (orient == 'L' && schurindex == p))) {
+        if (schurindex != 1 && schurindex != p) return *info = -7;  // rordschur.jl:25
+        return *info = PSD_INFO_NOTIMPL;
+    }
+    if ((*info = c->reserve(n, p, true, 16)) != 0) return *info;
+    const size_t nn = (size_t)n * n;
+    const bool left = orient == 'L';
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->dH + j * nn, T[j], nn * 8, c->stream));
+    if (wantZ)
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->dZ + j * nn, Z[j], nn * 8, c->stream));
+    auto flip = [&]() {
+        if (left && p > 1) {
+            PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, p / 2), 64, 0, c->stream, c->dH, n, n, 0, p);
+            if (wantZ && p > 2)
+                PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, (p - 1) / 2), 64, 0, c->stream, c->dZ, n, n, 1, p - 1);
+        }
+    };
+    flip();
+    int rc = rordschur_dev(c, n, p, c->dH, c->dZ, select, wantZ, wr, wi, stats, info);
+    flip();
+    if (rc < 0 || rc >= PSD_INFO_NOTIMPL) return rc;
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(T[j], c->dH + j * nn, nn * 8, c->stream));
+    if (wantZ)
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(Z[j], c->dZ + j * nn, nn * 8, c->stream));
     PSD_CHECK(psd_rt_sync(c->stream));
     return rc;
 }

@@ -1,0 +1,947 @@
+// Eigenvalue reordering on the GPU, Float64: ordschur!(P, select) with 1x1 and 2x2 blocks.
+//
+// Replaces /root/reference/src/rordschur.jl:3-132 (driver, conjugate-pair aware scan), :141-251
+// (_moveblock!), sylswap.jl:14-157 (_swapadjqr!: periodic Sylvester solution -> per-factor
+// orthogonal m x m transformation from QR of [X; I], fill-in repair by a 2x2 periodic Hessenberg
+// reduction :159-191 / rpschur2x2.jl:326-359, strong stability test), sylswap.jl:542-635 for the
+// 1x1/1x1 case, sylvester.jl:170-193 + babd.jl (cyclic block-bidiagonal solve), ordschur.jl:122-204
+// (_updateλ!) with rpschur2x2.jl:9-275 (_rpeigvals2x2) for the conjugate pairs.
+//
+// MI355X structure (as psd_zord.h): a block travelling upwards is a chase; one wavefront keeps the
+// diagonal window of all p factors in LDS, performs as many adjacent swaps as fit, and emits one
+// dense m x m (m <= 4) orthogonal block transform per factor and swap; psd_rord_apply updates the
+// off-window rows of T_m, columns of T_{m-1} and Z_m at bandwidth.  The O(p) small dense algebra of
+// a swap (block-cyclic QR, 2x2 Hessenberg repair, stability test) runs on one lane out of LDS.
+#pragma once
+#include "psd_real_qr.h"
+#include "psd_zord.h"
+
+#define PSD_RORD_SCR 96    // doubles of per-factor swap scratch
+#define PSD_RORD_CAP 24    // block transforms per owner and window
+
+struct psd_tq {  // dense orthogonal block transform acting on indices pos..pos+m-1
+    int pos, m;
+    double q[16];  // column-major, ld 4:  right: row <- row * Q ;  left: column <- Q' * column
+};
+
+enum { PSD_ROPH_SCAN = 0, PSD_ROPH_MOVE = 1, PSD_ROPH_DONE = 7 };
+
+struct psd_rostate {
+    int n, p, wantZ, W;
+    int phase, info;
+    int j, jdest, pairskip;          // driver scan (rordschur.jl:77-110)
+    int here, nbsrc, splitsrc, jtarget, jsrc0, pend1x1;  // _moveblock! state
+    int nswaps, nwindows;
+};
+
+struct psd_roparams {
+    double* H;
+    double* Z;
+    psd_rostate* st;
+    psd_apply_desc* desc;
+    psd_tq* tq;   // [p][PSD_RORD_CAP]
+    int* cnt;     // [p]
+    const unsigned char* select;
+    double* wr;
+    double* wi;
+    double* xscr;  // [n][p][8] scratch for _rpeigvals2x2
+};
+
+PSD_D psd_rparams P_as_r(const psd_roparams& P) {
+    psd_rparams R;
+    R.H = P.H;
+    R.Z = P.Z;
+    R.st = nullptr; R.desc = nullptr; R.tr = nullptr; R.cnt = nullptr;
+    R.hdiag = R.hsub = R.hsup = R.Pd = R.Pe = R.Pf = R.hnorms = R.wr = R.wi = nullptr;
+    R.log = nullptr;
+    return R;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tiny dense helpers (column-major, explicit leading dimension), executed by one lane
+
+// Householder QR of the first nc columns of the nr x ncols matrix S (ld), applied to all columns.
+// Returns false if a diagonal entry of R is exactly zero.
+PSD_D bool psd_sm_qr(double* S, int ld, int nr, int ncols, int nc) {
+    bool ok = true;
+    for (int k = 0; k < nc; ++k) {
+        double nrm = 0.0;
+        for (int i = k; i < nr; ++i) nrm = hypot(nrm, S[k * ld + i]);
+        if (nrm == 0.0) {
+            ok = false;
+            continue;
+        }
+        const double alpha = S[k * ld + k];
+        const double beta = -copysign(nrm, alpha);
+        double v[8];
+        v[k] = alpha - beta;
+        double vn2 = v[k] * v[k];
+        for (int i = k + 1; i < nr; ++i) {
+            v[i] = S[k * ld + i];
+            vn2 += v[i] * v[i];
+        }
+        if (vn2 == 0.0) continue;
+        const double tau2 = 2.0 / vn2;
+        for (int c = k; c < ncols; ++c) {
+            double d = 0.0;
+            for (int i = k; i < nr; ++i) d += v[i] * S[c * ld + i];
+            d *= tau2;
+            for (int i = k; i < nr; ++i) S[c * ld + i] -= d * v[i];
+        }
+        S[k * ld + k] = beta;
+        for (int i = k + 1; i < nr; ++i) S[k * ld + i] = 0.0;
+    }
+    for (int k = 0; k < nc; ++k)
+        if (S[k * ld + k] == 0.0) ok = false;
+    return ok;
+}
+
+// solve R x = b, R pp x pp upper triangular (ld)
+PSD_D void psd_sm_trsv(const double* R, int ld, int pp, double* b) {
+    for (int k = pp - 1; k >= 0; --k) {
+        double s = b[k];
+        for (int c = k + 1; c < pp; ++c) s -= R[c * ld + k] * b[c];
+        b[k] = s / R[k * ld + k];
+    }
+}
+
+// full m x m Q of the Householder QR of the m x nc matrix Xi (ld 4): Q' Xi = [R; 0]
+PSD_D void psd_sm_fullq(const double* Xi, int m, int nc, double* Q /*ld 4*/) {
+    double S[16];
+    for (int c = 0; c < nc; ++c)
+        for (int r = 0; r < m; ++r) S[c * 4 + r] = Xi[c * 4 + r];
+    for (int c = 0; c < m; ++c)
+        for (int r = 0; r < m; ++r) Q[c * 4 + r] = (r == c) ? 1.0 : 0.0;
+    const int kmax = (m - 1 < nc) ? (m - 1) : nc;
+    for (int k = 0; k < kmax; ++k) {
+        double nrm = 0.0;
+        for (int i = k; i < m; ++i) nrm = hypot(nrm, S[k * 4 + i]);
+        if (nrm == 0.0) continue;
+        const double alpha = S[k * 4 + k];
+        const double beta = -copysign(nrm, alpha);
+        double v[4];
+        v[k] = alpha - beta;
+        double vn2 = v[k] * v[k];
+        for (int i = k + 1; i < m; ++i) {
+            v[i] = S[k * 4 + i];
+            vn2 += v[i] * v[i];
+        }
+        if (vn2 == 0.0) continue;
+        const double tau2 = 2.0 / vn2;
+        for (int c = k; c < nc; ++c) {
+            double d = 0.0;
+            for (int i = k; i < m; ++i) d += v[i] * S[c * 4 + i];
+            d *= tau2;
+            for (int i = k; i < m; ++i) S[c * 4 + i] -= d * v[i];
+        }
+        for (int r = 0; r < m; ++r) {  // Q <- Q H
+            double d = 0.0;
+            for (int i = k; i < m; ++i) d += Q[i * 4 + r] * v[i];
+            d *= tau2;
+            for (int i = k; i < m; ++i) Q[i * 4 + r] -= d * v[i];
+        }
+    }
+}
+
+// C (m x m, ld 4) = A * B or A' * B etc.
+PSD_D void psd_sm_mul(const double* A, bool ta, const double* B, bool tb, int m, double* C) {
+    double T[16];
+    for (int c = 0; c < m; ++c)
+        for (int r = 0; r < m; ++r) {
+            double s = 0.0;
+            for (int k = 0; k < m; ++k) s += (ta ? A[r * 4 + k] : A[k * 4 + r]) * (tb ? B[k * 4 + c] : B[c * 4 + k]);
+            T[c * 4 + r] = s;
+        }
+    for (int c = 0; c < m; ++c)
+        for (int r = 0; r < m; ++r) C[c * 4 + r] = T[c * 4 + r];
+}
+
+// Periodic Sylvester system A_k X_k - X_{k+1} B_k = -C_k (k = 1..K cyclic), blocks p1 x p1, p2 x p2,
+// p1 x p2 (sylvester.jl:170-193).  Block-cyclic structured QR (the role of babd.jl:17-96): the
+// bottom block row is eliminated against the diagonal by Householder QR of stacked 2pp x pp
+// blocks, then back substitution.  Per-factor scratch layout (ld 2 blocks): scr[l] + 0: T11, +4: T12,
+// +8: T22, +12: X.  wk: K x 52 doubles (D 16, E 16, F 16, rhs 4).  Returns false if singular.
+PSD_D bool psd_rord_psylsolve(int K, int p1, int p2, double* scr, double* wk) {
+    const int pp = p1 * p2;
+    // kron(I_p2, A)[j*p1+i, j*p1+k] = A[i,k];  kron(B^T, -I_p1)[j*p1+i, k*p1+i] = -B[k,j]
+    auto fillA = [&](const double* A, double* M) {  // pp x pp, ld 4
+        for (int c = 0; c < pp; ++c)
+            for (int r = 0; r < pp; ++r) M[c * 4 + r] = 0.0;
+        for (int j = 0; j < p2; ++j)
+            for (int i = 0; i < p1; ++i)
+                for (int k = 0; k < p1; ++k) M[(j * p1 + k) * 4 + (j * p1 + i)] = A[k * 2 + i];
+    };
+    auto fillB = [&](const double* B, double* M) {
+        for (int c = 0; c < pp; ++c)
+            for (int r = 0; r < pp; ++r) M[c * 4 + r] = 0.0;
+        for (int j = 0; j < p2; ++j)
+            for (int i = 0; i < p1; ++i)
+                for (int k = 0; k < p2; ++k) M[(k * p1 + i) * 4 + (j * p1 + i)] = -B[j * 2 + k];
+    };
+    auto rhsC = [&](const double* C, double* y) {
+        for (int j = 0; j < p2; ++j)
+            for (int i = 0; i < p1; ++i) y[j * p1 + i] = -C[j * 2 + i];
+    };
+    if (K == 1) {
+        double S[8 * 5], MA[16], MB[16], y[4];
+        fillA(scr + 0, MA);
+        fillB(scr + 8, MB);
+        rhsC(scr + 4, y);
+        for (int c = 0; c < pp; ++c)
+            for (int r = 0; r < pp; ++r) S[c * 8 + r] = MA[c * 4 + r] + MB[c * 4 + r];
+        for (int r = 0; r < pp; ++r) S[pp * 8 + r] = y[r];
+        if (!psd_sm_qr(S, 8, pp, pp + 1, pp)) return false;
+        double R[16];
+        for (int c = 0; c < pp; ++c)
+            for (int r = 0; r < pp; ++r) R[c * 4 + r] = S[c * 8 + r];
+        for (int r = 0; r < pp; ++r) y[r] = S[pp * 8 + r];
+        psd_sm_trsv(R, 4, pp, y);
+        for (int q = 0; q < pp; ++q) scr[12 + (q / p1) * 2 + (q % p1)] = y[q];
+        return true;
+    }
+    // rows k = 0..K-2: D_k x_k + E_k x_{k+1} + F_k x_{K-1} = r_k ; bottom row: Lo x_k' + Hi x_{K-1} = rb
+    for (int k = 0; k < K; ++k) {
+        double* w = wk + k * 52;
+        fillA(scr + k * PSD_RORD_SCR + 0, w);        // D_k = kron(I, A_k)
+        fillB(scr + k * PSD_RORD_SCR + 8, w + 16);   // E_k = kron(B_k^T, -I)
+        for (int q = 0; q < 16; ++q) w[32 + q] = 0.0;
+        rhsC(scr + k * PSD_RORD_SCR + 4, w + 48);
+    }
+    double Lo[16], Hi[16], rb[4];
+    {
+        const double* w = wk + (K - 1) * 52;
+        for (int q = 0; q < 16; ++q) {
+            Lo[q] = w[16 + q];  // bottom equation: E_{K-1} multiplies x_0
+            Hi[q] = w[q];       // D_{K-1} multiplies x_{K-1}
+        }
+        for (int q = 0; q < 4; ++q) rb[q] = w[48 + q];
+    }
+    for (int k = 0; k < K - 1; ++k) {
+        double* w = wk + k * 52;
+        const bool lastcol = (k + 1 == K - 1);
+        // stack: rows 0..pp-1 = row k, rows pp..2pp-1 = bottom; column blocks: [col k | col k+1 | col K-1 | rhs]
+        double S[8 * 13];
+        const int nblk = lastcol ? 2 : 3;
+        const int ncols = nblk * pp + 1;
+        for (int c = 0; c < pp; ++c)
+            for (int r = 0; r < pp; ++r) {
+                S[c * 8 + r] = w[c * 4 + r];
+                S[c * 8 + pp + r] = Lo[c * 4 + r];
+                if (lastcol) {
+                    S[(pp + c) * 8 + r] = w[16 + c * 4 + r] + w[32 + c * 4 + r];
+                    S[(pp + c) * 8 + pp + r] = Hi[c * 4 + r];
+                } else {
+                    S[(pp + c) * 8 + r] = w[16 + c * 4 + r];
+                    S[(pp + c) * 8 + pp + r] = 0.0;
+                    S[(2 * pp + c) * 8 + r] = w[32 + c * 4 + r];
+                    S[(2 * pp + c) * 8 + pp + r] = Hi[c * 4 + r];
+                }
+            }
+        for (int r = 0; r < pp; ++r) {
+            S[(nblk * pp) * 8 + r] = w[48 + r];
+            S[(nblk * pp) * 8 + pp + r] = rb[r];
+        }
+        if (!psd_sm_qr(S, 8, 2 * pp, ncols, pp)) return false;
+        for (int c = 0; c < pp; ++c)
+            for (int r = 0; r < pp; ++r) {
+                w[c * 4 + r] = S[c * 8 + r];
+                w[16 + c * 4 + r] = S[(pp + c) * 8 + r];
+                if (lastcol) {
+                    w[32 + c * 4 + r] = 0.0;
+                    Hi[c * 4 + r] = S[(pp + c) * 8 + pp + r];
+                } else {
+                    Lo[c * 4 + r] = S[(pp + c) * 8 + pp + r];
+                    w[32 + c * 4 + r] = S[(2 * pp + c) * 8 + r];
+                    Hi[c * 4 + r] = S[(2 * pp + c) * 8 + pp + r];
+                }
+            }
+        for (int r = 0; r < pp; ++r) {
+            w[48 + r] = S[(nblk * pp) * 8 + r];
+            rb[r] = S[(nblk * pp) * 8 + pp + r];
+        }
+    }
+    // x_{K-1}: Hi x = rb
+    double xs[4];
+    {
+        double S[8 * 5];
+        for (int c = 0; c < pp; ++c)
+            for (int r = 0; r < pp; ++r) S[c * 8 + r] = Hi[c * 4 + r];
+        for (int r = 0; r < pp; ++r) S[pp * 8 + r] = rb[r];
+        if (!psd_sm_qr(S, 8, pp, pp + 1, pp)) return false;
+        double R[16];
+        for (int c = 0; c < pp; ++c)
+            for (int r = 0; r < pp; ++r) R[c * 4 + r] = S[c * 8 + r];
+        for (int r = 0; r < pp; ++r) xs[r] = S[pp * 8 + r];
+        psd_sm_trsv(R, 4, pp, xs);
+    }
+    double xlast[4], xnext[4];
+    for (int q = 0; q < pp; ++q) {
+        xlast[q] = xs[q];
+        xnext[q] = xs[q];
+        scr[(K - 1) * PSD_RORD_SCR + 12 + (q / p1) * 2 + (q % p1)] = xs[q];
+    }
+    for (int k = K - 2; k >= 0; --k) {
+        const double* w = wk + k * 52;
+        double y[4];
+        for (int r = 0; r < pp; ++r) {
+            double s = w[48 + r];
+            for (int c = 0; c < pp; ++c) s -= w[16 + c * 4 + r] * xnext[c];
+            if (k + 1 != K - 1)
+                for (int c = 0; c < pp; ++c) s -= w[32 + c * 4 + r] * xlast[c];
+            y[r] = s;
+        }
+        for (int r = 0; r < pp; ++r)
+            if (w[r * 4 + r] == 0.0) return false;
+        psd_sm_trsv(w, 4, pp, y);
+        for (int q = 0; q < pp; ++q) {
+            xnext[q] = y[q];
+            scr[k * PSD_RORD_SCR + 12 + (q / p1) * 2 + (q % p1)] = y[q];
+        }
+    }
+    return true;
+}
+
+// The scalar part of one swap of adjacent blocks (p1, p2) — sylswap.jl:14-129 (and :542-617 via the same
+// machinery for p1 = p2 = 1).  Per-factor scratch (index = position l-1 in the reference's left-oriented
+// sequence X_l): +0 T11, +4 T12, +8 T22, +12 X (ld 2); +16 Q, +32 Txx, +48 Ws, +64 Qfin (ld 4); +80 orig block
+// (ld 4).  Returns 0 ok, 1 rejected (strong test), 2 singular.
+PSD_D int psd_rord_swap_scalar(int K, int p1, int p2, double* scr, double* wk, double tnrm) {
+    const int m = p1 + p2;
+    if (!psd_rord_psylsolve(K, p1, p2, scr, wk)) return 2;
+    const double thresh = fmax(PSD_DBL_MIN, 100.0 * PSD_DBL_EPS * tnrm);
+    for (int l = 0; l < K; ++l) {
+        double* s = scr + l * PSD_RORD_SCR;
+        double Xi[16];
+        for (int q = 0; q < 16; ++q) Xi[q] = 0.0;
+        for (int b = 0; b < p2; ++b) {
+            for (int a = 0; a < p1; ++a) Xi[b * 4 + a] = s[12 + b * 2 + a];
+            Xi[b * 4 + p1 + b] = 1.0;
+        }
+        psd_sm_fullq(Xi, m, p2, s + 16);
+        for (int q = 0; q < 16; ++q) s[32 + q] = s[80 + q];  // Txx <- original [T11 T12; 0 T22]
+    }
+    for (int l = 0; l < K; ++l) {  // Txx[l] <- Txx[l] q_l ; Txx[l-1] <- q_l' Txx[l-1]
+        double* s = scr + l * PSD_RORD_SCR;
+        psd_sm_mul(s + 32, false, s + 16, false, m, s + 32);
+        double* sp = scr + ((l == 0) ? (K - 1) : (l - 1)) * PSD_RORD_SCR;
+        psd_sm_mul(s + 16, true, sp + 32, false, m, sp + 32);
+    }
+    bool fill1 = false, fill2 = false;
+    if (p2 > 1)
+        for (int l = 0; l < K; ++l) fill1 |= fabs(scr[l * PSD_RORD_SCR + 32 + 0 * 4 + 1]) > thresh;
+    if (p1 > 1)
+        for (int l = 0; l < K; ++l) fill2 |= fabs(scr[l * PSD_RORD_SCR + 32 + p2 * 4 + p2 + 1]) > thresh;
+    const bool fillin = fill1 || fill2;
+    for (int l = 0; l < K; ++l) {
+        double* s = scr + l * PSD_RORD_SCR;
+        for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 4; ++r) s[48 + c * 4 + r] = (r == c) ? 1.0 : 0.0;
+    }
+    for (int pass = 0; pass < 2; ++pass) {  // sylswap.jl:159-191 _filled2hess! at j0 = 0 and j0 = p2
+        if (pass == 0 && !fill1) continue;
+        if (pass == 1 && !fill2) continue;
+        const int j0 = (pass == 0) ? 0 : p2, j1 = j0 + 1;
+        // rpschur2x2.jl:326-359 on the 2x2 copies: Qs[lp] = hr' for l = 2..K
+        // (the solver's work array is free again: Th at wk + l*52, Hq at wk + l*52 + 4)
+        for (int l = 0; l < K; ++l) {
+            const double* t = scr + l * PSD_RORD_SCR + 32;
+            double* Th = wk + l * 52;
+            double* Hq = Th + 4;
+            Th[0] = t[j0 * 4 + j0];
+            Th[1] = t[j0 * 4 + j1];
+            Th[2] = t[j1 * 4 + j0];
+            Th[3] = t[j1 * 4 + j1];  // [a(0,0) a(1,0) a(0,1) a(1,1)] column-major 2x2
+            Hq[0] = 1.0; Hq[1] = 0.0; Hq[2] = 0.0; Hq[3] = 1.0;
+        }
+        for (int l = 2; l <= K; ++l) {
+            double* Al = wk + (l - 1) * 52;
+            const int lp = (l % K) + 1;
+            double* Ap = wk + (lp - 1) * 52;
+            double x0 = Al[0], x1 = Al[1];
+            double tau;
+            {
+                double xv[2] = {x0, x1};
+                tau = psd_reflector_small(xv, 2);
+                x0 = xv[0];
+                x1 = xv[1];
+            }
+            Al[0] = x0;
+            Al[1] = 0.0;
+            const double v1 = 1.0, v2 = x1;
+            {  // lmul!(hr', Al[:, 2])
+                const double sdot = v1 * Al[2] + v2 * Al[3];
+                Al[2] -= sdot * tau * v1;
+                Al[3] -= sdot * tau * v2;
+            }
+            {  // Qs[lp] <- hr' Qs[lp]
+                double* Q = wk + (lp - 1) * 52 + 4;
+                for (int c = 0; c < 2; ++c) {
+                    const double sdot = v1 * Q[c * 2 + 0] + v2 * Q[c * 2 + 1];
+                    Q[c * 2 + 0] -= sdot * tau * v1;
+                    Q[c * 2 + 1] -= sdot * tau * v2;
+                }
+            }
+            for (int r = 0; r < 2; ++r) {  // rmul!(Ap, hr)
+                const double sdot = Ap[0 * 2 + r] * v1 + Ap[1 * 2 + r] * v2;
+                Ap[0 * 2 + r] -= sdot * tau * v1;
+                Ap[1 * 2 + r] -= sdot * tau * v2;
+            }
+        }
+        for (int l = 1; l <= K; ++l) {
+            const int lp = (l % K) + 1;
+            const double* q = wk + (l - 1) * 52 + 4;
+            const double* qp = wk + (lp - 1) * 52 + 4;
+            double* Tl = scr + (l - 1) * PSD_RORD_SCR + 32;
+            double* W = scr + (l - 1) * PSD_RORD_SCR + 48;
+            for (int r = 0; r < m; ++r) {
+                const double a = Tl[j0 * 4 + r], b = Tl[j1 * 4 + r];
+                Tl[j0 * 4 + r] = a * q[0] + b * q[1];
+                Tl[j1 * 4 + r] = a * q[2] + b * q[3];
+            }
+            for (int c = 0; c < m; ++c) {
+                const double a = Tl[c * 4 + j0], b = Tl[c * 4 + j1];
+                Tl[c * 4 + j0] = qp[0] * a + qp[1] * b;
+                Tl[c * 4 + j1] = qp[2] * a + qp[3] * b;
+            }
+            for (int r = 0; r < m; ++r) {
+                const double a = W[j0 * 4 + r], b = W[j1 * 4 + r];
+                W[j0 * 4 + r] = a * q[0] + b * q[1];
+                W[j1 * 4 + r] = a * q[2] + b * q[3];
+            }
+        }
+    }
+    // final transform of factor l: Qfin = q_l W_l ; strong test: Qfin_{l+1} Txx[l] Qfin_l' ~ original block
+    for (int l = 0; l < K; ++l) {
+        double* s = scr + l * PSD_RORD_SCR;
+        if (fillin) psd_sm_mul(s + 16, false, s + 48, false, m, s + 64);
+        else
+            for (int q = 0; q < 16; ++q) s[64 + q] = s[16 + q];
+    }
+    bool ok = true;
+    for (int l = 0; l < K; ++l) {
+        const int l1 = (l + 1) % K;
+        double Tt[16];
+        psd_sm_mul(scr + l1 * PSD_RORD_SCR + 64, false, scr + l * PSD_RORD_SCR + 32, false, m, Tt);
+        psd_sm_mul(Tt, false, scr + l * PSD_RORD_SCR + 64, true, m, Tt);
+        double d = 0.0;
+        for (int c = 0; c < m; ++c)
+            for (int r = 0; r < m; ++r) d = hypot(d, Tt[c * 4 + r] - scr[l * PSD_RORD_SCR + 80 + c * 4 + r]);
+        if (d > thresh) ok = false;
+    }
+    return ok ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// in-window application of the block transform Q (m x m, ld 4) of sequence index l:
+// right on the columns i1.. of X_l = T_{sg}, left (Q') on the rows i1.. of X_{l-1} = T_{own}
+PSD_D void psd_rord_win_apply(const psd_win& w, int sg, int own, int i1, int m, const double* Q) {
+    const int nrow = (i1 + m - 1) - w.bs + 1;  // rows bs..i1+m-1 of T_sg
+    const int ncol = w.be - i1 + 1;            // columns i1..be of T_own
+    PSD_PAR_FOR(t, nrow + ncol) {
+        double a[4], b[4];
+        if (t < nrow) {
+            const int r = w.bs + t;
+            for (int q = 0; q < m; ++q) a[q] = w.at(sg, r, i1 + q);
+            for (int c = 0; c < m; ++c) {
+                double s = 0.0;
+                for (int q = 0; q < m; ++q) s += a[q] * Q[c * 4 + q];
+                b[c] = s;
+            }
+            for (int q = 0; q < m; ++q) w.at(sg, r, i1 + q) = b[q];
+        } else {
+            const int c = i1 + (t - nrow);
+            for (int q = 0; q < m; ++q) a[q] = w.at(own, i1 + q, c);
+            for (int r = 0; r < m; ++r) {
+                double s = 0.0;
+                for (int q = 0; q < m; ++q) s += Q[r * 4 + q] * a[q];
+                b[r] = s;
+            }
+            for (int q = 0; q < m; ++q) w.at(own, i1 + q, c) = b[q];
+        }
+    }
+    PSD_SYNC();
+}
+
+// one swap inside the window; returns 0 ok / 1 rejected / 2 singular
+PSD_D int psd_rord_swap(const psd_roparams& P, const psd_rostate& st, const psd_win& w, double* scr, double* wk,
+                        double* flagbuf, int* lcnt, int i1, int p1, int p2) {
+    const int p = st.p, m = p1 + p2;
+    PSD_SYNC();
+    PSD_PAR_FOR(t, p) {
+        const int l = t + 1, sg = psd_ord_sigma(p, l);
+        double* s = scr + t * PSD_RORD_SCR;
+        for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 4; ++r) s[80 + c * 4 + r] = (r < m && c < m) ? w.at(sg, i1 + r, i1 + c) : 0.0;
+        for (int b = 0; b < 2; ++b)
+            for (int a = 0; a < 2; ++a) {
+                s[0 + b * 2 + a] = (a < p1 && b < p1) ? s[80 + b * 4 + a] : 0.0;
+                s[4 + b * 2 + a] = (a < p1 && b < p2) ? s[80 + (p1 + b) * 4 + a] : 0.0;
+                s[8 + b * 2 + a] = (a < p2 && b < p2) ? s[80 + (p1 + b) * 4 + p1 + a] : 0.0;
+            }
+        // the reference's working copy is [T11 T12; 0 T22]: the lower-left block is not carried
+        for (int c = 0; c < p1; ++c)
+            for (int r = p1; r < m; ++r) s[80 + c * 4 + r] = 0.0;
+    }
+    PSD_SYNC();
+    PSD_ONE {
+        double tn = 0.0;
+        for (int t = 0; t < p; ++t) {
+            const int sg = psd_ord_sigma(p, t + 1);
+            for (int c = 0; c < m; ++c)
+                for (int r = 0; r < m; ++r) tn = hypot(tn, w.at(sg, i1 + r, i1 + c));
+        }
+        flagbuf[0] = (double)psd_rord_swap_scalar(p, p1, p2, scr, wk, tn);
+    }
+    PSD_SYNC();
+    const int flag = (int)flagbuf[0];
+    if (flag) return flag;
+    for (int l = 1; l <= p; ++l) {
+        const int own = psd_ord_owner(p, l), sg = psd_ord_sigma(p, l);
+        const double* Q = scr + (l - 1) * PSD_RORD_SCR + 64;
+        psd_rord_win_apply(w, sg, own, i1, m, Q);
+        PSD_ONE {
+            const int q = lcnt[own - 1];
+            if (q < PSD_RORD_CAP) {
+                psd_tq tr;
+                tr.pos = i1;
+                tr.m = m;
+                for (int e = 0; e < 16; ++e) tr.q[e] = Q[e];
+                P.tq[(size_t)(own - 1) * PSD_RORD_CAP + q] = tr;
+            }
+            lcnt[own - 1] = q + 1;
+        }
+    }
+    PSD_SYNC();
+    // sweep up the dust (sylswap.jl:150-154): T_1 keeps only the new block structure, the others are triangular
+    PSD_PAR_FOR(t, p) {
+        const int sg = psd_ord_sigma(p, t + 1);
+        if (sg == 1) {
+            for (int r = i1 + p2; r <= i1 + m - 1; ++r)
+                for (int c = i1; c <= i1 + p2 - 1; ++c) w.at(1, r, c) = 0.0;
+        } else {
+            for (int c = i1; c <= i1 + m - 1; ++c)
+                for (int r = c + 1; r <= i1 + m - 1; ++r) w.at(sg, r, c) = 0.0;
+        }
+    }
+    PSD_SYNC();
+    return 0;
+}
+
+PSD_KERNEL_B(PSD_STEP_NT) psd_rord_step(psd_roparams P) {
+    PSD_LDS_DECL;
+    psd_rostate st = *P.st;
+    PSD_ONE { P.desc->active = 0; }
+    if (st.phase == PSD_ROPH_DONE) return;
+    const int n = st.n, p = st.p;
+    const psd_mat<double> A1 = psd_mat<double>{P.H, n};
+    double* ldsd = (double*)psd_lds;
+    const size_t winb = (size_t)p * st.W * (st.W + 1);
+    double* scr = ldsd + winb;
+    double* wk = scr + (size_t)p * PSD_RORD_SCR;
+    double* flagbuf = wk + (size_t)p * 52;
+    int* lcnt = (int*)(flagbuf + 2);
+    // driver scan: rordschur.jl:77-110
+    while (st.phase == PSD_ROPH_SCAN) {
+        st.j += 1;
+        if (st.j > n) {
+            st.phase = PSD_ROPH_DONE;
+            break;
+        }
+        if (st.pairskip) {
+            st.pairskip = 0;
+            continue;
+        }
+        const int j = st.j;
+        bool swap = P.select[j - 1] != 0;
+        bool pair = false;
+        if (j < n && A1(j + 1, j) != 0) {
+            pair = true;
+            swap = swap || (P.select[j] != 0);
+        }
+        st.pairskip = pair ? 1 : 0;
+        if (swap) {
+            st.jdest += 1;
+            if (j != st.jdest) {
+                // _moveblock! prologue (rordschur.jl:149-172); jsrc already points at a block start
+                int jd = st.jdest;
+                if (jd > 1 && A1(jd, jd - 1) != 0) jd -= 1;
+                st.nbsrc = pair ? 2 : 1;
+                st.jsrc0 = j;
+                if (jd < j) {
+                    st.here = j;
+                    st.jtarget = jd;
+                    st.splitsrc = 0;
+                    st.pend1x1 = 0;
+                    st.phase = PSD_ROPH_MOVE;
+                } else {
+                    st.jdest = jd;
+                    if (pair) st.jdest += 1;
+                }
+            } else if (pair) {
+                st.jdest += 1;
+            }
+        }
+    }
+    if (st.phase == PSD_ROPH_MOVE) {
+        // window: bottom = end of the travelling block(s); top as high as the LDS window allows
+        const int width = st.splitsrc ? 2 : st.nbsrc;
+        psd_win w;
+        w.b = ldsd;
+        w.W = st.W;
+        w.ld = st.W + 1;
+        w.bsz = st.W * (st.W + 1);
+        w.be = st.here + width - 1;
+        w.bs = (w.be - st.W + 1 > st.jtarget) ? (w.be - st.W + 1) : st.jtarget;
+        PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
+        psd_win_load(P_as_r(P), w, n, p);
+        int fail = 0;
+        int here = st.here;
+        const int top0 = here;
+        // rordschur.jl:181-247 restricted to the blocks that fit the window
+        while (here > st.jtarget && !fail) {
+            if (st.pend1x1) {  // second 1x1 of a split pair follows its partner (rordschur.jl:207-215)
+                fail = psd_rord_swap(P, st, w, scr, wk, flagbuf, lcnt, here, 1, 1);
+                if (fail) break;
+                st.nswaps += 1;
+                st.pend1x1 = 0;
+                here -= 1;
+                continue;
+            }
+            int nbnext = 1;
+            if (here >= 3 && here - 2 >= w.bs) {
+                if (w.at(1, here - 1, here - 2) != 0) nbnext = 2;
+            } else if (here >= 3 && here - 1 != st.jtarget) {
+                break;  // the next block may start above the window (row jtarget itself is a block start)
+            }
+            if (here - nbnext < w.bs) break;
+            if (!st.splitsrc) {
+                fail = psd_rord_swap(P, st, w, scr, wk, flagbuf, lcnt, here - nbnext, nbnext, st.nbsrc);
+                if (fail) break;
+                st.nswaps += 1;
+                here -= nbnext;
+                if (st.nbsrc == 2 && w.at(1, here + 1, here) == 0) st.splitsrc = 1;
+            } else {
+                fail = psd_rord_swap(P, st, w, scr, wk, flagbuf, lcnt, here - nbnext, nbnext, 1);
+                if (fail) break;
+                st.nswaps += 1;
+                if (nbnext == 1) {
+                    st.pend1x1 = 1;  // handled at the top of the loop (position `here`)
+                } else {
+                    if (w.at(1, here, here - 1) == 0) nbnext = 1;
+                    if (nbnext == 2) {
+                        fail = psd_rord_swap(P, st, w, scr, wk, flagbuf, lcnt, here - 1, 2, 1);
+                        if (fail) break;
+                        st.nswaps += 1;
+                        here -= 2;
+                    } else {
+                        fail = psd_rord_swap(P, st, w, scr, wk, flagbuf, lcnt, here, 1, 1);
+                        if (fail) break;
+                        st.nswaps += 1;
+                        fail = psd_rord_swap(P, st, w, scr, wk, flagbuf, lcnt, here - 1, 1, 1);
+                        if (fail) break;
+                        st.nswaps += 1;
+                        here -= 2;
+                    }
+                }
+            }
+        }
+        if (fail) {
+            st.info = (fail == 2) ? PSD_INFO_SINGULAR : (PSD_INFO_ILLCOND_BASE + st.jsrc0);
+            st.phase = PSD_ROPH_DONE;
+        } else {
+            psd_win_store(P_as_r(P), w, n, p);
+            PSD_SYNC();
+            PSD_PAR_FOR(m, p) { P.cnt[m] = lcnt[m]; }
+            PSD_ONE {
+                psd_apply_desc d;
+                d.active = 1;
+                d.plo = w.bs;
+                d.phi = w.be;
+                d.lc0 = w.be + 1;
+                d.lc1 = n;
+                d.rr0 = 1;
+                d.rr1 = w.bs - 1;
+                d.zr0 = 1;
+                d.zr1 = st.wantZ ? n : 0;
+                *P.desc = d;
+            }
+            st.nwindows += 1;
+            st.here = here;
+            (void)top0;
+            if (here <= st.jtarget && !st.pend1x1) {
+                st.jdest = here;  // _moveblock! returns jdest = here
+                if (st.nbsrc == 2) st.jdest += 1;
+                st.phase = PSD_ROPH_SCAN;
+            }
+        }
+    }
+    PSD_SYNC();
+    PSD_ONE { *P.st = st; }
+}
+
+PSD_KERNEL psd_rord_init(psd_roparams P, int n, int p, int wantZ, int W) {
+    PSD_ONE {
+        psd_rostate st;
+        st.n = n; st.p = p; st.wantZ = wantZ; st.W = W;
+        st.phase = PSD_ROPH_SCAN; st.info = 0;
+        st.j = 0; st.jdest = 0; st.pairskip = 0;
+        st.here = 0; st.nbsrc = 1; st.splitsrc = 0; st.jtarget = 0; st.jsrc0 = 0; st.pend1x1 = 0;
+        st.nswaps = 0; st.nwindows = 0;
+        *P.st = st;
+        P.desc->active = 0;
+    }
+}
+
+// Bulk application of the window's block transforms: grid = (tiles, p owners, 3 roles) as psd_rq_apply.
+PSD_KERNEL_B(PSD_APPLY_NT) psd_rord_apply(psd_roparams P, int n, int p) {
+    PSD_LDS_DECL;
+    const psd_apply_desc d = *P.desc;
+    if (!d.active) return;
+    const int m = PSD_BLOCK_Y + 1;
+    const int role = PSD_BLOCK_Z;
+    const int cnt = P.cnt[m - 1] < PSD_RORD_CAP ? P.cnt[m - 1] : PSD_RORD_CAP;
+    if (cnt <= 0) return;
+    const int T = PSD_APPLY_NT;
+    const int S = d.phi - d.plo + 1;
+    psd_tq* ltr = (psd_tq*)psd_lds;
+    double* tile = (double*)(psd_lds + sizeof(psd_tq) * PSD_RORD_CAP);
+    PSD_PAR_FOR(e, cnt) { ltr[e] = P.tq[(size_t)(m - 1) * PSD_RORD_CAP + e]; }
+    if (role == 0) {
+        const int c0 = d.lc0 + PSD_BLOCK_X * T;
+        if (c0 > d.lc1) return;
+        const int nc = (d.lc1 - c0 + 1 < T) ? (d.lc1 - c0 + 1) : T;
+        const psd_mat<double> M = psd_mat<double>{P.H + (size_t)(m - 1) * n * n, n};
+        const int ldt = T + 1;
+        PSD_PAR_FOR(t, S * nc) {
+            const int r = t % S, c = t / S;
+            tile[r * ldt + c] = M(d.plo + r, c0 + c);
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(c, nc) {
+            for (int e = 0; e < cnt; ++e) {
+                const psd_tq& tr = ltr[e];
+                const int r = tr.pos - d.plo, mm = tr.m;
+                double a[4], b[4];
+                for (int q = 0; q < mm; ++q) a[q] = tile[(r + q) * ldt + c];
+                for (int rr = 0; rr < mm; ++rr) {
+                    double s = 0.0;
+                    for (int q = 0; q < mm; ++q) s += tr.q[rr * 4 + q] * a[q];
+                    b[rr] = s;
+                }
+                for (int q = 0; q < mm; ++q) tile[(r + q) * ldt + c] = b[q];
+            }
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(t, S * nc) {
+            const int r = t % S, c = t / S;
+            M(d.plo + r, c0 + c) = tile[r * ldt + c];
+        }
+    } else {
+        const int lo = (role == 1) ? d.rr0 : d.zr0;
+        const int hi = (role == 1) ? d.rr1 : d.zr1;
+        const int r0 = lo + PSD_BLOCK_X * T;
+        if (r0 > hi) return;
+        const int nr = (hi - r0 + 1 < T) ? (hi - r0 + 1) : T;
+        const int jm = (role == 1) ? ((m == 1) ? p : (m - 1)) : m;
+        double* base = (role == 1) ? P.H : P.Z;
+        const psd_mat<double> M = psd_mat<double>{base + (size_t)(jm - 1) * n * n, n};
+        PSD_PAR_FOR(t, S * nr) {
+            const int r = t % nr, c = t / nr;
+            tile[c * T + r] = M(r0 + r, d.plo + c);
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(r, nr) {
+            for (int e = 0; e < cnt; ++e) {
+                const psd_tq& tr = ltr[e];
+                const int c = tr.pos - d.plo, mm = tr.m;
+                double a[4], b[4];
+                for (int q = 0; q < mm; ++q) a[q] = tile[(c + q) * T + r];
+                for (int cc = 0; cc < mm; ++cc) {
+                    double s = 0.0;
+                    for (int q = 0; q < mm; ++q) s += a[q] * tr.q[cc * 4 + q];
+                    b[cc] = s;
+                }
+                for (int q = 0; q < mm; ++q) tile[(c + q) * T + r] = b[q];
+            }
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(t, S * nr) {
+            const int r = t % nr, c = t / nr;
+            M(r0 + r, d.plo + c) = tile[c * T + r];
+        }
+    }
+}
+
+
+// rpschur2x2.jl:9-275 (_rpeigvals2x2, S all true, schurindex 1) for the conjugate pair at rows j, j+1 of the
+// internal right-order sequence T_1 ... T_p; X: [p][8] complex 2x2 scratch of this thread.
+PSD_D void psd_rord_eigpair(const psd_roparams& P, int n, int p, int j, psd_z* X, double& l1r, double& l1i,
+                            double& l2r, double& l2i) {
+    for (int l = 0; l < p; ++l) {
+        const psd_mat<double> M = psd_mat<double>{P.H + (size_t)l * n * n, n};
+        X[4 * l + 0] = zmk(M(j, j), 0.0);
+        X[4 * l + 1] = zmk(M(j, j + 1), 0.0);
+        X[4 * l + 2] = zmk(M(j + 1, j), 0.0);
+        X[4 * l + 3] = zmk(M(j + 1, j + 1), 0.0);  // [a b; c d] = X[0], X[1]; X[2], X[3]
+    }
+    const int k = p;
+    for (int iter = 1; iter <= 80; ++iter) {
+        const double lhs = zabs(X[2]);
+        double rhs = fmax(zabs(X[0]), zabs(X[3]));
+        if (rhs == 0) rhs = zabs(X[1]);
+        if (lhs <= PSD_DBL_EPS * rhs) break;
+        double c;
+        psd_z s, r;
+        if (iter == 1) {
+            psd_zgivens(zmk(1.0, -2.0), zmk(2.0, 2.0), c, s, r);
+        } else if (iter % 40 == 0) {
+            psd_zgivens(zmk((double)k, 1.0), zmk(1.0, -2.0), c, s, r);
+        } else {
+            c = 1.0;
+            s = zmk(0.0, 0.0);
+            double ct;
+            psd_z st;
+            psd_zgivens(zmk(1.0, 0.0), zmk(1.0, 0.0), ct, st, r);
+            for (int l = k; l >= 2; --l) {
+                const psd_z* Xl = X + 4 * (l - 1);
+                psd_z Z[3][3];
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) Z[a][b] = zmk(0.0, 0.0);
+                Z[0][0] = Xl[0]; Z[1][1] = Xl[0]; Z[1][2] = Xl[1]; Z[2][1] = Xl[2]; Z[2][2] = Xl[3];
+                for (int q = 0; q < 3; ++q) psd_zrot_right_adj(ct, st, Z[q][0], Z[q][2]);
+                for (int q = 0; q < 3; ++q) psd_zrot_right_adj(c, s, Z[q][0], Z[q][1]);
+                psd_zgivens(Z[0][0], Z[2][0], ct, st, r);
+                psd_zgivens(Xl[0], Z[1][0], c, s, r);
+            }
+            psd_z Z[2][3];
+            Z[0][0] = X[0]; Z[0][1] = zneg(X[2]); Z[0][2] = zneg(X[3]);
+            Z[1][0] = X[2]; Z[1][1] = zmk(0.0, 0.0); Z[1][2] = zmk(0.0, 0.0);
+            for (int q = 0; q < 2; ++q) psd_zrot_right_adj(ct, st, Z[q][0], Z[q][2]);
+            for (int q = 0; q < 2; ++q) psd_zrot_right_adj(c, s, Z[q][0], Z[q][1]);
+            psd_zgivens(Z[0][0], Z[1][0], c, s, r);
+        }
+        const double ct0 = c;
+        const psd_z st0 = s;
+        for (int l = k; l >= 2; --l) {
+            psd_z* Y = X + 4 * (l - 1);
+            psd_zrot_right_adj(c, s, Y[0], Y[1]);
+            psd_zrot_right_adj(c, s, Y[2], Y[3]);
+            psd_zgivens(Y[0], Y[2], c, s, r);
+            Y[0] = r;
+            Y[2] = zmk(0.0, 0.0);
+            psd_zrot_left(c, s, Y[1], Y[3]);
+        }
+        psd_zrot_left(ct0, st0, X[0], X[2]);
+        psd_zrot_left(ct0, st0, X[1], X[3]);
+        psd_zrot_right_adj(c, s, X[0], X[1]);
+        psd_zrot_right_adj(c, s, X[2], X[3]);
+    }
+    psd_z alpha[2];
+    double scal[2];
+    for (int jj = 0; jj < 2; ++jj) {
+        psd_z aj = zmk(1.0, 0.0);
+        scal[jj] = 0.0;
+        for (int l = 1; l <= k; ++l) {
+            psd_z z = X[4 * (l - 1) + (jj == 0 ? 0 : 3)];
+            double rhs = zabs(z);
+            if (rhs != 0) {
+                const int sl = (int)floor(log2(rhs));
+                z = zscal(exp2(-(double)sl), z);
+                scal[jj] += sl;
+            }
+            aj = zmul(aj, z);
+            if ((l % 10 == 0) || (l == k)) {
+                rhs = zabs(aj);
+                if (rhs == 0) {
+                    scal[jj] = 0;
+                } else {
+                    const int sl = (int)floor(log2(rhs));
+                    aj = zscal(exp2(-(double)sl), aj);
+                    scal[jj] += sl;
+                }
+            }
+        }
+        alpha[jj] = aj;
+    }
+    if (alpha[1].im > 0) {
+        const psd_z ta = alpha[0];
+        alpha[0] = alpha[1];
+        alpha[1] = ta;
+        const double ts = scal[0];
+        scal[0] = scal[1];
+        scal[1] = ts;
+    }
+    if (alpha[0].im != 0 || alpha[1].im != 0) {  // rpschur2x2.jl:238-275 _sanitize_reigpair!
+        const double sl = scal[0] - scal[1];
+        psd_z zt1, zt2;
+        double cst;
+        if (sl >= 0) {
+            zt1 = zscal(exp2(-sl), alpha[1]);
+            zt2 = zsub(alpha[0], zconj(zt1));
+            cst = alpha[0].im;
+        } else {
+            zt1 = zscal(exp2(sl), alpha[0]);
+            zt2 = zsub(alpha[1], zconj(zt1));
+            cst = alpha[1].im;
+        }
+        const double misr = hypot(cst, zt1.im);
+        const double misc = zabs(zt2) / 2;
+        if (misr > misc) {
+            const int jx = (scal[0] >= scal[1]) ? 0 : 1;
+            const psd_z at = zscal(0.5, zadd(alpha[jx], zconj(zt1)));
+            alpha[0] = zmk(at.re, fabs(at.im));
+            alpha[1] = zconj(alpha[0]);
+        } else {
+            alpha[0].im = 0.0;
+            alpha[1].im = 0.0;
+        }
+    }
+    l1r = alpha[0].re * exp2(scal[0]);
+    l1i = alpha[0].im * exp2(scal[0]);
+    l2r = alpha[1].re * exp2(scal[1]);
+    l2i = alpha[1].im * exp2(scal[1]);
+}
+
+// ordschur.jl:122-204 _updateλ! (real): one thread per position j
+PSD_KERNEL psd_rord_values(psd_roparams P, int n, int p) {
+    const int NT = PSD_NTHREADS;
+    const psd_mat<double> A1 = psd_mat<double>{P.H, n};
+    PSD_PAR_FOR(t, NT) {
+        const int j = 1 + PSD_BLOCK_X * NT + t;
+        if (j <= n) {
+            const bool second = (j > 1) && (A1(j, j - 1) != 0);
+            const bool first = (j < n) && (A1(j + 1, j) != 0);
+            if (first && !second) {
+                double a, b, c, d;
+                psd_rord_eigpair(P, n, p, j, (psd_z*)(P.xscr + (size_t)(j - 1) * p * 8), a, b, c, d);
+                P.wr[j - 1] = a; P.wi[j - 1] = b;
+                P.wr[j] = c; P.wi[j] = d;
+            } else if (!second) {
+                double v = A1(j, j);
+                int sc = 0;
+                for (int l = 2; l <= p; ++l) {
+                    v *= P.H[(size_t)(l - 1) * n * n + (size_t)(j - 1) * n + (j - 1)];
+                    if (v != 0) {
+                        int e;
+                        v = frexp(v, &e);
+                        sc += e;
+                    }
+                }
+                P.wr[j - 1] = ldexp(v, sc);
+                P.wi[j - 1] = 0.0;
+            }
+        }
+    }
+}
+
+// rordschur.jl:117-130: zero everything below the (1x1 / 2x2) diagonal blocks of T_1.  grid over columns.
+PSD_KERNEL psd_rord_cleanup(psd_roparams P, int n) {
+    const int c = PSD_BLOCK_X + 1;
+    const psd_mat<double> A1 = psd_mat<double>{P.H, n};
+    // the pair's first eigenvalue has positive imaginary part (rpschur2x2.jl:263-266), the second negative
+    const int j0 = (P.wi[c - 1] > 0.0) ? (c + 2) : (c + 1);
+    PSD_PAR_FOR(t, n) {
+        const int r = j0 + t;
+        if (r <= n) A1(r, c) = 0.0;
+    }
+}

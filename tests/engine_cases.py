@@ -400,15 +400,108 @@ def case_zordschur_edge(eng):
         raise AssertionError("wrong select length must be rejected")
     except psd_amd.DimensionMismatch:
         pass
-    try:
-        eng.ordschur_(eng.pschur(pt.bench_factors(6, 3, seed=3), "R"), np.ones(6, dtype=bool))
-        raise AssertionError("real ordschur! is not in this build")
-    except psd_amd.NotImplementedPSD:
-        pass
     # two equal eigenvalues cannot be swapped: the periodic Sylvester system is singular / the swap is rejected
     n, p = 4, 2
     T = [np.asfortranarray(np.triu(np.ones((n, n))).astype(np.complex128)) for _ in range(p)]
     Z = [np.asfortranarray(np.eye(n, dtype=np.complex128)) for _ in range(p)]
+    P = psd_amd.PeriodicSchur(T, Z, np.ones(n, dtype=complex), "R", 1)
+    try:
+        eng.ordschur_(P, np.array([False, True, False, False]))
+        raise AssertionError("expected SingularException / IllConditionedException")
+    except (psd_amd.SingularException, psd_amd.IllConditionedException):
+        pass
+
+
+# ------------------------------------------------------------------------------------------------
+# ordschur! (real, 1x1 and 2x2 blocks): rordschur.jl:3-132, sylswap.jl:14-191
+def case_rordschur_reference_real(eng, p, lr):
+    """test/ordschur.jl:1-55 for Float64 (distinct real eigenvalues 4^j)."""
+    n, nsel = 7, 2
+    A = pt.ord_test_factors(n, p, seed=4000 + p)
+    if lr == "R":
+        A = A[::-1]
+    ps0 = eng.pschur(A, lr)
+    lam0 = ps0.values.copy()
+    for which in ("smallest", "largest"):
+        idx = np.argsort(np.abs(lam0))
+        if which == "largest":
+            idx = idx[::-1]
+        select = np.zeros(n, dtype=bool)
+        select[idx[:nsel]] = True
+        ps1 = eng.ordschur_(_clone(ps0), select)
+        pt.pschur_check(A, ps1, check_lam=False)
+        for j in range(nsel):
+            assert np.any(np.isclose(ps1.values[:nsel], lam0[idx[j]], rtol=1e-8))
+
+
+def case_rordschur_pairs(eng, p, selset):
+    """test/ordschur.jl:127-164: constructed real PSD (mkrps) with conjugate pairs at rows 3:4 and 6:7."""
+    import psd_amd
+
+    n = 7
+    ps0, A = pt.mkrps(n, p, [3, 6], seed=900 + p)
+    P0 = psd_amd.PeriodicSchur([t.copy(order="F") for t in ps0.Ts], [z.copy(order="F") for z in ps0.Z],
+                               ps0.values.copy(), "L", p)
+    select = np.zeros(n, dtype=bool)
+    select[[j - 1 for j in selset]] = True
+    ps1 = eng.ordschur_(P0, select)
+    pt.pschur_check(A, ps1, check_lam=False, tol=20000 if p == 1 else 32)
+    nsel = len(selset)
+    for j in selset:
+        assert np.any(np.isclose(ps1.values[:nsel], ps0.values[j - 1], rtol=1e-8))
+    po = pt.oracle_ordschur(ps0, select)
+    assert ps1.stats.nsweeps == po.nswaps
+    assert pt.match_eigs(po.values, ps1.values) < 1e-10 * abs(po.values).max()
+
+
+def case_rordschur_windows(eng, sizes):
+    """pschur! results with a generic mix of real eigenvalues and conjugate pairs; the smaller half is selected
+    (conjugates closed, as BASELINE config 5 selects by modulus): many swaps of all block-size combinations over
+    several windows, every window width, both orientations, with and without Z."""
+    for (n, p) in sizes:
+        for lr in "RL":
+            A = pt.bench_factors(n, p, seed=90 + n + p)
+            ps0 = eng.pschur(A, lr)
+            lam0 = ps0.values.copy()
+            thr = np.sort(np.abs(lam0))[n // 2]
+            select = np.abs(lam0) <= thr
+            ps1 = eng.ordschur_(_clone(ps0), select)
+            assert ps1.stats.nsweeps > 0
+            ok, err = pt.checkpsd(ps1, A, thresh=100 * np.sqrt(max(n / 32, 1)))
+            assert ok, (n, p, lr, err)
+            m = int(select.sum())
+            sc = abs(lam0).max()
+            assert pt.match_eigs(lam0[select], ps1.values[:m]) < 1e-8 * sc
+            assert pt.match_eigs(lam0[~select], ps1.values[m:]) < 1e-8 * sc
+            for i in range(n - 1):  # structure: sub-diagonal entries only inside conjugate pairs
+                if ps1.values[i].imag == 0 or ps1.values[i].imag < 0:
+                    assert ps1.T1[i + 1, i] == 0
+            po = pt.oracle_ordschur(pt.PSD(ps0.Ts, ps0.Z, lam0, ps0.orientation, ps0.schurindex), select)
+            assert po.info == 0 and ps1.stats.nsweeps == po.nswaps
+            ps2 = eng.ordschur_(_clone(ps0), select, wantZ=False)
+            assert all(np.array_equal(a, b) for a, b in zip(ps2.Z, ps0.Z))
+            assert max(np.abs(a - b).max() for a, b in zip(ps2.Ts, ps1.Ts)) < 1e-12 * max(1.0, sc)
+
+
+def case_rordschur_edge(eng):
+    import psd_amd
+
+    A = pt.bench_factors(8, 3, seed=5)
+    ps0 = eng.pschur(A, "R")
+    n = 8
+    assert eng.ordschur_(_clone(ps0), np.zeros(n, dtype=bool)).stats.nsweeps == 0
+    assert eng.ordschur_(_clone(ps0), np.ones(n, dtype=bool)).stats.nsweeps == 0
+    cp = np.where(ps0.values.imag > 0)[0]
+    if len(cp):  # selecting one member of a conjugate pair takes the partner along (rordschur.jl:46-75)
+        j = int(cp[-1])
+        sel = np.zeros(n, dtype=bool)
+        sel[j + 1] = True
+        ps1 = eng.ordschur_(_clone(ps0), sel)
+        pt.pschur_check(A, ps1, check_lam=False)
+        assert np.isclose(ps1.values[0], ps0.values[j]) and np.isclose(ps1.values[1], ps0.values[j + 1])
+    n, p = 4, 2  # equal eigenvalues: singular periodic Sylvester system / rejected swap
+    T = [np.asfortranarray(np.triu(np.ones((n, n)))) for _ in range(p)]
+    Z = [np.asfortranarray(np.eye(n)) for _ in range(p)]
     P = psd_amd.PeriodicSchur(T, Z, np.ones(n, dtype=complex), "R", 1)
     try:
         eng.ordschur_(P, np.array([False, True, False, False]))

@@ -121,3 +121,23 @@ def test_device_resident_entry(gpu_engine):
     ps = pt.PSD(Ts, Zs, lam, "R", si)
     pt.pschur_check(As, ps, tol=64)
     assert st.ms_iter > 0 and st.nwindows > 0
+
+
+@pytest.mark.parametrize("p", [5, 1])
+@pytest.mark.parametrize("lr", ["L", "R"])
+def test_rordschur_reference_real(gpu_engine, p, lr):
+    ec.case_rordschur_reference_real(gpu_engine, p, lr)
+
+
+@pytest.mark.parametrize("p", [5, 1])
+@pytest.mark.parametrize("selset", [[1, 2, 5], [1, 3, 4], [1, 2, 6, 7]])
+def test_rordschur_pairs(gpu_engine, p, selset):
+    ec.case_rordschur_pairs(gpu_engine, p, selset)
+
+
+def test_rordschur_windows(gpu_engine):
+    ec.case_rordschur_windows(gpu_engine, [(48, 3), (44, 12), (40, 22), (36, 34), (30, 70)])
+
+
+def test_rordschur_edge(gpu_engine):
+    ec.case_rordschur_edge(gpu_engine)

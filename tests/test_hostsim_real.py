@@ -50,3 +50,23 @@ def test_window_widths(sim_engine):
 
 def test_pschur_hess(sim_engine):
     ec.case_pschur_hess(sim_engine)
+
+
+@pytest.mark.parametrize("p", [5, 1])
+@pytest.mark.parametrize("lr", ["L", "R"])
+def test_rordschur_reference_real(sim_engine, p, lr):
+    ec.case_rordschur_reference_real(sim_engine, p, lr)
+
+
+@pytest.mark.parametrize("p", [5, 1])
+@pytest.mark.parametrize("selset", [[1, 2, 5], [1, 3, 4], [1, 2, 6, 7]])
+def test_rordschur_pairs(sim_engine, p, selset):
+    ec.case_rordschur_pairs(sim_engine, p, selset)
+
+
+def test_rordschur_windows(sim_engine):
+    ec.case_rordschur_windows(sim_engine, [(48, 3), (44, 12), (40, 22), (36, 34), (30, 70)])
+
+
+def test_rordschur_edge(sim_engine):
+    ec.case_rordschur_edge(sim_engine)
