@@ -5,6 +5,7 @@
 #include "psd_oracle_complex.hpp"
 #include "psd_oracle_ord.hpp"
 #include "psd_oracle_rord.hpp"
+#include "psd_oracle_sghess.hpp"
 
 #include <chrono>
 
@@ -267,6 +268,29 @@ int psdo_d_ordschur(int n, int p, double* Td, double* Zd, char orient, int schur
         wi[q] = lam[q].imag();
     }
     return info;
+}
+
+// _phessenberg!(A, S) — generalized.jl:988-1082.  is_complex selects the element type; A, Q are [p][n][n].
+int psdo_sg_phessenberg(int n, int p, int is_complex, double* A, const uint8_t* S, double* Q) {
+    std::vector<char> Sv(p + 1, 1);
+    for (int l = 1; l <= p; ++l) Sv[l] = S[l - 1] ? 1 : 0;
+    if (!Sv[1]) return -5;  // generalized.jl:990
+    if (is_complex) {
+        std::vector<MatT<cplx>> Av(p + 1), Qv(p + 1);
+        for (int l = 1; l <= p; ++l) {
+            Av[l] = MatT<cplx>{reinterpret_cast<cplx*>(A) + (size_t)(l - 1) * n * n, n};
+            Qv[l] = MatT<cplx>{reinterpret_cast<cplx*>(Q) + (size_t)(l - 1) * n * n, n};
+        }
+        sg_phessenberg<cplx>(n, p, Av, Sv, Qv, true);
+    } else {
+        std::vector<MatT<double>> Av(p + 1), Qv(p + 1);
+        for (int l = 1; l <= p; ++l) {
+            Av[l] = MatT<double>{A + (size_t)(l - 1) * n * n, n};
+            Qv[l] = MatT<double>{Q + (size_t)(l - 1) * n * n, n};
+        }
+        sg_phessenberg<double>(n, p, Av, Sv, Qv, true);
+    }
+    return 0;
 }
 
 }  // extern "C"

@@ -135,6 +135,7 @@ def oracle_lib():
     lib.psdo_z_ordschur.argtypes = [C.c_int, C.c_int, dp, dp, C.c_char, C.c_int, u8p, C.c_int, dp, dp, i32p, i64p]
     lib.psdo_d_ordschur_real1x1.argtypes = [C.c_int, C.c_int, dp, dp, C.c_char, C.c_int, u8p, C.c_int, dp, i64p]
     lib.psdo_d_ordschur.argtypes = [C.c_int, C.c_int, dp, dp, C.c_char, C.c_int, u8p, C.c_int, dp, dp, i64p]
+    lib.psdo_sg_phessenberg.argtypes = [C.c_int, C.c_int, C.c_int, dp, u8p, dp]
     _oracle = lib
     return lib
 
@@ -403,6 +404,36 @@ def mkrps(n, p, jcs, seed, nnfac=1e-2):
     full = [np.asfortranarray(t) for t in Ts] + [np.asfortranarray(T1)]
     ps = PSD(full, [np.asfortranarray(z) for z in Zs], lam, "L", p)
     return ps, [np.asfortranarray(a) for a in As]
+
+
+def oracle_sg_phessenberg(As, S):
+    """CPU restatement of _phessenberg!(A, S) (generalized.jl:988-1082): returns (Hs, Qs)."""
+    lib = oracle_lib()
+    p = len(As)
+    n = As[0].shape[0]
+    cplx = any(np.iscomplexobj(a) for a in As)
+    dt = np.complex128 if cplx else np.float64
+    A = pack(As, dt)
+    Q = np.zeros((p, n, n), dtype=dt)
+    Sarr = (C.c_uint8 * p)(*[1 if x else 0 for x in S])
+    ptr = _zp if cplx else _dp
+    info = lib.psdo_sg_phessenberg(n, p, int(cplx), ptr(A), Sarr, ptr(Q))
+    assert info == 0
+    return unpack(A), unpack(Q)
+
+
+def sg_hess_check(A, S, Hs, Qs, tol=20, qtol=10):
+    """test/generalized.jl:16-36."""
+    p = len(A)
+    n = A[0].shape[0]
+    assert np.all(np.tril(Hs[0], -2) == 0)
+    for j in range(p):
+        if j > 0:
+            assert np.all(np.tril(Hs[j], -1) == 0)
+        assert np.linalg.norm(Qs[j] @ Qs[j].conj().T - np.eye(n)) < qtol * EPS * n
+        jn = (j + 1) % p
+        Ax = Qs[j] @ Hs[j] @ Qs[jn].conj().T if S[j] else Qs[jn] @ Hs[j] @ Qs[j].conj().T
+        assert np.linalg.norm(A[j] - Ax) < tol * EPS * n * max(1.0, np.linalg.norm(A[j], 1) / n), (j, np.linalg.norm(A[j] - Ax))
 
 
 def oracle_phessenberg(As):
