@@ -6,6 +6,7 @@
 #include "psd_oracle_ord.hpp"
 #include "psd_oracle_rord.hpp"
 #include "psd_oracle_sghess.hpp"
+#include "psd_oracle_rgen.hpp"
 
 #include <chrono>
 
@@ -291,6 +292,84 @@ int psdo_sg_phessenberg(int n, int p, int is_complex, double* A, const uint8_t* 
         sg_phessenberg<double>(n, p, Av, Sv, Qv, true);
     }
     return 0;
+}
+
+// pschur!(H1, Hs, S; wantT, wantZ, Q, maxitfac) for Float64 — rgeneralized.jl:49-1083.  H, Z [p][n][n]; Z holds Q on
+// entry (identity for Q = nothing).  alpha is complex (2n doubles).  counters[8]: niter, sweeps, zero-shift passes,
+// Case II, Case III, 2x2 real deflations, 2x2 complex blocks, iwarn.
+int psdo_d_gpschur_hess(int n, int p, double* H, const uint8_t* S, double* Z, int wantT, int wantZ, int maxitfac,
+                        double* alpha, double* beta, int32_t* ascale, int64_t* counters) {
+    std::vector<MatT<double>> Hv(p + 1), Zv(p + 1);
+    std::vector<char> Sv(p + 1, 1);
+    for (int l = 1; l <= p; ++l) {
+        Hv[l] = MatT<double>{H + (size_t)(l - 1) * n * n, n};
+        Zv[l] = MatT<double>{(wantZ && Z) ? Z + (size_t)(l - 1) * n * n : nullptr, n};
+        Sv[l] = S ? (S[l - 1] ? 1 : 0) : 1;
+    }
+    std::vector<int> sc(n, 0);
+    RGLog log;
+    int info = rg_pschur_hess(n, p, Hv, Sv, Zv, wantT != 0, wantZ != 0 && Z, maxitfac, reinterpret_cast<cplx*>(alpha),
+                              beta, sc.data(), &log);
+    for (int q = 0; q < n; ++q) ascale[q] = sc[q];
+    if (counters) {
+        counters[0] = log.niter; counters[1] = log.nsweeps; counters[2] = log.nzero; counters[3] = log.ncase2;
+        counters[4] = log.ncase3; counters[5] = log.n2x2real; counters[6] = log.n2x2cplx; counters[7] = log.iwarn;
+    }
+    return info;
+}
+
+// pschur!(A, S, lr; wantZ, wantT) — real: rgeneralized.jl:3-45; complex: generalized.jl:108-148.  User-order in/out
+// (A[l] -> T_l, Z[l]); *schurindex = 1 ('R') or p ('L').  The Hessenberg-triangular stage is _phessenberg!(A, S) for
+// every signature (the reference takes the Householder phessenberg! when all(S); same contract).
+int psdo_gpschur(int n, int p, int is_complex, double* A, const uint8_t* S, char orient, int wantT, int wantZ,
+                 int maxitfac, double* Z, double* alpha, double* beta, int32_t* ascale, int* schurindex,
+                 int64_t* counters) {
+    if (orient != 'R' && orient != 'L') return -4;
+    const bool left = orient == 'L';
+    auto slotA = [&](int j) { return left ? (p + 1 - j) : j; };
+    auto slotZ = [&](int j) { return (!left || j == 1) ? j : (p + 2 - j); };
+    std::vector<char> Sv(p + 1, 1);
+    for (int j = 1; j <= p; ++j) Sv[j] = S[slotA(j) - 1] ? 1 : 0;
+    if (!Sv[1]) return -5;
+    std::vector<int> sc(n, 0);
+    int info;
+    std::vector<double> Zloc;
+    if (!Z) {
+        Zloc.assign((size_t)p * n * n * (is_complex ? 2 : 1), 0.0);
+        Z = Zloc.data();
+    }
+    if (is_complex) {
+        std::vector<MatT<cplx>> Av(p + 1), Qv(p + 1);
+        std::vector<MatZ> Hz(p + 1), Zz(p + 1);
+        for (int j = 1; j <= p; ++j) {
+            Av[j] = MatT<cplx>{reinterpret_cast<cplx*>(A) + (size_t)(slotA(j) - 1) * n * n, n};
+            Qv[j] = MatT<cplx>{reinterpret_cast<cplx*>(Z) + (size_t)(slotZ(j) - 1) * n * n, n};
+            Hz[j] = MatZ{Av[j].a, n};
+            Zz[j] = MatZ{Qv[j].a, n};
+        }
+        sg_phessenberg<cplx>(n, p, Av, Sv, Qv, true);
+        int64_t niter = 0;
+        info = pschur_hess_z(n, p, Hz, Sv, Zz, wantT != 0, wantZ != 0, maxitfac, reinterpret_cast<cplx*>(alpha), beta,
+                             sc.data(), &niter, nullptr);
+        if (counters) counters[0] = niter;
+    } else {
+        std::vector<MatT<double>> Av(p + 1), Qv(p + 1);
+        for (int j = 1; j <= p; ++j) {
+            Av[j] = MatT<double>{A + (size_t)(slotA(j) - 1) * n * n, n};
+            Qv[j] = MatT<double>{Z + (size_t)(slotZ(j) - 1) * n * n, n};
+        }
+        sg_phessenberg<double>(n, p, Av, Sv, Qv, true);
+        RGLog log;
+        info = rg_pschur_hess(n, p, Av, Sv, Qv, wantT != 0, wantZ != 0, maxitfac, reinterpret_cast<cplx*>(alpha), beta,
+                              sc.data(), &log);
+        if (counters) {
+            counters[0] = log.niter; counters[1] = log.nsweeps; counters[2] = log.nzero; counters[3] = log.ncase2;
+            counters[4] = log.ncase3; counters[5] = log.n2x2real; counters[6] = log.n2x2cplx; counters[7] = log.iwarn;
+        }
+    }
+    for (int q = 0; q < n; ++q) ascale[q] = sc[q];
+    if (schurindex) *schurindex = left ? p : 1;
+    return info;
 }
 
 }  // extern "C"

@@ -397,9 +397,12 @@ inline bool sanitize_reigpair(cplx* alpha, double* scal) {
     return good;
 }
 
-// rpschur2x2.jl:9-235 _rpeigvals2x2 with S all true, Aord = 1:k, schurindex = 1, recip = false:
-// eigenvalues (alpha * 2^scal) of X_1 X_2 ... X_k for real 2x2 blocks, X_1 full, others upper triangular
-inline void rpeigvals2x2(int k, const std::vector<SM>& Xin, cplx* alpha, double* scal, bool& converged, bool& good) {
+// rpschur2x2.jl:9-235 _rpeigvals2x2 with Aord = 1:k, schurindex = 1, recip = false:
+// eigenvalues (alpha / beta * 2^scal) of X_1 X_2^{s_2} ... X_k^{s_k} for real 2x2 blocks, X_1 full, others upper
+// triangular.  S == nullptr means all true (the ordschur callers); S[l-1] is the signature of X_l.
+inline void rpeigvals2x2(int k, const std::vector<SM>& Xin, cplx* alpha, double* scal, bool& converged, bool& good,
+                         const char* S = nullptr, double* beta = nullptr) {
+    auto sg = [&](int l) { return S == nullptr || S[l - 1]; };
     struct Z2 { cplx a, b, c, d; };  // [a b; c d]
     std::vector<Z2> Xs(k);
     for (int l = 0; l < k; ++l) Xs[l] = Z2{cplx(Xin[l](0, 0)), cplx(Xin[l](0, 1)), cplx(Xin[l](1, 0)), cplx(Xin[l](1, 1))};
@@ -430,6 +433,29 @@ inline void rpeigvals2x2(int k, const std::vector<SM>& Xin, cplx* alpha, double*
             for (int l = k; l >= 2; --l) {
                 const Z2& Xl = Xs[l - 1];
                 cplx Z[3][3] = {{Xl.a, 0.0, 0.0}, {0.0, Xl.a, Xl.b}, {0.0, Xl.c, Xl.d}};
+                if (!sg(l)) {  // rpschur2x2.jl:116-130
+                    for (int q = 0; q < 3; ++q) {  // lmul!(Givens(1,3,ct,st), Z)
+                        cplx a1 = Z[0][q], a2 = Z[2][q];
+                        Z[0][q] = ct * a1 + st * a2;
+                        Z[2][q] = -std::conj(st) * a1 + ct * a2;
+                    }
+                    for (int q = 0; q < 3; ++q) {  // lmul!(Givens(1,2,c,s), Z)
+                        cplx a1 = Z[0][q], a2 = Z[1][q];
+                        Z[0][q] = c * a1 + s * a2;
+                        Z[1][q] = -std::conj(s) * a1 + c * a2;
+                    }
+                    giv(Z[2][2], Z[2][0], ct, st, r);
+                    Z[2][2] = r;
+                    st = -st;
+                    for (int q = 0; q < 2; ++q) {  // rmul!(view(Z, 1:2, :), Givens(1,3,ct,st)')
+                        cplx a1 = Z[q][0], a2 = Z[q][2];
+                        Z[q][0] = a1 * ct + a2 * std::conj(st);
+                        Z[q][2] = -a1 * st + a2 * ct;
+                    }
+                    giv(Z[1][1], Z[1][0], c, s, r);
+                    s = -s;
+                    continue;
+                }
                 // S true: rmul!(Z, G1') with G1 = Givens(1,3,ct,st); rmul!(Z, G2') with G2 = Givens(1,2,c,s)
                 for (int q = 0; q < 3; ++q) {
                     cplx a1 = Z[q][0], a2 = Z[q][2];
@@ -462,6 +488,23 @@ inline void rpeigvals2x2(int k, const std::vector<SM>& Xin, cplx* alpha, double*
         const cplx st0 = s;
         for (int l = k; l >= 2; --l) {
             Z2 Y = Xs[l - 1];
+            if (!sg(l)) {  // rpschur2x2.jl:162-176
+                cplx a1 = Y.a, a2 = Y.c;
+                Y.a = c * a1 + s * a2;
+                Y.c = -std::conj(s) * a1 + c * a2;
+                a1 = Y.b; a2 = Y.d;
+                Y.b = c * a1 + s * a2;
+                Y.d = -std::conj(s) * a1 + c * a2;
+                giv(Y.d, Y.c, c, s, r);
+                Y.d = r;
+                Y.c = cplx(0.0);
+                s = -s;
+                a1 = Y.a; a2 = Y.b;
+                Y.a = a1 * c + a2 * std::conj(s);
+                Y.b = -a1 * s + a2 * c;
+                Xs[l - 1] = Y;
+                continue;
+            }
             {  // rmul!(Y, G')
                 cplx a1 = Y.a, a2 = Y.b;
                 Y.a = a1 * c + a2 * std::conj(s);
@@ -499,6 +542,7 @@ inline void rpeigvals2x2(int k, const std::vector<SM>& Xin, cplx* alpha, double*
         }
         Xs[0] = Y;
     }
+    double bet[2] = {1.0, 1.0};
     for (int j = 0; j < 2; ++j) {
         cplx aj(1.0);
         scal[j] = 0.0;
@@ -510,8 +554,15 @@ inline void rpeigvals2x2(int k, const std::vector<SM>& Xin, cplx* alpha, double*
                 sl = (int)std::floor(std::log2(rhs));
                 z *= std::exp2(-(double)sl);
             }
-            aj *= z;
-            scal[j] += sl;
+            if (sg(l)) {
+                aj *= z;
+                scal[j] += sl;
+            } else if (rhs == 0) {
+                bet[j] = 0.0;
+            } else {
+                aj /= z;
+                scal[j] -= sl;
+            }
             if ((l % 10 == 0) || (l == k)) {
                 rhs = std::abs(aj);
                 if (rhs == 0) {
@@ -528,6 +579,11 @@ inline void rpeigvals2x2(int k, const std::vector<SM>& Xin, cplx* alpha, double*
     if (alpha[1].imag() > 0) {
         std::swap(alpha[0], alpha[1]);
         std::swap(scal[0], scal[1]);
+        std::swap(bet[0], bet[1]);
+    }
+    if (beta) {
+        beta[0] = bet[0];
+        beta[1] = bet[1];
     }
     good = sanitize_reigpair(alpha, scal);
 }

@@ -136,6 +136,10 @@ def oracle_lib():
     lib.psdo_d_ordschur_real1x1.argtypes = [C.c_int, C.c_int, dp, dp, C.c_char, C.c_int, u8p, C.c_int, dp, i64p]
     lib.psdo_d_ordschur.argtypes = [C.c_int, C.c_int, dp, dp, C.c_char, C.c_int, u8p, C.c_int, dp, dp, i64p]
     lib.psdo_sg_phessenberg.argtypes = [C.c_int, C.c_int, C.c_int, dp, u8p, dp]
+    i32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    lib.psdo_d_gpschur_hess.argtypes = [C.c_int, C.c_int, dp, u8p, dp, C.c_int, C.c_int, C.c_int, dp, dp, i32p, i64p]
+    lib.psdo_gpschur.argtypes = [C.c_int, C.c_int, C.c_int, dp, u8p, C.c_char, C.c_int, C.c_int, C.c_int, dp, dp, dp,
+                                 i32p, C.POINTER(C.c_int), i64p]
     _oracle = lib
     return lib
 
@@ -310,6 +314,113 @@ def gpschur_check(As, S, ps, qtol=10, tol=100):
         else:
             assert not np.isfinite(ps.values[j])
     return out
+
+
+RG_COUNTERS = ("niter", "sweeps", "zero", "case2", "case3", "real2x2", "cplx2x2", "iwarn")
+
+
+def oracle_gpschur_hess(H1, Hs, S, Q=None, wantZ=True, wantT=True, maxitfac=120, rev=False):
+    """CPU restatement of pschur!(H1, Hs, S; wantT, wantZ, Q, rev) for Float64 (rgeneralized.jl:49-1083)."""
+    lib = oracle_lib()
+    Hl = [H1] + list(Hs)
+    p = len(Hl)
+    n = H1.shape[0]
+    S = list(S)
+    H = pack(Hl, np.float64)
+    Z = pack(Q if Q is not None else [np.eye(n)] * p, np.float64)
+    alpha = np.zeros(n, dtype=np.complex128)
+    beta = np.zeros(n)
+    sc = np.zeros(n, dtype=np.int32)
+    cnt = np.zeros(8, dtype=np.int64)
+    Sarr = (C.c_uint8 * p)(*[1 if x else 0 for x in S])
+    info = lib.psdo_d_gpschur_hess(n, p, _dp(H), Sarr, _dp(Z), int(wantT), int(wantZ), maxitfac, _zp(alpha), _dp(beta),
+                                   sc.ctypes.data_as(C.POINTER(C.c_int32)), cnt.ctypes.data_as(C.POINTER(C.c_int64)))
+    Ts, Zs = unpack(H), (unpack(Z) if wantZ else [])
+    if rev:  # rgeneralized.jl:1062-1079
+        Zr = ([Zs[0]] + [Zs[p + 1 - l] for l in range(2, p + 1)]) if wantZ else Zs
+        Tr = [Ts[p - l] for l in range(1, p)] + [Ts[0]]
+        out = GPSD(S[::-1], Tr, Zr, alpha, beta, sc, "L", p, info, int(cnt[0]))
+    else:
+        out = GPSD(S, Ts, Zs, alpha, beta, sc, "R", 1, info, int(cnt[0]))
+    out.counters = dict(zip(RG_COUNTERS, cnt.tolist()))
+    return out
+
+
+def oracle_gpschur(As, S, lr="R", wantZ=True, wantT=True, maxitfac=None):
+    """CPU restatement of pschur!(A, S, lr) — Float64: rgeneralized.jl:3-45, ComplexF64: generalized.jl:108-148."""
+    lib = oracle_lib()
+    p = len(As)
+    n = As[0].shape[0]
+    cplx = any(np.iscomplexobj(a) for a in As)
+    dt = np.complex128 if cplx else np.float64
+    if maxitfac is None:
+        maxitfac = 30 if cplx else 120
+    A = pack(As, dt)
+    Z = np.zeros((p, n, n), dtype=dt)
+    alpha = np.zeros(n, dtype=np.complex128)
+    beta = np.zeros(n)
+    sc = np.zeros(n, dtype=np.int32)
+    cnt = np.zeros(8, dtype=np.int64)
+    si = C.c_int(0)
+    Sarr = (C.c_uint8 * p)(*[1 if x else 0 for x in S])
+    ptr = _zp if cplx else _dp
+    info = lib.psdo_gpschur(n, p, int(cplx), ptr(A), Sarr, lr.encode()[0:1], int(wantT), int(wantZ), maxitfac, ptr(Z),
+                            _zp(alpha), _dp(beta), sc.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(si),
+                            cnt.ctypes.data_as(C.POINTER(C.c_int64)))
+    out = GPSD(list(S), unpack(A), unpack(Z) if wantZ else [], alpha, beta, sc, lr, si.value, info, int(cnt[0]))
+    out.counters = dict(zip(RG_COUNTERS, cnt.tolist()))
+    return out
+
+
+def rgpschur_check(As, S, ps, qtol=10, tol=100, lam_check=True):
+    """test/testfuncs.jl:238-382 (real eltype, non-developing branch) plus, when every eigenvalue is finite, a
+    comparison of the spectrum with LAPACK's for the explicitly formed product."""
+    p = len(S)
+    n = As[0].shape[0]
+    left = ps.orientation == "L"
+    Ts, Zs = ps.Ts, ps.Z
+    js = ps.schurindex - 1
+    for l in range(p):
+        ln = (l + 1) % p
+        if bool(S[l]) != left:
+            Ax = Zs[l] @ Ts[l] @ Zs[ln].T
+        else:
+            Ax = Zs[ln] @ Ts[l] @ Zs[l].T
+        if l == js:
+            for i in range(n - 1):
+                if ps.values[i].imag == 0:
+                    assert Ts[l][i + 1, i] == 0, (i, Ts[l][i + 1, i])
+        assert np.all(np.tril(Ts[l], -2 if l == js else -1) == 0)
+        orth = np.linalg.norm(Zs[l] @ Zs[l].T - np.eye(n))
+        assert orth < qtol * EPS * n, f"Z[{l+1}] orthogonality {orth:.3e}"
+        res = np.linalg.norm(As[l] - Ax)
+        assert res < tol * EPS * n * max(1.0, np.linalg.norm(As[l], 1) / n), f"residual[{l+1}] {res:.3e}"
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        lam_s = np.ones(n)
+        for l in range(p):
+            d = np.diag(Ts[l])
+            lam_s = lam_s * (d if ps.S[l] else 1.0 / d)
+    for j in range(n):
+        if ps.values[j].imag != 0:
+            continue
+        if np.isfinite(lam_s[j]):
+            assert np.isclose(ps.values[j].real, lam_s[j], rtol=1e-8, atol=0), (j, ps.values[j], lam_s[j])
+        else:
+            assert not np.isfinite(ps.values[j])
+    if lam_check and np.all(np.isfinite(ps.values)):
+        P = np.eye(n)
+        for l in range(p):
+            F = As[l] if S[l] else np.linalg.inv(As[l])
+            P = F @ P if left else P @ F
+        ref = np.linalg.eigvals(P)
+        scale = np.linalg.cond(P) * EPS * np.linalg.norm(P, 2)
+        lam = np.array(ps.values)
+        used = np.zeros(n, dtype=bool)
+        for z in lam:
+            d = np.abs(ref - z) + used * 1e300
+            k = int(np.argmin(d))
+            assert d[k] <= max(1e-8 * abs(z), 100 * scale), (z, ref[k], d[k], scale)
+            used[k] = True
 
 
 def rand_uniform_zfactors(n, p, seed):

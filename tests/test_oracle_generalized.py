@@ -25,3 +25,91 @@ def test_generalized_phessenberg_patterns(built, cplx):
         A = pt.bench_factors(n, p, seed=3, dtype=np.complex128 if cplx else np.float64)
         Hs, Qs = pt.oracle_sg_phessenberg(A, S)
         pt.sg_hess_check(A, S, Hs, Qs)
+
+
+def _hess_ut(n, p, seed):
+    A = [np.triu(a) for a in pt.rand_uniform_factors(n, p, seed)]
+    A[0] = np.triu(pt.rand_uniform_factors(n, 1, seed + 77)[0], -1)
+    return [np.asfortranarray(a) for a in A]
+
+
+def _run_hess(A, S, **kw):
+    ps = pt.oracle_gpschur_hess(A[0].copy(), [a.copy() for a in A[1:]], S, **kw)
+    assert ps.info == 0, ps.info
+    pt.rgpschur_check(A, S, ps)
+    return ps
+
+
+# test/generalized.jl:67-76 "Generalized Periodic Schur Hess+UT Float64 (small)"
+@pytest.mark.parametrize("p", [2, 3, 5])
+def test_rgen_hess_ut_small(built, p):
+    for seed in range(6):
+        S = [True, False] + [True] * (p - 2)
+        _run_hess(_hess_ut(5, p, 800 + 10 * p + seed), S)
+
+
+# test/generalized.jl:77-152: holes in +/- factors (both signature variants of SINGLE_MINUS_SIG)
+HOLES = [
+    ("early +hole", [True, True, False, True, True], [True, True, False, True, False], 2, 3),
+    ("late +hole", [True, True, False, True, True], [True, True, False, True, False], 4, 3),
+    ("late upper -hole", [True, True, True, False, True], [True, False, True, False, True], 4, 2),
+    ("late lower -hole", [True, True, True, False, True], [True, False, True, False, True], 4, 4),
+    ("upper -hole", [True, False, True, True, True], [True, False, True, False, True], 2, 2),
+    ("lower -hole", [True, False, True, True, True], [True, False, True, False, True], 2, 4),
+]
+
+
+@pytest.mark.parametrize("name,S1,S2,l,j", HOLES, ids=[h[0] for h in HOLES])
+def test_rgen_holes(built, name, S1, S2, l, j):
+    for S in (S1, S2):
+        for seed in range(4):
+            A = _hess_ut(5, 5, 900 + seed)
+            A[l - 1][j - 1, j - 1] = 0.0
+            ps = _run_hess(A, S)
+            if not S[l - 1]:
+                assert np.sum(~np.isfinite(ps.values)) >= 1  # an infinite eigenvalue
+
+
+# test/generalized.jl:42-65 full matrices, both orientations
+@pytest.mark.parametrize("lr", ["R", "L"])
+def test_rgen_full(built, lr):
+    n, p = 5, 4
+    S = [True, False, True, False] if lr == "R" else [False, True, False, True]
+    for seed in range(6):
+        A = pt.rand_uniform_factors(n, p, 950 + seed)
+        ps = pt.oracle_gpschur(A, S, lr)
+        assert ps.info == 0 and ps.schurindex == (1 if lr == "R" else p)
+        pt.rgpschur_check(A, S, ps)
+
+
+@pytest.mark.parametrize("n,p", [(12, 3), (24, 6), (40, 4)])
+def test_rgen_moderate(built, n, p):
+    S = [True] + [bool((l * 7 + n) % 3) for l in range(1, p)]
+    A = pt.bench_factors(n, p, seed=n + p)
+    ps = pt.oracle_gpschur(A, S, "R")
+    assert ps.info == 0
+    pt.rgpschur_check(A, S, ps, tol=100 * max(1.0, np.sqrt(n / 32)))
+    assert ps.counters["sweeps"] > 0
+
+
+# all(S): the generalized driver must agree with the standard periodic QR on the spectrum
+def test_rgen_all_true_matches_standard(built):
+    n, p = 16, 5
+    A = pt.bench_factors(n, p, seed=5)
+    ps = pt.oracle_gpschur(A, [True] * p, "R")
+    assert ps.info == 0
+    pt.rgpschur_check(A, [True] * p, ps)
+    ref = pt.oracle_pschur(A, "R")
+    pt.compare_reigvals(ps.values, ref.values, 1e-10 * max(1.0, np.max(np.abs(ref.values))))
+
+
+# complex signed full driver (generalized.jl:108-148), test/generalized.jl:188-232
+@pytest.mark.parametrize("lr", ["R", "L"])
+def test_zgen_full(built, lr):
+    n, p = 5, 4
+    S = [True, False, True, False] if lr == "R" else [False, True, False, True]
+    for seed in range(4):
+        A = pt.rand_uniform_zfactors(n, p, 970 + seed)
+        ps = pt.oracle_gpschur(A, S, lr)
+        assert ps.info == 0
+        pt.gpschur_check(A, S, ps)
