@@ -115,6 +115,14 @@ int psd_z_pschur_hess(psd_ctx* ctx, int n, int p, double* const* H, const uint8_
                       int wantZ, int maxitfac, double* alpha, double* beta, int32_t* ascale, psd_stats* stats,
                       int32_t* sweeplog, int64_t maxlog, int* info);
 
+/* pschur!(H1, Hs, S; wantT, wantZ, Q, maxitfac) for Float64 with a signature — rgeneralized.jl:49-59 (MB03BD type
+ * real periodic QZ).  H[0] Hessenberg, H[1..p-1] upper triangular, S[0] must be true (rgeneralized.jl:73, info -5);
+ * Q (p matrices) is accumulated when wantZ; alpha is complex (2n doubles), values = alpha / beta * 2^ascale.
+ * stats->reserved = ncase2 + 1000 * ncase3, ndefl2 = 2x2 blocks, nrqpass = zero-shift passes. */
+int psd_d_gpschur_hess(psd_ctx* ctx, int n, int p, double* const* H, const uint8_t* S, double* const* Q, int wantT,
+                       int wantZ, int maxitfac, double* alpha, double* beta, int32_t* ascale, psd_stats* stats,
+                       int32_t* sweeplog, int64_t maxlog, int* info);
+
 /* device-resident variant of psd_z_pschur */
 int psd_z_pschur_dev(psd_ctx* ctx, int n, int p, double* dA, char orient, int wantT, int wantZ, int maxitfac,
                      double* dZ, double* alpha, double* beta, int32_t* ascale, int* schurindex, psd_stats* stats,

@@ -161,6 +161,7 @@ class Engine:
                                      C.c_int, C.c_int, dpp, dp, dp, i32p, ip, C.POINTER(Stats), i32p, C.c_int64, ip]
         lib.psd_z_pschur_hess.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, C.POINTER(C.c_uint8), dpp, C.c_int,
                                           C.c_int, C.c_int, dp, dp, i32p, C.POINTER(Stats), i32p, C.c_int64, ip]
+        lib.psd_d_gpschur_hess.argtypes = lib.psd_z_pschur_hess.argtypes
         lib.psd_z_pschur_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p, dp, dp, i32p, ip, C.POINTER(Stats), i32p, C.c_int64, ip]
         lib.psd_z_ordschur.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, dpp, C.c_char, C.c_int, C.POINTER(C.c_uint8),
@@ -353,6 +354,44 @@ class Engine:
         slog = log[: 3 * nl].reshape(-1, 3).copy()
         Z = list(Q) if wantZ else []
         if rev:  # src/generalized.jl:910-927
+            Zr = ([Z[0]] + [Z[p + 1 - l] for l in range(2, p + 1)]) if wantZ else Z
+            Ts = [H[p - l] for l in range(1, p)] + [H[0]]
+            return GeneralizedPeriodicSchur(S[::-1], Ts, Zr, alpha, beta, sc, "L", p, st, slog)
+        return GeneralizedPeriodicSchur(S, H, Z, alpha, beta, sc, "R", 1, st, slog)
+
+    def gpschur_hess_(self, H1, Hs, S, Q=None, wantT=True, wantZ=True, maxitfac=120, rev=False):
+        """pschur!(H1, Hs, S; wantT, wantZ, Q, maxitfac, rev) for Float64 — src/rgeneralized.jl:49-59."""
+        H = [H1] + list(Hs)
+        n = _check_square(H)
+        self._as_work(H)
+        p = len(H)
+        S = list(S)
+        if len(S) != p:
+            raise DimensionMismatch("S must have one entry per factor")
+        if not S[0]:
+            raise ValueError("Signature entry S[1] must be true")  # src/rgeneralized.jl:73
+        if wantZ:
+            if Q is None:
+                Q = [np.asfortranarray(np.eye(n)) for _ in range(p)]
+            self._as_work(Q)
+        alpha = np.zeros(n, dtype=np.complex128)
+        beta = np.zeros(n)
+        sc = np.zeros(n, dtype=np.int32)
+        st = Stats()
+        maxlog = 2 * maxitfac * n + n + 16
+        log = np.zeros(3 * maxlog, dtype=np.int32)
+        info = C.c_int(0)
+        Sarr = (C.c_uint8 * p)(*[1 if x else 0 for x in S])
+        dp = C.POINTER(C.c_double)
+        self.lib.psd_d_gpschur_hess(self.ctx, n, p, self._ptrs(H), Sarr, self._ptrs(Q) if wantZ else None, int(wantT),
+                                    int(wantZ), int(maxitfac), alpha.view(np.float64).ctypes.data_as(dp),
+                                    beta.ctypes.data_as(dp), sc.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(st),
+                                    log.ctypes.data_as(C.POINTER(C.c_int32)), maxlog, C.byref(info))
+        self._raise(info.value)
+        nl = min(st.nlog, maxlog)
+        slog = log[: 3 * nl].reshape(-1, 3).copy()
+        Z = list(Q) if wantZ else []
+        if rev:  # src/rgeneralized.jl:1062-1079
             Zr = ([Z[0]] + [Z[p + 1 - l] for l in range(2, p + 1)]) if wantZ else Z
             Ts = [H[p - l] for l in range(1, p)] + [H[0]]
             return GeneralizedPeriodicSchur(S[::-1], Ts, Zr, alpha, beta, sc, "L", p, st, slog)

@@ -7,6 +7,7 @@
 #include "psd_zqz.h"
 #include "psd_zord.h"
 #include "psd_rord.h"
+#include "psd_rgz.h"
 
 #include "../../include/psd_mi355x.h"
 
@@ -110,6 +111,46 @@ struct psd_ctx {
     psd_ostate* ost = nullptr;
     unsigned char* osel = nullptr;
     size_t ostep_lds_set = 0;
+    // real generalized path
+    int gcap_n = 0, gcap_p = 0, glogcap = 0;
+    psd_gstate* gst = nullptr;
+    psd_gapply_desc* gdesc = nullptr;
+    psd_gtr *gtr = nullptr, *gdG = nullptr;
+    unsigned char* gS = nullptr;
+    psd_z* galpha = nullptr;
+    double *gbeta = nullptr, *gxscr = nullptr;
+    int *gascale = nullptr, *gcnt = nullptr, *glog = nullptr;
+    size_t gstep_lds_set = 0;
+
+    void grelease() {
+        void* ptrs[] = {gst, gdesc, gtr, gdG, gS, galpha, gbeta, gxscr, gascale, gcnt, glog};
+        for (void* q : ptrs)
+            if (q) psd_rt_free(q);
+        gst = nullptr; gdesc = nullptr; gtr = gdG = nullptr; gS = nullptr; galpha = nullptr;
+        gbeta = gxscr = nullptr; gascale = gcnt = glog = nullptr;
+        gcap_n = gcap_p = glogcap = 0;
+    }
+    int greserve(int n, int p, int maxlog) {
+        if (n <= gcap_n && p <= gcap_p && maxlog <= glogcap) return 0;
+        grelease();
+#define PSD_ALLOC(ptr, type, count) PSD_CHECK(psd_rt_malloc((void**)&ptr, sizeof(type) * (size_t)(count)))
+        PSD_ALLOC(gst, psd_gstate, 1);
+        PSD_ALLOC(gdesc, psd_gapply_desc, 1);
+        PSD_ALLOC(gtr, psd_gtr, (size_t)p * PSD_GTR_CAP);
+        PSD_ALLOC(gdG, psd_gtr, n + 8);
+        PSD_ALLOC(gS, unsigned char, p + 16);
+        PSD_ALLOC(galpha, psd_z, n + 8);
+        PSD_ALLOC(gbeta, double, n + 8);
+        PSD_ALLOC(gxscr, double, (size_t)16 * p + 16);
+        PSD_ALLOC(gascale, int, n + 8);
+        PSD_ALLOC(gcnt, int, p + 8);
+        PSD_ALLOC(glog, int, 3 * (size_t)maxlog + 8);
+#undef PSD_ALLOC
+        gcap_n = n;
+        gcap_p = p;
+        glogcap = maxlog;
+        return 0;
+    }
 
     void release() {
         void* ptrs[] = {dH, dZ, tau, vbuf, hdiag, hsub, hsup, Pd, Pe, Pf, hnorms, wr, wi, st, desc, tr, cnt, log};
@@ -458,6 +499,7 @@ int psd_create(psd_ctx** ctx, int device) {
 
 int psd_destroy(psd_ctx* c) {
     if (!c) return 0;
+    c->grelease();
     c->release();
     c->zrelease();
     c->rorelease();
@@ -1222,6 +1264,199 @@ int psd_d_ordschur(psd_ctx* c, int n, int p, double* const* T, double* const* Z,
     for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(T[j], c->dH + j * nn, nn * 8, c->stream));
     if (wantZ)
         for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(Z[j], c->dZ + j * nn, nn * 8, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    return rc;
+}
+
+}  // extern "C"
+
+
+// =================================================================================================
+// real generalized (signed) periodic QZ — rgeneralized.jl
+namespace {
+
+// dH [p][n][n] (H_1 Hessenberg), dZ [p][n][n] or nullptr; S host signature (S[0] true)
+int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t* S, int wantT, int wantZ, int maxitfac,
+                 psd_gstate* st_out, psd_stats* stats, int maxlog) {
+    const int W = choose_window(p, 8);
+    if (W == 0) return PSD_INFO_NOTIMPL;
+    std::vector<unsigned char> hS(p, 1);
+    for (int l = 0; l < p; ++l) hS[l] = (!S || S[l]) ? 1 : 0;
+    PSD_CHECK(psd_rt_h2d(c->gS, hS.data(), (size_t)p, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    psd_gparams P;
+    P.H = dH;
+    P.Z = wantZ ? dZ : nullptr;
+    P.S = c->gS;
+    P.st = c->gst;
+    P.desc = c->gdesc;
+    P.tr = c->gtr;
+    P.cnt = c->gcnt;
+    P.dG = c->gdG;
+    P.alpha = c->galpha;
+    P.beta = c->gbeta;
+    P.ascale = c->gascale;
+    P.log = c->glog;
+    P.xscr = c->gxscr;
+    const size_t lds_step = step_lds_bytes(p, W, 8);
+#ifndef PSD_HOSTSIM
+    if (lds_step > c->gstep_lds_set) {
+        PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_gq_step),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
+        c->gstep_lds_set = lds_step;
+    }
+#endif
+    PSD_LAUNCH(psd_gq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog);
+    const size_t lds_apply = sizeof(psd_gtr) * PSD_GTR_CAP + (size_t)32 * (PSD_GAPPLY_NT + 1) * sizeof(double);
+    const int tiles = (n + PSD_GAPPLY_NT - 1) / PSD_GAPPLY_NT;
+    const int dtiles = (n + 255) / 256;
+    const int batch = 32;
+    psd_gstate hst;
+    memset(&hst, 0, sizeof(hst));
+    long long launched = 0;
+    const int nbmin = (W - 5 > 0) ? (W - 5) : 1;
+    const long long cap = (long long)maxitfac * n * ((long long)n / nbmin + 8) + 8LL * n + 1024;
+    double sample_ms = 0.0;
+    int samples = 0;
+#ifndef PSD_HOSTSIM
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pend;
+#endif
+    for (;;) {
+        for (int b = 0; b < batch; ++b) {
+#ifndef PSD_HOSTSIM
+            const bool sample = c->profile && ((launched & 3) == 0);
+            if (sample) {
+                (void)hipEventCreate(&ev0);
+                (void)hipEventCreate(&ev1);
+                (void)hipEventRecord(ev0, c->stream);
+            }
+#endif
+            PSD_LAUNCH(psd_gq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
+#ifndef PSD_HOSTSIM
+            if (sample) {
+                (void)hipEventRecord(ev1, c->stream);
+                pend.emplace_back(ev0, ev1);
+            }
+#endif
+            PSD_LAUNCH(psd_gq_apply, psd_dim3(tiles, p, 3), PSD_GAPPLY_NT, lds_apply, c->stream, P, n, p);
+            PSD_LAUNCH(psd_gq_defer, psd_dim3(dtiles), 256, 0, c->stream, P, n);
+            ++launched;
+        }
+        PSD_CHECK(psd_rt_d2h(&hst, c->gst, sizeof(hst), c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+#ifndef PSD_HOSTSIM
+        for (auto& pr : pend) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                sample_ms += ms;
+                ++samples;
+            }
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        pend.clear();
+#endif
+        if (hst.phase == PSD_GPH_DONE) break;
+        if (launched > cap) {
+            *st_out = hst;
+            return PSD_INFO_RUNTIME + 0xfffd;
+        }
+    }
+    PSD_CHECK(psd_rt_last_error());
+    *st_out = hst;
+    if (stats) {
+        stats->nlaunch_step = (int32_t)launched;
+        stats->window = W;
+        stats->step_kernel_ms_avg = samples ? sample_ms / samples : 0.0;
+        stats->step_kernel_samples = samples;
+    }
+    return 0;
+}
+
+int grun_iteration(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t* S, int wantT, int wantZ,
+                   int maxitfac, double* alpha, double* beta, int32_t* ascale, psd_stats* stats, int32_t* sweeplog,
+                   int64_t maxlog_user, int* info) {
+    const int maxlog = 2 * maxitfac * n + n + 16;
+    if ((*info = c->greserve(n, p, maxlog)) != 0) return *info;
+    psd_gstate st;
+    int rc = giterate_dev(c, n, p, dH, dZ, S, wantT, wantZ, maxitfac, &st, stats, maxlog);
+    if (rc != 0) {
+        *info = rc;
+        return rc;
+    }
+    if (stats) {
+        stats->niter = st.jiter;
+        stats->nsweeps = st.nsweeps;
+        stats->nrqpass = st.nzshift;
+        stats->ndefl1 = st.nsplit;
+        stats->ndefl2 = st.n2real + st.n2cplx;
+        stats->nwindows = st.nwindows;
+        stats->nlog = st.nlog;
+        stats->reserved = st.ncase2 + 1000 * st.ncase3;
+        for (int q = 0; q < 6; ++q) stats->step_cycles[q] = st.cyc[q];
+    }
+    PSD_CHECK(psd_rt_d2h(alpha, c->galpha, sizeof(psd_z) * n, c->stream));
+    PSD_CHECK(psd_rt_d2h(beta, c->gbeta, sizeof(double) * n, c->stream));
+    std::vector<int> hsc(n, 0);
+    PSD_CHECK(psd_rt_d2h(hsc.data(), c->gascale, sizeof(int) * n, c->stream));
+    const int nl = st.nlog < maxlog ? st.nlog : maxlog;
+    std::vector<int> hlog((size_t)3 * nl + 3, 0);
+    if (nl > 0) PSD_CHECK(psd_rt_d2h(hlog.data(), c->glog, sizeof(int) * 3 * (size_t)nl, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    for (int q = 0; q < n; ++q) ascale[q] = hsc[q];
+    if (stats) {  // algorithmic bytes of the sweeps: two rotations per (j, l), E = 8
+        double b = 0.0;
+        for (int q = 0; q < nl; ++q)
+            if (hlog[3 * q] == 0 || hlog[3 * q] == 4) {
+                const double w = hlog[3 * q + 2] - hlog[3 * q + 1] + 1;
+                const double rot = (hlog[3 * q] == 0) ? 2.0 : 1.0;
+                if (!wantT) b += rot * 2 * 8.0 * p * w * w + (wantZ ? rot * 2 * 8.0 * p * w * n : 0.0);
+                else b += rot * 2 * 8.0 * p * w * (wantZ ? (2.0 * n + 1) : (n + 1.0));
+            }
+        stats->bytes_sweeps = b;
+    }
+    if (sweeplog) {
+        const int64_t m = nl < maxlog_user ? nl : maxlog_user;
+        for (int64_t q = 0; q < 3 * m; ++q) sweeplog[q] = hlog[q];
+    }
+    *info = (st.info != 0) ? (PSD_INFO_NOCONV + st.info) : 0;
+    return *info;
+}
+
+}  // namespace
+
+extern "C" {
+
+int psd_d_gpschur_hess(psd_ctx* c, int n, int p, double* const* H, const uint8_t* S, double* const* Q, int wantT,
+                       int wantZ, int maxitfac, double* alpha, double* beta, int32_t* ascale, psd_stats* stats,
+                       int32_t* sweeplog, int64_t maxlog, int* info) {
+    int dummy;
+    if (!info) info = &dummy;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!c) return *info = -1;
+    if ((*info = check_dims(n, p)) != 0) return *info;
+    if (!H) return *info = -4;
+    if (S && !S[0]) return *info = -5;  // rgeneralized.jl:73
+    if (wantZ && !Q) return *info = -6;
+    if (maxitfac < 1) return *info = -9;
+    if ((*info = c->reserve(n, p, true, 16)) != 0) return *info;
+    const size_t nn = (size_t)n * n;
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->dH + j * nn, H[j], nn * 8, c->stream));
+    if (wantZ)
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->dZ + j * nn, Q[j], nn * 8, c->stream));
+    psd_stats local;
+    memset(&local, 0, sizeof(local));
+    psd_stats* s = stats ? stats : &local;
+    Timer t;
+    t.start(c->stream);
+    int rc = grun_iteration(c, n, p, c->dH, wantZ ? c->dZ : nullptr, S, wantT, wantZ, maxitfac, alpha, beta, ascale, s,
+                            sweeplog, maxlog, info);
+    s->ms_iter = s->ms_total = t.stop(c->stream);
+    if (rc < 0 || rc >= PSD_INFO_NOTIMPL) return rc;
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(H[j], c->dH + j * nn, nn * 8, c->stream));
+    if (wantZ)
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(Q[j], c->dZ + j * nn, nn * 8, c->stream));
     PSD_CHECK(psd_rt_sync(c->stream));
     return rc;
 }

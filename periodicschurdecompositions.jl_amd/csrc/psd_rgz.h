@@ -1,0 +1,1442 @@
+// Real generalized (signed) periodic QZ iteration on the GPU: device-resident state machine.
+//
+// Replaces pschur!(H1, Hs, S; wantT, wantZ, Q, maxitfac) for Float64 —
+// /root/reference/src/rgeneralized.jl:49-1083 (after SLICOT MB03BD): Z_l' H_l Z_{l+1} = T_l for S[l], and
+// Z_{l+1}' H_l Z_l = T_l for !S[l]; T_1 quasi-triangular, the others upper triangular.
+//
+// MI355X structure as in psd_real_qr.h / psd_zqz.h: one wavefront chases a diagonal window of all p factors in
+// LDS and emits one rotation list per owner (the orthogonal factor Z_m a rotation belongs to); a wide kernel applies
+// the lists to the off-window rows/columns.  With a signature the side an owner acts on depends on the factor:
+//     rows    of H_l  <- owner  l      if S[l]  else  l+1
+//     columns of H_l  <- owner  l+1    if S[l]  else  l        (cyclic)
+// so the bulk kernel is organised by factor (rows role, columns role, Z role).
+//
+// Implemented: deflation tests 1-3 (:192-226), controlled zero shift (test 4, :229-324), Case II (:329-442) and
+// Case III (:444-616), 1x1 split (:617-642), 2x2 blocks (:661-790: real single-shift PQZ `_rp2x2ssr!` with
+// perfect-shift deflation, else the conjugate pair by `_rpeigvals2x2`), implicit double-shift sweep with the
+// `_qzrots` starting rotations (:796-803, :890-1054).  The reference's explicit-shift branch (:804-887) is defective
+//  and is not reproduced; every sweep uses the implicit shift.  Cases II/III (exactly singular
+// factors) are rare and run directly on HBM from the step kernel instead of through windows.
+#pragma once
+#include "psd_zqz.h"
+
+enum { PSD_GPH_CHECK = 0, PSD_GPH_SWEEP = 1, PSD_GPH_ZSHIFT = 2, PSD_GPH_DONE = 7 };
+#define PSD_GTR_CAP 80  // rotations per owner and window
+#define PSD_GAPPLY_NT 128
+
+struct psd_gtr {  // Givens rotation on (pos, pos+1): [c s; -s c]
+    int pos, pad;
+    double c, s;
+};
+
+struct psd_gapply_desc {
+    int active;
+    int plo, phi;
+    int lc0, lc1;  // rows role: columns lc0..lc1
+    int rr0, rr1;  // columns role: rows rr0..rr1
+    int zr0, zr1;  // Z role
+    int defer_h1;  // 1: the column updates of H_1 are deferred to the end of the (zero-shift) pass
+    int defer_run;
+    int djlo, djhi, drow0;
+};
+
+struct psd_gstate {
+    int n, p, wantT, wantZ, W;
+    int phase, info;
+    int ilast, ifirst, ifirstm, ilastm, ziter, jiter, maxit;
+    int jlo, kcur, zflag;
+    int nsweeps, nzshift, nsplit, ncase2, ncase3, n2real, n2cplx, nwindows, nlog, maxlog, iwarn, pad;
+    double c1, s1, c2, s2;  // starting rotations of the current sweep
+    double smlnum, ulp;
+    long long cyc[6];
+};
+
+struct psd_gparams {
+    double* H;                // [p][n][n], H_1 Hessenberg
+    double* Z;                // [p][n][n] or nullptr
+    const unsigned char* S;   // [p] signature
+    psd_gstate* st;
+    psd_gapply_desc* desc;
+    psd_gtr* tr;   // [p][PSD_GTR_CAP]
+    int* cnt;      // [p]
+    psd_gtr* dG;   // [n+2]
+    psd_z* alpha;  // [n]
+    double* beta;  // [n]
+    int* ascale;   // [n]
+    int* log;
+    double* xscr;  // [16 p] scratch of the 2x2 solvers
+};
+
+PSD_HD psd_mat<double> psd_gfac(const psd_gparams& P, int n, int l) {
+    return psd_mat<double>{P.H + (size_t)(l - 1) * n * n, n};
+}
+PSD_HD bool psd_gsig(const psd_gparams& P, int l) { return P.S[l - 1] != 0; }
+PSD_HD int psd_gnext(int l, int p) { return (l % p) + 1; }
+PSD_HD int psd_growner(const psd_gparams& P, int l, int p) { return psd_gsig(P, l) ? l : psd_gnext(l, p); }
+PSD_HD int psd_gcowner(const psd_gparams& P, int l, int p) { return psd_gsig(P, l) ? psd_gnext(l, p) : l; }
+
+struct psd_gwin {
+    double* b;
+    int W, ld, bsz, bs, be;
+    PSD_HD double& at(int l, int r, int c) const { return b[(l - 1) * bsz + (c - bs) * ld + (r - bs)]; }
+};
+
+PSD_D void psd_gwin_load(const psd_gparams& P, const psd_gwin& w, int n, int p) {
+    const int m = w.be - w.bs + 1;
+    const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
+    const int total = p * m;
+    PSD_PAR_FOR(t, PSD_STEP_NT) {
+        const int r = t & (RW - 1), g = t >> sh;
+        if (r < m) {
+            for (int q0 = g; q0 < total; q0 += 8 * ncg) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int q = q0 + u * ncg;
+                    if (q < total) {
+                        const int l = q / m, c = q - l * m;
+                        v[u] = P.H[(size_t)l * n * n + (size_t)(w.bs - 1 + c) * n + (w.bs - 1 + r)];
+                    } else {
+                        v[u] = 0.0;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int q = q0 + u * ncg;
+                    if (q < total) {
+                        const int l = q / m, c = q - l * m;
+                        w.b[l * w.bsz + c * w.ld + r] = v[u];
+                    }
+                }
+            }
+        }
+    }
+    PSD_SYNC();
+}
+PSD_D void psd_gwin_store(const psd_gparams& P, const psd_gwin& w, int n, int p) {
+    const int m = w.be - w.bs + 1;
+    const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
+    const int total = p * m;
+    PSD_SYNC();
+    PSD_PAR_FOR(t, PSD_STEP_NT) {
+        const int r = t & (RW - 1), g = t >> sh;
+        if (r < m) {
+            for (int q = g; q < total; q += ncg) {
+                const int l = q / m, c = q - l * m;
+                P.H[(size_t)l * n * n + (size_t)(w.bs - 1 + c) * n + (w.bs - 1 + r)] = w.b[l * w.bsz + c * w.ld + r];
+            }
+        }
+    }
+    PSD_SYNC();
+}
+
+// in-window rmul!(view(H_l, r0:r1, :), G') on columns (j, j+1)
+PSD_D void psd_gwin_right(const psd_gwin& w, int l, int j, double c, double s, int r0, int r1) {
+    if (r0 < w.bs) r0 = w.bs;
+    if (r1 > w.be) r1 = w.be;
+    PSD_PAR_FOR(t, r1 - r0 + 1) {
+        const int r = r0 + t;
+        const double a1 = w.at(l, r, j), a2 = w.at(l, r, j + 1);
+        w.at(l, r, j) = c * a1 + s * a2;
+        w.at(l, r, j + 1) = c * a2 - s * a1;
+    }
+    PSD_WAVE_SYNC();
+}
+// in-window lmul!(G, view(H_l, :, c0:c1)) on rows (j, j+1)
+PSD_D void psd_gwin_left(const psd_gwin& w, int l, int j, double c, double s, int c0, int c1) {
+    if (c0 < w.bs) c0 = w.bs;
+    if (c1 > w.be) c1 = w.be;
+    PSD_PAR_FOR(t, c1 - c0 + 1) {
+        const int cc = c0 + t;
+        const double a1 = w.at(l, j, cc), a2 = w.at(l, j + 1, cc);
+        w.at(l, j, cc) = c * a1 + s * a2;
+        w.at(l, j + 1, cc) = c * a2 - s * a1;
+    }
+    PSD_WAVE_SYNC();
+}
+PSD_D void psd_gwin_set2(const psd_gwin& w, int l, int r1, int c1, double v1, int r2, int c2, double v2) {
+    PSD_WAVE_SYNC();
+    PSD_ONE {
+        w.at(l, r1, c1) = v1;
+        w.at(l, r2, c2) = v2;
+    }
+    PSD_WAVE_SYNC();
+}
+
+PSD_D void psd_grecord(const psd_gparams& P, int* lcnt, int m, int pos, double c, double s) {
+    PSD_ONE {
+        const int q = lcnt[m - 1];
+        if (q < PSD_GTR_CAP) {
+            psd_gtr tr;
+            tr.pos = pos;
+            tr.pad = 0;
+            tr.c = c;
+            tr.s = s;
+            P.tr[(size_t)(m - 1) * PSD_GTR_CAP + q] = tr;
+        }
+        lcnt[m - 1] = q + 1;
+    }
+    PSD_WAVE_SYNC();
+}
+
+PSD_D void psd_glog(const psd_gparams& P, psd_gstate& st, int kind, int lo, int hi) {
+    PSD_ONE {
+        if (st.nlog < st.maxlog) {
+            P.log[3 * st.nlog + 0] = kind;
+            P.log[3 * st.nlog + 1] = lo;
+            P.log[3 * st.nlog + 2] = hi;
+        }
+    }
+    st.nlog += 1;
+}
+
+PSD_D void psd_gdesc_write(const psd_gparams& P, const psd_gstate& st, const int* lcnt, int plo, int phi, int lc0,
+                           int lc1, int rr0, int rr1, int defer_h1, int defer_run, int djlo, int djhi) {
+    PSD_SYNC();
+    PSD_PAR_FOR(m, st.p) { P.cnt[m] = lcnt[m]; }
+    PSD_ONE {
+        psd_gapply_desc d;
+        d.active = 1;
+        d.plo = plo;
+        d.phi = phi;
+        d.lc0 = lc0;
+        d.lc1 = lc1;
+        d.rr0 = rr0;
+        d.rr1 = rr1;
+        d.zr0 = 1;
+        d.zr1 = st.wantZ ? st.n : 0;
+        d.defer_h1 = defer_h1;
+        d.defer_run = defer_run;
+        d.djlo = djlo;
+        d.djhi = djhi;
+        d.drow0 = st.ifirstm;
+        *P.desc = d;
+    }
+    PSD_SYNC();
+}
+
+// One factor of a rotation chain inside the window.  Incoming rotation (c, s) at (q, q+1):
+//   cols_in:  it acts on the columns of H_l; the fill H_l[q+1,q] is removed by a new row rotation
+//             (rgeneralized.jl:980-991 for S[l] in the downward chain, :922-933 for !S[l] in the forward chain)
+//   !cols_in: it acts on the rows; the fill is removed by a new column rotation generated from
+//             (H_l[q+1,q+1], -H_l[q+1,q])  (:993-1004, :906-920).  A "backwards" Givens(q+1, q, c, s') of the
+//             zero-shift / Case II text (:294-300) is the same rotation.
+// Returns the new rotation in (c, s); it acts on the rows (cols_in) or columns (!cols_in) of H_l.
+PSD_D void psd_g_link(const psd_gwin& w, int l, int q, bool cols_in, double& c, double& s, int rlo, int chi) {
+    double r;
+    if (cols_in) {
+        psd_gwin_right(w, l, q, c, s, rlo, q + 1);
+        psd_givens(w.at(l, q, q), w.at(l, q + 1, q), c, s, r);
+        psd_gwin_set2(w, l, q, q, r, q + 1, q, 0.0);
+        psd_gwin_left(w, l, q, c, s, q + 1, chi);
+    } else {
+        psd_gwin_left(w, l, q, c, s, q, chi);
+        psd_givens(w.at(l, q + 1, q + 1), -w.at(l, q + 1, q), c, s, r);
+        psd_gwin_set2(w, l, q + 1, q + 1, r, q + 1, q, 0.0);
+        psd_gwin_right(w, l, q, c, s, rlo, q);
+    }
+}
+
+// rgeneralized.jl:1140-1359 `_qzrots` (MB03AF 'Double'): starting rotations of an implicit double-shift sweep
+// on the active block i1..i1+nb-1, from HBM.
+PSD_D void psd_g_qzrots(const psd_gparams& P, int n, int p, int i1, int nb, double& c1o, double& s1o, double& c2o,
+                        double& s2o) {
+    const psd_mat<double> H1 = psd_gfac(P, n, 1);
+    double c1, s1, c2, s2, r, al, be, ga, de;
+    psd_givens(H1(i1, i1), H1(i1 + 1, i1), c1, s1, r);
+    psd_givens(r, 1.0, c2, s2, r);
+    const int i2 = i1 + nb - 1;
+    for (int l = p; l >= 2; --l) {
+        const psd_mat<double> Hl = psd_gfac(P, n, l);
+        if (psd_gsig(P, l)) {
+            al = c2 * (c1 * Hl(i1, i1) + s1 * Hl(i1, i1 + 1));
+            be = s1 * c2 * Hl(i1 + 1, i1 + 1);
+            ga = s2 * Hl(i2, i2);
+            psd_givens(al, be, c1, s1, r);
+            double v;
+            psd_givens(r, ga, c2, s2, v);
+        } else {
+            al = c1 * s2 * Hl(i1, i1);
+            ga = s1 * Hl(i1, i1);
+            be = s2 * (c1 * Hl(i1, i1 + 1) + s1 * Hl(i1 + 1, i1 + 1));
+            de = c1 * Hl(i1 + 1, i1 + 1) - s1 * Hl(i1, i1 + 1);
+            psd_givens(de, ga, c1, s1, r);
+            al = c1 * al + s1 * be;
+            be = c2 * Hl(i2, i2);
+            psd_givens(be, al, c2, s2, r);
+        }
+    }
+    al = s2 * H1(i2, i2) - c1 * c2;
+    be = -s1 * c2;
+    const int nn = nb, m = nb - 1;
+#define PSD_V1(a, b) H1(i1 - 1 + (a), i1 - 1 + (b))
+    ga = -s2 * PSD_V1(nn, m);
+    psd_givens(al, ga, c2, s2, r);
+    psd_givens(r, be, c1, s1, r);
+    const double cx = c1 * c2, sx = c1 * s2;
+    be = s1 * PSD_V1(nn, m);
+    al = cx * PSD_V1(nn, m) + sx * PSD_V1(nn, nn);
+    ga = s1 * PSD_V1(m, m);
+    de = cx * PSD_V1(m, m) + sx * PSD_V1(m, nn);
+    double val1 = s1 * PSD_V1(3, 2), val2 = cx * PSD_V1(2, 1) + s1 * PSD_V1(2, 2),
+           val3 = cx * PSD_V1(1, 1) + s1 * PSD_V1(1, 2);
+#undef PSD_V1
+    double c3, s3, c4, s4, c5, s5, c6, s6;
+    psd_givens(al, be, c1, s1, r);
+    psd_givens(ga, r, c2, s2, r);
+    psd_givens(de, r, c3, s3, r);
+    psd_givens(val1, r, c4, s4, r);
+    psd_givens(val2, r, c5, s5, r);
+    psd_givens(val3, r, c6, s6, r);
+    for (int i = p; i >= 2; --i) {
+        const psd_mat<double> Hi = psd_gfac(P, n, i);
+#define PSD_V(a, b) Hi(i1 - 1 + (a), i1 - 1 + (b))
+        if (psd_gsig(P, i)) {
+            double ss = s3 * s4;
+            const double sss = s2 * ss, ssss = s1 * sss;
+            val1 = c4 * PSD_V(1, 3);
+            val2 = c4 * PSD_V(2, 3);
+            val3 = c4 * PSD_V(3, 3);
+            al = s4 * c3 * PSD_V(m, m) + sss * c1 * PSD_V(m, nn);
+            be = ss * c2 * PSD_V(m, m) + ssss * PSD_V(m, nn);
+            ga = sss * c1 * PSD_V(nn, nn);
+            de = ssss * PSD_V(nn, nn);
+            ss = s5 * s6;
+            const double cs = c5 * s6;
+            val1 = ss * val1 + cs * PSD_V(1, 2) + c6 * PSD_V(1, 1);
+            val2 = ss * val2 + cs * PSD_V(2, 2);
+            val3 = ss * val3;
+            al = ss * al;
+            be = ss * be;
+            ga = ss * ga;
+            de = ss * de;
+            psd_givens(ga, de, c1, s1, r);
+            psd_givens(be, r, c2, s2, r);
+            psd_givens(al, r, c3, s3, r);
+            psd_givens(val3, r, c4, s4, r);
+            psd_givens(val2, r, c5, s5, r);
+            psd_givens(val1, r, c6, s6, r);
+        } else {
+            double ep, ze, et, th, val4, val5;
+            double c2R, s2R, c3R, s3R, c4R, s4R, c5R, s5R, c6R, s6R;
+            de = c1 * PSD_V(nn, nn);
+            ep = s1 * PSD_V(nn, nn);
+            al = c2 * PSD_V(m, m);
+            be = s2 * de;
+            ga = -s2 * PSD_V(m, m);
+            ze = c2 * PSD_V(m, nn) + s2 * ep;
+            et = -s2 * PSD_V(m, nn) + c2 * ep;
+            de = c1 * c2 * de + s1 * et;
+            psd_givens(de, -ga, c2R, s2R, r);
+            de = c3 * PSD_V(m, m);
+            ep = s3 * al;
+            et = c3 * PSD_V(m, nn) + s3 * be;
+            th = s3 * ze;
+            ga = -s3 * PSD_V(m, m);
+            be = -s3 * PSD_V(m, nn) + c3 * be;
+            al = c2R * c3 * al + s2R * (c1 * be + s1 * c3 * ze);
+            psd_givens(al, -ga, c3R, s3R, r);
+            val1 = c4 * PSD_V(3, 3);
+            val2 = s4 * de;
+            val3 = s4 * ep;
+            val4 = s4 * et;
+            val5 = s4 * th;
+            be = -s4 * PSD_V(3, 3);
+            de = c4 * de;
+            ep = c4 * ep;
+            ze = c4 * et;
+            et = c4 * th;
+            al = c3R * de + s3R * (c2R * ep + s2R * (c1 * ze + s1 * et));
+            psd_givens(al, -be, c4R, s4R, r);
+            be = c5 * PSD_V(2, 2);
+            de = c5 * PSD_V(2, 3) + s5 * val1;
+            ep = s5 * val2;
+            ze = s5 * val3;
+            et = s5 * val4;
+            th = s5 * val5;
+            ga = -s5 * PSD_V(2, 2);
+            val1 = c5 * val1 - s5 * PSD_V(2, 3);
+            val2 = c5 * val2;
+            val3 = c5 * val3;
+            val4 = c5 * val4;
+            val5 = c5 * val5;
+            al = c4R * val1 + s4R * (c3R * val2 + s3R * (c2R * val3 + s2R * (c1 * val4 + s1 * val5)));
+            psd_givens(al, -ga, c5R, s5R, r);
+            ga = -s6 * PSD_V(1, 1);
+            be = c6 * be - s6 * PSD_V(1, 2);
+            de = c6 * de - s6 * PSD_V(1, 3);
+            ep = c6 * ep;
+            ze = c6 * ze;
+            et = c6 * et;
+            th = c6 * th;
+            al = c5R * be + s5R * (c4R * de + s4R * (c3R * ep + s3R * (c2R * ze + s2R * (c1 * et + s1 * th))));
+            psd_givens(al, -ga, c6R, s6R, r);
+            c2 = c2R; s2 = s2R; c3 = c3R; s3 = s3R; c4 = c4R; s4 = s4R; c5 = c5R; s5 = s5R; c6 = c6R; s6 = s6R;
+        }
+#undef PSD_V
+    }
+    val1 = s5 * s6;
+    val2 = s4 * val1;
+    val3 = s3 * val2;
+    al = c3 * val2 - c6;
+    be = c2 * val3 - c5 * s6;
+    ga = -c4 * val1;
+    psd_givens(be, ga, c2, s2, r);
+    psd_givens(al, r, c1, s1, r);
+    c1o = c1; s1o = s1; c2o = c2; s2o = s2;
+}
+
+// ---- 2x2 solvers: serial, called by one lane on HBM scratch ------------------------------------------------------
+// X[4 l + (0..3)] = [a b; c d] of block l (0-based), Hessenberg (full) block LAST; sg2[l] its signature
+
+// rgeneralized.jl:1364-1396 `_qzrot2x2`
+PSD_D void psd_g_qzrot2x2(int p, const double* X, const psd_gparams& P, double& c1, double& s1) {
+    // order of the blocks: factors 2, 3, ..., p, 1  ->  signature of block l (0-based) is S[l+2] (S[1] for the last)
+    double c2, s2, r, al, be, ga, de;
+    const double* Hp = X + 4 * (p - 1);
+    psd_givens(Hp[0], Hp[2], c1, s1, r);
+    psd_givens(r, 1.0, c2, s2, r);
+    for (int l = p - 2; l >= 0; --l) {
+        const double* Hl = X + 4 * l;
+        if (psd_gsig(P, l + 2)) {
+            al = c2 * (c1 * Hl[0] + s1 * Hl[1]);
+            be = s1 * c2 * Hl[3];
+            ga = s2 * Hl[3];
+            psd_givens(al, be, c1, s1, r);
+            double v;
+            psd_givens(r, ga, c2, s2, v);
+        } else {
+            al = c1 * s2 * Hl[0];
+            ga = s1 * Hl[0];
+            be = s2 * (c1 * Hl[1] + s1 * Hl[3]);
+            de = c1 * Hl[3] - s1 * Hl[1];
+            psd_givens(de, ga, c1, s1, r);
+            al = c1 * al + s1 * be;
+            be = c2 * Hl[3];
+            psd_givens(be, al, c2, s2, r);
+        }
+    }
+    al = s2 * Hp[3] - c1 * c2;
+    be = -s1 * c2;
+    psd_givens(al, be, c1, s1, r);
+}
+
+// rpschur2x2.jl:280-318 `_rp2x2ssr!`
+PSD_D bool psd_g_rp2x2ssr(int p, double* X, const psd_gparams& P) {
+    bool done = false;
+    for (int iter = 1; iter <= 20; ++iter) {
+        double c, s, r;
+        psd_g_qzrot2x2(p, X, P, c, s);
+        {
+            double* Y = X + 4 * (p - 1);  // rmul!(H2s[p], G')
+            double a1 = Y[0], a2 = Y[1];
+            Y[0] = a1 * c + a2 * s;
+            Y[1] = -a1 * s + a2 * c;
+            a1 = Y[2]; a2 = Y[3];
+            Y[2] = a1 * c + a2 * s;
+            Y[3] = -a1 * s + a2 * c;
+        }
+        for (int l = 0; l < p - 1; ++l) {
+            double* Y = X + 4 * l;
+            if (psd_gsig(P, l + 2)) {
+                double a1 = Y[0], a2 = Y[2];
+                Y[0] = c * a1 + s * a2;
+                Y[2] = -s * a1 + c * a2;
+                a1 = Y[1]; a2 = Y[3];
+                Y[1] = c * a1 + s * a2;
+                Y[3] = -s * a1 + c * a2;
+                psd_givens(Y[3], -Y[2], c, s, r);
+                Y[3] = r;
+                Y[2] = 0.0;
+                const double t1 = c * Y[0] + s * Y[1], t2 = c * Y[1] - s * Y[0];
+                Y[0] = t1;
+                Y[1] = t2;
+            } else {
+                double a1 = Y[0], a2 = Y[1];
+                Y[0] = a1 * c + a2 * s;
+                Y[1] = -a1 * s + a2 * c;
+                a1 = Y[2]; a2 = Y[3];
+                Y[2] = a1 * c + a2 * s;
+                Y[3] = -a1 * s + a2 * c;
+                psd_givens(Y[0], Y[2], c, s, r);
+                Y[0] = r;
+                Y[2] = 0.0;
+                const double t1 = c * Y[1] + s * Y[3], t2 = c * Y[3] - s * Y[1];
+                Y[1] = t1;
+                Y[3] = t2;
+            }
+        }
+        double* Y = X + 4 * (p - 1);
+        double a1 = Y[0], a2 = Y[2];
+        Y[0] = c * a1 + s * a2;
+        Y[2] = -s * a1 + c * a2;
+        a1 = Y[1]; a2 = Y[3];
+        Y[1] = c * a1 + s * a2;
+        Y[3] = -s * a1 + c * a2;
+        done = fabs(Y[2]) < PSD_DBL_EPS * fmax(fabs(Y[0]), fmax(fabs(Y[1]), fabs(Y[3])));
+        if (done) break;
+    }
+    return done;
+}
+
+// rpschur2x2.jl:9-275 `_rpeigvals2x2` + `_sanitize_reigpair!` with a signature (Aord = 1:p, schurindex 1,
+// recip = false).  X: [p][4] complex scratch holding the blocks in natural order (block 1 full).
+PSD_D void psd_g_eigpair(const psd_gparams& P, int p, psd_z* X, psd_z* alpha, double* beta, double* scal,
+                         bool& converged, bool& good) {
+    const int k = p;
+    converged = false;
+    for (int iter = 1; iter <= 80; ++iter) {
+        const double lhs = zabs(X[2]);
+        double rhs = fmax(zabs(X[0]), zabs(X[3]));
+        if (rhs == 0) rhs = zabs(X[1]);
+        if (lhs <= PSD_DBL_EPS * rhs) {
+            converged = true;
+            break;
+        }
+        double c;
+        psd_z s, r;
+        if (iter == 1) {
+            psd_zgivens(zmk(1.0, -2.0), zmk(2.0, 2.0), c, s, r);
+        } else if (iter % 40 == 0) {
+            psd_zgivens(zmk((double)k, 1.0), zmk(1.0, -2.0), c, s, r);
+        } else {
+            c = 1.0;
+            s = zmk(0.0, 0.0);
+            double ct;
+            psd_z st;
+            psd_zgivens(zmk(1.0, 0.0), zmk(1.0, 0.0), ct, st, r);
+            for (int l = k; l >= 2; --l) {
+                const psd_z* Xl = X + 4 * (l - 1);
+                psd_z Z[3][3];
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) Z[a][b] = zmk(0.0, 0.0);
+                Z[0][0] = Xl[0]; Z[1][1] = Xl[0]; Z[1][2] = Xl[1]; Z[2][1] = Xl[2]; Z[2][2] = Xl[3];
+                if (psd_gsig(P, l)) {
+                    for (int q = 0; q < 3; ++q) psd_zrot_right_adj(ct, st, Z[q][0], Z[q][2]);
+                    for (int q = 0; q < 3; ++q) psd_zrot_right_adj(c, s, Z[q][0], Z[q][1]);
+                    psd_zgivens(Z[0][0], Z[2][0], ct, st, r);
+                    psd_zgivens(Xl[0], Z[1][0], c, s, r);
+                } else {
+                    for (int q = 0; q < 3; ++q) psd_zrot_left(ct, st, Z[0][q], Z[2][q]);
+                    for (int q = 0; q < 3; ++q) psd_zrot_left(c, s, Z[0][q], Z[1][q]);
+                    psd_zgivens(Z[2][2], Z[2][0], ct, st, r);
+                    Z[2][2] = r;
+                    st = zneg(st);
+                    for (int q = 0; q < 2; ++q) psd_zrot_right_adj(ct, st, Z[q][0], Z[q][2]);
+                    psd_zgivens(Z[1][1], Z[1][0], c, s, r);
+                    s = zneg(s);
+                }
+            }
+            psd_z Z[2][3];
+            Z[0][0] = X[0]; Z[0][1] = zneg(X[2]); Z[0][2] = zneg(X[3]);
+            Z[1][0] = X[2]; Z[1][1] = zmk(0.0, 0.0); Z[1][2] = zmk(0.0, 0.0);
+            for (int q = 0; q < 2; ++q) psd_zrot_right_adj(ct, st, Z[q][0], Z[q][2]);
+            for (int q = 0; q < 2; ++q) psd_zrot_right_adj(c, s, Z[q][0], Z[q][1]);
+            psd_zgivens(Z[0][0], Z[1][0], c, s, r);
+        }
+        const double ct0 = c;
+        const psd_z st0 = s;
+        for (int l = k; l >= 2; --l) {
+            psd_z* Y = X + 4 * (l - 1);
+            if (psd_gsig(P, l)) {
+                psd_zrot_right_adj(c, s, Y[0], Y[1]);
+                psd_zrot_right_adj(c, s, Y[2], Y[3]);
+                psd_zgivens(Y[0], Y[2], c, s, r);
+                Y[0] = r;
+                Y[2] = zmk(0.0, 0.0);
+                psd_zrot_left(c, s, Y[1], Y[3]);
+            } else {
+                psd_zrot_left(c, s, Y[0], Y[2]);
+                psd_zrot_left(c, s, Y[1], Y[3]);
+                psd_zgivens(Y[3], Y[2], c, s, r);
+                Y[3] = r;
+                Y[2] = zmk(0.0, 0.0);
+                s = zneg(s);
+                psd_zrot_right_adj(c, s, Y[0], Y[1]);
+            }
+        }
+        psd_zrot_left(ct0, st0, X[0], X[2]);
+        psd_zrot_left(ct0, st0, X[1], X[3]);
+        psd_zrot_right_adj(c, s, X[0], X[1]);
+        psd_zrot_right_adj(c, s, X[2], X[3]);
+    }
+    for (int jj = 0; jj < 2; ++jj) {
+        psd_z aj = zmk(1.0, 0.0);
+        scal[jj] = 0.0;
+        beta[jj] = 1.0;
+        for (int l = 1; l <= k; ++l) {
+            psd_z z = X[4 * (l - 1) + (jj == 0 ? 0 : 3)];
+            double rhs = zabs(z);
+            int sl = 0;
+            if (rhs != 0) {
+                sl = (int)floor(log2(rhs));
+                z = zscal(exp2(-(double)sl), z);
+            }
+            if (psd_gsig(P, l)) {
+                aj = zmul(aj, z);
+                scal[jj] += sl;
+            } else if (rhs == 0) {
+                beta[jj] = 0.0;
+            } else {
+                aj = zdiv(aj, z);
+                scal[jj] -= sl;
+            }
+            if ((l % 10 == 0) || (l == k)) {
+                rhs = zabs(aj);
+                if (rhs == 0) {
+                    scal[jj] = 0;
+                } else {
+                    const int s2 = (int)floor(log2(rhs));
+                    aj = zscal(exp2(-(double)s2), aj);
+                    scal[jj] += s2;
+                }
+            }
+        }
+        alpha[jj] = aj;
+    }
+    if (alpha[1].im > 0) {
+        const psd_z ta = alpha[0];
+        alpha[0] = alpha[1];
+        alpha[1] = ta;
+        double ts = scal[0];
+        scal[0] = scal[1];
+        scal[1] = ts;
+        ts = beta[0];
+        beta[0] = beta[1];
+        beta[1] = ts;
+    }
+    good = true;
+    if (alpha[0].im != 0 || alpha[1].im != 0) {
+        const double sl = scal[0] - scal[1];
+        psd_z zt1, zt2;
+        double cst;
+        if (sl >= 0) {
+            zt1 = zscal(exp2(-sl), alpha[1]);
+            zt2 = zsub(alpha[0], zconj(zt1));
+            cst = alpha[0].im;
+        } else {
+            zt1 = zscal(exp2(sl), alpha[0]);
+            zt2 = zsub(alpha[1], zconj(zt1));
+            cst = alpha[1].im;
+        }
+        const double misr = hypot(cst, zt1.im);
+        const double misc = zabs(zt2) / 2;
+        const double cs = fmax(zabs(alpha[0]), fmax(1.0, zabs(alpha[1])));
+        good = fmin(misr, misc) <= cs * sqrt(PSD_DBL_EPS);
+        if (misr > misc) {
+            const int jx = (scal[0] >= scal[1]) ? 0 : 1;
+            const psd_z at = zscal(0.5, zadd(alpha[jx], zconj(zt1)));
+            alpha[0] = zmk(at.re, fabs(at.im));
+            alpha[1] = zconj(alpha[0]);
+        } else {
+            alpha[0].im = 0.0;
+            alpha[1].im = 0.0;
+        }
+    }
+}
+
+// generalized.jl:939-976 `_safeprod` with a signature, for the diagonal entry idx of all factors
+PSD_D void psd_g_safeprod(const psd_gparams& P, int n, int p, int idx, double& alpha, double& beta, int& scale) {
+    alpha = 1.0;
+    beta = 1.0;
+    scale = 0;
+    for (int l = 1; l <= p; ++l) {
+        const double xi = psd_gfac(P, n, l)(idx, idx);
+        if (psd_gsig(P, l)) {
+            alpha *= xi;
+        } else if (xi == 0) {
+            beta = 0.0;
+        } else {
+            alpha /= xi;
+        }
+        if (alpha == 0) {
+            alpha = 0.0;
+            scale = 0;
+            if (beta == 0.0) return;
+        } else {
+            int guard = 0;
+            while (fabs(alpha) < 1.0 && guard < 2200) {
+                alpha *= 2.0;
+                scale -= 1;
+                ++guard;
+            }
+            while (fabs(alpha) >= 2.0 && guard < 4400) {
+                alpha *= 0.5;
+                scale += 1;
+                ++guard;
+            }
+        }
+    }
+}
+
+// ---- rotations applied directly on HBM by the whole workgroup (Cases II / III only) --------------------------------
+PSD_D void psd_gg_left(const psd_mat<double>& M, int j, double c, double s, int c0, int c1) {
+    PSD_SYNC();
+    PSD_PAR_FOR(t, c1 - c0 + 1) {
+        const int cc = c0 + t;
+        const double a1 = M(j, cc), a2 = M(j + 1, cc);
+        M(j, cc) = c * a1 + s * a2;
+        M(j + 1, cc) = c * a2 - s * a1;
+    }
+    PSD_SYNC();
+}
+PSD_D void psd_gg_right(const psd_mat<double>& M, int j, double c, double s, int r0, int r1) {
+    PSD_SYNC();
+    PSD_PAR_FOR(t, r1 - r0 + 1) {
+        const int r = r0 + t;
+        const double a1 = M(r, j), a2 = M(r, j + 1);
+        M(r, j) = c * a1 + s * a2;
+        M(r, j + 1) = c * a2 - s * a1;
+    }
+    PSD_SYNC();
+}
+PSD_D void psd_gg_z(const psd_gparams& P, const psd_gstate& st, int m, int j, double c, double s) {
+    if (!st.wantZ) return;
+    psd_gg_right(psd_mat<double>{P.Z + (size_t)(m - 1) * st.n * st.n, st.n}, j, c, s, 1, st.n);
+}
+PSD_D void psd_gg_set2(const psd_mat<double>& M, int r1, int c1, double v1, int r2, int c2, double v2) {
+    PSD_SYNC();
+    PSD_ONE {
+        M(r1, c1) = v1;
+        M(r2, c2) = v2;
+    }
+    PSD_SYNC();
+}
+// one factor of a chain on HBM (same roles as psd_g_link)
+PSD_D void psd_gg_link(const psd_mat<double>& M, int q, bool cols_in, double& c, double& s, int rlo, int chi) {
+    double r;
+    if (cols_in) {
+        psd_gg_right(M, q, c, s, rlo, q + 1);
+        psd_givens(M(q, q), M(q + 1, q), c, s, r);
+        psd_gg_set2(M, q, q, r, q + 1, q, 0.0);
+        psd_gg_left(M, q, c, s, q + 1, chi);
+    } else {
+        psd_gg_left(M, q, c, s, q, chi);
+        psd_givens(M(q + 1, q + 1), -M(q + 1, q), c, s, r);
+        psd_gg_set2(M, q + 1, q + 1, r, q + 1, q, 0.0);
+        psd_gg_right(M, q, c, s, rlo, q);
+    }
+}
+
+// rgeneralized.jl:329-442 Case II: zero on the diagonal of a positive factor
+PSD_D void psd_gq_case2(const psd_gparams& P, psd_gstate& st, int ldeflate, int jdeflate) {
+    const int n = st.n, p = st.p, jlo = st.jlo, ilast = st.ilast, ifirstm = st.ifirstm, ilastm = st.ilastm;
+    const psd_mat<double> H1 = psd_gfac(P, n, 1);
+    st.ncase2 += 1;
+    psd_glog(P, st, 2, jlo, ilast);
+    // first unshifted step, from the top, up to the zero
+    for (int j = jlo; j <= jdeflate - 1; ++j) {
+        double c, s, r;
+        psd_givens(H1(j, j), H1(j + 1, j), c, s, r);
+        psd_gg_set2(H1, j, j, r, j + 1, j, 0.0);
+        psd_gg_left(H1, j, c, s, j + 1, ilastm);
+        psd_gg_z(P, st, 1, j, c, s);
+        for (int l = p; l >= 2; --l) {
+            const int ntra = (l < ldeflate) ? (jdeflate - 2) : (jdeflate - 1);
+            if (j > ntra) break;  // every later factor has the smaller count as well
+            psd_gg_link(psd_gfac(P, n, l), j, psd_gsig(P, l), c, s, ifirstm, ilastm);
+            psd_gg_z(P, st, l, j, c, s);
+        }
+        PSD_ONE {  // right side of H_1 only after every row rotation has been generated (:383-386)
+            psd_gtr tr;
+            tr.pos = j;
+            tr.pad = 0;
+            tr.c = c;
+            tr.s = s;
+            P.dG[j] = tr;
+        }
+    }
+    PSD_SYNC();
+    for (int j = jlo; j <= jdeflate - 2; ++j) {
+        const psd_gtr g = P.dG[j];
+        psd_gg_right(H1, j, g.c, g.s, ifirstm, j + 1);
+    }
+    // second unshifted step, from the bottom
+    for (int j = ilast; j >= jdeflate + 1; --j) {
+        double c, s, r;
+        psd_givens(H1(j, j), -H1(j, j - 1), c, s, r);  // Givens(j, j-1, c, s') == standard (j-1, j; c, -s)
+        psd_gg_set2(H1, j, j, r, j, j - 1, 0.0);
+        psd_gg_right(H1, j - 1, c, s, ifirstm, j - 1);
+        psd_gg_z(P, st, psd_gnext(1, p), j - 1, c, s);
+        bool alive = true;
+        for (int l = 2; l <= p; ++l) {
+            const int ntra = (l > ldeflate) ? (jdeflate + 2) : (jdeflate + 1);
+            if (j < ntra) {
+                alive = false;
+                break;
+            }
+            psd_gg_link(psd_gfac(P, n, l), j - 1, !psd_gsig(P, l), c, s, ifirstm, ilastm);
+            psd_gg_z(P, st, psd_gnext(l, p), j - 1, c, s);
+        }
+        PSD_ONE {  // left side of H_1 after the whole pass (:437-440)
+            psd_gtr tr;
+            tr.pos = alive ? (j - 1) : -1;
+            tr.pad = 0;
+            tr.c = c;
+            tr.s = s;
+            P.dG[j] = tr;
+        }
+    }
+    PSD_SYNC();
+    for (int j = ilast; j >= jdeflate + 2; --j) {
+        const psd_gtr g = P.dG[j];
+        if (g.pos > 0) psd_gg_left(H1, j - 1, g.c, g.s, j - 1, ilastm);
+    }
+}
+
+// rgeneralized.jl:444-616 Case III: zero on the diagonal of a negative factor
+PSD_D void psd_gq_case3(const psd_gparams& P, psd_gstate& st, int ldeflate, int jdeflate) {
+    const int n = st.n, p = st.p, jlo = st.jlo, ilast = st.ilast, ifirstm = st.ifirstm, ilastm = st.ilastm;
+    const psd_mat<double> H1 = psd_gfac(P, n, 1);
+    const psd_mat<double> Hd = psd_gfac(P, n, ldeflate);
+    st.ncase3 += 1;
+    psd_glog(P, st, 3, jlo, ilast);
+    double c, s, r;
+    if (jdeflate > (ilast - jlo + 1) / 2.0) {
+        for (int j1 = jdeflate; j1 <= ilast - 1; ++j1) {  // chase the zero down
+            int j = j1;
+            psd_givens(Hd(j, j + 1), Hd(j + 1, j + 1), c, s, r);
+            psd_gg_set2(Hd, j, j + 1, r, j + 1, j + 1, 0.0);
+            psd_gg_left(Hd, j, c, s, j + 2, ilastm);
+            int ln = psd_gnext(ldeflate, p);
+            psd_gg_z(P, st, ln, j, c, s);
+            for (int l = 1; l <= p - 1; ++l) {
+                if (ln == 1) {
+                    psd_gg_left(H1, j, c, s, j - 1, ilastm);
+                    psd_givens(H1(j + 1, j), -H1(j + 1, j - 1), c, s, r);  // standard (j-1, j; c, s)
+                    psd_gg_set2(H1, j + 1, j, r, j + 1, j - 1, 0.0);
+                    psd_gg_right(H1, j - 1, c, s, ifirstm, j);
+                    j -= 1;
+                } else {
+                    psd_gg_link(psd_gfac(P, n, ln), j, !psd_gsig(P, ln), c, s, ifirstm, ilastm);
+                }
+                ln = psd_gnext(ln, p);
+                psd_gg_z(P, st, ln, j, c, s);
+            }
+            psd_gg_right(Hd, j, c, s, ifirstm, j);
+        }
+        const int j = ilast;  // deflate the last element of the Hessenberg factor
+        psd_givens(H1(j, j), -H1(j, j - 1), c, s, r);
+        psd_gg_set2(H1, j, j, r, j, j - 1, 0.0);
+        psd_gg_right(H1, j - 1, c, s, ifirstm, j - 1);
+        psd_gg_z(P, st, psd_gnext(1, p), j - 1, c, s);
+        for (int l = 2; l <= ldeflate - 1; ++l) {
+            psd_gg_link(psd_gfac(P, n, l), j - 1, !psd_gsig(P, l), c, s, ifirstm, ilastm);
+            psd_gg_z(P, st, psd_gnext(l, p), j - 1, c, s);
+        }
+        psd_gg_right(Hd, j - 1, c, s, ifirstm, j);
+    } else {
+        for (int j1 = jdeflate; j1 >= jlo + 1; --j1) {  // chase the zero up
+            int j = j1;
+            psd_givens(Hd(j - 1, j), -Hd(j - 1, j - 1), c, s, r);  // standard (j-1, j; c, s)
+            psd_gg_set2(Hd, j - 1, j, r, j - 1, j - 1, 0.0);
+            psd_gg_right(Hd, j - 1, c, s, ifirstm, j - 2);
+            psd_gg_z(P, st, ldeflate, j - 1, c, s);
+            int ln = ldeflate - 1;
+            for (int l = 1; l <= p - 1; ++l) {
+                if (ln == 1) {
+                    psd_gg_right(H1, j - 1, c, s, ifirstm, j + 1);
+                    psd_givens(H1(j, j - 1), H1(j + 1, j - 1), c, s, r);
+                    psd_gg_set2(H1, j, j - 1, r, j + 1, j - 1, 0.0);
+                    psd_gg_left(H1, j, c, s, j, ilastm);
+                    j += 1;
+                } else {
+                    psd_gg_link(psd_gfac(P, n, ln), j - 1, psd_gsig(P, ln), c, s, ifirstm, ilastm);
+                }
+                psd_gg_z(P, st, ln, j - 1, c, s);
+                ln = (ln == 1) ? p : (ln - 1);
+            }
+            psd_gg_left(Hd, j - 1, c, s, j, ilastm);
+        }
+        const int j = jlo;  // deflate the first element of the Hessenberg factor
+        psd_givens(H1(j, j), H1(j + 1, j), c, s, r);
+        psd_gg_set2(H1, j, j, r, j + 1, j, 0.0);
+        psd_gg_left(H1, j, c, s, j + 1, ilastm);
+        psd_gg_z(P, st, 1, j, c, s);
+        for (int l = p; l >= ldeflate + 1; --l) {
+            psd_gg_link(psd_gfac(P, n, l), j, psd_gsig(P, l), c, s, ifirstm, ilastm);
+            psd_gg_z(P, st, l, j, c, s);
+        }
+        psd_gg_left(Hd, j, c, s, j + 1, ilastm);
+    }
+}
+
+// rgeneralized.jl:1015-1048 (section 510 of MB03BD): a single rotation at (j, j+1) = (ilast-1, ilast) through
+// all factors, inside the window; `given`: (c, s) is the perfect-shift rotation of a 2x2 deflation (:717-742),
+// otherwise it is generated from column j-1 of H_1.
+PSD_D void psd_gq_tail(const psd_gparams& P, const psd_gstate& st, const psd_gwin& w, int* lcnt, int j, bool given,
+                       double c, double s) {
+    const int p = st.p;
+    if (!given) {
+        double r;
+        psd_givens(w.at(1, j, j - 1), w.at(1, j + 1, j - 1), c, s, r);
+        psd_gwin_set2(w, 1, j, j - 1, r, j + 1, j - 1, 0.0);
+    }
+    psd_gwin_left(w, 1, j, c, s, j, st.ilastm);
+    psd_grecord(P, lcnt, 1, j, c, s);
+    for (int l = p; l >= 2; --l) {
+        const bool sg = psd_gsig(P, l);
+        psd_g_link(w, l, j, sg, c, s, st.ifirstm, st.ilastm);
+        psd_grecord(P, lcnt, sg ? l : l, j, c, s);  // rows owner of l if S[l], columns owner of l if !S[l]: both l
+    }
+    psd_gwin_right(w, 1, j, c, s, st.ifirstm, st.ilastm);
+}
+
+// rgeneralized.jl:890-1054: one window of the implicit double-shift sweep
+PSD_D void psd_gq_sweep_window(const psd_gparams& P, psd_gstate& st, double* ldsd, int* lcnt) {
+    const int n = st.n, p = st.p, ifirst = st.ifirst, ilast = st.ilast, ifirstm = st.ifirstm, ilastm = st.ilastm;
+    const int ks = st.kcur;
+    const bool first = (ks == ifirst);
+    int ke = first ? (ifirst + st.W - 4) : (ks + st.W - 5);
+    if (ke > ilast - 2) ke = ilast - 2;
+    psd_gwin w;
+    w.b = ldsd;
+    w.W = st.W;
+    w.ld = st.W + 1;
+    w.bsz = st.W * (st.W + 1);
+    w.bs = first ? ifirst : (ks - 1);
+    w.be = (ke + 3 < ilast) ? (ke + 3) : ilast;
+    const long long tc0 = psd_clock();
+    PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
+    psd_gwin_load(P, w, n, p);
+    const long long tc1 = psd_clock();
+    int jstart = ks;
+    if (first && p > 1) {
+        // initial transformation (:890-943): the shift rotations enter H_1 from the right and travel forward
+        const int j = ifirst;
+        double c2 = st.c2, s2 = st.s2, c1 = st.c1, s1 = st.s1;
+        const int own = psd_gnext(1, p);
+        psd_gwin_right(w, 1, j + 1, c2, s2, ifirstm, ilast);
+        psd_gwin_right(w, 1, j, c1, s1, ifirstm, ilast);
+        psd_grecord(P, lcnt, own, j + 1, c2, s2);
+        psd_grecord(P, lcnt, own, j, c1, s1);
+        for (int l = 2; l <= p; ++l) {
+            const bool sg = psd_gsig(P, l);
+            const int ownl = psd_gnext(l, p);
+            psd_g_link(w, l, j + 1, !sg, c2, s2, ifirstm, ilastm);
+            psd_grecord(P, lcnt, ownl, j + 1, c2, s2);
+            psd_g_link(w, l, j, !sg, c1, s1, ifirstm, ilastm);
+            psd_grecord(P, lcnt, ownl, j, c1, s1);
+        }
+        psd_gwin_left(w, 1, j + 1, c2, s2, ifirst, ilastm);
+        psd_gwin_left(w, 1, j, c1, s1, ifirst, ilastm);
+        jstart = ifirst + 1;
+    }
+    for (int j = jstart; j <= ke; ++j) {
+        double c1, s1, c2, s2;
+        if (first && p == 1 && j == ifirst) {  // :955-958
+            c1 = st.c1; s1 = st.s1; c2 = st.c2; s2 = st.s2;
+        } else {  // :960-968
+            double r2, r1;
+            psd_givens(w.at(1, j + 1, j - 1), w.at(1, j + 2, j - 1), c2, s2, r2);
+            psd_givens(w.at(1, j, j - 1), r2, c1, s1, r1);
+            PSD_WAVE_SYNC();
+            PSD_ONE {
+                w.at(1, j, j - 1) = r1;
+                w.at(1, j + 1, j - 1) = 0.0;
+                w.at(1, j + 2, j - 1) = 0.0;
+            }
+            PSD_WAVE_SYNC();
+        }
+        psd_gwin_left(w, 1, j + 1, c2, s2, j, ilastm);
+        psd_gwin_left(w, 1, j, c1, s1, j, ilastm);
+        psd_grecord(P, lcnt, 1, j + 1, c2, s2);
+        psd_grecord(P, lcnt, 1, j, c1, s1);
+        for (int l = p; l >= 2; --l) {
+            const bool sg = psd_gsig(P, l);
+            psd_g_link(w, l, j + 1, sg, c2, s2, ifirstm, ilastm);
+            psd_grecord(P, lcnt, l, j + 1, c2, s2);
+            psd_g_link(w, l, j, sg, c1, s1, ifirstm, ilastm);
+            psd_grecord(P, lcnt, l, j, c1, s1);
+        }
+        const int lm = (j + 3 < ilastm) ? (j + 3) : ilastm;
+        psd_gwin_right(w, 1, j + 1, c2, s2, ifirstm, lm);
+        psd_gwin_right(w, 1, j, c1, s1, ifirstm, lm);
+    }
+    const bool last = ke >= ilast - 2;
+    if (last) psd_gq_tail(P, st, w, lcnt, ilast - 1, false, 0.0, 0.0);
+    const long long tc2 = psd_clock();
+    psd_gwin_store(P, w, n, p);
+    st.cyc[1] += tc1 - tc0;
+    st.cyc[2] += tc2 - tc1;
+    st.cyc[3] += psd_clock() - tc2;
+    psd_gdesc_write(P, st, lcnt, w.bs, w.be, w.be + 1, ilastm, ifirstm, w.bs - 1, 0, 0, 0, 0);
+    st.nwindows += 1;
+    st.kcur = ke + 1;
+    if (last) st.phase = PSD_GPH_CHECK;
+}
+
+// rgeneralized.jl:229-324: one window of the controlled zero shift (positions kcur..)
+PSD_D void psd_gq_zshift_window(const psd_gparams& P, psd_gstate& st, double* ldsd, int* lcnt) {
+    const int n = st.n, p = st.p, jlo = st.jlo, ilast = st.ilast, ifirstm = st.ifirstm, ilastm = st.ilastm;
+    const int nb = st.W - 2;
+    const int ks = st.kcur;
+    const int jend = ilast - 1;
+    const int ke = (ks + nb - 1 < jend) ? (ks + nb - 1) : jend;
+    psd_gwin w;
+    w.b = ldsd;
+    w.W = st.W;
+    w.ld = st.W + 1;
+    w.bsz = st.W * (st.W + 1);
+    w.bs = ks;
+    w.be = ke + 1;
+    PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
+    psd_gwin_load(P, w, n, p);
+    for (int j = ks; j <= ke; ++j) {
+        double c, s, r;
+        psd_givens(w.at(1, j, j), w.at(1, j + 1, j), c, s, r);
+        psd_gwin_set2(w, 1, j, j, r, j + 1, j, 0.0);
+        psd_gwin_left(w, 1, j, c, s, j + 1, ilastm);
+        psd_grecord(P, lcnt, 1, j, c, s);
+        for (int l = p; l >= 2 && s != 0.0; --l) {
+            const bool sg = psd_gsig(P, l);
+            if (sg) psd_gwin_right(w, l, j, c, s, ifirstm, j + 1);
+            else psd_gwin_left(w, l, j, c, s, j, ilastm);
+            double tol = fabs(w.at(l, j, j)) + fabs(w.at(l, j + 1, j + 1));
+            if (tol == 0) {  // opnorm(view(Hl, jlo:j+1, jlo:j+1), 1) restricted to the window
+                for (int cc = w.bs; cc <= j + 1; ++cc) {
+                    double cs = 0.0;
+                    for (int rr = w.bs; rr <= j + 1; ++rr) cs += fabs(w.at(l, rr, cc));
+                    tol = fmax(tol, cs);
+                }
+            }
+            tol = fmax(st.ulp * tol, st.smlnum);
+            const double sub = w.at(l, j + 1, j);
+            if (fabs(sub) <= tol) {
+                c = 1.0;
+                s = 0.0;
+                psd_gwin_set2(w, l, j + 1, j, 0.0, j + 1, j, 0.0);
+            } else if (sg) {
+                psd_givens(w.at(l, j, j), sub, c, s, r);
+                psd_gwin_set2(w, l, j, j, r, j + 1, j, 0.0);
+                psd_gwin_left(w, l, j, c, s, j + 1, ilastm);
+                psd_grecord(P, lcnt, l, j, c, s);
+            } else {
+                psd_givens(w.at(l, j + 1, j + 1), -sub, c, s, r);
+                psd_gwin_set2(w, l, j + 1, j + 1, r, j + 1, j, 0.0);
+                psd_gwin_right(w, l, j, c, s, ifirstm, j);
+                psd_grecord(P, lcnt, l, j, c, s);
+            }
+        }
+        PSD_ONE {  // the right side of H_1 is applied after the whole pass (:312-320)
+            psd_gtr tr;
+            tr.pos = j;
+            tr.pad = 0;
+            tr.c = c;
+            tr.s = s;
+            P.dG[j] = tr;
+        }
+        if (s == 0.0) st.zflag = 1;
+    }
+    psd_gwin_store(P, w, n, p);
+    const bool last = ke >= jend;
+    psd_gdesc_write(P, st, lcnt, ks, ke + 1, w.be + 1, ilastm, ifirstm, w.bs - 1, 1, last ? 1 : 0, jlo, jend);
+    st.nwindows += 1;
+    st.kcur = ke + 1;
+    if (last) {
+        st.ziter = st.zflag ? 1 : 0;
+        st.phase = PSD_GPH_CHECK;
+    }
+}
+
+// first (smallest l) factor of the given sign with a negligible diagonal entry in jlo..ilast, largest j
+// (rgeneralized.jl:198-226, 1114-1136); returns l * (n + 2) + (n + 1 - j) or INT_MAX
+PSD_D int psd_gq_scan_diag(const psd_gparams& P, const psd_gstate& st, int* redi, int jlo, bool sign) {
+    const int n = st.n, p = st.p, ilast = st.ilast;
+    const int NT = PSD_NTHREADS;
+    const int wd = ilast - jlo + 1;
+    PSD_SYNC();
+    PSD_PAR_FOR(t, NT) {
+        int key = 0x7fffffff;
+        for (int q = t; q < (p - 1) * wd; q += NT) {
+            const int l = 2 + q / wd, j = jlo + q % wd;
+            if (psd_gsig(P, l) != sign) continue;
+            const psd_mat<double> Hl = psd_gfac(P, n, l);
+            double tol;
+            if (j == ilast) tol = fabs(Hl(j - 1, j));
+            else if (j == jlo) tol = fabs(Hl(j, j + 1));
+            else tol = fabs(Hl(j - 1, j)) + fabs(Hl(j, j + 1));
+            tol = fmax(st.ulp * tol, st.smlnum);  // (tol == 0 fallback of the reference: smlnum floor)
+            if (fabs(Hl(j, j)) <= tol) {
+                const int k = l * (n + 2) + (n + 1 - j);
+                if (k < key) key = k;
+            }
+        }
+        redi[t] = key;
+    }
+    PSD_SYNC();
+    int key = 0x7fffffff;
+    for (int t = 0; t < NT; ++t)
+        if (redi[t] < key) key = redi[t];
+    PSD_SYNC();
+    return key;
+}
+
+// rgeneralized.jl:169-803: deflation tests, split, zero-shift decision, 2x2 blocks, starting rotations.
+// Returns true when a window was emitted (2x2 real deflation).
+PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, double* red, int* redi, int* lcnt) {
+    const int n = st.n, p = st.p;
+    const int NT = PSD_NTHREADS;
+    st.jiter += 1;
+    if (st.jiter > st.maxit) {  // :1057-1059
+        st.info = st.ilast;
+        st.phase = PSD_GPH_DONE;
+        return false;
+    }
+    const psd_mat<double> H1 = psd_gfac(P, n, 1);
+    const int ilast = st.ilast;
+    bool split = false;
+    int jlo = 1;
+    if (ilast == 1) {
+        split = true;
+    } else {
+        // Test 1 (:1086-1112): first negligible subdiagonal of H_1 from the bottom
+        PSD_SYNC();
+        PSD_PAR_FOR(t, NT) {
+            int best = 0;
+            for (int j = ilast - t; j >= 2; j -= NT) {
+                double tol = fabs(H1(j - 1, j - 1)) + fabs(H1(j, j));
+                if (tol == 0) {  // opnorm(view(H1, 1:j, 1:j), 1): columns j-1, j carry the only candidates > 0 nearby
+                    for (int cc = 1; cc <= j; ++cc) {
+                        double cs = 0.0;
+                        const int rmax = (cc + 1 < j) ? (cc + 1) : j;
+                        for (int rr = 1; rr <= rmax; ++rr) cs += fabs(H1(rr, cc));
+                        tol = fmax(tol, cs);
+                    }
+                }
+                tol = fmax(st.ulp * tol, st.smlnum);
+                if (fabs(H1(j, j - 1)) <= tol) {
+                    best = j;
+                    break;
+                }
+            }
+            redi[t] = best;
+        }
+        PSD_SYNC();
+        int jfound = 0;
+        for (int t = 0; t < NT; ++t)
+            if (redi[t] > jfound) jfound = redi[t];
+        PSD_SYNC();
+        if (jfound > 0) {
+            PSD_ONE { H1(jfound, jfound - 1) = 0.0; }
+            PSD_SYNC();
+            jlo = jfound;
+            if (jfound == ilast) split = true;
+        }
+    }
+    if (split) {  // :617-642
+        double a, b;
+        int sc;
+        psd_g_safeprod(P, n, p, ilast, a, b, sc);
+        PSD_ONE {
+            P.alpha[ilast - 1] = zmk(a, 0.0);
+            P.beta[ilast - 1] = b;
+            P.ascale[ilast - 1] = sc;
+        }
+        st.nsplit += 1;
+        st.ilast -= 1;
+        if (st.ilast < 1) {
+            st.phase = PSD_GPH_DONE;
+            return false;
+        }
+        if (st.ziter != -1) st.ziter = 0;
+        if (!st.wantT) {
+            st.ilastm = st.ilast;
+            if (st.ifirstm > st.ilast) st.ifirstm = 1;
+        }
+        return false;
+    }
+    st.jlo = jlo;
+    // Tests 2 and 3 (:198-226)
+    const int key2 = psd_gq_scan_diag(P, st, redi, jlo, true);
+    const int key3 = (key2 == 0x7fffffff) ? psd_gq_scan_diag(P, st, redi, jlo, false) : 0x7fffffff;
+    // Test 4 (:229): controlled zero shift; a pending zero diagonal entry is found again afterwards (the
+    // reference's fall-through into Case II/III with stale indices is a defect)
+    if (st.ziter >= 7 || st.ziter < 0) {
+        st.phase = PSD_GPH_ZSHIFT;
+        st.kcur = jlo;
+        st.zflag = 0;
+        st.nzshift += 1;
+        psd_glog(P, st, 4, jlo, ilast);
+        return false;
+    }
+    if (key2 != 0x7fffffff || key3 != 0x7fffffff) {
+        const int key = (key2 != 0x7fffffff) ? key2 : key3;
+        const int l = key / (n + 2), j = (n + 1) - key % (n + 2);
+        PSD_ONE { psd_gfac(P, n, l)(j, j) = 0.0; }
+        PSD_SYNC();
+        if (key2 != 0x7fffffff) psd_gq_case2(P, st, l, j);
+        else psd_gq_case3(P, st, l, j);
+        return false;
+    }
+    // QZ step (:644-803)
+    st.ifirst = jlo;
+    st.ziter += 1;
+    if (!st.wantT) st.ifirstm = st.ifirst;
+    const int ifirst = st.ifirst;
+    if (ifirst + 1 == ilast) {  // 2x2 block (:661-790)
+        const int j = ilast - 1;
+        PSD_SYNC();
+        PSD_ONE {
+            double* X = P.xscr;
+            for (int l = 1; l <= p; ++l) {  // order 2, 3, ..., p, 1 (:669-672)
+                const psd_mat<double> M = psd_gfac(P, n, (l == p) ? 1 : (l + 1));
+                X[4 * (l - 1) + 0] = M(j, j);
+                X[4 * (l - 1) + 1] = M(j, j + 1);
+                X[4 * (l - 1) + 2] = M(j + 1, j);
+                X[4 * (l - 1) + 3] = M(j + 1, j + 1);
+            }
+            bool done2 = false;
+            for (int titer = 1; titer <= 2 && !done2; ++titer) {
+                psd_g_rp2x2ssr(p, X, P);
+                const double* Xp = X + 4 * (p - 1);
+                done2 = fabs(Xp[2]) < PSD_DBL_EPS * fmax(fabs(Xp[0]), fmax(fabs(Xp[1]), fabs(Xp[3])));
+            }
+            red[0] = done2 ? 1.0 : 0.0;
+            if (done2) {  // perfect-shift rotation (:694-709)
+                double c1 = 1.0, s1 = 1.0, r;
+                for (int l = p; l >= 2; --l) {
+                    const double rr = X[4 * (l - 2) + 3];
+                    const double hjj = psd_gfac(P, n, l)(j, j);
+                    if (psd_gsig(P, l)) psd_givens(c1 * hjj, s1 * rr, c1, s1, r);
+                    else psd_givens(c1 * rr, s1 * hjj, c1, s1, r);
+                }
+                const double rr = X[4 * (p - 1) + 3];
+                psd_givens(c1 * H1(j, j) - rr * s1, c1 * H1(j + 1, j), c1, s1, r);
+                red[1] = c1;
+                red[2] = s1;
+            } else {  // conjugate pair (:748-771)
+                psd_z* Xc = (psd_z*)(P.xscr + 4 * p);
+                for (int l = 1; l <= p; ++l) {
+                    const psd_mat<double> M = psd_gfac(P, n, l);
+                    Xc[4 * (l - 1) + 0] = zmk(M(j, j), 0.0);
+                    Xc[4 * (l - 1) + 1] = zmk(M(j, j + 1), 0.0);
+                    Xc[4 * (l - 1) + 2] = zmk(M(j + 1, j), 0.0);
+                    Xc[4 * (l - 1) + 3] = zmk(M(j + 1, j + 1), 0.0);
+                }
+                psd_z a2[2];
+                double b2[2], sc2[2];
+                bool cvg, good;
+                psd_g_eigpair(P, p, Xc, a2, b2, sc2, cvg, good);
+                for (int q = 0; q < 2; ++q) {
+                    P.alpha[j - 1 + q] = a2[q];
+                    P.beta[j - 1 + q] = b2[q];
+                    P.ascale[j - 1 + q] = (int)sc2[q];
+                }
+                red[1] = cvg ? 1.0 : 0.0;
+                red[2] = good ? 1.0 : 0.0;
+            }
+        }
+        PSD_SYNC();
+        const bool done2 = red[0] != 0.0;
+        const double r1 = red[1], r2 = red[2];
+        PSD_SYNC();
+        if (done2) {
+            st.n2real += 1;
+            psd_glog(P, st, 5, j, ilast);
+            psd_gwin w;
+            w.b = ldsd;
+            w.W = st.W;
+            w.ld = st.W + 1;
+            w.bsz = st.W * (st.W + 1);
+            w.bs = j;
+            w.be = ilast;
+            PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
+            psd_gwin_load(P, w, n, p);
+            psd_gq_tail(P, st, w, lcnt, j, true, r1, r2);
+            psd_gwin_store(P, w, n, p);
+            psd_gdesc_write(P, st, lcnt, w.bs, w.be, w.be + 1, st.ilastm, st.ifirstm, w.bs - 1, 0, 0, 0, 0);
+            st.nwindows += 1;
+            return true;
+        }
+        st.n2cplx += 1;
+        psd_glog(P, st, 6, j, ilast);
+        if (r1 == 0.0) st.iwarn = (st.iwarn > j) ? st.iwarn : j;
+        else if (r2 == 0.0 && st.iwarn == 0) st.iwarn = n;
+        st.ilast = ifirst - 1;
+        if (st.ilast < 1) {
+            st.phase = PSD_GPH_DONE;
+            return false;
+        }
+        if (st.ziter != -1) st.ziter = 0;
+        if (!st.wantT) {
+            st.ilastm = st.ilast;
+            if (st.ifirstm > st.ilast) st.ifirstm = 1;
+        }
+        return false;
+    }
+    PSD_SYNC();
+    psd_g_qzrots(P, n, p, ifirst, ilast - ifirst + 1, st.c1, st.s1, st.c2, st.s2);
+    st.phase = PSD_GPH_SWEEP;
+    st.kcur = ifirst;
+    st.nsweeps += 1;
+    psd_glog(P, st, 0, ifirst, ilast);
+    return false;
+}
+
+PSD_KERNEL_B(PSD_STEP_NT) psd_gq_step(psd_gparams P) {
+    PSD_LDS_DECL;
+    psd_gstate st = *P.st;
+    if (st.phase == PSD_GPH_DONE) {
+        PSD_ONE { P.desc->active = 0; P.desc->defer_run = 0; }
+        return;
+    }
+    const int NT = PSD_NTHREADS;
+    double* ldsd = (double*)psd_lds;
+    const size_t winb = (size_t)st.p * st.W * (st.W + 1);
+    double* red = ldsd + winb;
+    int* redi = (int*)(red + NT);
+    int* lcnt = redi + 2 * NT;
+    PSD_ONE { P.desc->active = 0; P.desc->defer_run = 0; }
+    const long long tk0 = psd_clock(), tw0 = psd_wallclock();
+    bool emitted = false;
+    int guard = 0;
+    while (!emitted && st.phase != PSD_GPH_DONE && guard < 64) {
+        ++guard;
+        if (st.phase == PSD_GPH_CHECK) {
+            const long long td0 = psd_clock();
+            const int nc = st.ncase2 + st.ncase3;
+            emitted = psd_gq_check(P, st, ldsd, red, redi, lcnt);
+            st.cyc[0] += psd_clock() - td0;
+            if (st.ncase2 + st.ncase3 != nc) break;  // a Case II/III pass ran on HBM: end this launch
+        } else if (st.phase == PSD_GPH_SWEEP) {
+            psd_gq_sweep_window(P, st, ldsd, lcnt);
+            emitted = true;
+        } else if (st.phase == PSD_GPH_ZSHIFT) {
+            psd_gq_zshift_window(P, st, ldsd, lcnt);
+            emitted = true;
+        } else {
+            st.phase = PSD_GPH_DONE;
+        }
+    }
+    st.cyc[4] += psd_clock() - tk0;
+    st.cyc[5] += psd_wallclock() - tw0;
+    PSD_SYNC();
+    PSD_ONE { *P.st = st; }
+}
+
+// Bulk application of one window's rotation lists, by factor: grid = (tiles, p factors, 3 roles).
+PSD_KERNEL_B(PSD_GAPPLY_NT) psd_gq_apply(psd_gparams P, int n, int p) {
+    PSD_LDS_DECL;
+    const psd_gapply_desc d = *P.desc;
+    if (!d.active) return;
+    const int l = PSD_BLOCK_Y + 1;
+    const int role = PSD_BLOCK_Z;
+    const int own = (role == 0) ? psd_growner(P, l, p) : (role == 1) ? psd_gcowner(P, l, p) : l;
+    const int cnt = P.cnt[own - 1] < PSD_GTR_CAP ? P.cnt[own - 1] : PSD_GTR_CAP;
+    if (cnt <= 0) return;
+    const int T = PSD_GAPPLY_NT;
+    const int S = d.phi - d.plo + 1;
+    psd_gtr* ltr = (psd_gtr*)psd_lds;
+    double* tile = (double*)(psd_lds + sizeof(psd_gtr) * PSD_GTR_CAP);
+    if (role == 0) {
+        const int c0 = d.lc0 + PSD_BLOCK_X * T;
+        if (c0 > d.lc1) return;
+        const int nc = (d.lc1 - c0 + 1 < T) ? (d.lc1 - c0 + 1) : T;
+        const psd_mat<double> M = psd_gfac(P, n, l);
+        const int ldt = T + 1;
+        PSD_PAR_FOR(e, cnt) { ltr[e] = P.tr[(size_t)(own - 1) * PSD_GTR_CAP + e]; }
+        PSD_PAR_FOR(t, S * nc) {
+            const int r = t % S, c = t / S;
+            tile[r * ldt + c] = M(d.plo + r, c0 + c);
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(c, nc) {
+            for (int e = 0; e < cnt; ++e) {
+                const psd_gtr tr = ltr[e];
+                const int r = tr.pos - d.plo;
+                const double a1 = tile[r * ldt + c], a2 = tile[(r + 1) * ldt + c];
+                tile[r * ldt + c] = tr.c * a1 + tr.s * a2;
+                tile[(r + 1) * ldt + c] = tr.c * a2 - tr.s * a1;
+            }
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(t, S * nc) {
+            const int r = t % S, c = t / S;
+            M(d.plo + r, c0 + c) = tile[r * ldt + c];
+        }
+    } else {
+        if (role == 1 && d.defer_h1 == 1 && l == 1) return;  // H_1's column updates are deferred (zero-shift pass)
+        const int lo = (role == 1) ? d.rr0 : d.zr0;
+        const int hi = (role == 1) ? d.rr1 : d.zr1;
+        const int r0 = lo + PSD_BLOCK_X * T;
+        if (r0 > hi) return;
+        const int nr = (hi - r0 + 1 < T) ? (hi - r0 + 1) : T;
+        double* base = (role == 1) ? P.H : P.Z;
+        const psd_mat<double> M = psd_mat<double>{base + (size_t)(l - 1) * n * n, n};
+        PSD_PAR_FOR(e, cnt) { ltr[e] = P.tr[(size_t)(own - 1) * PSD_GTR_CAP + e]; }
+        PSD_PAR_FOR(t, S * nr) {
+            const int r = t % nr, c = t / nr;
+            tile[c * T + r] = M(r0 + r, d.plo + c);
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(r, nr) {
+            for (int e = 0; e < cnt; ++e) {
+                const psd_gtr tr = ltr[e];
+                const int c = tr.pos - d.plo;
+                const double a1 = tile[c * T + r], a2 = tile[(c + 1) * T + r];
+                tile[c * T + r] = tr.c * a1 + tr.s * a2;
+                tile[(c + 1) * T + r] = tr.c * a2 - tr.s * a1;
+            }
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(t, S * nr) {
+            const int r = t % nr, c = t / nr;
+            M(r0 + r, d.plo + c) = tile[c * T + r];
+        }
+    }
+}
+
+// Deferred right side of H_1 after a zero-shift pass (rgeneralized.jl:312-320):
+// for j = djlo..djhi: rmul!(view(H1, drow0:(j+1), :), G_j').  One thread per row.
+PSD_KERNEL psd_gq_defer(psd_gparams P, int n) {
+    const psd_gapply_desc d = *P.desc;
+    if (!d.active || d.defer_run != 1) return;
+    const psd_mat<double> H1 = psd_mat<double>{P.H, n};
+    const int NT = PSD_NTHREADS;
+    const int rbase = d.drow0 + PSD_BLOCK_X * NT;
+    PSD_PAR_FOR(t, NT) {
+        const int r = rbase + t;
+        if (r <= d.djhi + 1 && d.djhi >= d.djlo) {
+            int j = (r - 1 > d.djlo) ? (r - 1) : d.djlo;
+            double a1 = H1(r, j);
+            for (; j <= d.djhi; ++j) {
+                const psd_gtr g = P.dG[j];
+                const double a2 = H1(r, j + 1);
+                H1(r, j) = g.c * a1 + g.s * a2;
+                a1 = g.c * a2 - g.s * a1;
+            }
+            H1(r, d.djhi + 1) = a1;
+        }
+    }
+}
+
+PSD_KERNEL psd_gq_init(psd_gparams P, int n, int p, int wantT, int wantZ, int W, int maxitfac, int maxlog) {
+    const psd_mat<double> H1 = psd_mat<double>{P.H, n};
+    PSD_PAR_FOR(c, n) {
+        for (int r = c + 3; r <= n; ++r) H1(r, c + 1) = 0.0;  // _gethess!
+        for (int l = 2; l <= p; ++l) {                          // :112 triu!(Hs[j-1], -1), then treated as triangular
+            const psd_mat<double> Hl = psd_gfac(P, n, l);
+            for (int r = c + 2; r <= n; ++r) Hl(r, c + 1) = 0.0;
+        }
+    }
+    PSD_ONE {
+        psd_gstate st;
+        st.n = n; st.p = p; st.wantT = wantT; st.wantZ = wantZ; st.W = W;
+        st.phase = PSD_GPH_CHECK; st.info = 0;
+        st.ilast = n; st.ifirst = 1; st.ifirstm = 1; st.ilastm = n;
+        st.ziter = (p >= 20) ? -1 : 0;  // :107: p >= log2(floatmin)/log2(eps) = 19.65
+        st.jiter = 0; st.maxit = maxitfac * n;
+        st.jlo = 1; st.kcur = 0; st.zflag = 0;
+        st.nsweeps = st.nzshift = st.nsplit = st.ncase2 = st.ncase3 = st.n2real = st.n2cplx = 0;
+        st.nwindows = st.nlog = 0; st.maxlog = maxlog; st.iwarn = 0; st.pad = 0;
+        st.c1 = st.c2 = 1.0; st.s1 = st.s2 = 0.0;
+        st.ulp = PSD_DBL_EPS;
+        st.smlnum = PSD_DBL_MIN * ((double)n / PSD_DBL_EPS);
+        for (int q = 0; q < 6; ++q) st.cyc[q] = 0;
+        if (n == 0) st.phase = PSD_GPH_DONE;
+        *P.st = st;
+        P.desc->active = 0;
+        P.desc->defer_run = 0;
+    }
+}

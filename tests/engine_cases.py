@@ -1,6 +1,7 @@
 """Parity cases shared by the simulated-device tier (CPU, tests/hostsim) and the GPU tier: every case drives the
 engine through the C ABI (via the Python mirror) and judges it with the reference's own checkers against the
 oracle / goldens."""
+import pytest
 import numpy as np
 
 import psdtest as pt
@@ -508,3 +509,119 @@ def case_rordschur_edge(eng):
         raise AssertionError("expected SingularException / IllConditionedException")
     except (psd_amd.SingularException, psd_amd.IllConditionedException):
         pass
+
+
+# ---- real generalized (signed) periodic QZ: rgeneralized.jl / test/generalized.jl Float64 parts ----------------
+def rg_hess_ut(n, p, seed, shift=0.0):
+    A = [np.triu(a) for a in pt.rand_uniform_factors(n, p, seed)]
+    A[0] = np.triu(pt.rand_uniform_factors(n, 1, seed + 77)[0], -1)
+    if shift:
+        A = [a if k == 0 else a + shift * np.eye(n) for k, a in enumerate(A)]
+    return [np.asfortranarray(a) for a in A]
+
+
+def _rg_run(eng, A, S, tol=100, **kw):
+    ps = eng.gpschur_hess_(A[0].copy(order="F"), [a.copy(order="F") for a in A[1:]], S, **kw)
+    pt.rgpschur_check(A, S, ps, tol=tol)
+    return ps
+
+
+def _rg_match_oracle(A, S, ps, rtol=1e-9):
+    po = pt.oracle_gpschur_hess(A[0], A[1:], S)
+    assert po.info == 0
+    fin = np.isfinite(po.values)
+    assert fin.sum() == np.isfinite(ps.values).sum()
+    if fin.any():
+        scale = abs(po.values[fin]).max()
+        assert pt.match_eigs(po.values[fin], ps.values[np.isfinite(ps.values)]) < rtol * max(scale, 1.0)
+    return po
+
+
+def case_rg_hess_ut(eng, p):
+    # test/generalized.jl:67-76
+    S = [True, False] + [True] * (p - 2)
+    for seed in range(3):
+        A = rg_hess_ut(5, p, 800 + 10 * p + seed)
+        ps = _rg_run(eng, A, S)
+        _rg_match_oracle(A, S, ps)
+    # rev = true (rgeneralized.jl:1062-1079)
+    A = rg_hess_ut(5, p, 831 + p)
+    pr = eng.gpschur_hess_(A[0].copy(order="F"), [a.copy(order="F") for a in A[1:]], S, rev=True)
+    assert pr.orientation == "L" and pr.schurindex == p and pr.S == S[::-1]
+    Arev = A[1:][::-1] + [A[0]]
+    pt.rgpschur_check(Arev, S[::-1], pr)
+
+
+RG_HOLES = [
+    ([True, True, False, True, True], 2, 3), ([True, True, False, True, False], 2, 3),
+    ([True, True, False, True, True], 4, 3), ([True, True, False, True, False], 4, 3),
+    ([True, True, True, False, True], 4, 2), ([True, False, True, False, True], 4, 2),
+    ([True, True, True, False, True], 4, 4), ([True, False, True, False, True], 4, 4),
+    ([True, False, True, True, True], 2, 2), ([True, False, True, False, True], 2, 2),
+    ([True, False, True, True, True], 2, 4), ([True, False, True, False, True], 2, 4),
+]
+
+
+def case_rg_holes(eng):
+    """test/generalized.jl:77-152: exact zeros on the diagonal of positive (Case II) and negative (Case III) factors."""
+    for (S, l, j) in RG_HOLES:
+        for seed in range(2):
+            A = rg_hess_ut(5, 5, 900 + seed)
+            A[l - 1][j - 1, j - 1] = 0.0
+            ps = _rg_run(eng, A, S)
+            po = _rg_match_oracle(A, S, ps)
+            c2, c3 = ps.stats.reserved % 1000, ps.stats.reserved // 1000
+            assert (c2, c3) == (po.counters["case2"], po.counters["case3"])
+            assert c2 + c3 >= 1
+    # larger: holes inside multi-window problems, both halves of Case III, p >= 20 (zero shift first)
+    for (n, p, l, j) in [(40, 4, 2, 30), (40, 4, 3, 8), (40, 4, 4, 20), (30, 21, 5, 11), (30, 21, 12, 25)]:
+        S = [True] + [bool((q * 5 + 1) % 3) for q in range(1, p)]
+        A = rg_hess_ut(n, p, 40 + n + p, shift=2.0)
+        A[l - 1][j - 1, j - 1] = 0.0
+        ps = _rg_run(eng, A, S, tol=100 * max(1, n / 32))
+        _rg_match_oracle(A, S, ps, rtol=1e-8)
+
+
+def case_rg_windows(eng, sizes):
+    """multi-window sweeps, zero-shift passes, 2x2 blocks of both kinds, every signature pattern class"""
+    for (n, p, pat) in sizes:
+        if pat == "alt":
+            S = [True] + [bool(q % 2 == 0) for q in range(1, p)]
+        elif pat == "true":
+            S = [True] * p
+        elif pat == "neg":
+            S = [True] + [False] * (p - 1)
+        else:
+            S = [True] + [bool((q * 7 + n) % 3) for q in range(1, p)]
+        A = rg_hess_ut(n, p, 300 + n + p, shift=1.0)
+        ps = _rg_run(eng, A, S, tol=100 * max(1, np.sqrt(n / 32)))
+        _rg_match_oracle(A, S, ps, rtol=1e-8)
+        assert ps.stats.nsweeps > 0
+
+
+def case_rg_fast_paths(eng):
+    # wantT / wantZ variants (rgeneralized.jl:636-641, 658-660, 784-789)
+    n, p = 24, 4
+    S = [True, False, True, False]
+    A = rg_hess_ut(n, p, 77, shift=1.0)
+    full = _rg_run(eng, A, S)
+    noz = eng.gpschur_hess_(A[0].copy(order="F"), [a.copy(order="F") for a in A[1:]], S, wantZ=False)
+    assert noz.Z == []
+    assert pt.match_eigs(full.values, noz.values) < 1e-10 * abs(full.values).max()
+    for l in range(p):
+        assert np.linalg.norm(noz.Ts[l] - full.Ts[l]) < 1e-10 * np.linalg.norm(full.Ts[l])
+    fast = eng.gpschur_hess_(A[0].copy(order="F"), [a.copy(order="F") for a in A[1:]], S, wantZ=False, wantT=False)
+    assert pt.match_eigs(full.values, fast.values) < 1e-9 * abs(full.values).max()
+
+
+def case_rg_edge(eng):
+    # n = 1, n = 2 (real pair / complex pair), n = 3, p = 1
+    for (n, p) in [(1, 3), (2, 3), (2, 4), (3, 2), (4, 1), (7, 1)]:
+        for seed in range(3):
+            S = [True] + [bool((q + seed) % 2) for q in range(1, p)]
+            A = rg_hess_ut(n, p, 500 + 10 * n + p + seed)
+            ps = _rg_run(eng, A, S)
+            _rg_match_oracle(A, S, ps)
+    with pytest.raises(ValueError):
+        A = rg_hess_ut(4, 2, 1)
+        eng.gpschur_hess_(A[0], A[1:], [False, True])

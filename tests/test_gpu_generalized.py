@@ -1,0 +1,43 @@
+"""GPU tier (MI355X): parity of the real signed periodic QZ (csrc/psd_rgz.h) through the C ABI: the same cases as
+the simulated tier plus larger sizes (BASELINE config 4 shape at the Hessenberg-triangular entry)."""
+import numpy as np
+import pytest
+
+import engine_cases as ec
+import psdtest as pt
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("p", [2, 3, 5])
+def test_rg_hess_ut(gpu_engine, p):
+    ec.case_rg_hess_ut(gpu_engine, p)
+
+
+def test_rg_holes(gpu_engine):
+    ec.case_rg_holes(gpu_engine)
+
+
+def test_rg_windows(gpu_engine):
+    ec.case_rg_windows(gpu_engine, [(40, 3, "alt"), (50, 6, "mix"), (36, 4, "true"), (33, 5, "neg"), (30, 22, "mix"),
+                                    (70, 2, "alt"), (130, 8, "alt"), (100, 17, "mix")])
+
+
+def test_rg_fast_paths(gpu_engine):
+    ec.case_rg_fast_paths(gpu_engine)
+
+
+def test_rg_edge(gpu_engine):
+    ec.case_rg_edge(gpu_engine)
+
+
+def test_rg_config4_shape(gpu_engine):
+    """n = 256, p = 8, alternating signature (BASELINE config 4) from a Hessenberg-triangular start."""
+    n, p = 256, 8
+    S = [True] + [bool(q % 2 == 0) for q in range(1, p)]
+    A = ec.rg_hess_ut(n, p, 4242, shift=4.0)
+    ps = gpu_engine.gpschur_hess_(A[0].copy(order="F"), [a.copy(order="F") for a in A[1:]], S)
+    pt.rgpschur_check(A, S, ps, tol=100 * np.sqrt(n / 32), lam_check=False)
+    po = pt.oracle_gpschur_hess(A[0], A[1:], S)
+    assert po.info == 0
+    assert pt.match_eigs(po.values, ps.values) < 1e-8 * abs(po.values).max()

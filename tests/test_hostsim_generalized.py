@@ -1,0 +1,27 @@
+"""CPU tier: the device state machine of the real signed periodic QZ (csrc/psd_rgz.h), run through the TEST-ONLY
+serial simulation (tests/hostsim) and checked with the reference's invariants and against the oracle."""
+import pytest
+
+import engine_cases as ec
+
+
+@pytest.mark.parametrize("p", [2, 3, 5])
+def test_rg_hess_ut(sim_engine, p):
+    ec.case_rg_hess_ut(sim_engine, p)
+
+
+def test_rg_holes(sim_engine):
+    ec.case_rg_holes(sim_engine)
+
+
+def test_rg_windows(sim_engine):
+    ec.case_rg_windows(sim_engine, [(40, 3, "alt"), (50, 6, "mix"), (36, 4, "true"), (33, 5, "neg"), (30, 22, "mix"),
+                                    (70, 2, "alt")])
+
+
+def test_rg_fast_paths(sim_engine):
+    ec.case_rg_fast_paths(sim_engine)
+
+
+def test_rg_edge(sim_engine):
+    ec.case_rg_edge(sim_engine)
