@@ -123,6 +123,18 @@ int psd_d_gpschur_hess(psd_ctx* ctx, int n, int p, double* const* H, const uint8
                        int wantZ, int maxitfac, double* alpha, double* beta, int32_t* ascale, psd_stats* stats,
                        int32_t* sweeplog, int64_t maxlog, int* info);
 
+/* _phessenberg!(A, S; wantQ) for Float64 — generalized.jl:988-1082: signed periodic Hessenberg-triangular reduction.
+ * A[l] is overwritten by H_l (H_1 Hessenberg, the others upper triangular), Q[l] (may be NULL) receives Qs[l]:
+ * A_l = Q_l H_l Q_{l+1}' for S[l], A_l = Q_{l+1} H_l Q_l' for !S[l].  S[0] must be true (info -5). */
+int psd_d_gphessenberg(psd_ctx* ctx, int n, int p, double* const* A, const uint8_t* S, double* const* Q,
+                       psd_stats* stats, int* info);
+
+/* pschur!(A, S, lr; wantZ, wantT) for Float64 — rgeneralized.jl:3-45.  User-order in/out as psd_d_pschur; the entry of
+ * S that lands leftmost in the working order (S[0] for 'R', S[p-1] for 'L') must be true (info -5, :37). */
+int psd_d_gpschur(psd_ctx* ctx, int n, int p, double* const* A, const uint8_t* S, char orient, int wantT, int wantZ,
+                  int maxitfac, double* const* Z, double* alpha, double* beta, int32_t* ascale, int* schurindex,
+                  psd_stats* stats, int* info);
+
 /* device-resident variant of psd_z_pschur */
 int psd_z_pschur_dev(psd_ctx* ctx, int n, int p, double* dA, char orient, int wantT, int wantZ, int maxitfac,
                      double* dZ, double* alpha, double* beta, int32_t* ascale, int* schurindex, psd_stats* stats,

@@ -162,6 +162,10 @@ class Engine:
         lib.psd_z_pschur_hess.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, C.POINTER(C.c_uint8), dpp, C.c_int,
                                           C.c_int, C.c_int, dp, dp, i32p, C.POINTER(Stats), i32p, C.c_int64, ip]
         lib.psd_d_gpschur_hess.argtypes = lib.psd_z_pschur_hess.argtypes
+        lib.psd_d_gphessenberg.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, C.POINTER(C.c_uint8), dpp,
+                                           C.POINTER(Stats), ip]
+        lib.psd_d_gpschur.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, C.POINTER(C.c_uint8), C.c_char, C.c_int,
+                                      C.c_int, C.c_int, dpp, dp, dp, i32p, ip, C.POINTER(Stats), ip]
         lib.psd_z_pschur_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p, dp, dp, i32p, ip, C.POINTER(Stats), i32p, C.c_int64, ip]
         lib.psd_z_ordschur.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, dpp, C.c_char, C.c_int, C.POINTER(C.c_uint8),
@@ -257,6 +261,8 @@ class Engine:
             return self._zpschur_(A, orient, S, wantZ, wantT, maxitfac)
         self._as_work(A)
         p = len(A)
+        if S is not None:  # pschur!(A, S, lr) — src/rgeneralized.jl:3-45 (also for all(S), as the reference)
+            return self._gpschur_(A, S, orient, wantZ, wantT, 120 if maxitfac == 30 else maxitfac)
         Z = [np.zeros((n, n), order="F") for _ in range(p)] if wantZ else []
         wr = np.zeros(n)
         wi = np.zeros(n)
@@ -278,6 +284,51 @@ class Engine:
         self._raise(info.value)
         nl = min(st.nlog, maxlog)
         return PeriodicSchur(list(A), Z, wr + 1j * wi, orient, si.value, st, log[: 3 * nl].reshape(-1, 3).copy())
+
+    def _gpschur_(self, A, S, orient, wantZ, wantT, maxitfac):
+        """pschur!(A, S, lr; wantZ, wantT) for Float64 — src/rgeneralized.jl:3-45 -> GeneralizedPeriodicSchur."""
+        n = A[0].shape[0]
+        p = len(A)
+        if len(S) != p:
+            raise DimensionMismatch("length of S must match the period")
+        first = S[p - 1] if orient == "L" else S[0]
+        if not first:
+            raise ValueError("The leftmost entry in S must be true")  # src/rgeneralized.jl:37
+        Z = [np.zeros((n, n), order="F") for _ in range(p)] if wantZ else []
+        alpha = np.zeros(n, dtype=np.complex128)
+        beta = np.zeros(n)
+        sc = np.zeros(n, dtype=np.int32)
+        si = C.c_int(0)
+        st = Stats()
+        info = C.c_int(0)
+        Sarr = (C.c_uint8 * p)(*[1 if x else 0 for x in S])
+        dp = C.POINTER(C.c_double)
+        self.lib.psd_d_gpschur(self.ctx, n, p, self._ptrs(A), Sarr, orient.encode(), int(wantT), int(wantZ),
+                               int(maxitfac), self._ptrs(Z) if wantZ else None,
+                               alpha.view(np.float64).ctypes.data_as(dp), beta.ctypes.data_as(dp),
+                               sc.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(si), C.byref(st), C.byref(info))
+        self._raise(info.value)
+        return GeneralizedPeriodicSchur(list(S), list(A), Z, alpha, beta, sc, orient, si.value, st, None)
+
+    def gphessenberg_(self, A, S, wantQ=True):
+        """_phessenberg!(A, S; wantQ) for Float64 — src/generalized.jl:988-1082.  Overwrites A with the Hessenberg /
+        triangular factors; returns (A, Qs)."""
+        n = _check_square(A)
+        self._as_work(A)
+        p = len(A)
+        if len(S) != p:
+            raise DimensionMismatch("length of S must match the period")
+        if not S[0]:
+            raise ValueError("The leftmost entry in S must be true")  # src/generalized.jl:990
+        Q = [np.zeros((n, n), order="F") for _ in range(p)] if wantQ else []
+        st = Stats()
+        info = C.c_int(0)
+        Sarr = (C.c_uint8 * p)(*[1 if x else 0 for x in S])
+        self.lib.psd_d_gphessenberg(self.ctx, n, p, self._ptrs(A), Sarr, self._ptrs(Q) if wantQ else None,
+                                    C.byref(st), C.byref(info))
+        self._raise(info.value)
+        self.last_stats = st
+        return list(A), Q
 
     def _zpschur_(self, A, orient, S, wantZ, wantT, maxitfac):
         """pschur!(A::Vector{Matrix{ComplexF64}}[, S], lr) — src/PeriodicSchurDecompositions.jl:1106-1111,

@@ -1276,8 +1276,9 @@ int psd_d_ordschur(psd_ctx* c, int n, int p, double* const* T, double* const* Z,
 namespace {
 
 // dH [p][n][n] (H_1 Hessenberg), dZ [p][n][n] or nullptr; S host signature (S[0] true)
+// hessmode: run stage 2 of the signed Hessenberg reduction instead of the QZ iteration (same step/apply machinery)
 int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t* S, int wantT, int wantZ, int maxitfac,
-                 psd_gstate* st_out, psd_stats* stats, int maxlog) {
+                 psd_gstate* st_out, psd_stats* stats, int maxlog, int hessmode = 0) {
     const int W = choose_window(p, 8);
     if (W == 0) return PSD_INFO_NOTIMPL;
     std::vector<unsigned char> hS(p, 1);
@@ -1306,7 +1307,7 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
         c->gstep_lds_set = lds_step;
     }
 #endif
-    PSD_LAUNCH(psd_gq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog);
+    PSD_LAUNCH(psd_gq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, hessmode);
     const size_t lds_apply = sizeof(psd_gtr) * PSD_GTR_CAP + (size_t)32 * (PSD_GAPPLY_NT + 1) * sizeof(double);
     const int tiles = (n + PSD_GAPPLY_NT - 1) / PSD_GAPPLY_NT;
     const int dtiles = (n + 255) / 256;
@@ -1315,7 +1316,7 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
     memset(&hst, 0, sizeof(hst));
     long long launched = 0;
     const int nbmin = (W - 5 > 0) ? (W - 5) : 1;
-    const long long cap = (long long)maxitfac * n * ((long long)n / nbmin + 8) + 8LL * n + 1024;
+    const long long cap = (long long)maxitfac * n * ((long long)n / nbmin + 8) + 8LL * n + 1024 + (hessmode ? (long long)n * n : 0);
     double sample_ms = 0.0;
     int samples = 0;
 #ifndef PSD_HOSTSIM
@@ -1424,9 +1425,161 @@ int grun_iteration(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8
     return *info;
 }
 
+// _phessenberg!(A, S; wantQ) on device — generalized.jl:988-1082.  dA [p][n][n] internal order, overwritten by
+// H_1 (Hessenberg), H_l (upper triangular); dQ [p][n][n] or nullptr.
+int sghess_dev(psd_ctx* c, int n, int p, double* dA, double* dQ, const uint8_t* S, psd_stats* stats) {
+    const size_t nn = (size_t)n * n;
+    const size_t lds_refl = PSD_HESS_NT * 8;
+    const size_t lds_apply = (PSD_HESS_NT + (size_t)n + 8) * 8;
+    auto sg = [&](int l) { return !S || S[l - 1]; };
+    if (dQ) PSD_LAUNCH(psd_set_identity, psd_dim3(n, p), 64, 0, c->stream, dQ, n);
+    Timer t;
+    t.start(c->stream);
+    for (int l = p; l >= 2; --l) {  // stage 1 (:1009-1028)
+        double* Al = dA + (size_t)(l - 1) * nn;
+        double* Am = dA + (size_t)(l - 2) * nn;
+        double* Ql = dQ ? dQ + (size_t)(l - 1) * nn : nullptr;
+        const bool rq = !sg(l);
+        const int mrows = sg(l - 1) ? 0 : 1;  // A_{l-1} takes U from the right (columns) or U' from the left (rows)
+        if (rq) {
+            PSD_LAUNCH(psd_antitranspose, psd_dim3(n), 256, 0, c->stream, Al, n);
+            PSD_LAUNCH(psd_flip, psd_dim3(n), 256, 0, c->stream, Am, n, mrows);
+            if (Ql) PSD_LAUNCH(psd_flip, psd_dim3(n), 256, 0, c->stream, Ql, n, 0);
+        }
+        for (int i = 1; i <= n - 1; ++i) {
+            PSD_LAUNCH(psd_hess_refl, psd_dim3(1), PSD_HESS_NT, lds_refl, c->stream, Al, n, i, i, c->vbuf,
+                       (double*)nullptr);
+            const int nL = (n - i + 3) / 4;   // columns i+1..n of A_l
+            const int nR = (n + 31) / 32;
+            PSD_LAUNCH(psd_hess_apply, psd_dim3(nL + (Ql ? nR : 0)), PSD_HESS_NT, lds_apply, c->stream, Al, Ql, n, i,
+                       i + 1, (const double*)c->vbuf, nL);
+            if (mrows == 0) {
+                PSD_LAUNCH(psd_hess_apply, psd_dim3(nR), PSD_HESS_NT, lds_apply, c->stream, (double*)nullptr, Am, n, i,
+                           1, (const double*)c->vbuf, 0);
+            } else {
+                const int nLm = (n + 3) / 4;
+                PSD_LAUNCH(psd_hess_apply, psd_dim3(nLm), PSD_HESS_NT, lds_apply, c->stream, Am, (double*)nullptr, n, i,
+                           1, (const double*)c->vbuf, nLm);
+            }
+        }
+        PSD_LAUNCH(psd_tril_zero, psd_dim3(n), 256, 0, c->stream, Al, n);
+        if (rq) {
+            PSD_LAUNCH(psd_antitranspose, psd_dim3(n), 256, 0, c->stream, Al, n);
+            PSD_LAUNCH(psd_flip, psd_dim3(n), 256, 0, c->stream, Am, n, mrows);
+            if (Ql) PSD_LAUNCH(psd_flip, psd_dim3(n), 256, 0, c->stream, Ql, n, 0);
+        }
+    }
+    const double ms1 = t.stop(c->stream);
+    t.start(c->stream);
+    // stage 2 (:1034-1079): same step/apply machinery as the QZ iteration
+    if (int rc = c->greserve(n, p, 16)) return rc;
+    psd_gstate st;
+    int rc = giterate_dev(c, n, p, dA, dQ, S, 1, dQ ? 1 : 0, 1, &st, nullptr, 16, 1);
+    const double ms2 = t.stop(c->stream);
+    if (stats) {
+        stats->ms_hess = ms1 + ms2;
+        stats->ms_formq = ms1;  // stage 1 (QR/RQ sweeps incl. the accumulation of Q)
+        // stage 2 moves about n^3 element pairs per factor incl. Q
+        stats->bytes_hess = 2.0 * 8.0 * p * (double)n * n * n;
+    }
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
+
+// _phessenberg!(A, S) — generalized.jl:988-1082 (Float64).  A[l] overwritten by H_l, Q[l] = Qs[l].
+int psd_d_gphessenberg(psd_ctx* c, int n, int p, double* const* A, const uint8_t* S, double* const* Q, psd_stats* stats,
+                       int* info) {
+    int dummy;
+    if (!info) info = &dummy;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!c) return *info = -1;
+    if ((*info = check_dims(n, p)) != 0) return *info;
+    if (!A) return *info = -4;
+    if (S && !S[0]) return *info = -5;  // generalized.jl:990
+    if ((*info = c->reserve(n, p, true, 16)) != 0) return *info;
+    const size_t nn = (size_t)n * n;
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->dH + j * nn, A[j], nn * 8, c->stream));
+    *info = sghess_dev(c, n, p, c->dH, Q ? c->dZ : nullptr, S, stats);
+    if (*info != 0) return *info;
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(A[j], c->dH + j * nn, nn * 8, c->stream));
+    if (Q)
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(Q[j], c->dZ + j * nn, nn * 8, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    return 0;
+}
+
+// pschur!(A, S, lr; wantZ, wantT) for Float64 — rgeneralized.jl:3-45.  User-order in/out as psd_d_pschur.
+int psd_d_gpschur(psd_ctx* c, int n, int p, double* const* A, const uint8_t* S, char orient, int wantT, int wantZ,
+                  int maxitfac, double* const* Z, double* alpha, double* beta, int32_t* ascale, int* schurindex,
+                  psd_stats* stats, int* info) {
+    int dummy;
+    if (!info) info = &dummy;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!c) return *info = -1;
+    if ((*info = check_dims(n, p)) != 0) return *info;
+    if (!A) return *info = -4;
+    if (orient != 'R' && orient != 'L') return *info = -6;
+    if (wantZ && !Z) return *info = -10;
+    if (maxitfac < 1) return *info = -9;
+    const bool left = orient == 'L';
+    auto slotA = [&](int j) { return left ? (p + 1 - j) : j; };               // internal j <- user slot (1-based)
+    auto slotZ = [&](int j) { return (!left || j == 1) ? j : (p + 2 - j); };  // rgeneralized.jl:1062-1071
+    std::vector<uint8_t> Sarg(p, 1);
+    bool alltrue = true;
+    for (int j = 1; j <= p; ++j) {
+        Sarg[j - 1] = (!S || S[slotA(j) - 1]) ? 1 : 0;
+        alltrue = alltrue && Sarg[j - 1];
+    }
+    if (!Sarg[0]) return *info = -5;  // rgeneralized.jl:37
+    if ((*info = c->reserve(n, p, true, 16)) != 0) return *info;
+    const size_t nn = (size_t)n * n;
+    Timer tc;
+    tc.start(c->stream);
+    for (int j = 1; j <= p; ++j) PSD_CHECK(psd_rt_h2d(c->dH + (size_t)(j - 1) * nn, A[slotA(j) - 1], nn * 8, c->stream));
+    double ms_copy = tc.stop(c->stream);
+    psd_stats local;
+    memset(&local, 0, sizeof(local));
+    psd_stats* s = stats ? stats : &local;
+    Timer tt;
+    tt.start(c->stream);
+    if (alltrue) {  // rgeneralized.jl:21-34: Householder phessenberg!, explicit Q
+        Timer t;
+        t.start(c->stream);
+        if ((*info = hessenberg_dev(c, n, p, c->dH, c->tau)) != 0) return *info;
+        s->ms_hess = t.stop(c->stream);
+        if (wantZ) {
+            t.start(c->stream);
+            if ((*info = formq_dev(c, n, p, c->dH, c->tau, c->dZ)) != 0) return *info;
+            s->ms_formq = t.stop(c->stream);
+        }
+        PSD_LAUNCH(psd_triu, psd_dim3(n, p), 64, 0, c->stream, c->dH, n);
+    } else {
+        if ((*info = sghess_dev(c, n, p, c->dH, wantZ ? c->dZ : nullptr, Sarg.data(), s)) != 0) return *info;
+    }
+    Timer ti;
+    ti.start(c->stream);
+    const double keep_hess = s->ms_hess, keep_formq = s->ms_formq, keep_bh = s->bytes_hess;
+    int rc = grun_iteration(c, n, p, c->dH, wantZ ? c->dZ : nullptr, Sarg.data(), wantT, wantZ, maxitfac, alpha, beta,
+                            ascale, s, nullptr, 0, info);
+    s->ms_hess = keep_hess;
+    s->ms_formq = keep_formq;
+    s->bytes_hess = keep_bh;
+    s->ms_iter = ti.stop(c->stream);
+    s->ms_total = tt.stop(c->stream);
+    if (schurindex) *schurindex = left ? p : 1;
+    if (rc < 0 || rc >= PSD_INFO_NOTIMPL) return rc;
+    tc.start(c->stream);
+    for (int j = 1; j <= p; ++j) PSD_CHECK(psd_rt_d2h(A[slotA(j) - 1], c->dH + (size_t)(j - 1) * nn, nn * 8, c->stream));
+    if (wantZ)
+        for (int j = 1; j <= p; ++j)
+            PSD_CHECK(psd_rt_d2h(Z[slotZ(j) - 1], c->dZ + (size_t)(j - 1) * nn, nn * 8, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    s->ms_copy = ms_copy + tc.stop(c->stream);
+    return rc;
+}
 
 int psd_d_gpschur_hess(psd_ctx* c, int n, int p, double* const* H, const uint8_t* S, double* const* Q, int wantT,
                        int wantZ, int maxitfac, double* alpha, double* beta, int32_t* ascale, psd_stats* stats,

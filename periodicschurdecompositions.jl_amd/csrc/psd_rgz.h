@@ -20,7 +20,7 @@
 #pragma once
 #include "psd_zqz.h"
 
-enum { PSD_GPH_CHECK = 0, PSD_GPH_SWEEP = 1, PSD_GPH_ZSHIFT = 2, PSD_GPH_DONE = 7 };
+enum { PSD_GPH_CHECK = 0, PSD_GPH_SWEEP = 1, PSD_GPH_ZSHIFT = 2, PSD_GPH_HESS = 3, PSD_GPH_DONE = 7 };
 #define PSD_GTR_CAP 80  // rotations per owner and window
 #define PSD_GAPPLY_NT 128
 
@@ -38,14 +38,16 @@ struct psd_gapply_desc {
     int defer_h1;  // 1: the column updates of H_1 are deferred to the end of the (zero-shift) pass
     int defer_run;
     int djlo, djhi, drow0;
+    int h1mode;  // 1 (signed Hessenberg stage 2): H_1 takes its row list on columns h1c0..lc1 and its column list on
+    int h1c0;    //   rows 1..n, both outside the window plo..phi
 };
 
 struct psd_gstate {
     int n, p, wantT, wantZ, W;
     int phase, info;
     int ilast, ifirst, ifirstm, ilastm, ziter, jiter, maxit;
-    int jlo, kcur, zflag;
-    int nsweeps, nzshift, nsplit, ncase2, ncase3, n2real, n2cplx, nwindows, nlog, maxlog, iwarn, pad;
+    int jlo, kcur, zflag, hj;
+    int nsweeps, nzshift, nsplit, ncase2, ncase3, n2real, n2cplx, nwindows, nlog, maxlog, iwarn;
     double c1, s1, c2, s2;  // starting rotations of the current sweep
     double smlnum, ulp;
     long long cyc[6];
@@ -191,7 +193,8 @@ PSD_D void psd_glog(const psd_gparams& P, psd_gstate& st, int kind, int lo, int 
 }
 
 PSD_D void psd_gdesc_write(const psd_gparams& P, const psd_gstate& st, const int* lcnt, int plo, int phi, int lc0,
-                           int lc1, int rr0, int rr1, int defer_h1, int defer_run, int djlo, int djhi) {
+                           int lc1, int rr0, int rr1, int defer_h1, int defer_run, int djlo, int djhi, int h1mode = 0,
+                           int h1c0 = 0) {
     PSD_SYNC();
     PSD_PAR_FOR(m, st.p) { P.cnt[m] = lcnt[m]; }
     PSD_ONE {
@@ -210,6 +213,8 @@ PSD_D void psd_gdesc_write(const psd_gparams& P, const psd_gstate& st, const int
         d.djlo = djlo;
         d.djhi = djhi;
         d.drow0 = st.ifirstm;
+        d.h1mode = h1mode;
+        d.h1c0 = h1c0;
         *P.desc = d;
     }
     PSD_SYNC();
@@ -861,25 +866,67 @@ PSD_D void psd_gq_case3(const psd_gparams& P, psd_gstate& st, int ldeflate, int 
     }
 }
 
-// rgeneralized.jl:1015-1048 (section 510 of MB03BD): a single rotation at (j, j+1) = (ilast-1, ilast) through
-// all factors, inside the window; `given`: (c, s) is the perfect-shift rotation of a 2x2 deflation (:717-742),
-// otherwise it is generated from column j-1 of H_1.
-PSD_D void psd_gq_tail(const psd_gparams& P, const psd_gstate& st, const psd_gwin& w, int* lcnt, int j, bool given,
-                       double c, double s) {
+// rgeneralized.jl:1015-1048 (section 510 of MB03BD): a single rotation at (j, j+1) through all factors, inside the
+// window.  mode 0: generated from column j-1 of H_1 (tail of a sweep); mode 1: (c, s) given (perfect-shift rotation
+// of a 2x2 deflation, :717-742); mode 2: generated from `side` = column hj of H_1 outside the window (stage 2 of the
+// signed Hessenberg reduction, generalized.jl:1036-1044).
+PSD_D void psd_gq_tail(const psd_gparams& P, const psd_gstate& st, const psd_gwin& w, int* lcnt, int j, int mode,
+                       double c, double s, double* side) {
     const int p = st.p;
-    if (!given) {
+    if (mode == 0) {
         double r;
         psd_givens(w.at(1, j, j - 1), w.at(1, j + 1, j - 1), c, s, r);
         psd_gwin_set2(w, 1, j, j - 1, r, j + 1, j - 1, 0.0);
+    } else if (mode == 2) {
+        double r;
+        psd_givens(side[j - w.bs], side[j + 1 - w.bs], c, s, r);
+        PSD_WAVE_SYNC();
+        PSD_ONE {
+            side[j - w.bs] = r;
+            side[j + 1 - w.bs] = 0.0;
+        }
+        PSD_WAVE_SYNC();
     }
-    psd_gwin_left(w, 1, j, c, s, j, st.ilastm);
+    // (stage 2: A_1 is still full to the left of the position, the rows take the rotation on every window column)
+    psd_gwin_left(w, 1, j, c, s, (mode == 2) ? w.bs : j, st.ilastm);
     psd_grecord(P, lcnt, 1, j, c, s);
     for (int l = p; l >= 2; --l) {
-        const bool sg = psd_gsig(P, l);
-        psd_g_link(w, l, j, sg, c, s, st.ifirstm, st.ilastm);
-        psd_grecord(P, lcnt, sg ? l : l, j, c, s);  // rows owner of l if S[l], columns owner of l if !S[l]: both l
+        psd_g_link(w, l, j, psd_gsig(P, l), c, s, st.ifirstm, st.ilastm);
+        psd_grecord(P, lcnt, l, j, c, s);  // rows owner of l if S[l], columns owner of l if !S[l]: both are l
     }
     psd_gwin_right(w, 1, j, c, s, st.ifirstm, st.ilastm);
+}
+
+// generalized.jl:1034-1079: one window of stage 2 of the signed Hessenberg reduction: column hj of A_1 is
+// annihilated below the subdiagonal by row rotations (bottom-up), every rotation travels through all factors.
+// Positions qs..qe (processed downwards from qe), window rows/columns qs..qe+1.
+PSD_D void psd_gq_hess_window(const psd_gparams& P, psd_gstate& st, double* ldsd, double* side, int* lcnt) {
+    const int n = st.n, p = st.p, hj = st.hj;
+    const int nb = st.W - 1;
+    const int qe = st.kcur;
+    const int qs = (qe - nb + 1 > hj + 1) ? (qe - nb + 1) : (hj + 1);
+    psd_gwin w;
+    w.b = ldsd;
+    w.W = st.W;
+    w.ld = st.W + 1;
+    w.bsz = st.W * (st.W + 1);
+    w.bs = qs;
+    w.be = qe + 1;
+    const psd_mat<double> A1 = psd_gfac(P, n, 1);
+    PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
+    PSD_PAR_FOR(t, w.be - w.bs + 1) { side[t] = A1(w.bs + t, hj); }
+    psd_gwin_load(P, w, n, p);
+    for (int q = qe; q >= qs; --q) psd_gq_tail(P, st, w, lcnt, q, 2, 0.0, 0.0, side);
+    psd_gwin_store(P, w, n, p);
+    PSD_PAR_FOR(t, w.be - w.bs + 1) { A1(w.bs + t, hj) = side[t]; }
+    psd_gdesc_write(P, st, lcnt, w.bs, w.be, w.be + 1, n, 1, w.bs - 1, 0, 0, 0, 0, 1, hj + 1);
+    st.nwindows += 1;
+    st.kcur = qs - 1;
+    if (st.kcur < hj + 1) {
+        st.hj = hj + 1;
+        st.kcur = n - 1;
+        if (st.hj > n - 2) st.phase = PSD_GPH_DONE;
+    }
 }
 
 // rgeneralized.jl:890-1054: one window of the implicit double-shift sweep
@@ -954,7 +1001,7 @@ PSD_D void psd_gq_sweep_window(const psd_gparams& P, psd_gstate& st, double* lds
         psd_gwin_right(w, 1, j, c1, s1, ifirstm, lm);
     }
     const bool last = ke >= ilast - 2;
-    if (last) psd_gq_tail(P, st, w, lcnt, ilast - 1, false, 0.0, 0.0);
+    if (last) psd_gq_tail(P, st, w, lcnt, ilast - 1, 0, 0.0, 0.0, nullptr);
     const long long tc2 = psd_clock();
     psd_gwin_store(P, w, n, p);
     st.cyc[1] += tc1 - tc0;
@@ -1243,7 +1290,7 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
             w.be = ilast;
             PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
             psd_gwin_load(P, w, n, p);
-            psd_gq_tail(P, st, w, lcnt, j, true, r1, r2);
+            psd_gq_tail(P, st, w, lcnt, j, 1, r1, r2, nullptr);
             psd_gwin_store(P, w, n, p);
             psd_gdesc_write(P, st, lcnt, w.bs, w.be, w.be + 1, st.ilastm, st.ifirstm, w.bs - 1, 0, 0, 0, 0);
             st.nwindows += 1;
@@ -1305,6 +1352,9 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_gq_step(psd_gparams P) {
         } else if (st.phase == PSD_GPH_ZSHIFT) {
             psd_gq_zshift_window(P, st, ldsd, lcnt);
             emitted = true;
+        } else if (st.phase == PSD_GPH_HESS) {
+            psd_gq_hess_window(P, st, ldsd, red, lcnt);
+            emitted = true;
         } else {
             st.phase = PSD_GPH_DONE;
         }
@@ -1329,10 +1379,12 @@ PSD_KERNEL_B(PSD_GAPPLY_NT) psd_gq_apply(psd_gparams P, int n, int p) {
     const int S = d.phi - d.plo + 1;
     psd_gtr* ltr = (psd_gtr*)psd_lds;
     double* tile = (double*)(psd_lds + sizeof(psd_gtr) * PSD_GTR_CAP);
+    const bool h1x = d.h1mode == 1 && l == 1;  // stage 2 of the signed Hessenberg reduction: H_1 outside the window
     if (role == 0) {
-        const int c0 = d.lc0 + PSD_BLOCK_X * T;
+        const int c0 = (h1x ? d.h1c0 : d.lc0) + PSD_BLOCK_X * T;
         if (c0 > d.lc1) return;
         const int nc = (d.lc1 - c0 + 1 < T) ? (d.lc1 - c0 + 1) : T;
+        if (h1x && c0 >= d.plo && c0 + nc - 1 <= d.phi) return;
         const psd_mat<double> M = psd_gfac(P, n, l);
         const int ldt = T + 1;
         PSD_PAR_FOR(e, cnt) { ltr[e] = P.tr[(size_t)(own - 1) * PSD_GTR_CAP + e]; }
@@ -1342,6 +1394,7 @@ PSD_KERNEL_B(PSD_GAPPLY_NT) psd_gq_apply(psd_gparams P, int n, int p) {
         }
         PSD_SYNC();
         PSD_PAR_FOR(c, nc) {
+            if (h1x && c0 + c >= d.plo && c0 + c <= d.phi) continue;
             for (int e = 0; e < cnt; ++e) {
                 const psd_gtr tr = ltr[e];
                 const int r = tr.pos - d.plo;
@@ -1353,12 +1406,14 @@ PSD_KERNEL_B(PSD_GAPPLY_NT) psd_gq_apply(psd_gparams P, int n, int p) {
         PSD_SYNC();
         PSD_PAR_FOR(t, S * nc) {
             const int r = t % S, c = t / S;
+            if (h1x && c0 + c >= d.plo && c0 + c <= d.phi) continue;
             M(d.plo + r, c0 + c) = tile[r * ldt + c];
         }
     } else {
         if (role == 1 && d.defer_h1 == 1 && l == 1) return;  // H_1's column updates are deferred (zero-shift pass)
-        const int lo = (role == 1) ? d.rr0 : d.zr0;
-        const int hi = (role == 1) ? d.rr1 : d.zr1;
+        const bool h1r = h1x && role == 1;
+        const int lo = (role == 1) ? (h1r ? 1 : d.rr0) : d.zr0;
+        const int hi = (role == 1) ? (h1r ? n : d.rr1) : d.zr1;
         const int r0 = lo + PSD_BLOCK_X * T;
         if (r0 > hi) return;
         const int nr = (hi - r0 + 1 < T) ? (hi - r0 + 1) : T;
@@ -1371,6 +1426,7 @@ PSD_KERNEL_B(PSD_GAPPLY_NT) psd_gq_apply(psd_gparams P, int n, int p) {
         }
         PSD_SYNC();
         PSD_PAR_FOR(r, nr) {
+            if (h1r && r0 + r >= d.plo && r0 + r <= d.phi) continue;
             for (int e = 0; e < cnt; ++e) {
                 const psd_gtr tr = ltr[e];
                 const int c = tr.pos - d.plo;
@@ -1382,6 +1438,7 @@ PSD_KERNEL_B(PSD_GAPPLY_NT) psd_gq_apply(psd_gparams P, int n, int p) {
         PSD_SYNC();
         PSD_PAR_FOR(t, S * nr) {
             const int r = t % nr, c = t / nr;
+            if (h1r && r0 + r >= d.plo && r0 + r <= d.phi) continue;
             M(r0 + r, d.plo + c) = tile[c * T + r];
         }
     }
@@ -1411,9 +1468,10 @@ PSD_KERNEL psd_gq_defer(psd_gparams P, int n) {
     }
 }
 
-PSD_KERNEL psd_gq_init(psd_gparams P, int n, int p, int wantT, int wantZ, int W, int maxitfac, int maxlog) {
+PSD_KERNEL psd_gq_init(psd_gparams P, int n, int p, int wantT, int wantZ, int W, int maxitfac, int maxlog,
+                       int hessmode) {
     const psd_mat<double> H1 = psd_mat<double>{P.H, n};
-    PSD_PAR_FOR(c, n) {
+    if (!hessmode) PSD_PAR_FOR(c, n) {
         for (int r = c + 3; r <= n; ++r) H1(r, c + 1) = 0.0;  // _gethess!
         for (int l = 2; l <= p; ++l) {                          // :112 triu!(Hs[j-1], -1), then treated as triangular
             const psd_mat<double> Hl = psd_gfac(P, n, l);
@@ -1429,14 +1487,65 @@ PSD_KERNEL psd_gq_init(psd_gparams P, int n, int p, int wantT, int wantZ, int W,
         st.jiter = 0; st.maxit = maxitfac * n;
         st.jlo = 1; st.kcur = 0; st.zflag = 0;
         st.nsweeps = st.nzshift = st.nsplit = st.ncase2 = st.ncase3 = st.n2real = st.n2cplx = 0;
-        st.nwindows = st.nlog = 0; st.maxlog = maxlog; st.iwarn = 0; st.pad = 0;
+        st.nwindows = st.nlog = 0; st.maxlog = maxlog; st.iwarn = 0; st.hj = 0;
         st.c1 = st.c2 = 1.0; st.s1 = st.s2 = 0.0;
         st.ulp = PSD_DBL_EPS;
         st.smlnum = PSD_DBL_MIN * ((double)n / PSD_DBL_EPS);
         for (int q = 0; q < 6; ++q) st.cyc[q] = 0;
         if (n == 0) st.phase = PSD_GPH_DONE;
+        if (hessmode) {  // stage 2 of _phessenberg!(A, S): columns 1..n-2, positions n-1 down to hj+1
+            st.phase = (n >= 3) ? PSD_GPH_HESS : PSD_GPH_DONE;
+            st.hj = 1;
+            st.kcur = n - 1;
+            st.wantT = 1;
+        }
         *P.st = st;
         P.desc->active = 0;
         P.desc->defer_run = 0;
+    }
+}
+
+// ---- stage 1 helpers of the signed Hessenberg reduction (generalized.jl:1009-1028) -------------------------------------
+// RQ of A is taken as the QR of B = J A' J (reflection about the anti-diagonal), so the QR kernels of psd_hess.h serve
+// both signs; the neighbours that receive the orthogonal factor are flipped to the same index space and back.
+// in place B(r, c) = A(n+1-c, n+1-r).  grid = n (columns)
+PSD_KERNEL psd_antitranspose(double* A, int n) {
+    const psd_mat<double> M = psd_mat<double>{A, n};
+    const int c = PSD_BLOCK_X + 1;
+    PSD_PAR_FOR(t, n) {
+        const int r = t + 1;
+        const int r2 = n + 1 - c, c2 = n + 1 - r;
+        if (r + c < n + 1) {  // strictly above the anti-diagonal: swap with the mirror image
+            const double x = M(r, c);
+            M(r, c) = M(r2, c2);
+            M(r2, c2) = x;
+        }
+    }
+}
+// reverse the column order (rows == 0) or the row order (rows == 1).  grid = n
+PSD_KERNEL psd_flip(double* A, int n, int rows) {
+    const psd_mat<double> M = psd_mat<double>{A, n};
+    const int k = PSD_BLOCK_X + 1;
+    if (rows == 0) {
+        if (k > n / 2) return;
+        PSD_PAR_FOR(t, n) {
+            const double x = M(t + 1, k);
+            M(t + 1, k) = M(t + 1, n + 1 - k);
+            M(t + 1, n + 1 - k) = x;
+        }
+    } else {
+        PSD_PAR_FOR(t, n / 2) {
+            const double x = M(t + 1, k);
+            M(t + 1, k) = M(n - t, k);
+            M(n - t, k) = x;
+        }
+    }
+}
+// zero everything strictly below the diagonal.  grid = n
+PSD_KERNEL psd_tril_zero(double* A, int n) {
+    const psd_mat<double> M = psd_mat<double>{A, n};
+    const int c = PSD_BLOCK_X + 1;
+    PSD_PAR_FOR(t, n) {
+        if (t + 1 > c) M(t + 1, c) = 0.0;
     }
 }

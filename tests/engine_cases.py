@@ -625,3 +625,51 @@ def case_rg_edge(eng):
     with pytest.raises(ValueError):
         A = rg_hess_ut(4, 2, 1)
         eng.gpschur_hess_(A[0], A[1:], [False, True])
+
+
+def case_rg_phessenberg(eng, p):
+    # test/generalized.jl:1-40 "Generalized Periodic Hessenberg" (Float64): n = 5, alternating signature
+    n = 5
+    S = [True]
+    for _ in range(1, p):
+        S.append(not S[-1])
+    A = pt.rand_uniform_factors(n, p, seed=700 + p)
+    Hs, Qs = eng.gphessenberg_([a.copy(order="F") for a in A], S)
+    pt.sg_hess_check(A, S, Hs, Qs)
+    # every signature class, multi-window stage 2
+    for (n2, p2, S2) in [(9, 6, [True] * 6), (9, 6, [True, True, False, False, True, False]),
+                         (33, 4, [True, False, False, False]), (70, 3, [True, False, True]), (45, 22, None)]:
+        if S2 is None:
+            S2 = [True] + [bool((q * 5) % 3) for q in range(1, p2)]
+        A = pt.bench_factors(n2, p2, seed=3 + n2)
+        Hs, Qs = eng.gphessenberg_([a.copy(order="F") for a in A], S2)
+        pt.sg_hess_check(A, S2, Hs, Qs, tol=20 * max(1, n2 / 8), qtol=10 * max(1, n2 / 16))
+
+
+def case_rg_full(eng, lr):
+    # test/generalized.jl:42-65
+    n, p = 5, 4
+    S = [True, False, True, False] if lr == "R" else [False, True, False, True]
+    for seed in range(4):
+        A = pt.rand_uniform_factors(n, p, 950 + seed)
+        ps = eng.pschur_([a.copy(order="F") for a in A], lr, S=S)
+        assert ps.schurindex == (1 if lr == "R" else p) and ps.orientation == lr
+        pt.rgpschur_check(A, S, ps)
+        po = pt.oracle_gpschur(A, S, lr)
+        assert pt.match_eigs(po.values, ps.values) < 1e-9 * max(1.0, abs(po.values).max())
+    with pytest.raises(ValueError):
+        eng.pschur_([a.copy(order="F") for a in A], lr, S=S[::-1])
+
+
+def case_rg_full_sizes(eng, sizes):
+    for (n, p, lr, pat) in sizes:
+        if pat == "true":
+            S = [True] * p
+        else:
+            S = [bool((q * 7 + n) % 3) for q in range(p)]
+            S[p - 1 if lr == "L" else 0] = True
+        A = pt.bench_factors(n, p, seed=n + p)
+        ps = eng.pschur_([a.copy(order="F") for a in A], lr, S=S)
+        pt.rgpschur_check(A, S, ps, tol=100 * max(1.0, np.sqrt(n / 32)), qtol=10 * max(1.0, np.sqrt(n / 32)))
+        po = pt.oracle_gpschur(A, S, lr)
+        assert pt.match_eigs(po.values, ps.values) < 1e-8 * max(1.0, abs(po.values).max())

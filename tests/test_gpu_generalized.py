@@ -41,3 +41,30 @@ def test_rg_config4_shape(gpu_engine):
     po = pt.oracle_gpschur_hess(A[0], A[1:], S)
     assert po.info == 0
     assert pt.match_eigs(po.values, ps.values) < 1e-8 * abs(po.values).max()
+
+
+@pytest.mark.parametrize("p", [2, 5])
+def test_rg_phessenberg(gpu_engine, p):
+    ec.case_rg_phessenberg(gpu_engine, p)
+
+
+@pytest.mark.parametrize("lr", ["R", "L"])
+def test_rg_full(gpu_engine, lr):
+    ec.case_rg_full(gpu_engine, lr)
+
+
+def test_rg_full_sizes(gpu_engine):
+    ec.case_rg_full_sizes(gpu_engine, [(24, 3, "R", "mix"), (40, 6, "L", "mix"), (30, 4, "R", "true"),
+                                       (33, 21, "L", "mix"), (150, 5, "R", "mix"), (128, 8, "L", "mix")])
+
+
+def test_rg_config4_full(gpu_engine):
+    """BASELINE config 4: pschur!(A, S, :R), n = 256, p = 8, Float64, alternating signature, full matrices."""
+    n, p = 256, 8
+    S = [True] + [bool(q % 2 == 0) for q in range(1, p)]
+    A = pt.bench_factors(n, p, seed=4)
+    ps = gpu_engine.pschur_([a.copy(order="F") for a in A], "R", S=S)
+    pt.rgpschur_check(A, S, ps, tol=100 * np.sqrt(n / 32), qtol=10 * np.sqrt(n / 32), lam_check=False)
+    po = pt.oracle_gpschur(A, S, "R")
+    assert po.info == 0
+    assert pt.match_eigs(po.values, ps.values) < 1e-8 * abs(po.values).max()

@@ -25,3 +25,17 @@ def test_rg_fast_paths(sim_engine):
 
 def test_rg_edge(sim_engine):
     ec.case_rg_edge(sim_engine)
+
+
+@pytest.mark.parametrize("p", [2, 5])
+def test_rg_phessenberg(sim_engine, p):
+    ec.case_rg_phessenberg(sim_engine, p)
+
+
+@pytest.mark.parametrize("lr", ["R", "L"])
+def test_rg_full(sim_engine, lr):
+    ec.case_rg_full(sim_engine, lr)
+
+
+def test_rg_full_sizes(sim_engine):
+    ec.case_rg_full_sizes(sim_engine, [(24, 3, "R", "mix"), (40, 6, "L", "mix"), (30, 4, "R", "true"), (33, 21, "L", "mix")])
