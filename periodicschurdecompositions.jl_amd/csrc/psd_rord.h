@@ -156,13 +156,91 @@ PSD_D void psd_sm_mul(const double* A, bool ta, const double* B, bool tb, int m,
         for (int r = 0; r < m; ++r) C[c * 4 + r] = T[c * 4 + r];
 }
 
+// Householder QR of the first nc columns of the nr x ncols matrix S (LDS, ld), applied to all columns, by the whole
+// wavefront: the reflector is evaluated redundantly by every lane (broadcast LDS reads), the trailing columns are
+// updated one per lane.  Returns false (uniformly) if a diagonal entry of R is exactly zero.
+PSD_D bool psd_sm_qr_par(double* S, int ld, int nr, int ncols, int nc) {
+    bool ok = true;
+    for (int k = 0; k < nc; ++k) {
+        PSD_WAVE_SYNC();
+        double v[8];  // fixed trip counts + predicates: stays in registers
+        double amax = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool in = (i >= k) && (i < nr);
+            v[i] = in ? S[k * ld + i] : 0.0;
+            amax = fmax(amax, fabs(v[i]));
+        }
+        if (amax == 0.0) {
+            ok = false;
+            continue;
+        }
+        double ssq = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double y = v[i] / amax;
+            ssq += y * y;
+        }
+        const double nrm = amax * sqrt(ssq);
+        double alpha = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i == k) alpha = v[i];
+        const double beta = -copysign(nrm, alpha);
+        double vn2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i == k) v[i] = alpha - beta;
+            vn2 += v[i] * v[i];
+        }
+        if (vn2 == 0.0) continue;
+        const double tau2 = 2.0 / vn2;
+        PSD_WAVE_SYNC();
+        PSD_PAR_FOR(t, ncols - k) {
+            const int c = k + t;
+            if (t == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (i == k) S[k * ld + i] = beta;
+                    else if (i > k && i < nr) S[k * ld + i] = 0.0;
+                }
+            } else {
+                double x[8];
+                double d = 0.0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool in = (i >= k) && (i < nr);
+                    x[i] = in ? S[c * ld + i] : 0.0;
+                    d += v[i] * x[i];
+                }
+                d *= tau2;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if ((i >= k) && (i < nr)) S[c * ld + i] = x[i] - d * v[i];
+            }
+        }
+    }
+    PSD_WAVE_SYNC();
+    for (int k = 0; k < nc; ++k)
+        if (S[k * ld + k] == 0.0) ok = false;
+    return ok;
+}
+
 // Periodic Sylvester system A_k X_k - X_{k+1} B_k = -C_k (k = 1..K cyclic), blocks p1 x p1, p2 x p2,
 // p1 x p2 (sylvester.jl:170-193).  Block-cyclic structured QR (the role of babd.jl:17-96): the
 // bottom block row is eliminated against the diagonal by Householder QR of stacked 2pp x pp
 // blocks, then back substitution.  Per-factor scratch layout (ld 2 blocks): scr[l] + 0: T11, +4: T12,
-// +8: T22, +12: X.  wk: K x 52 doubles (D 16, E 16, F 16, rhs 4).  Returns false if singular.
-PSD_D bool psd_rord_psylsolve(int K, int p1, int p2, double* scr, double* wk) {
+// +8: T22, +12: X.  wk: K x 52 doubles (D 16, E 16, F 16, rhs 4); ws: 192 doubles of LDS work space
+// (S 8 x 13, Lo, Hi, rb, x).  Whole wavefront, uniform control.  Returns false if singular.
+PSD_D bool psd_rord_psylsolve(int K, int p1, int p2, double* scr, double* wk, double* ws) {
     const int pp = p1 * p2;
+    double* S = ws;          // 8 x 13
+    double* Lo = ws + 104;   // 16
+    double* Hi = ws + 120;   // 16
+    double* rb = ws + 136;   // 4
+    double* xs = ws + 140;   // 4
+    double* xnext = ws + 144;
+    double* xlast = ws + 148;
     // kron(I_p2, A)[j*p1+i, j*p1+k] = A[i,k];  kron(B^T, -I_p1)[j*p1+i, k*p1+i] = -B[k,j]
     auto fillA = [&](const double* A, double* M) {  // pp x pp, ld 4
         for (int c = 0; c < pp; ++c)
@@ -182,49 +260,55 @@ PSD_D bool psd_rord_psylsolve(int K, int p1, int p2, double* scr, double* wk) {
         for (int j = 0; j < p2; ++j)
             for (int i = 0; i < p1; ++i) y[j * p1 + i] = -C[j * 2 + i];
     };
-    if (K == 1) {
-        double S[8 * 5], MA[16], MB[16], y[4];
-        fillA(scr + 0, MA);
-        fillB(scr + 8, MB);
-        rhsC(scr + 4, y);
-        for (int c = 0; c < pp; ++c)
-            for (int r = 0; r < pp; ++r) S[c * 8 + r] = MA[c * 4 + r] + MB[c * 4 + r];
-        for (int r = 0; r < pp; ++r) S[pp * 8 + r] = y[r];
-        if (!psd_sm_qr(S, 8, pp, pp + 1, pp)) return false;
-        double R[16];
-        for (int c = 0; c < pp; ++c)
-            for (int r = 0; r < pp; ++r) R[c * 4 + r] = S[c * 8 + r];
-        for (int r = 0; r < pp; ++r) y[r] = S[pp * 8 + r];
-        psd_sm_trsv(R, 4, pp, y);
-        for (int q = 0; q < pp; ++q) scr[12 + (q / p1) * 2 + (q % p1)] = y[q];
-        return true;
-    }
-    // rows k = 0..K-2: D_k x_k + E_k x_{k+1} + F_k x_{K-1} = r_k ; bottom row: Lo x_k' + Hi x_{K-1} = rb
-    for (int k = 0; k < K; ++k) {
+    PSD_SYNC();
+    PSD_PAR_FOR(k, K) {
         double* w = wk + k * 52;
         fillA(scr + k * PSD_RORD_SCR + 0, w);        // D_k = kron(I, A_k)
         fillB(scr + k * PSD_RORD_SCR + 8, w + 16);   // E_k = kron(B_k^T, -I)
         for (int q = 0; q < 16; ++q) w[32 + q] = 0.0;
         rhsC(scr + k * PSD_RORD_SCR + 4, w + 48);
     }
-    double Lo[16], Hi[16], rb[4];
+    PSD_SYNC();
+    if (K == 1) {
+        const double* w = wk;
+        PSD_PAR_FOR(t, 16) {
+            const int c = t >> 2, r = t & 3;
+            if (c < pp && r < pp) S[c * 8 + r] = w[c * 4 + r] + w[16 + c * 4 + r];
+            if (c == 0 && r < pp) S[pp * 8 + r] = w[48 + r];
+        }
+        PSD_SYNC();
+        if (!psd_sm_qr_par(S, 8, pp, pp + 1, pp)) return false;
+        double y[4];
+        for (int k = pp - 1; k >= 0; --k) {
+            double sum = S[pp * 8 + k];
+            for (int c = k + 1; c < pp; ++c) sum -= S[c * 8 + k] * y[c];
+            y[k] = sum / S[k * 8 + k];
+        }
+        PSD_ONE {
+            for (int q = 0; q < pp; ++q) scr[12 + (q / p1) * 2 + (q % p1)] = y[q];
+        }
+        PSD_SYNC();
+        return true;
+    }
+    // rows k = 0..K-2: D_k x_k + E_k x_{k+1} + F_k x_{K-1} = r_k ; bottom row: Lo x_k' + Hi x_{K-1} = rb
     {
         const double* w = wk + (K - 1) * 52;
-        for (int q = 0; q < 16; ++q) {
+        PSD_PAR_FOR(q, 16) {
             Lo[q] = w[16 + q];  // bottom equation: E_{K-1} multiplies x_0
             Hi[q] = w[q];       // D_{K-1} multiplies x_{K-1}
+            if (q < 4) rb[q] = w[48 + q];
         }
-        for (int q = 0; q < 4; ++q) rb[q] = w[48 + q];
     }
+    PSD_SYNC();
     for (int k = 0; k < K - 1; ++k) {
         double* w = wk + k * 52;
         const bool lastcol = (k + 1 == K - 1);
         // stack: rows 0..pp-1 = row k, rows pp..2pp-1 = bottom; column blocks: [col k | col k+1 | col K-1 | rhs]
-        double S[8 * 13];
         const int nblk = lastcol ? 2 : 3;
         const int ncols = nblk * pp + 1;
-        for (int c = 0; c < pp; ++c)
-            for (int r = 0; r < pp; ++r) {
+        PSD_PAR_FOR(t, 16) {
+            const int c = t >> 2, r = t & 3;
+            if (c < pp && r < pp) {
                 S[c * 8 + r] = w[c * 4 + r];
                 S[c * 8 + pp + r] = Lo[c * 4 + r];
                 if (lastcol) {
@@ -237,13 +321,16 @@ PSD_D bool psd_rord_psylsolve(int K, int p1, int p2, double* scr, double* wk) {
                     S[(2 * pp + c) * 8 + pp + r] = Hi[c * 4 + r];
                 }
             }
-        for (int r = 0; r < pp; ++r) {
-            S[(nblk * pp) * 8 + r] = w[48 + r];
-            S[(nblk * pp) * 8 + pp + r] = rb[r];
+            if (c == 0 && r < pp) {
+                S[(nblk * pp) * 8 + r] = w[48 + r];
+                S[(nblk * pp) * 8 + pp + r] = rb[r];
+            }
         }
-        if (!psd_sm_qr(S, 8, 2 * pp, ncols, pp)) return false;
-        for (int c = 0; c < pp; ++c)
-            for (int r = 0; r < pp; ++r) {
+        PSD_SYNC();
+        if (!psd_sm_qr_par(S, 8, 2 * pp, ncols, pp)) return false;
+        PSD_PAR_FOR(t, 16) {
+            const int c = t >> 2, r = t & 3;
+            if (c < pp && r < pp) {
                 w[c * 4 + r] = S[c * 8 + r];
                 w[16 + c * 4 + r] = S[(pp + c) * 8 + r];
                 if (lastcol) {
@@ -255,61 +342,81 @@ PSD_D bool psd_rord_psylsolve(int K, int p1, int p2, double* scr, double* wk) {
                     Hi[c * 4 + r] = S[(2 * pp + c) * 8 + pp + r];
                 }
             }
-        for (int r = 0; r < pp; ++r) {
-            w[48 + r] = S[(nblk * pp) * 8 + r];
-            rb[r] = S[(nblk * pp) * 8 + pp + r];
+            if (c == 0 && r < pp) {
+                w[48 + r] = S[(nblk * pp) * 8 + r];
+                rb[r] = S[(nblk * pp) * 8 + pp + r];
+            }
         }
+        PSD_SYNC();
     }
     // x_{K-1}: Hi x = rb
-    double xs[4];
+    PSD_PAR_FOR(t, 16) {
+        const int c = t >> 2, r = t & 3;
+        if (c < pp && r < pp) S[c * 8 + r] = Hi[c * 4 + r];
+        if (c == 0 && r < pp) S[pp * 8 + r] = rb[r];
+    }
+    PSD_SYNC();
+    if (!psd_sm_qr_par(S, 8, pp, pp + 1, pp)) return false;
     {
-        double S[8 * 5];
-        for (int c = 0; c < pp; ++c)
-            for (int r = 0; r < pp; ++r) S[c * 8 + r] = Hi[c * 4 + r];
-        for (int r = 0; r < pp; ++r) S[pp * 8 + r] = rb[r];
-        if (!psd_sm_qr(S, 8, pp, pp + 1, pp)) return false;
-        double R[16];
-        for (int c = 0; c < pp; ++c)
-            for (int r = 0; r < pp; ++r) R[c * 4 + r] = S[c * 8 + r];
-        for (int r = 0; r < pp; ++r) xs[r] = S[pp * 8 + r];
-        psd_sm_trsv(R, 4, pp, xs);
+        double y[4];
+        for (int k = pp - 1; k >= 0; --k) {
+            double sum = S[pp * 8 + k];
+            for (int c = k + 1; c < pp; ++c) sum -= S[c * 8 + k] * y[c];
+            y[k] = sum / S[k * 8 + k];
+        }
+        PSD_SYNC();
+        PSD_ONE {
+            for (int q = 0; q < pp; ++q) {
+                xs[q] = y[q];
+                xlast[q] = y[q];
+                xnext[q] = y[q];
+                scr[(K - 1) * PSD_RORD_SCR + 12 + (q / p1) * 2 + (q % p1)] = y[q];
+            }
+        }
+        PSD_SYNC();
     }
-    double xlast[4], xnext[4];
-    for (int q = 0; q < pp; ++q) {
-        xlast[q] = xs[q];
-        xnext[q] = xs[q];
-        scr[(K - 1) * PSD_RORD_SCR + 12 + (q / p1) * 2 + (q % p1)] = xs[q];
-    }
+    bool ok = true;
     for (int k = K - 2; k >= 0; --k) {
         const double* w = wk + k * 52;
         double y[4];
         for (int r = 0; r < pp; ++r) {
-            double s = w[48 + r];
-            for (int c = 0; c < pp; ++c) s -= w[16 + c * 4 + r] * xnext[c];
+            double sum = w[48 + r];
+            for (int c = 0; c < pp; ++c) sum -= w[16 + c * 4 + r] * xnext[c];
             if (k + 1 != K - 1)
-                for (int c = 0; c < pp; ++c) s -= w[32 + c * 4 + r] * xlast[c];
-            y[r] = s;
+                for (int c = 0; c < pp; ++c) sum -= w[32 + c * 4 + r] * xlast[c];
+            y[r] = sum;
         }
         for (int r = 0; r < pp; ++r)
-            if (w[r * 4 + r] == 0.0) return false;
-        psd_sm_trsv(w, 4, pp, y);
-        for (int q = 0; q < pp; ++q) {
-            xnext[q] = y[q];
-            scr[k * PSD_RORD_SCR + 12 + (q / p1) * 2 + (q % p1)] = y[q];
+            if (w[r * 4 + r] == 0.0) ok = false;
+        if (!ok) break;
+        for (int kk = pp - 1; kk >= 0; --kk) {
+            double sum = y[kk];
+            for (int c = kk + 1; c < pp; ++c) sum -= w[c * 4 + kk] * y[c];
+            y[kk] = sum / w[kk * 4 + kk];
         }
+        PSD_SYNC();
+        PSD_ONE {
+            for (int q = 0; q < pp; ++q) {
+                xnext[q] = y[q];
+                scr[k * PSD_RORD_SCR + 12 + (q / p1) * 2 + (q % p1)] = y[q];
+            }
+        }
+        PSD_SYNC();
     }
-    return true;
+    return ok;
 }
 
-// The scalar part of one swap of adjacent blocks (p1, p2) — sylswap.jl:14-129 (and :542-617 via the same
+// The small dense part of one swap of adjacent blocks (p1, p2) — sylswap.jl:14-129 (and :542-617 via the same
 // machinery for p1 = p2 = 1).  Per-factor scratch (index = position l-1 in the reference's left-oriented
 // sequence X_l): +0 T11, +4 T12, +8 T22, +12 X (ld 2); +16 Q, +32 Txx, +48 Ws, +64 Qfin (ld 4); +80 orig block
-// (ld 4).  Returns 0 ok, 1 rejected (strong test), 2 singular.
-PSD_D int psd_rord_swap_scalar(int K, int p1, int p2, double* scr, double* wk, double tnrm) {
+// (ld 4).  Whole wavefront: the cyclic solve and the 2x2 Hessenberg repair are chains over the factors, everything
+// else runs one factor per lane.  Returns (uniformly) 0 ok, 1 rejected (strong test), 2 singular.
+PSD_D int psd_rord_swap_scalar(int K, int p1, int p2, double* scr, double* wk, double* ws, double tnrm) {
     const int m = p1 + p2;
-    if (!psd_rord_psylsolve(K, p1, p2, scr, wk)) return 2;
+    if (!psd_rord_psylsolve(K, p1, p2, scr, wk, ws)) return 2;
     const double thresh = fmax(PSD_DBL_MIN, 100.0 * PSD_DBL_EPS * tnrm);
-    for (int l = 0; l < K; ++l) {
+    PSD_SYNC();
+    PSD_PAR_FOR(l, K) {
         double* s = scr + l * PSD_RORD_SCR;
         double Xi[16];
         for (int q = 0; q < 16; ++q) Xi[q] = 0.0;
@@ -319,31 +426,31 @@ PSD_D int psd_rord_swap_scalar(int K, int p1, int p2, double* scr, double* wk, d
         }
         psd_sm_fullq(Xi, m, p2, s + 16);
         for (int q = 0; q < 16; ++q) s[32 + q] = s[80 + q];  // Txx <- original [T11 T12; 0 T22]
+        for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 4; ++r) s[48 + c * 4 + r] = (r == c) ? 1.0 : 0.0;
+        psd_sm_mul(s + 32, false, s + 16, false, m, s + 32);  // Txx[l] <- Txx[l] q_l
     }
-    for (int l = 0; l < K; ++l) {  // Txx[l] <- Txx[l] q_l ; Txx[l-1] <- q_l' Txx[l-1]
+    PSD_SYNC();
+    PSD_PAR_FOR(l, K) {  // Txx[l-1] <- q_l' Txx[l-1]
         double* s = scr + l * PSD_RORD_SCR;
-        psd_sm_mul(s + 32, false, s + 16, false, m, s + 32);
         double* sp = scr + ((l == 0) ? (K - 1) : (l - 1)) * PSD_RORD_SCR;
         psd_sm_mul(s + 16, true, sp + 32, false, m, sp + 32);
     }
+    PSD_SYNC();
     bool fill1 = false, fill2 = false;
     if (p2 > 1)
         for (int l = 0; l < K; ++l) fill1 |= fabs(scr[l * PSD_RORD_SCR + 32 + 0 * 4 + 1]) > thresh;
     if (p1 > 1)
         for (int l = 0; l < K; ++l) fill2 |= fabs(scr[l * PSD_RORD_SCR + 32 + p2 * 4 + p2 + 1]) > thresh;
     const bool fillin = fill1 || fill2;
-    for (int l = 0; l < K; ++l) {
-        double* s = scr + l * PSD_RORD_SCR;
-        for (int c = 0; c < 4; ++c)
-            for (int r = 0; r < 4; ++r) s[48 + c * 4 + r] = (r == c) ? 1.0 : 0.0;
-    }
     for (int pass = 0; pass < 2; ++pass) {  // sylswap.jl:159-191 _filled2hess! at j0 = 0 and j0 = p2
         if (pass == 0 && !fill1) continue;
         if (pass == 1 && !fill2) continue;
         const int j0 = (pass == 0) ? 0 : p2, j1 = j0 + 1;
         // rpschur2x2.jl:326-359 on the 2x2 copies: Qs[lp] = hr' for l = 2..K
         // (the solver's work array is free again: Th at wk + l*52, Hq at wk + l*52 + 4)
-        for (int l = 0; l < K; ++l) {
+        PSD_SYNC();
+        PSD_PAR_FOR(l, K) {
             const double* t = scr + l * PSD_RORD_SCR + 32;
             double* Th = wk + l * 52;
             double* Hq = Th + 4;
@@ -353,41 +460,46 @@ PSD_D int psd_rord_swap_scalar(int K, int p1, int p2, double* scr, double* wk, d
             Th[3] = t[j1 * 4 + j1];  // [a(0,0) a(1,0) a(0,1) a(1,1)] column-major 2x2
             Hq[0] = 1.0; Hq[1] = 0.0; Hq[2] = 0.0; Hq[3] = 1.0;
         }
-        for (int l = 2; l <= K; ++l) {
-            double* Al = wk + (l - 1) * 52;
-            const int lp = (l % K) + 1;
-            double* Ap = wk + (lp - 1) * 52;
-            double x0 = Al[0], x1 = Al[1];
-            double tau;
-            {
-                double xv[2] = {x0, x1};
-                tau = psd_reflector_small(xv, 2);
-                x0 = xv[0];
-                x1 = xv[1];
-            }
-            Al[0] = x0;
-            Al[1] = 0.0;
-            const double v1 = 1.0, v2 = x1;
-            {  // lmul!(hr', Al[:, 2])
-                const double sdot = v1 * Al[2] + v2 * Al[3];
-                Al[2] -= sdot * tau * v1;
-                Al[3] -= sdot * tau * v2;
-            }
-            {  // Qs[lp] <- hr' Qs[lp]
-                double* Q = wk + (lp - 1) * 52 + 4;
-                for (int c = 0; c < 2; ++c) {
-                    const double sdot = v1 * Q[c * 2 + 0] + v2 * Q[c * 2 + 1];
-                    Q[c * 2 + 0] -= sdot * tau * v1;
-                    Q[c * 2 + 1] -= sdot * tau * v2;
+        PSD_SYNC();
+        PSD_ONE {
+            for (int l = 2; l <= K; ++l) {
+                double* Al = wk + (l - 1) * 52;
+                const int lp = (l % K) + 1;
+                double* Ap = wk + (lp - 1) * 52;
+                double x0 = Al[0], x1 = Al[1];
+                double tau;
+                {
+                    double xv[2] = {x0, x1};
+                    tau = psd_reflector_small(xv, 2);
+                    x0 = xv[0];
+                    x1 = xv[1];
+                }
+                Al[0] = x0;
+                Al[1] = 0.0;
+                const double v1 = 1.0, v2 = x1;
+                {  // lmul!(hr', Al[:, 2])
+                    const double sdot = v1 * Al[2] + v2 * Al[3];
+                    Al[2] -= sdot * tau * v1;
+                    Al[3] -= sdot * tau * v2;
+                }
+                {  // Qs[lp] <- hr' Qs[lp]
+                    double* Q = wk + (lp - 1) * 52 + 4;
+                    for (int c = 0; c < 2; ++c) {
+                        const double sdot = v1 * Q[c * 2 + 0] + v2 * Q[c * 2 + 1];
+                        Q[c * 2 + 0] -= sdot * tau * v1;
+                        Q[c * 2 + 1] -= sdot * tau * v2;
+                    }
+                }
+                for (int r = 0; r < 2; ++r) {  // rmul!(Ap, hr)
+                    const double sdot = Ap[0 * 2 + r] * v1 + Ap[1 * 2 + r] * v2;
+                    Ap[0 * 2 + r] -= sdot * tau * v1;
+                    Ap[1 * 2 + r] -= sdot * tau * v2;
                 }
             }
-            for (int r = 0; r < 2; ++r) {  // rmul!(Ap, hr)
-                const double sdot = Ap[0 * 2 + r] * v1 + Ap[1 * 2 + r] * v2;
-                Ap[0 * 2 + r] -= sdot * tau * v1;
-                Ap[1 * 2 + r] -= sdot * tau * v2;
-            }
         }
-        for (int l = 1; l <= K; ++l) {
+        PSD_SYNC();
+        PSD_PAR_FOR(t, K) {
+            const int l = t + 1;
             const int lp = (l % K) + 1;
             const double* q = wk + (l - 1) * 52 + 4;
             const double* qp = wk + (lp - 1) * 52 + 4;
@@ -409,25 +521,35 @@ PSD_D int psd_rord_swap_scalar(int K, int p1, int p2, double* scr, double* wk, d
                 W[j1 * 4 + r] = a * q[2] + b * q[3];
             }
         }
+        PSD_SYNC();
     }
     // final transform of factor l: Qfin = q_l W_l ; strong test: Qfin_{l+1} Txx[l] Qfin_l' ~ original block
-    for (int l = 0; l < K; ++l) {
+    PSD_SYNC();
+    PSD_PAR_FOR(l, K) {
         double* s = scr + l * PSD_RORD_SCR;
         if (fillin) psd_sm_mul(s + 16, false, s + 48, false, m, s + 64);
         else
             for (int q = 0; q < 16; ++q) s[64 + q] = s[16 + q];
     }
-    bool ok = true;
-    for (int l = 0; l < K; ++l) {
+    PSD_SYNC();
+    PSD_PAR_FOR(l, K) {
         const int l1 = (l + 1) % K;
         double Tt[16];
         psd_sm_mul(scr + l1 * PSD_RORD_SCR + 64, false, scr + l * PSD_RORD_SCR + 32, false, m, Tt);
         psd_sm_mul(Tt, false, scr + l * PSD_RORD_SCR + 64, true, m, Tt);
         double d = 0.0;
         for (int c = 0; c < m; ++c)
-            for (int r = 0; r < m; ++r) d = hypot(d, Tt[c * 4 + r] - scr[l * PSD_RORD_SCR + 80 + c * 4 + r]);
-        if (d > thresh) ok = false;
+            for (int r = 0; r < m; ++r) {
+                const double e = Tt[c * 4 + r] - scr[l * PSD_RORD_SCR + 80 + c * 4 + r];
+                d += e * e;
+            }
+        wk[l * 52 + 12] = (sqrt(d) > thresh) ? 1.0 : 0.0;
     }
+    PSD_SYNC();
+    bool ok = true;
+    for (int l = 0; l < K; ++l)
+        if (wk[l * 52 + 12] != 0.0) ok = false;
+    PSD_SYNC();
     return ok ? 0 : 1;
 }
 
@@ -464,7 +586,7 @@ PSD_D void psd_rord_win_apply(const psd_win& w, int sg, int own, int i1, int m, 
 
 // one swap inside the window; returns 0 ok / 1 rejected / 2 singular
 PSD_D int psd_rord_swap(const psd_roparams& P, const psd_rostate& st, const psd_win& w, double* scr, double* wk,
-                        double* flagbuf, int* lcnt, int i1, int p1, int p2) {
+                        double* ws, double* flagbuf, int* lcnt, int i1, int p1, int p2) {
     const int p = st.p, m = p1 + p2;
     PSD_SYNC();
     PSD_PAR_FOR(t, p) {
@@ -483,15 +605,23 @@ PSD_D int psd_rord_swap(const psd_roparams& P, const psd_rostate& st, const psd_
             for (int r = p1; r < m; ++r) s[80 + c * 4 + r] = 0.0;
     }
     PSD_SYNC();
-    PSD_ONE {
-        double tn = 0.0;
-        for (int t = 0; t < p; ++t) {
-            const int sg = psd_ord_sigma(p, t + 1);
-            for (int c = 0; c < m; ++c)
-                for (int r = 0; r < m; ++r) tn = hypot(tn, w.at(sg, i1 + r, i1 + c));
-        }
-        flagbuf[0] = (double)psd_rord_swap_scalar(p, p1, p2, scr, wk, tn);
+    PSD_PAR_FOR(t, p) {  // Frobenius norm of the window blocks (sylswap.jl:41), one factor per lane
+        const int sg = psd_ord_sigma(p, t + 1);
+        double ssq = 0.0;
+        for (int c = 0; c < m; ++c)
+            for (int r = 0; r < m; ++r) {
+                const double x = w.at(sg, i1 + r, i1 + c);
+                ssq += x * x;
+            }
+        wk[t * 52 + 12] = ssq;
     }
+    PSD_SYNC();
+    double tn = 0.0;
+    for (int t = 0; t < p; ++t) tn += wk[t * 52 + 12];
+    tn = sqrt(tn);
+    PSD_SYNC();
+    const int flag0 = psd_rord_swap_scalar(p, p1, p2, scr, wk, ws, tn);
+    PSD_ONE { flagbuf[0] = (double)flag0; }
     PSD_SYNC();
     const int flag = (int)flagbuf[0];
     if (flag) return flag;
@@ -539,7 +669,8 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rord_step(psd_roparams P) {
     double* scr = ldsd + winb;
     double* wk = scr + (size_t)p * PSD_RORD_SCR;
     double* flagbuf = wk + (size_t)p * 52;
-    int* lcnt = (int*)(flagbuf + 2);
+    double* ws = flagbuf + 4;
+    int* lcnt = (int*)(ws + 192);
     // driver scan: rordschur.jl:77-110
     while (st.phase == PSD_ROPH_SCAN) {
         st.j += 1;
@@ -600,7 +731,7 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rord_step(psd_roparams P) {
         // rordschur.jl:181-247 restricted to the blocks that fit the window
         while (here > st.jtarget && !fail) {
             if (st.pend1x1) {  // second 1x1 of a split pair follows its partner (rordschur.jl:207-215)
-                fail = psd_rord_swap(P, st, w, scr, wk, flagbuf, lcnt, here, 1, 1);
+                fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here, 1, 1);
                 if (fail) break;
                 st.nswaps += 1;
                 st.pend1x1 = 0;
@@ -615,13 +746,13 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rord_step(psd_roparams P) {
             }
             if (here - nbnext < w.bs) break;
             if (!st.splitsrc) {
-                fail = psd_rord_swap(P, st, w, scr, wk, flagbuf, lcnt, here - nbnext, nbnext, st.nbsrc);
+                fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - nbnext, nbnext, st.nbsrc);
                 if (fail) break;
                 st.nswaps += 1;
                 here -= nbnext;
                 if (st.nbsrc == 2 && w.at(1, here + 1, here) == 0) st.splitsrc = 1;
             } else {
-                fail = psd_rord_swap(P, st, w, scr, wk, flagbuf, lcnt, here - nbnext, nbnext, 1);
+                fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - nbnext, nbnext, 1);
                 if (fail) break;
                 st.nswaps += 1;
                 if (nbnext == 1) {
@@ -629,15 +760,15 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rord_step(psd_roparams P) {
                 } else {
                     if (w.at(1, here, here - 1) == 0) nbnext = 1;
                     if (nbnext == 2) {
-                        fail = psd_rord_swap(P, st, w, scr, wk, flagbuf, lcnt, here - 1, 2, 1);
+                        fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - 1, 2, 1);
                         if (fail) break;
                         st.nswaps += 1;
                         here -= 2;
                     } else {
-                        fail = psd_rord_swap(P, st, w, scr, wk, flagbuf, lcnt, here, 1, 1);
+                        fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here, 1, 1);
                         if (fail) break;
                         st.nswaps += 1;
-                        fail = psd_rord_swap(P, st, w, scr, wk, flagbuf, lcnt, here - 1, 1, 1);
+                        fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - 1, 1, 1);
                         if (fail) break;
                         st.nswaps += 1;
                         here -= 2;
