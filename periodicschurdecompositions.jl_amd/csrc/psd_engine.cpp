@@ -1219,6 +1219,7 @@ int rordschur_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_
         stats->ms_iter = stats->ms_total = ms;
         stats->nsweeps = hst.nswaps;
         stats->nwindows = hst.nwindows;
+        for (int q = 0; q < 6; ++q) stats->step_cycles[q] = hst.cyc[q];
         stats->nlaunch_step = (int32_t)launched;
         stats->window = W;
     }

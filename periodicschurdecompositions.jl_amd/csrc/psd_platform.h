@@ -64,6 +64,7 @@ typedef int psd_stream_t;
         psd_dim3 _g = (grid_);                                                        \
         size_t _lb = (ldsbytes_);                                                      \
         char* _lds = (char*)malloc(_lb ? _lb : 16);                                   \
+        memset(_lds, 0xFF, _lb ? _lb : 16); /* LDS is not zero on the GPU: poison with NaNs */ \
         psd_sim.grid = _g;                                                            \
         psd_sim.nthreads = (nthreads_);                                               \
         psd_sim.lds = _lds;                                                           \

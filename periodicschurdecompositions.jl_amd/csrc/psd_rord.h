@@ -32,6 +32,9 @@ struct psd_rostate {
     int j, jdest, pairskip;          // driver scan (rordschur.jl:77-110)
     int here, nbsrc, splitsrc, jtarget, jsrc0, pend1x1;  // _moveblock! state
     int nswaps, nwindows;
+    // in-kernel cycle accounting: 0 step total, 1 window load/store, 2 Sylvester solve, 3 per-factor small algebra,
+    // 4 in-window application + recording, 5 total in 100 MHz wall ticks
+    long long cyc[6];
 };
 
 struct psd_roparams {
@@ -105,55 +108,89 @@ PSD_D void psd_sm_trsv(const double* R, int ld, int pp, double* b) {
     }
 }
 
-// full m x m Q of the Householder QR of the m x nc matrix Xi (ld 4): Q' Xi = [R; 0]
+// full m x m Q of the Householder QR of the m x nc matrix Xi (ld 4): Q' Xi = [R; 0].  Q is written as a full
+// 4 x 4 matrix, identity outside m x m (so that fixed-size 4 x 4 products need no masks).  Fixed trip counts and
+// predicates keep everything in registers.
 PSD_D void psd_sm_fullq(const double* Xi, int m, int nc, double* Q /*ld 4*/) {
-    double S[16];
-    for (int c = 0; c < nc; ++c)
-        for (int r = 0; r < m; ++r) S[c * 4 + r] = Xi[c * 4 + r];
-    for (int c = 0; c < m; ++c)
-        for (int r = 0; r < m; ++r) Q[c * 4 + r] = (r == c) ? 1.0 : 0.0;
+    double S[16], Qr[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = q >> 2, r = q & 3;
+        S[q] = (c < nc && r < m) ? Xi[q] : 0.0;
+        Qr[q] = (r == c) ? 1.0 : 0.0;
+    }
     const int kmax = (m - 1 < nc) ? (m - 1) : nc;
-    for (int k = 0; k < kmax; ++k) {
-        double nrm = 0.0;
-        for (int i = k; i < m; ++i) nrm = hypot(nrm, S[k * 4 + i]);
-        if (nrm == 0.0) continue;
-        const double alpha = S[k * 4 + k];
-        const double beta = -copysign(nrm, alpha);
-        double v[4];
-        v[k] = alpha - beta;
-        double vn2 = v[k] * v[k];
-        for (int i = k + 1; i < m; ++i) {
-            v[i] = S[k * 4 + i];
-            vn2 += v[i] * v[i];
-        }
-        if (vn2 == 0.0) continue;
-        const double tau2 = 2.0 / vn2;
-        for (int c = k; c < nc; ++c) {
-            double d = 0.0;
-            for (int i = k; i < m; ++i) d += v[i] * S[c * 4 + i];
-            d *= tau2;
-            for (int i = k; i < m; ++i) S[c * 4 + i] -= d * v[i];
-        }
-        for (int r = 0; r < m; ++r) {  // Q <- Q H
-            double d = 0.0;
-            for (int i = k; i < m; ++i) d += Q[i * 4 + r] * v[i];
-            d *= tau2;
-            for (int i = k; i < m; ++i) Q[i * 4 + r] -= d * v[i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k < kmax) {
+            double v[4];
+            double amax = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = (i >= k && i < m) ? S[k * 4 + i] : 0.0;
+                amax = fmax(amax, fabs(v[i]));
+            }
+            if (amax != 0.0) {
+                int ex;
+                (void)frexp(amax, &ex);
+                double ssq = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = ldexp(v[i], -ex);
+                    ssq += v[i] * v[i];
+                }
+                double nrm, rnrm;
+                psd_sqrt_pair_fast(ssq, nrm, rnrm);
+                const double alpha = v[k];
+                const double beta = -copysign(nrm, alpha);
+                const double tau2 = psd_rcp_fast(nrm * (nrm + fabs(alpha)));
+                v[k] = alpha - beta;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {  // nc <= 2
+                    if (c >= k && c < nc) {
+                        double d = 0.0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) d += v[i] * S[c * 4 + i];
+                        d *= tau2;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) S[c * 4 + i] -= d * v[i];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {  // Q <- Q H
+                    double d = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d += Qr[i * 4 + r] * v[i];
+                    d *= tau2;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) Qr[i * 4 + r] -= d * v[i];
+                }
+            }
         }
     }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Q[q] = Qr[q];
 }
 
-// C (m x m, ld 4) = A * B or A' * B etc.
+// C (4 x 4, ld 4) = op(A) * op(B) on zero-/identity-padded 4 x 4 operands (C may alias A or B)
 PSD_D void psd_sm_mul(const double* A, bool ta, const double* B, bool tb, int m, double* C) {
-    double T[16];
-    for (int c = 0; c < m; ++c)
-        for (int r = 0; r < m; ++r) {
-            double s = 0.0;
-            for (int k = 0; k < m; ++k) s += (ta ? A[r * 4 + k] : A[k * 4 + r]) * (tb ? B[k * 4 + c] : B[c * 4 + k]);
-            T[c * 4 + r] = s;
+    double a[16], b[16], t[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        a[q] = A[q];
+        b[q] = B[q];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double sum = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sum += (ta ? a[r * 4 + k] : a[k * 4 + r]) * (tb ? b[k * 4 + c] : b[c * 4 + k]);
+            t[c * 4 + r] = sum;
         }
-    for (int c = 0; c < m; ++c)
-        for (int r = 0; r < m; ++r) C[c * 4 + r] = T[c * 4 + r];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) C[q] = t[q];
 }
 
 // Householder QR of the first nc columns of the nr x ncols matrix S (LDS, ld), applied to all columns, by the whole
@@ -175,33 +212,32 @@ PSD_D bool psd_sm_qr_par(double* S, int ld, int nr, int ncols, int nc) {
             ok = false;
             continue;
         }
-        double ssq = 0.0;
+        // scale by a power of two (exact), so that the fast rsqrt / reciprocal forms are in range; the reflector
+        // I - v v' / (nrm (nrm + |alpha|)) does not depend on the scaling of v
+        int ex;
+        (void)frexp(amax, &ex);
+        double ssq = 0.0, alpha = 0.0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const double y = v[i] / amax;
-            ssq += y * y;
+            v[i] = ldexp(v[i], -ex);
+            ssq += v[i] * v[i];
+            if (i == k) alpha = v[i];
         }
-        const double nrm = amax * sqrt(ssq);
-        double alpha = 0.0;
+        double nrm, rnrm;
+        psd_sqrt_pair_fast(ssq, nrm, rnrm);
+        const double beta = -copysign(nrm, alpha);
+        const double tau2 = psd_rcp_fast(nrm * (nrm + fabs(alpha)));
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            if (i == k) alpha = v[i];
-        const double beta = -copysign(nrm, alpha);
-        double vn2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
             if (i == k) v[i] = alpha - beta;
-            vn2 += v[i] * v[i];
-        }
-        if (vn2 == 0.0) continue;
-        const double tau2 = 2.0 / vn2;
+        const double beta_out = ldexp(beta, ex);
         PSD_WAVE_SYNC();
         PSD_PAR_FOR(t, ncols - k) {
             const int c = k + t;
             if (t == 0) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    if (i == k) S[k * ld + i] = beta;
+                    if (i == k) S[k * ld + i] = beta_out;
                     else if (i > k && i < nr) S[k * ld + i] = 0.0;
                 }
             } else {
@@ -411,18 +447,26 @@ PSD_D bool psd_rord_psylsolve(int K, int p1, int p2, double* scr, double* wk, do
 // sequence X_l): +0 T11, +4 T12, +8 T22, +12 X (ld 2); +16 Q, +32 Txx, +48 Ws, +64 Qfin (ld 4); +80 orig block
 // (ld 4).  Whole wavefront: the cyclic solve and the 2x2 Hessenberg repair are chains over the factors, everything
 // else runs one factor per lane.  Returns (uniformly) 0 ok, 1 rejected (strong test), 2 singular.
-PSD_D int psd_rord_swap_scalar(int K, int p1, int p2, double* scr, double* wk, double* ws, double tnrm) {
+PSD_D int psd_rord_swap_scalar(int K, int p1, int p2, double* scr, double* wk, double* ws, double tnrm, long long* cyc) {
     const int m = p1 + p2;
-    if (!psd_rord_psylsolve(K, p1, p2, scr, wk, ws)) return 2;
+    const long long tq0 = psd_clock();
+    const bool solved = psd_rord_psylsolve(K, p1, p2, scr, wk, ws);
+    cyc[2] += psd_clock() - tq0;
+    if (!solved) return 2;
     const double thresh = fmax(PSD_DBL_MIN, 100.0 * PSD_DBL_EPS * tnrm);
     PSD_SYNC();
     PSD_PAR_FOR(l, K) {
         double* s = scr + l * PSD_RORD_SCR;
-        double Xi[16];
-        for (int q = 0; q < 16; ++q) Xi[q] = 0.0;
-        for (int b = 0; b < p2; ++b) {
-            for (int a = 0; a < p1; ++a) Xi[b * 4 + a] = s[12 + b * 2 + a];
-            Xi[b * 4 + p1 + b] = 1.0;
+        double Xi[16];  // [X; I] (m x p2), ld 4
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = q >> 2, r = q & 3;
+            double x = 0.0;
+            if (c < p2) {
+                if (r < p1) x = s[12 + (c & 1) * 2 + (r & 1)];
+                else if (r == p1 + c) x = 1.0;
+            }
+            Xi[q] = x;
         }
         psd_sm_fullq(Xi, m, p2, s + 16);
         for (int q = 0; q < 16; ++q) s[32 + q] = s[80 + q];  // Txx <- original [T11 T12; 0 T22]
@@ -534,7 +578,7 @@ PSD_D int psd_rord_swap_scalar(int K, int p1, int p2, double* scr, double* wk, d
     PSD_SYNC();
     PSD_PAR_FOR(l, K) {
         const int l1 = (l + 1) % K;
-        double Tt[16];
+        double* Tt = wk + l * 52 + 16;  // (the E block of the solver is free again)
         psd_sm_mul(scr + l1 * PSD_RORD_SCR + 64, false, scr + l * PSD_RORD_SCR + 32, false, m, Tt);
         psd_sm_mul(Tt, false, scr + l * PSD_RORD_SCR + 64, true, m, Tt);
         double d = 0.0;
@@ -556,37 +600,59 @@ PSD_D int psd_rord_swap_scalar(int K, int p1, int p2, double* scr, double* wk, d
 // ------------------------------------------------------------------------------------------------
 // in-window application of the block transform Q (m x m, ld 4) of sequence index l:
 // right on the columns i1.. of X_l = T_{sg}, left (Q') on the rows i1.. of X_{l-1} = T_{own}
+PSD_D void psd_rord_win_apply_lane(const psd_win& w, int sg, int own, int i1, int m, const double* q, int t,
+                                   int nrow) {
+    double a[4], b[4];
+    if (t < nrow) {
+        const int r = w.bs + t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = (e < m) ? w.at(sg, r, i1 + e) : 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            double sum = 0.0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += a[e] * q[c * 4 + e];
+            b[c] = sum;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < m) w.at(sg, r, i1 + e) = b[e];
+    } else {
+        const int c = i1 + (t - nrow);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = (e < m) ? w.at(own, i1 + e, c) : 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double sum = 0.0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += q[r * 4 + e] * a[e];
+            b[r] = sum;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < m) w.at(own, i1 + e, c) = b[e];
+    }
+}
 PSD_D void psd_rord_win_apply(const psd_win& w, int sg, int own, int i1, int m, const double* Q) {
     const int nrow = (i1 + m - 1) - w.bs + 1;  // rows bs..i1+m-1 of T_sg
     const int ncol = w.be - i1 + 1;            // columns i1..be of T_own
-    PSD_PAR_FOR(t, nrow + ncol) {
-        double a[4], b[4];
-        if (t < nrow) {
-            const int r = w.bs + t;
-            for (int q = 0; q < m; ++q) a[q] = w.at(sg, r, i1 + q);
-            for (int c = 0; c < m; ++c) {
-                double s = 0.0;
-                for (int q = 0; q < m; ++q) s += a[q] * Q[c * 4 + q];
-                b[c] = s;
-            }
-            for (int q = 0; q < m; ++q) w.at(sg, r, i1 + q) = b[q];
-        } else {
-            const int c = i1 + (t - nrow);
-            for (int q = 0; q < m; ++q) a[q] = w.at(own, i1 + q, c);
-            for (int r = 0; r < m; ++r) {
-                double s = 0.0;
-                for (int q = 0; q < m; ++q) s += Q[r * 4 + q] * a[q];
-                b[r] = s;
-            }
-            for (int q = 0; q < m; ++q) w.at(own, i1 + q, c) = b[q];
-        }
+    double q[16];  // identity-padded 4 x 4
+#pragma unroll
+    for (int e = 0; e < 16; ++e) q[e] = Q[e];
+    if (sg != own) {
+        PSD_PAR_FOR(t, nrow + ncol) { psd_rord_win_apply_lane(w, sg, own, i1, m, q, t, nrow); }
+    } else {
+        // p == 1: both sides act on the same factor and overlap in the diagonal block -> two ordered passes
+        PSD_PAR_FOR(t, nrow) { psd_rord_win_apply_lane(w, sg, own, i1, m, q, t, nrow); }
+        PSD_SYNC();
+        PSD_PAR_FOR(t, ncol) { psd_rord_win_apply_lane(w, sg, own, i1, m, q, nrow + t, nrow); }
     }
     PSD_SYNC();
 }
 
 // one swap inside the window; returns 0 ok / 1 rejected / 2 singular
 PSD_D int psd_rord_swap(const psd_roparams& P, const psd_rostate& st, const psd_win& w, double* scr, double* wk,
-                        double* ws, double* flagbuf, int* lcnt, int i1, int p1, int p2) {
+                        double* ws, double* flagbuf, int* lcnt, int i1, int p1, int p2, long long* cyc) {
     const int p = st.p, m = p1 + p2;
     PSD_SYNC();
     PSD_PAR_FOR(t, p) {
@@ -620,7 +686,10 @@ PSD_D int psd_rord_swap(const psd_roparams& P, const psd_rostate& st, const psd_
     for (int t = 0; t < p; ++t) tn += wk[t * 52 + 12];
     tn = sqrt(tn);
     PSD_SYNC();
-    const int flag0 = psd_rord_swap_scalar(p, p1, p2, scr, wk, ws, tn);
+    const long long ts0 = psd_clock();
+    const int flag0 = psd_rord_swap_scalar(p, p1, p2, scr, wk, ws, tn, cyc);
+    cyc[3] += psd_clock() - ts0;
+    const long long ta0 = psd_clock();
     PSD_ONE { flagbuf[0] = (double)flag0; }
     PSD_SYNC();
     const int flag = (int)flagbuf[0];
@@ -629,16 +698,18 @@ PSD_D int psd_rord_swap(const psd_roparams& P, const psd_rostate& st, const psd_
         const int own = psd_ord_owner(p, l), sg = psd_ord_sigma(p, l);
         const double* Q = scr + (l - 1) * PSD_RORD_SCR + 64;
         psd_rord_win_apply(w, sg, own, i1, m, Q);
-        PSD_ONE {
+        {
             const int q = lcnt[own - 1];
+            PSD_SYNC();
             if (q < PSD_RORD_CAP) {
-                psd_tq tr;
-                tr.pos = i1;
-                tr.m = m;
-                for (int e = 0; e < 16; ++e) tr.q[e] = Q[e];
-                P.tq[(size_t)(own - 1) * PSD_RORD_CAP + q] = tr;
+                psd_tq* tr = P.tq + ((size_t)(own - 1) * PSD_RORD_CAP + q);
+                PSD_PAR_FOR(e, 16) { tr->q[e] = Q[e]; }
+                PSD_ONE {
+                    tr->pos = i1;
+                    tr->m = m;
+                }
             }
-            lcnt[own - 1] = q + 1;
+            PSD_ONE { lcnt[own - 1] = q + 1; }
         }
     }
     PSD_SYNC();
@@ -654,6 +725,7 @@ PSD_D int psd_rord_swap(const psd_roparams& P, const psd_rostate& st, const psd_
         }
     }
     PSD_SYNC();
+    cyc[4] += psd_clock() - ta0;
     return 0;
 }
 
@@ -663,6 +735,8 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rord_step(psd_roparams P) {
     PSD_ONE { P.desc->active = 0; }
     if (st.phase == PSD_ROPH_DONE) return;
     const int n = st.n, p = st.p;
+    long long cyc[6] = {0, 0, 0, 0, 0, 0};
+    const long long tk0 = psd_clock(), tw0 = psd_wallclock();
     const psd_mat<double> A1 = psd_mat<double>{P.H, n};
     double* ldsd = (double*)psd_lds;
     const size_t winb = (size_t)p * st.W * (st.W + 1);
@@ -724,14 +798,16 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rord_step(psd_roparams P) {
         w.be = st.here + width - 1;
         w.bs = (w.be - st.W + 1 > st.jtarget) ? (w.be - st.W + 1) : st.jtarget;
         PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
+        const long long tl0 = psd_clock();
         psd_win_load(P_as_r(P), w, n, p);
+        cyc[1] += psd_clock() - tl0;
         int fail = 0;
         int here = st.here;
         const int top0 = here;
         // rordschur.jl:181-247 restricted to the blocks that fit the window
         while (here > st.jtarget && !fail) {
             if (st.pend1x1) {  // second 1x1 of a split pair follows its partner (rordschur.jl:207-215)
-                fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here, 1, 1);
+                fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here, 1, 1, cyc);
                 if (fail) break;
                 st.nswaps += 1;
                 st.pend1x1 = 0;
@@ -746,13 +822,13 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rord_step(psd_roparams P) {
             }
             if (here - nbnext < w.bs) break;
             if (!st.splitsrc) {
-                fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - nbnext, nbnext, st.nbsrc);
+                fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - nbnext, nbnext, st.nbsrc, cyc);
                 if (fail) break;
                 st.nswaps += 1;
                 here -= nbnext;
                 if (st.nbsrc == 2 && w.at(1, here + 1, here) == 0) st.splitsrc = 1;
             } else {
-                fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - nbnext, nbnext, 1);
+                fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - nbnext, nbnext, 1, cyc);
                 if (fail) break;
                 st.nswaps += 1;
                 if (nbnext == 1) {
@@ -760,15 +836,15 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rord_step(psd_roparams P) {
                 } else {
                     if (w.at(1, here, here - 1) == 0) nbnext = 1;
                     if (nbnext == 2) {
-                        fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - 1, 2, 1);
+                        fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - 1, 2, 1, cyc);
                         if (fail) break;
                         st.nswaps += 1;
                         here -= 2;
                     } else {
-                        fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here, 1, 1);
+                        fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here, 1, 1, cyc);
                         if (fail) break;
                         st.nswaps += 1;
-                        fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - 1, 1, 1);
+                        fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - 1, 1, 1, cyc);
                         if (fail) break;
                         st.nswaps += 1;
                         here -= 2;
@@ -780,7 +856,9 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rord_step(psd_roparams P) {
             st.info = (fail == 2) ? PSD_INFO_SINGULAR : (PSD_INFO_ILLCOND_BASE + st.jsrc0);
             st.phase = PSD_ROPH_DONE;
         } else {
+            const long long tl1 = psd_clock();
             psd_win_store(P_as_r(P), w, n, p);
+            cyc[1] += psd_clock() - tl1;
             PSD_SYNC();
             PSD_PAR_FOR(m, p) { P.cnt[m] = lcnt[m]; }
             PSD_ONE {
@@ -806,6 +884,9 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rord_step(psd_roparams P) {
             }
         }
     }
+    cyc[0] = psd_clock() - tk0;
+    cyc[5] = psd_wallclock() - tw0;
+    for (int q = 0; q < 6; ++q) st.cyc[q] += cyc[q];
     PSD_SYNC();
     PSD_ONE { *P.st = st; }
 }
@@ -818,6 +899,7 @@ PSD_KERNEL psd_rord_init(psd_roparams P, int n, int p, int wantZ, int W) {
         st.j = 0; st.jdest = 0; st.pairskip = 0;
         st.here = 0; st.nbsrc = 1; st.splitsrc = 0; st.jtarget = 0; st.jsrc0 = 0; st.pend1x1 = 0;
         st.nswaps = 0; st.nwindows = 0;
+        for (int q = 0; q < 6; ++q) st.cyc[q] = 0;
         *P.st = st;
         P.desc->active = 0;
     }

@@ -134,11 +134,9 @@ def case_edge(eng):
         raise AssertionError("ragged input must be rejected")
     except psd_amd.DimensionMismatch:
         pass
-    try:
-        eng.pschur([np.eye(3), np.eye(3)], S=[True, False])
-        raise AssertionError("signed case is not in this build")
-    except psd_amd.NotImplementedPSD:
-        pass
+    # the signed case dispatches to the generalized driver (rgeneralized.jl:3-45)
+    gs = eng.pschur([np.eye(3) * 2.0, np.eye(3) * 4.0], S=[True, False])
+    assert isinstance(gs, psd_amd.GeneralizedPeriodicSchur) and np.allclose(gs.values, 0.5)
     # non-convergence is reported, not hidden: maxitfac=1 cannot converge a 12x12 problem
     A = pt.rand_uniform_factors(12, 3, seed=99)
     try:

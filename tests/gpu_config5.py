@@ -31,7 +31,7 @@ e_rest = pt.match_eigs(lam0[~select], ps1.values[m:]) / sc
 out = {"config": f"pschur!(A,:L) then ordschur!(P, select) n={n} p={p} Float64, select = {mode} n/4 by modulus, |select| = {m}", "pschur_wall_s": t_ps,
        "pschur_ms": {"hessenberg": s0.ms_hess, "formq": s0.ms_formq, "iteration": s0.ms_iter}, "pschur_sweeps": s0.nsweeps,
        "ordschur_wall_s": t_ord, "ordschur_device_ms": s1.ms_total, "swaps": s1.nsweeps, "windows": s1.nwindows,
-       "swaps_per_s": s1.nsweeps / (s1.ms_total * 1e-3), "window": s1.window,
+       "swaps_per_s": s1.nsweeps / (s1.ms_total * 1e-3), "window": s1.window, "step_cycles": list(s1.step_cycles),
        "alg_GBps_ordschur": s1.nsweeps * 2 * 8 * p * 3 * n * 2.5 / (s1.ms_total * 1e-3) / 1e9,
        "checkpsd_ok": bool(ok), "checkpsd_max_err_eps": float(err.max()), "selected_match": e_sel, "rest_match": e_rest}
 print(json.dumps(out), flush=True)
