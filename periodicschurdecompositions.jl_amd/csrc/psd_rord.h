@@ -193,73 +193,76 @@ PSD_D void psd_sm_mul(const double* A, bool ta, const double* B, bool tb, int m,
     for (int q = 0; q < 16; ++q) C[q] = t[q];
 }
 
-// Householder QR of the first nc columns of the nr x ncols matrix S (LDS, ld), applied to all columns, by the whole
+// Householder QR of the first NC columns of the NR x ncols matrix S (LDS, ld 8), applied to all columns, by the whole
 // wavefront: the reflector is evaluated redundantly by every lane (broadcast LDS reads), the trailing columns are
-// updated one per lane.  Returns false (uniformly) if a diagonal entry of R is exactly zero.
-PSD_D bool psd_sm_qr_par(double* S, int ld, int nr, int ncols, int nc) {
+// updated one per lane.  NR, NC are compile-time so that every loop unrolls without predicates (a lone wavefront is
+// bound by its instruction count).  Returns false (uniformly) if a diagonal entry of R is exactly zero.
+template <int NR, int NC>
+PSD_D bool psd_sm_qr_par_t(double* S, int ncols) {
     bool ok = true;
-    for (int k = 0; k < nc; ++k) {
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
         PSD_WAVE_SYNC();
-        double v[8];  // fixed trip counts + predicates: stays in registers
+        double v[NR];
         double amax = 0.0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const bool in = (i >= k) && (i < nr);
-            v[i] = in ? S[k * ld + i] : 0.0;
+        for (int i = k; i < NR; ++i) {
+            v[i] = S[k * 8 + i];
             amax = fmax(amax, fabs(v[i]));
         }
         if (amax == 0.0) {
             ok = false;
-            continue;
-        }
-        // scale by a power of two (exact), so that the fast rsqrt / reciprocal forms are in range; the reflector
-        // I - v v' / (nrm (nrm + |alpha|)) does not depend on the scaling of v
-        int ex;
-        (void)frexp(amax, &ex);
-        double ssq = 0.0, alpha = 0.0;
+        } else {
+            // scale by a power of two (exact), so that the fast rsqrt / reciprocal forms are in range; the reflector
+            // I - v v' / (nrm (nrm + |alpha|)) does not depend on the scaling of v
+            int ex;
+            (void)frexp(amax, &ex);
+            double ssq = 0.0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            v[i] = ldexp(v[i], -ex);
-            ssq += v[i] * v[i];
-            if (i == k) alpha = v[i];
-        }
-        double nrm, rnrm;
-        psd_sqrt_pair_fast(ssq, nrm, rnrm);
-        const double beta = -copysign(nrm, alpha);
-        const double tau2 = psd_rcp_fast(nrm * (nrm + fabs(alpha)));
+            for (int i = k; i < NR; ++i) {
+                v[i] = ldexp(v[i], -ex);
+                ssq += v[i] * v[i];
+            }
+            const double alpha = v[k];
+            double nrm, rnrm;
+            psd_sqrt_pair_fast(ssq, nrm, rnrm);
+            const double beta = -copysign(nrm, alpha);
+            const double tau2 = psd_rcp_fast(nrm * (nrm + fabs(alpha)));
+            v[k] = alpha - beta;
+            const double beta_out = ldexp(beta, ex);
+            PSD_WAVE_SYNC();
+            PSD_PAR_FOR(t, ncols - k) {
+                const int c = k + t;
+                if (t == 0) {
+                    S[k * 8 + k] = beta_out;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i == k) v[i] = alpha - beta;
-        const double beta_out = ldexp(beta, ex);
-        PSD_WAVE_SYNC();
-        PSD_PAR_FOR(t, ncols - k) {
-            const int c = k + t;
-            if (t == 0) {
+                    for (int i = k + 1; i < NR; ++i) S[k * 8 + i] = 0.0;
+                } else {
+                    double x[NR];
+                    double d = 0.0;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    if (i == k) S[k * ld + i] = beta_out;
-                    else if (i > k && i < nr) S[k * ld + i] = 0.0;
+                    for (int i = k; i < NR; ++i) {
+                        x[i] = S[c * 8 + i];
+                        d += v[i] * x[i];
+                    }
+                    d *= tau2;
+#pragma unroll
+                    for (int i = k; i < NR; ++i) S[c * 8 + i] = x[i] - d * v[i];
                 }
-            } else {
-                double x[8];
-                double d = 0.0;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const bool in = (i >= k) && (i < nr);
-                    x[i] = in ? S[c * ld + i] : 0.0;
-                    d += v[i] * x[i];
-                }
-                d *= tau2;
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if ((i >= k) && (i < nr)) S[c * ld + i] = x[i] - d * v[i];
             }
         }
     }
     PSD_WAVE_SYNC();
-    for (int k = 0; k < nc; ++k)
-        if (S[k * ld + k] == 0.0) ok = false;
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+        if (S[k * 8 + k] == 0.0) ok = false;
     return ok;
+}
+// nr = 2 pp (stacked elimination step) or pp (square solve), nc = pp, pp in {1, 2, 4}
+PSD_D bool psd_sm_qr_par(double* S, int nr, int ncols, int pp) {
+    if (pp == 4) return (nr == 8) ? psd_sm_qr_par_t<8, 4>(S, ncols) : psd_sm_qr_par_t<4, 4>(S, ncols);
+    if (pp == 2) return (nr == 4) ? psd_sm_qr_par_t<4, 2>(S, ncols) : psd_sm_qr_par_t<2, 2>(S, ncols);
+    return (nr == 2) ? psd_sm_qr_par_t<2, 1>(S, ncols) : psd_sm_qr_par_t<1, 1>(S, ncols);
 }
 
 // Periodic Sylvester system A_k X_k - X_{k+1} B_k = -C_k (k = 1..K cyclic), blocks p1 x p1, p2 x p2,
@@ -313,7 +316,7 @@ PSD_D bool psd_rord_psylsolve(int K, int p1, int p2, double* scr, double* wk, do
             if (c == 0 && r < pp) S[pp * 8 + r] = w[48 + r];
         }
         PSD_SYNC();
-        if (!psd_sm_qr_par(S, 8, pp, pp + 1, pp)) return false;
+        if (!psd_sm_qr_par(S, pp, pp + 1, pp)) return false;
         double y[4];
         for (int k = pp - 1; k >= 0; --k) {
             double sum = S[pp * 8 + k];
@@ -363,7 +366,7 @@ PSD_D bool psd_rord_psylsolve(int K, int p1, int p2, double* scr, double* wk, do
             }
         }
         PSD_SYNC();
-        if (!psd_sm_qr_par(S, 8, 2 * pp, ncols, pp)) return false;
+        if (!psd_sm_qr_par(S, 2 * pp, ncols, pp)) return false;
         PSD_PAR_FOR(t, 16) {
             const int c = t >> 2, r = t & 3;
             if (c < pp && r < pp) {
@@ -392,7 +395,7 @@ PSD_D bool psd_rord_psylsolve(int K, int p1, int p2, double* scr, double* wk, do
         if (c == 0 && r < pp) S[pp * 8 + r] = rb[r];
     }
     PSD_SYNC();
-    if (!psd_sm_qr_par(S, 8, pp, pp + 1, pp)) return false;
+    if (!psd_sm_qr_par(S, pp, pp + 1, pp)) return false;
     {
         double y[4];
         for (int k = pp - 1; k >= 0; --k) {
