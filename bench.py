@@ -58,6 +58,18 @@ def cpu_baseline(n, p, seed):
             "seconds": dt, "phase_ms": [float(x) for x in po.phase_ms]}
 
 
+def pmc_traffic(n, p):
+    """HBM bytes per chase launch (step + apply kernels) from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, separate runs, gfx950 correction of the guide applied; profiles/r01/pmc_traffic_cfg2.json says how).
+    Counters cannot be collected from inside this process, so the figure is the one measured for this configuration
+    with tools/psd_profile; None for any other configuration."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic_cfg2.json")
+    if (n, p) != (512, 16) or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        return json.load(fh)["traffic_bytes_per_step_launch"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,7 +151,7 @@ def main():
         if kms:
             achieved = bytes_per_launch / (kms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "psd_rq_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, p),
                     "alg_bytes_per_launch": bytes_per_launch, "avg_launch_ms": kms, "launch_samples": ksamples,
                     "note": "algorithmic bytes of the sweep window one launch chases (2*8*p*w_win*(2n+1)) / HIP-event "
                             "duration of the chase kernel; the chase is latency-bound on the serial reflector chain"}
