@@ -73,7 +73,8 @@ const char* psd_version(void);
 int psd_d_phessenberg(psd_ctx* ctx, int n, int p, double* const* A, double* tau, psd_stats* stats, int* info);
 
 /* pschur!(A, lr; wantZ, wantT, maxitfac), Float64 — PeriodicSchurDecompositions.jl:120-152.
- * S must be NULL or all-true in this build (signed/generalized case: PSD_INFO_NOTIMPL).
+ * S must be NULL or all-true here (PSD_INFO_NOTIMPL otherwise): the signed case returns eigenvalues in the scaled
+ * (alpha, beta, scale) form and has its own entry, psd_d_gpschur.
  * On exit A[s] holds the user-order factor T_s; the quasi-triangular one is A[*schurindex - 1]
  * (schurindex = 1 for 'R', p for 'L').  Z[s] (p pointers, may be NULL when !wantZ) receive Z_s.
  * wr/wi: n eigenvalues of the product.  sweeplog: optional [3*maxlog] (kind,l,i) per iteration. */
@@ -104,8 +105,8 @@ int psd_d_pschur_dev(psd_ctx* ctx, int n, int p, double* dA, char orient, int wa
 int psd_z_phessenberg(psd_ctx* ctx, int n, int p, double* const* A, double* tau, psd_stats* stats, int* info);
 
 /* pschur!(A::Vector{Matrix{ComplexF64}}, lr; wantZ, wantT) — PeriodicSchurDecompositions.jl:1106-1111, which runs
- * generalized.jl:108-137 with S = trues.  A non-true S (generalized.jl:138-146) returns PSD_INFO_NOTIMPL in this
- * build, as does a zero on the diagonal of a triangular factor (deflation Case II, generalized.jl:453-566). */
+ * generalized.jl:108-137 with S = trues; with a signed S the signed Hessenberg reduction and the signed periodic QZ of
+ * generalized.jl:138-146 run (the leftmost entry of S in working order must be true, info -5). */
 int psd_z_pschur(psd_ctx* ctx, int n, int p, double* const* A, const uint8_t* S, char orient, int wantT, int wantZ,
                  int maxitfac, double* const* Z, double* alpha, double* beta, int32_t* ascale, int* schurindex,
                  psd_stats* stats, int32_t* sweeplog, int64_t maxlog, int* info);
@@ -134,6 +135,10 @@ int psd_d_gphessenberg(psd_ctx* ctx, int n, int p, double* const* A, const uint8
 int psd_d_gpschur(psd_ctx* ctx, int n, int p, double* const* A, const uint8_t* S, char orient, int wantT, int wantZ,
                   int maxitfac, double* const* Z, double* alpha, double* beta, int32_t* ascale, int* schurindex,
                   psd_stats* stats, int* info);
+
+/* _phessenberg!(A, S; wantQ) for ComplexF64 — generalized.jl:988-1082 (see psd_d_gphessenberg) */
+int psd_z_gphessenberg(psd_ctx* ctx, int n, int p, double* const* A, const uint8_t* S, double* const* Q,
+                       psd_stats* stats, int* info);
 
 /* device-resident variant of psd_z_pschur */
 int psd_z_pschur_dev(psd_ctx* ctx, int n, int p, double* dA, char orient, int wantT, int wantZ, int maxitfac,

@@ -164,6 +164,7 @@ class Engine:
         lib.psd_d_gpschur_hess.argtypes = lib.psd_z_pschur_hess.argtypes
         lib.psd_d_gphessenberg.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, C.POINTER(C.c_uint8), dpp,
                                            C.POINTER(Stats), ip]
+        lib.psd_z_gphessenberg.argtypes = lib.psd_d_gphessenberg.argtypes
         lib.psd_d_gpschur.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, C.POINTER(C.c_uint8), C.c_char, C.c_int,
                                       C.c_int, C.c_int, dpp, dp, dp, i32p, ip, C.POINTER(Stats), ip]
         lib.psd_z_pschur_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char, C.c_int, C.c_int, C.c_int,
@@ -311,21 +312,23 @@ class Engine:
         return GeneralizedPeriodicSchur(list(S), list(A), Z, alpha, beta, sc, orient, si.value, st, None)
 
     def gphessenberg_(self, A, S, wantQ=True):
-        """_phessenberg!(A, S; wantQ) for Float64 — src/generalized.jl:988-1082.  Overwrites A with the Hessenberg /
+        """_phessenberg!(A, S; wantQ) for Float64 / ComplexF64 — src/generalized.jl:988-1082.  Overwrites A with the Hessenberg /
         triangular factors; returns (A, Qs)."""
         n = _check_square(A)
-        self._as_work(A)
+        cplx = self._is_complex(A)
+        dt = np.complex128 if cplx else np.float64
+        self._as_work(A, dt)
         p = len(A)
         if len(S) != p:
             raise DimensionMismatch("length of S must match the period")
         if not S[0]:
             raise ValueError("The leftmost entry in S must be true")  # src/generalized.jl:990
-        Q = [np.zeros((n, n), order="F") for _ in range(p)] if wantQ else []
+        Q = [np.zeros((n, n), dtype=dt, order="F") for _ in range(p)] if wantQ else []
         st = Stats()
         info = C.c_int(0)
         Sarr = (C.c_uint8 * p)(*[1 if x else 0 for x in S])
-        self.lib.psd_d_gphessenberg(self.ctx, n, p, self._ptrs(A), Sarr, self._ptrs(Q) if wantQ else None,
-                                    C.byref(st), C.byref(info))
+        fn = self.lib.psd_z_gphessenberg if cplx else self.lib.psd_d_gphessenberg
+        fn(self.ctx, n, p, self._ptrs(A), Sarr, self._ptrs(Q) if wantQ else None, C.byref(st), C.byref(info))
         self._raise(info.value)
         self.last_stats = st
         return list(A), Q

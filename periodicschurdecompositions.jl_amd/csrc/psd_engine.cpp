@@ -8,6 +8,7 @@
 #include "psd_zord.h"
 #include "psd_rord.h"
 #include "psd_rgz.h"
+#include "psd_zgz.h"
 
 #include "../../include/psd_mi355x.h"
 
@@ -121,6 +122,37 @@ struct psd_ctx {
     double *gbeta = nullptr, *gxscr = nullptr;
     int *gascale = nullptr, *gcnt = nullptr, *glog = nullptr;
     size_t gstep_lds_set = 0;
+    // complex generalized path (shares zalpha/zbeta/zascale/zlog/zvbuf with the complex path)
+    int zgcap_n = 0, zgcap_p = 0;
+    psd_zgstate* zgst = nullptr;
+    psd_gapply_desc* zgdesc = nullptr;
+    psd_ztr *zgtr = nullptr, *zgdG = nullptr;
+    unsigned char* zgS = nullptr;
+    int* zgcnt = nullptr;
+    size_t zgstep_lds_set = 0;
+
+    void zgrelease() {
+        void* ptrs[] = {zgst, zgdesc, zgtr, zgdG, zgS, zgcnt};
+        for (void* q : ptrs)
+            if (q) psd_rt_free(q);
+        zgst = nullptr; zgdesc = nullptr; zgtr = zgdG = nullptr; zgS = nullptr; zgcnt = nullptr;
+        zgcap_n = zgcap_p = 0;
+    }
+    int zgreserve(int n, int p) {
+        if (n <= zgcap_n && p <= zgcap_p) return 0;
+        zgrelease();
+#define PSD_ALLOC(ptr, type, count) PSD_CHECK(psd_rt_malloc((void**)&ptr, sizeof(type) * (size_t)(count)))
+        PSD_ALLOC(zgst, psd_zgstate, 1);
+        PSD_ALLOC(zgdesc, psd_gapply_desc, 1);
+        PSD_ALLOC(zgtr, psd_ztr, (size_t)p * PSD_GTR_CAP);
+        PSD_ALLOC(zgdG, psd_ztr, n + 8);
+        PSD_ALLOC(zgS, unsigned char, p + 16);
+        PSD_ALLOC(zgcnt, int, p + 8);
+#undef PSD_ALLOC
+        zgcap_n = n;
+        zgcap_p = p;
+        return 0;
+    }
 
     void grelease() {
         void* ptrs[] = {gst, gdesc, gtr, gdG, gS, galpha, gbeta, gxscr, gascale, gcnt, glog};
@@ -500,6 +532,7 @@ int psd_create(psd_ctx** ctx, int device) {
 int psd_destroy(psd_ctx* c) {
     if (!c) return 0;
     c->grelease();
+    c->zgrelease();
     c->release();
     c->zrelease();
     c->rorelease();
@@ -857,7 +890,248 @@ int zrun_iteration(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, in
 
 }  // namespace
 
+namespace {
+
+int zgiterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t* S, int wantT, int wantZ, int maxitfac,
+                  psd_zgstate* st_out, psd_stats* stats, int maxlog, int hessmode) {
+    const int W = choose_window(p, 16);
+    if (W == 0) return PSD_INFO_NOTIMPL;
+    std::vector<unsigned char> hS(p, 1);
+    for (int l = 0; l < p; ++l) hS[l] = (!S || S[l]) ? 1 : 0;
+    PSD_CHECK(psd_rt_h2d(c->zgS, hS.data(), (size_t)p, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    psd_zgparams P;
+    P.H = dH;
+    P.Z = wantZ ? dZ : nullptr;
+    P.S = c->zgS;
+    P.st = c->zgst;
+    P.desc = c->zgdesc;
+    P.tr = c->zgtr;
+    P.cnt = c->zgcnt;
+    P.dG = c->zgdG;
+    P.alpha = c->zalpha;
+    P.beta = c->zbeta;
+    P.ascale = c->zascale;
+    P.log = c->zlog;
+    const size_t lds_step = step_lds_bytes(p, W, 16);
+#ifndef PSD_HOSTSIM
+    if (lds_step > c->zgstep_lds_set) {
+        PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_zgq_step),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
+        c->zgstep_lds_set = lds_step;
+    }
+#endif
+    PSD_LAUNCH(psd_zgq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, hessmode);
+    const size_t lds_apply = sizeof(psd_ztr) * PSD_GTR_CAP + (size_t)32 * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
+    const int tiles = (n + PSD_ZAPPLY_NT - 1) / PSD_ZAPPLY_NT;
+    const int dtiles = (n + 255) / 256;
+    const int batch = 32;
+    psd_zgstate hst;
+    memset(&hst, 0, sizeof(hst));
+    long long launched = 0;
+    const int nbmin = (W - 3 > 0) ? (W - 3) : 1;
+    const long long cap = (long long)maxitfac * n * ((long long)n / nbmin + 8) + 8LL * n + 1024 + (hessmode ? (long long)n * n : 0);
+    for (;;) {
+        for (int b = 0; b < batch; ++b) {
+            PSD_LAUNCH(psd_zgq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
+            PSD_LAUNCH(psd_zgq_apply, psd_dim3(tiles, p, 3), PSD_ZAPPLY_NT, lds_apply, c->stream, P, n, p);
+            PSD_LAUNCH(psd_zgq_defer, psd_dim3(dtiles), 256, 0, c->stream, P, n);
+            ++launched;
+        }
+        PSD_CHECK(psd_rt_d2h(&hst, c->zgst, sizeof(hst), c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+        if (hst.phase == PSD_GPH_DONE) break;
+        if (launched > cap) {
+            *st_out = hst;
+            return PSD_INFO_RUNTIME + 0xfffc;
+        }
+    }
+    if (!hessmode && hst.info == 0 && wantT) {  // generalized.jl:860-908
+        for (int l = p; l >= 2; --l) PSD_LAUNCH(psd_zgq_phase, psd_dim3(n), 64, 64, c->stream, P, n, l, wantZ);
+    }
+    PSD_CHECK(psd_rt_last_error());
+    *st_out = hst;
+    if (stats) {
+        stats->nlaunch_step = (int32_t)launched;
+        stats->window = W;
+    }
+    return 0;
+}
+
+int zgrun_iteration(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t* S, int wantT, int wantZ,
+                    int maxitfac, double* alpha, double* beta, int32_t* ascale, psd_stats* stats, int* info) {
+    const int maxlog = 2 * maxitfac * n + n + 16;
+    psd_zgstate st;
+    int rc = zgiterate_dev(c, n, p, dH, dZ, S, wantT, wantZ, maxitfac, &st, stats, maxlog, 0);
+    if (rc != 0) return *info = rc;
+    if (stats) {
+        stats->niter = st.jiter;
+        stats->nsweeps = st.nsweeps;
+        stats->nrqpass = st.nzshift;
+        stats->ndefl1 = st.nsplit;
+        stats->ndefl2 = st.ncase2;
+        stats->reserved = st.ncase2 + 1000 * st.ncase3;
+        stats->nwindows = st.nwindows;
+        stats->nlog = st.nlog;
+    }
+    PSD_CHECK(psd_rt_d2h(alpha, c->zalpha, sizeof(psd_z) * n, c->stream));
+    PSD_CHECK(psd_rt_d2h(beta, c->zbeta, sizeof(double) * n, c->stream));
+    std::vector<int> hsc(n, 0);
+    PSD_CHECK(psd_rt_d2h(hsc.data(), c->zascale, sizeof(int) * n, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    for (int q = 0; q < n; ++q) ascale[q] = hsc[q];
+    return *info = (st.info != 0) ? (PSD_INFO_NOCONV + st.info) : 0;
+}
+
+// _phessenberg!(A, S; wantQ) for ComplexF64 on device — generalized.jl:988-1082
+int zsghess_dev(psd_ctx* c, int n, int p, psd_z* dA, psd_z* dQ, const uint8_t* S, psd_stats* stats) {
+    const size_t nn = (size_t)n * n;
+    const size_t lds_refl = PSD_HESS_NT * 8;
+    const size_t lds_apply = (PSD_HESS_NT + (size_t)n + 8) * sizeof(psd_z);
+    auto sg = [&](int l) { return !S || S[l - 1]; };
+    if (dQ) PSD_LAUNCH(psd_zset_identity, psd_dim3(n, p), 64, 0, c->stream, dQ, n);
+    Timer t;
+    t.start(c->stream);
+    for (int l = p; l >= 2; --l) {
+        psd_z* Al = dA + (size_t)(l - 1) * nn;
+        psd_z* Am = dA + (size_t)(l - 2) * nn;
+        psd_z* Ql = dQ ? dQ + (size_t)(l - 1) * nn : nullptr;
+        const bool rq = !sg(l);
+        const int mrows = sg(l - 1) ? 0 : 1;
+        if (rq) {
+            PSD_LAUNCH(psd_zantitranspose, psd_dim3(n), 256, 0, c->stream, Al, n);
+            PSD_LAUNCH(psd_zflip, psd_dim3(n), 256, 0, c->stream, Am, n, mrows);
+            if (Ql) PSD_LAUNCH(psd_zflip, psd_dim3(n), 256, 0, c->stream, Ql, n, 0);
+        }
+        for (int i = 1; i <= n - 1; ++i) {
+            PSD_LAUNCH(psd_zhess_refl, psd_dim3(1), PSD_HESS_NT, lds_refl, c->stream, Al, n, i, i, c->zvbuf, (psd_z*)nullptr);
+            const int nL = (n - i + 3) / 4;
+            const int nR = (n + 31) / 32;
+            PSD_LAUNCH(psd_zhess_apply, psd_dim3(nL + (Ql ? nR : 0)), PSD_HESS_NT, lds_apply, c->stream, Al, Ql, n, i,
+                       i + 1, (const psd_z*)c->zvbuf, nL);
+            if (mrows == 0) {
+                PSD_LAUNCH(psd_zhess_apply, psd_dim3(nR), PSD_HESS_NT, lds_apply, c->stream, (psd_z*)nullptr, Am, n, i, 1,
+                           (const psd_z*)c->zvbuf, 0);
+            } else {
+                const int nLm = (n + 3) / 4;
+                PSD_LAUNCH(psd_zhess_apply, psd_dim3(nLm), PSD_HESS_NT, lds_apply, c->stream, Am, (psd_z*)nullptr, n, i, 1,
+                           (const psd_z*)c->zvbuf, nLm);
+            }
+        }
+        PSD_LAUNCH(psd_ztril_zero, psd_dim3(n), 256, 0, c->stream, Al, n);
+        if (rq) {
+            PSD_LAUNCH(psd_zantitranspose, psd_dim3(n), 256, 0, c->stream, Al, n);
+            PSD_LAUNCH(psd_zflip, psd_dim3(n), 256, 0, c->stream, Am, n, mrows);
+            if (Ql) PSD_LAUNCH(psd_zflip, psd_dim3(n), 256, 0, c->stream, Ql, n, 0);
+        }
+    }
+    const double ms1 = t.stop(c->stream);
+    t.start(c->stream);
+    psd_zgstate st;
+    int rc = zgiterate_dev(c, n, p, dA, dQ, S, 1, dQ ? 1 : 0, 1, &st, nullptr, 16, 1);
+    const double ms2 = t.stop(c->stream);
+    if (stats) {
+        stats->ms_hess = ms1 + ms2;
+        stats->ms_formq = ms1;
+        stats->bytes_hess = 2.0 * 16.0 * p * (double)n * n * n;
+    }
+    return rc;
+}
+
+// pschur!(A, S, lr) for ComplexF64 with a signed S — generalized.jl:108-148
+int zsigned_pschur_host(psd_ctx* c, int n, int p, double* const* A, const uint8_t* S, char orient, int wantT, int wantZ,
+                        int maxitfac, double* const* Z, double* alpha, double* beta, int32_t* ascale, int* schurindex,
+                        psd_stats* stats, int* info) {
+    if (maxitfac < 1) return *info = -9;
+    const bool left = orient == 'L';
+    auto slotA = [&](int j) { return left ? (p + 1 - j) : j; };
+    auto slotZ = [&](int j) { return (!left || j == 1) ? j : (p + 2 - j); };  // generalized.jl:910-927
+    std::vector<uint8_t> Sarg(p, 1);
+    for (int j = 1; j <= p; ++j) Sarg[j - 1] = S[slotA(j) - 1] ? 1 : 0;
+    if (!Sarg[0]) return *info = -5;  // generalized.jl:140
+    const int mlog = 2 * maxitfac * n + n + 16;
+    if ((*info = c->zreserve(n, p, true, mlog)) != 0) return *info;
+    if ((*info = c->zgreserve(n, p)) != 0) return *info;
+    const size_t nn = (size_t)n * n;
+    for (int j = 1; j <= p; ++j) PSD_CHECK(psd_rt_h2d(c->zH + (size_t)(j - 1) * nn, A[slotA(j) - 1], nn * 16, c->stream));
+    psd_stats local;
+    memset(&local, 0, sizeof(local));
+    psd_stats* s = stats ? stats : &local;
+    Timer tt;
+    tt.start(c->stream);
+    if ((*info = zsghess_dev(c, n, p, c->zH, wantZ ? c->zZ : nullptr, Sarg.data(), s)) != 0) return *info;
+    const double keep_hess = s->ms_hess, keep_formq = s->ms_formq, keep_bh = s->bytes_hess;
+    Timer ti;
+    ti.start(c->stream);
+    int rc = zgrun_iteration(c, n, p, c->zH, wantZ ? c->zZ : nullptr, Sarg.data(), wantT, wantZ, maxitfac, alpha, beta,
+                             ascale, s, info);
+    s->ms_hess = keep_hess;
+    s->ms_formq = keep_formq;
+    s->bytes_hess = keep_bh;
+    s->ms_iter = ti.stop(c->stream);
+    s->ms_total = tt.stop(c->stream);
+    if (schurindex) *schurindex = left ? p : 1;
+    if (rc < 0 || rc >= PSD_INFO_NOTIMPL) return rc;
+    for (int j = 1; j <= p; ++j) PSD_CHECK(psd_rt_d2h(A[slotA(j) - 1], c->zH + (size_t)(j - 1) * nn, nn * 16, c->stream));
+    if (wantZ)
+        for (int j = 1; j <= p; ++j)
+            PSD_CHECK(psd_rt_d2h(Z[slotZ(j) - 1], c->zZ + (size_t)(j - 1) * nn, nn * 16, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    return rc;
+}
+
+// pschur!(H1, Hs, S; ...) for ComplexF64 with a signed S — generalized.jl:166-931
+int zsigned_hess_host(psd_ctx* c, int n, int p, double* const* H, const uint8_t* S, double* const* Q, int wantT,
+                      int wantZ, int maxitfac, double* alpha, double* beta, int32_t* ascale, psd_stats* stats, int* info) {
+    const int mlog = 2 * maxitfac * n + n + 16;
+    if ((*info = c->zreserve(n, p, true, mlog)) != 0) return *info;
+    if ((*info = c->zgreserve(n, p)) != 0) return *info;
+    const size_t nn = (size_t)n * n;
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->zH + j * nn, H[j], nn * 16, c->stream));
+    if (wantZ)
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->zZ + j * nn, Q[j], nn * 16, c->stream));
+    psd_stats local;
+    memset(&local, 0, sizeof(local));
+    psd_stats* s = stats ? stats : &local;
+    Timer t;
+    t.start(c->stream);
+    int rc = zgrun_iteration(c, n, p, c->zH, wantZ ? c->zZ : nullptr, S, wantT, wantZ, maxitfac, alpha, beta, ascale, s,
+                             info);
+    s->ms_iter = s->ms_total = t.stop(c->stream);
+    if (rc < 0 || rc >= PSD_INFO_NOTIMPL) return rc;
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(H[j], c->zH + j * nn, nn * 16, c->stream));
+    if (wantZ)
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(Q[j], c->zZ + j * nn, nn * 16, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    return rc;
+}
+
+}  // namespace
+
 extern "C" {
+
+// _phessenberg!(A, S) for ComplexF64 — generalized.jl:988-1082
+int psd_z_gphessenberg(psd_ctx* c, int n, int p, double* const* A, const uint8_t* S, double* const* Q, psd_stats* stats,
+                       int* info) {
+    int dummy;
+    if (!info) info = &dummy;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!c) return *info = -1;
+    if ((*info = check_dims(n, p)) != 0) return *info;
+    if (!A) return *info = -4;
+    if (S && !S[0]) return *info = -5;
+    if ((*info = c->zreserve(n, p, true, 16)) != 0) return *info;
+    if ((*info = c->zgreserve(n, p)) != 0) return *info;
+    const size_t nn = (size_t)n * n;
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->zH + j * nn, A[j], nn * 16, c->stream));
+    *info = zsghess_dev(c, n, p, c->zH, Q ? c->zZ : nullptr, S, stats);
+    if (*info != 0) return *info;
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(A[j], c->zH + j * nn, nn * 16, c->stream));
+    if (Q)
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(Q[j], c->zZ + j * nn, nn * 16, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    return 0;
+}
 
 int psd_z_phessenberg(psd_ctx* c, int n, int p, double* const* A, double* tau, psd_stats* stats, int* info) {
     int dummy;
@@ -944,11 +1218,13 @@ int psd_z_pschur(psd_ctx* c, int n, int p, double* const* A, const uint8_t* S, c
     if (!c) return *info = -1;
     if ((*info = check_dims(n, p)) != 0) return *info;
     if (!A) return *info = -4;
-    if (S)
-        for (int j = 0; j < p; ++j)
-            if (!S[j]) return *info = PSD_INFO_NOTIMPL;  // signed complex case (generalized.jl:138-146): next rounds
     if (orient != 'R' && orient != 'L') return *info = -6;
     if (wantZ && !Z) return *info = -10;
+    if (S)
+        for (int j = 0; j < p; ++j)
+            if (!S[j])  // signed case (generalized.jl:138-146)
+                return zsigned_pschur_host(c, n, p, A, S, orient, wantT, wantZ, maxitfac, Z, alpha, beta, ascale,
+                                           schurindex, stats, info);
     const int mlog = 2 * (maxitfac > 0 ? maxitfac : 1) * n + n + 16;
     if ((*info = c->zreserve(n, p, true, mlog)) != 0) return *info;
     const size_t nn = (size_t)n * n;
@@ -981,13 +1257,14 @@ int psd_z_pschur_hess(psd_ctx* c, int n, int p, double* const* H, const uint8_t*
     if (!c) return *info = -1;
     if ((*info = check_dims(n, p)) != 0) return *info;
     if (!H) return *info = -4;
+    bool signedS = false;
     if (S) {
         if (!S[0]) return *info = -5;  // generalized.jl:182
-        for (int j = 0; j < p; ++j)
-            if (!S[j]) return *info = PSD_INFO_NOTIMPL;
+        for (int j = 0; j < p; ++j) signedS = signedS || !S[j];
     }
     if (wantZ && !Q) return *info = -6;
     if (maxitfac < 1) return *info = -9;
+    if (signedS) return zsigned_hess_host(c, n, p, H, S, Q, wantT, wantZ, maxitfac, alpha, beta, ascale, stats, info);
     const int mlog = 2 * maxitfac * n + n + 16;
     if ((*info = c->zreserve(n, p, true, mlog)) != 0) return *info;
     const size_t nn = (size_t)n * n;

@@ -1,0 +1,954 @@
+// Complex generalized (signed) periodic QZ iteration and signed Hessenberg reduction on the GPU.
+//
+// Replaces, for ComplexF64 and a signature with negative entries,
+//   pschur!(H1, Hs, S; wantT, wantZ, Q, maxitfac)   /root/reference/src/generalized.jl:166-931 (MB03BZ type)
+//   _phessenberg!(A, S; wantQ), stage 2              generalized.jl:1034-1079
+// (the all-true signature keeps the tuned path of psd_zqz.h).  Same structure as the real signed engine psd_rgz.h:
+// one wavefront chases a diagonal window of all p factors in LDS and emits one rotation list per owner Z_m; the bulk
+// kernel is organised by factor, because the side an owner acts on depends on the signature:
+//     rows    of H_l  <- owner  l      if S[l]  else  l+1
+//     columns of H_l  <- owner  l+1    if S[l]  else  l        (cyclic)
+// Implemented: deflation tests 1-3 (:323-353), controlled zero shift (:356-448), Case II (:453-566) and Case III
+// (:568-740) directly on HBM (exactly singular factors only), 1x1 split with `_safeprod` (:741-762), single-shift
+// sweep with the signed shift chain (:770-852), phase normalisation with signature (:860-908).
+#pragma once
+#include "psd_rgz.h"
+
+struct psd_zgstate {
+    int n, p, wantT, wantZ, W;
+    int phase, info;
+    int ilast, ifirst, ifirstm, ilastm, iiter, ziter, jiter, maxit;
+    int jlo, kcur, zflag, hj;
+    int nsweeps, nzshift, nsplit, ncase2, ncase3, nwindows, nlog, maxlog;
+    double c0;
+    psd_z s0;
+    double smlnum, ulp, safmin;
+    long long cyc[6];
+};
+
+struct psd_zgparams {
+    psd_z* H;
+    psd_z* Z;
+    const unsigned char* S;
+    psd_zgstate* st;
+    psd_gapply_desc* desc;
+    psd_ztr* tr;   // [p][PSD_GTR_CAP]
+    int* cnt;      // [p]
+    psd_ztr* dG;   // [n+2]
+    psd_z* alpha;  // [n]
+    double* beta;  // [n]
+    int* ascale;   // [n]
+    int* log;
+};
+
+PSD_HD psd_mat<psd_z> psd_zgfac(const psd_zgparams& P, int n, int l) {
+    return psd_mat<psd_z>{P.H + (size_t)(l - 1) * n * n, n};
+}
+PSD_HD bool psd_zgsig(const psd_zgparams& P, int l) { return P.S[l - 1] != 0; }
+PSD_HD int psd_zgrowner(const psd_zgparams& P, int l, int p) { return psd_zgsig(P, l) ? l : psd_gnext(l, p); }
+PSD_HD int psd_zgcowner(const psd_zgparams& P, int l, int p) { return psd_zgsig(P, l) ? psd_gnext(l, p) : l; }
+
+PSD_D void psd_zgwin_load(const psd_zgparams& P, const psd_zwin& w, int n, int p) {
+    psd_zparams Q;
+    Q.H = P.H;
+    psd_zwin_load(Q, w, n, p);
+}
+PSD_D void psd_zgwin_store(const psd_zgparams& P, const psd_zwin& w, int n, int p) {
+    psd_zparams Q;
+    Q.H = P.H;
+    psd_zwin_store(Q, w, n, p);
+}
+PSD_D void psd_zgwin_set2(const psd_zwin& w, int l, int r1, int c1, psd_z v1, int r2, int c2, psd_z v2) {
+    PSD_WAVE_SYNC();
+    PSD_ONE {
+        w.at(l, r1, c1) = v1;
+        w.at(l, r2, c2) = v2;
+    }
+    PSD_WAVE_SYNC();
+}
+PSD_D void psd_zgrecord(const psd_zgparams& P, int* lcnt, int m, int pos, double c, psd_z s) {
+    PSD_ONE {
+        const int q = lcnt[m - 1];
+        if (q < PSD_GTR_CAP) {
+            psd_ztr tr;
+            tr.pos = pos;
+            tr.pad = 0;
+            tr.c = c;
+            tr.s = s;
+            P.tr[(size_t)(m - 1) * PSD_GTR_CAP + q] = tr;
+        }
+        lcnt[m - 1] = q + 1;
+    }
+    PSD_WAVE_SYNC();
+}
+PSD_D void psd_zglog(const psd_zgparams& P, psd_zgstate& st, int kind, int lo, int hi) {
+    PSD_ONE {
+        if (st.nlog < st.maxlog) {
+            P.log[3 * st.nlog + 0] = kind;
+            P.log[3 * st.nlog + 1] = lo;
+            P.log[3 * st.nlog + 2] = hi;
+        }
+    }
+    st.nlog += 1;
+}
+PSD_D void psd_zgdesc_write(const psd_zgparams& P, const psd_zgstate& st, const int* lcnt, int plo, int phi, int lc0,
+                            int lc1, int rr0, int rr1, int defer_h1, int defer_run, int djlo, int djhi, int h1mode = 0,
+                            int h1c0 = 0) {
+    PSD_SYNC();
+    PSD_PAR_FOR(m, st.p) { P.cnt[m] = lcnt[m]; }
+    PSD_ONE {
+        psd_gapply_desc d;
+        d.active = 1;
+        d.plo = plo;
+        d.phi = phi;
+        d.lc0 = lc0;
+        d.lc1 = lc1;
+        d.rr0 = rr0;
+        d.rr1 = rr1;
+        d.zr0 = 1;
+        d.zr1 = st.wantZ ? st.n : 0;
+        d.defer_h1 = defer_h1;
+        d.defer_run = defer_run;
+        d.djlo = djlo;
+        d.djhi = djhi;
+        d.drow0 = st.ifirstm;
+        d.h1mode = h1mode;
+        d.h1c0 = h1c0;
+        *P.desc = d;
+    }
+    PSD_SYNC();
+}
+
+// One factor of a rotation chain inside the window (see psd_g_link): incoming (c, s) at (q, q+1);
+//   cols_in:  right on the columns, new row rotation from (H[q,q], H[q+1,q])          (generalized.jl:823-832)
+//   !cols_in: left on the rows, new column rotation from (H[q+1,q+1], H[q+1,q]): the reference's backwards
+//             Givens(q+1, q, c, s') is the standard rotation (q, q+1; c, -s)            (:833-845)
+PSD_D void psd_zg_link(const psd_zwin& w, int l, int q, bool cols_in, double& c, psd_z& s, int rlo, int chi) {
+    psd_z r;
+    if (cols_in) {
+        psd_zwin_right(w, l, q, c, s, rlo, q + 1);
+        psd_zgivens(w.at(l, q, q), w.at(l, q + 1, q), c, s, r);
+        psd_zgwin_set2(w, l, q, q, r, q + 1, q, zmk(0.0, 0.0));
+        psd_zwin_left(w, l, q, c, s, q + 1, chi);
+    } else {
+        psd_zwin_left(w, l, q, c, s, q, chi);
+        psd_zgivens(w.at(l, q + 1, q + 1), zneg(w.at(l, q + 1, q)), c, s, r);
+        psd_zgwin_set2(w, l, q + 1, q + 1, r, q + 1, q, zmk(0.0, 0.0));
+        psd_zwin_right(w, l, q, c, s, rlo, q);
+    }
+}
+
+// generalized.jl:939-976 `_safeprod` with a signature
+PSD_D void psd_zg_safeprod(const psd_zgparams& P, int n, int p, int idx, psd_z& alpha, double& beta, int& scale) {
+    alpha = zmk(1.0, 0.0);
+    beta = 1.0;
+    scale = 0;
+    for (int l = 1; l <= p; ++l) {
+        const psd_z xi = psd_zgfac(P, n, l)(idx, idx);
+        if (psd_zgsig(P, l)) {
+            alpha = zmul(alpha, xi);
+        } else if (ziszero(xi)) {
+            beta = 0.0;
+        } else {
+            alpha = zdiv(alpha, xi);
+        }
+        if (zabs(alpha) == 0) {
+            alpha = zmk(0.0, 0.0);
+            scale = 0;
+            if (beta == 0.0) return;
+        } else {
+            int guard = 0;
+            while (zabs(alpha) < 1.0 && guard < 2200) {
+                alpha = zscal(2.0, alpha);
+                scale -= 1;
+                ++guard;
+            }
+            while (zabs(alpha) >= 2.0 && guard < 4400) {
+                alpha = zscal(0.5, alpha);
+                scale += 1;
+                ++guard;
+            }
+        }
+    }
+}
+
+// ---- rotations applied directly on HBM by the whole workgroup (Cases II / III only) --------------------------------
+PSD_D void psd_zgg_left(const psd_mat<psd_z>& M, int j, double c, psd_z s, int c0, int c1) {
+    PSD_SYNC();
+    PSD_PAR_FOR(t, c1 - c0 + 1) {
+        const int cc = c0 + t;
+        psd_z a1 = M(j, cc), a2 = M(j + 1, cc);
+        psd_zrot_left(c, s, a1, a2);
+        M(j, cc) = a1;
+        M(j + 1, cc) = a2;
+    }
+    PSD_SYNC();
+}
+PSD_D void psd_zgg_right(const psd_mat<psd_z>& M, int j, double c, psd_z s, int r0, int r1) {
+    PSD_SYNC();
+    PSD_PAR_FOR(t, r1 - r0 + 1) {
+        const int r = r0 + t;
+        psd_z a1 = M(r, j), a2 = M(r, j + 1);
+        psd_zrot_right_adj(c, s, a1, a2);
+        M(r, j) = a1;
+        M(r, j + 1) = a2;
+    }
+    PSD_SYNC();
+}
+PSD_D void psd_zgg_z(const psd_zgparams& P, const psd_zgstate& st, int m, int j, double c, psd_z s) {
+    if (!st.wantZ) return;
+    psd_zgg_right(psd_mat<psd_z>{P.Z + (size_t)(m - 1) * st.n * st.n, st.n}, j, c, s, 1, st.n);
+}
+PSD_D void psd_zgg_set2(const psd_mat<psd_z>& M, int r1, int c1, psd_z v1, int r2, int c2, psd_z v2) {
+    PSD_SYNC();
+    PSD_ONE {
+        M(r1, c1) = v1;
+        M(r2, c2) = v2;
+    }
+    PSD_SYNC();
+}
+PSD_D void psd_zgg_link(const psd_mat<psd_z>& M, int q, bool cols_in, double& c, psd_z& s, int rlo, int chi) {
+    psd_z r;
+    const psd_z z0 = zmk(0.0, 0.0);
+    if (cols_in) {
+        psd_zgg_right(M, q, c, s, rlo, q + 1);
+        psd_zgivens(M(q, q), M(q + 1, q), c, s, r);
+        psd_zgg_set2(M, q, q, r, q + 1, q, z0);
+        psd_zgg_left(M, q, c, s, q + 1, chi);
+    } else {
+        psd_zgg_left(M, q, c, s, q, chi);
+        psd_zgivens(M(q + 1, q + 1), zneg(M(q + 1, q)), c, s, r);
+        psd_zgg_set2(M, q + 1, q + 1, r, q + 1, q, z0);
+        psd_zgg_right(M, q, c, s, rlo, q);
+    }
+}
+
+// generalized.jl:453-566 Case II
+PSD_D void psd_zgq_case2(const psd_zgparams& P, psd_zgstate& st, int ldeflate, int jdeflate) {
+    const int n = st.n, p = st.p, jlo = st.jlo, ilast = st.ilast, ifirstm = st.ifirstm, ilastm = st.ilastm;
+    const psd_mat<psd_z> H1 = psd_zgfac(P, n, 1);
+    const psd_z z0 = zmk(0.0, 0.0);
+    st.ncase2 += 1;
+    psd_zglog(P, st, 2, jlo, ilast);
+    for (int j = jlo; j <= jdeflate - 1; ++j) {
+        double c;
+        psd_z s, r;
+        psd_zgivens(H1(j, j), H1(j + 1, j), c, s, r);
+        psd_zgg_set2(H1, j, j, r, j + 1, j, z0);
+        psd_zgg_left(H1, j, c, s, j + 1, ilastm);
+        psd_zgg_z(P, st, 1, j, c, s);
+        for (int l = p; l >= 2; --l) {
+            const int ntra = (l < ldeflate) ? (jdeflate - 2) : (jdeflate - 1);
+            if (j > ntra) break;
+            psd_zgg_link(psd_zgfac(P, n, l), j, psd_zgsig(P, l), c, s, ifirstm, ilastm);
+            psd_zgg_z(P, st, l, j, c, s);
+        }
+        PSD_ONE {
+            psd_ztr tr;
+            tr.pos = j;
+            tr.pad = 0;
+            tr.c = c;
+            tr.s = s;
+            P.dG[j] = tr;
+        }
+    }
+    PSD_SYNC();
+    for (int j = jlo; j <= jdeflate - 2; ++j) {
+        const psd_ztr g = P.dG[j];
+        psd_zgg_right(H1, j, g.c, g.s, ifirstm, j + 1);
+    }
+    for (int j = ilast; j >= jdeflate + 1; --j) {
+        double c;
+        psd_z s, r;
+        psd_zgivens(H1(j, j), zneg(H1(j, j - 1)), c, s, r);  // Givens(j, j-1, c, s') == standard (j-1, j; c, -s)
+        psd_zgg_set2(H1, j, j, r, j, j - 1, z0);
+        psd_zgg_right(H1, j - 1, c, s, ifirstm, j - 1);
+        psd_zgg_z(P, st, psd_gnext(1, p), j - 1, c, s);
+        bool alive = true;
+        for (int l = 2; l <= p; ++l) {
+            const int ntra = (l > ldeflate) ? (jdeflate + 2) : (jdeflate + 1);
+            if (j < ntra) {
+                alive = false;
+                break;
+            }
+            psd_zgg_link(psd_zgfac(P, n, l), j - 1, !psd_zgsig(P, l), c, s, ifirstm, ilastm);
+            psd_zgg_z(P, st, psd_gnext(l, p), j - 1, c, s);
+        }
+        PSD_ONE {
+            psd_ztr tr;
+            tr.pos = alive ? (j - 1) : -1;
+            tr.pad = 0;
+            tr.c = c;
+            tr.s = s;
+            P.dG[j] = tr;
+        }
+    }
+    PSD_SYNC();
+    for (int j = ilast; j >= jdeflate + 2; --j) {
+        const psd_ztr g = P.dG[j];
+        if (g.pos > 0) psd_zgg_left(H1, j - 1, g.c, g.s, j - 1, ilastm);
+    }
+}
+
+// generalized.jl:568-740 Case III
+PSD_D void psd_zgq_case3(const psd_zgparams& P, psd_zgstate& st, int ldeflate, int jdeflate) {
+    const int n = st.n, p = st.p, jlo = st.jlo, ilast = st.ilast, ifirstm = st.ifirstm, ilastm = st.ilastm;
+    const psd_mat<psd_z> H1 = psd_zgfac(P, n, 1);
+    const psd_mat<psd_z> Hd = psd_zgfac(P, n, ldeflate);
+    const psd_z z0 = zmk(0.0, 0.0);
+    st.ncase3 += 1;
+    psd_zglog(P, st, 3, jlo, ilast);
+    double c;
+    psd_z s, r;
+    if (jdeflate > (ilast - jlo + 1) / 2.0) {
+        for (int j1 = jdeflate; j1 <= ilast - 1; ++j1) {
+            int j = j1;
+            psd_zgivens(Hd(j, j + 1), Hd(j + 1, j + 1), c, s, r);
+            psd_zgg_set2(Hd, j, j + 1, r, j + 1, j + 1, z0);
+            psd_zgg_left(Hd, j, c, s, j + 2, ilastm);
+            int ln = psd_gnext(ldeflate, p);
+            psd_zgg_z(P, st, ln, j, c, s);
+            for (int l = 1; l <= p - 1; ++l) {
+                if (ln == 1) {
+                    psd_zgg_left(H1, j, c, s, j - 1, ilastm);
+                    psd_zgivens(H1(j + 1, j), zneg(H1(j + 1, j - 1)), c, s, r);
+                    psd_zgg_set2(H1, j + 1, j, r, j + 1, j - 1, z0);
+                    psd_zgg_right(H1, j - 1, c, s, ifirstm, j);
+                    j -= 1;
+                } else {
+                    psd_zgg_link(psd_zgfac(P, n, ln), j, !psd_zgsig(P, ln), c, s, ifirstm, ilastm);
+                }
+                ln = psd_gnext(ln, p);
+                psd_zgg_z(P, st, ln, j, c, s);
+            }
+            psd_zgg_right(Hd, j, c, s, ifirstm, j);
+        }
+        const int j = ilast;
+        psd_zgivens(H1(j, j), zneg(H1(j, j - 1)), c, s, r);
+        psd_zgg_set2(H1, j, j, r, j, j - 1, z0);
+        psd_zgg_right(H1, j - 1, c, s, ifirstm, j - 1);
+        psd_zgg_z(P, st, psd_gnext(1, p), j - 1, c, s);
+        for (int l = 2; l <= ldeflate - 1; ++l) {
+            psd_zgg_link(psd_zgfac(P, n, l), j - 1, !psd_zgsig(P, l), c, s, ifirstm, ilastm);
+            psd_zgg_z(P, st, psd_gnext(l, p), j - 1, c, s);
+        }
+        psd_zgg_right(Hd, j - 1, c, s, ifirstm, j);
+    } else {
+        for (int j1 = jdeflate; j1 >= jlo + 1; --j1) {
+            int j = j1;
+            psd_zgivens(Hd(j - 1, j), zneg(Hd(j - 1, j - 1)), c, s, r);
+            psd_zgg_set2(Hd, j - 1, j, r, j - 1, j - 1, z0);
+            psd_zgg_right(Hd, j - 1, c, s, ifirstm, j - 2);
+            psd_zgg_z(P, st, ldeflate, j - 1, c, s);
+            int ln = ldeflate - 1;
+            for (int l = 1; l <= p - 1; ++l) {
+                if (ln == 1) {
+                    psd_zgg_right(H1, j - 1, c, s, ifirstm, j + 1);
+                    psd_zgivens(H1(j, j - 1), H1(j + 1, j - 1), c, s, r);
+                    psd_zgg_set2(H1, j, j - 1, r, j + 1, j - 1, z0);
+                    psd_zgg_left(H1, j, c, s, j, ilastm);
+                    j += 1;
+                } else {
+                    psd_zgg_link(psd_zgfac(P, n, ln), j - 1, psd_zgsig(P, ln), c, s, ifirstm, ilastm);
+                }
+                psd_zgg_z(P, st, ln, j - 1, c, s);
+                ln = (ln == 1) ? p : (ln - 1);
+            }
+            psd_zgg_left(Hd, j - 1, c, s, j, ilastm);
+        }
+        const int j = jlo;
+        psd_zgivens(H1(j, j), H1(j + 1, j), c, s, r);
+        psd_zgg_set2(H1, j, j, r, j + 1, j, z0);
+        psd_zgg_left(H1, j, c, s, j + 1, ilastm);
+        psd_zgg_z(P, st, 1, j, c, s);
+        for (int l = p; l >= ldeflate + 1; --l) {
+            psd_zgg_link(psd_zgfac(P, n, l), j, psd_zgsig(P, l), c, s, ifirstm, ilastm);
+            psd_zgg_z(P, st, l, j, c, s);
+        }
+        psd_zgg_left(Hd, j, c, s, j + 1, ilastm);
+    }
+}
+
+// One position of a downward chain inside the window: rotation at (j, j+1) through H_1 (rows), H_p .. H_2, and the
+// columns of H_1 (rows ifirstm..hmax).  mode 0: generated from column j-1 of H_1 (sweep, :812-816); mode 1: given
+// (first position of a sweep); mode 2: generated from `side` = column hj of A_1 (signed Hessenberg, stage 2).
+PSD_D void psd_zgq_chain(const psd_zgparams& P, const psd_zgstate& st, const psd_zwin& w, int* lcnt, int j, int mode,
+                         double c, psd_z s, psd_z* side, int hmax) {
+    const int p = st.p;
+    const psd_z z0 = zmk(0.0, 0.0);
+    psd_z r;
+    if (mode == 0) {
+        psd_zgivens(w.at(1, j, j - 1), w.at(1, j + 1, j - 1), c, s, r);
+        psd_zgwin_set2(w, 1, j, j - 1, r, j + 1, j - 1, z0);
+    } else if (mode == 2) {
+        psd_zgivens(side[j - w.bs], side[j + 1 - w.bs], c, s, r);
+        PSD_WAVE_SYNC();
+        PSD_ONE {
+            side[j - w.bs] = r;
+            side[j + 1 - w.bs] = z0;
+        }
+        PSD_WAVE_SYNC();
+    }
+    psd_zwin_left(w, 1, j, c, s, (mode == 2) ? w.bs : j, st.ilastm);
+    psd_zgrecord(P, lcnt, 1, j, c, s);
+    for (int l = p; l >= 2; --l) {
+        psd_zg_link(w, l, j, psd_zgsig(P, l), c, s, st.ifirstm, st.ilastm);
+        psd_zgrecord(P, lcnt, l, j, c, s);
+    }
+    psd_zwin_right(w, 1, j, c, s, st.ifirstm, hmax);
+}
+
+// generalized.jl:808-852: one window of the single-shift sweep
+PSD_D void psd_zgq_sweep_window(const psd_zgparams& P, psd_zgstate& st, psd_z* ldsz, int* lcnt) {
+    const int n = st.n, p = st.p, ifirst = st.ifirst, ilast = st.ilast, ifirstm = st.ifirstm, ilastm = st.ilastm;
+    const int nb = st.W - 3;
+    const int ks = st.kcur;
+    const int ke = (ks + nb - 1 < ilast - 1) ? (ks + nb - 1) : (ilast - 1);
+    psd_zwin w;
+    w.b = ldsz;
+    w.W = st.W;
+    w.ld = st.W + 1;
+    w.bsz = st.W * (st.W + 1);
+    w.bs = (ks > ifirst) ? (ks - 1) : ifirst;
+    w.be = (ke + 2 < ilast) ? (ke + 2) : ilast;
+    PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
+    psd_zgwin_load(P, w, n, p);
+    for (int j = ks; j <= ke; ++j) {
+        const int itmp = (j + 2 < ilastm) ? (j + 2) : ilastm;
+        psd_zgq_chain(P, st, w, lcnt, j, (j > ifirst) ? 0 : 1, st.c0, st.s0, nullptr, itmp);
+    }
+    psd_zgwin_store(P, w, n, p);
+    psd_zgdesc_write(P, st, lcnt, w.bs, w.be, w.be + 1, ilastm, ifirstm, w.bs - 1, 0, 0, 0, 0);
+    st.nwindows += 1;
+    st.kcur = ke + 1;
+    if (ke >= ilast - 1) st.phase = PSD_GPH_CHECK;
+}
+
+// generalized.jl:356-448: one window of the controlled zero shift
+PSD_D void psd_zgq_zshift_window(const psd_zgparams& P, psd_zgstate& st, psd_z* ldsz, int* lcnt) {
+    const int n = st.n, p = st.p, jlo = st.jlo, ilast = st.ilast, ifirstm = st.ifirstm, ilastm = st.ilastm;
+    const int nb = st.W - 2;
+    const int ks = st.kcur;
+    const int jend = ilast - 1;
+    const int ke = (ks + nb - 1 < jend) ? (ks + nb - 1) : jend;
+    const psd_z z0 = zmk(0.0, 0.0);
+    psd_zwin w;
+    w.b = ldsz;
+    w.W = st.W;
+    w.ld = st.W + 1;
+    w.bsz = st.W * (st.W + 1);
+    w.bs = ks;
+    w.be = ke + 1;
+    PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
+    psd_zgwin_load(P, w, n, p);
+    for (int j = ks; j <= ke; ++j) {
+        double c;
+        psd_z s, r;
+        psd_zgivens(w.at(1, j, j), w.at(1, j + 1, j), c, s, r);
+        psd_zgwin_set2(w, 1, j, j, r, j + 1, j, z0);
+        psd_zwin_left(w, 1, j, c, s, j + 1, ilastm);
+        psd_zgrecord(P, lcnt, 1, j, c, s);
+        for (int l = p; l >= 2 && !ziszero(s); --l) {
+            const bool sg = psd_zgsig(P, l);
+            if (sg) psd_zwin_right(w, l, j, c, s, ifirstm, j + 1);
+            else psd_zwin_left(w, l, j, c, s, j, ilastm);
+            double tol = zabs(w.at(l, j, j)) + zabs(w.at(l, j + 1, j + 1));
+            if (tol == 0) {
+                for (int cc = w.bs; cc <= j + 1; ++cc) {
+                    double cs = 0.0;
+                    for (int rr = w.bs; rr <= j + 1; ++rr) cs += zabs(w.at(l, rr, cc));
+                    tol = fmax(tol, cs);
+                }
+            }
+            tol = fmax(st.ulp * tol, st.smlnum);
+            const psd_z sub = w.at(l, j + 1, j);
+            if (zabs(sub) <= tol) {
+                c = 1.0;
+                s = z0;
+                psd_zgwin_set2(w, l, j + 1, j, z0, j + 1, j, z0);
+            } else if (sg) {
+                psd_zgivens(w.at(l, j, j), sub, c, s, r);
+                psd_zgwin_set2(w, l, j, j, r, j + 1, j, z0);
+                psd_zwin_left(w, l, j, c, s, j + 1, ilastm);
+                psd_zgrecord(P, lcnt, l, j, c, s);
+            } else {
+                psd_zgivens(w.at(l, j + 1, j + 1), zneg(sub), c, s, r);
+                psd_zgwin_set2(w, l, j + 1, j + 1, r, j + 1, j, z0);
+                psd_zwin_right(w, l, j, c, s, ifirstm, j);
+                psd_zgrecord(P, lcnt, l, j, c, s);
+            }
+        }
+        PSD_ONE {
+            psd_ztr tr;
+            tr.pos = j;
+            tr.pad = 0;
+            tr.c = c;
+            tr.s = s;
+            P.dG[j] = tr;
+        }
+        if (ziszero(s)) st.zflag = 1;
+    }
+    psd_zgwin_store(P, w, n, p);
+    const bool last = ke >= jend;
+    psd_zgdesc_write(P, st, lcnt, ks, ke + 1, w.be + 1, ilastm, ifirstm, w.bs - 1, 1, last ? 1 : 0, jlo, jend);
+    st.nwindows += 1;
+    st.kcur = ke + 1;
+    if (last) {
+        st.ziter = st.zflag ? 1 : 0;
+        st.phase = PSD_GPH_CHECK;
+    }
+}
+
+// generalized.jl:1034-1079 (ComplexF64): one window of stage 2 of the signed Hessenberg reduction
+PSD_D void psd_zgq_hess_window(const psd_zgparams& P, psd_zgstate& st, psd_z* ldsz, psd_z* side, int* lcnt) {
+    const int n = st.n, p = st.p, hj = st.hj;
+    const int nb = st.W - 1;
+    const int qe = st.kcur;
+    const int qs = (qe - nb + 1 > hj + 1) ? (qe - nb + 1) : (hj + 1);
+    psd_zwin w;
+    w.b = ldsz;
+    w.W = st.W;
+    w.ld = st.W + 1;
+    w.bsz = st.W * (st.W + 1);
+    w.bs = qs;
+    w.be = qe + 1;
+    const psd_mat<psd_z> A1 = psd_zgfac(P, n, 1);
+    PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
+    PSD_PAR_FOR(t, w.be - w.bs + 1) { side[t] = A1(w.bs + t, hj); }
+    psd_zgwin_load(P, w, n, p);
+    for (int q = qe; q >= qs; --q) psd_zgq_chain(P, st, w, lcnt, q, 2, 0.0, zmk(0.0, 0.0), side, n);
+    psd_zgwin_store(P, w, n, p);
+    PSD_PAR_FOR(t, w.be - w.bs + 1) { A1(w.bs + t, hj) = side[t]; }
+    psd_zgdesc_write(P, st, lcnt, w.bs, w.be, w.be + 1, n, 1, w.bs - 1, 0, 0, 0, 0, 1, hj + 1);
+    st.nwindows += 1;
+    st.kcur = qs - 1;
+    if (st.kcur < hj + 1) {
+        st.hj = hj + 1;
+        st.kcur = n - 1;
+        if (st.hj > n - 2) st.phase = PSD_GPH_DONE;
+    }
+}
+
+PSD_D int psd_zgq_scan_diag(const psd_zgparams& P, const psd_zgstate& st, int* redi, int jlo, bool sign) {
+    const int n = st.n, p = st.p, ilast = st.ilast;
+    const int NT = PSD_NTHREADS;
+    const int wd = ilast - jlo + 1;
+    PSD_SYNC();
+    PSD_PAR_FOR(t, NT) {
+        int key = 0x7fffffff;
+        for (int q = t; q < (p - 1) * wd; q += NT) {
+            const int l = 2 + q / wd, j = jlo + q % wd;
+            if (psd_zgsig(P, l) != sign) continue;
+            const psd_mat<psd_z> Hl = psd_zgfac(P, n, l);
+            double tol;
+            if (j == ilast) tol = zabs(Hl(j - 1, j));
+            else if (j == jlo) tol = zabs(Hl(j, j + 1));
+            else tol = zabs(Hl(j - 1, j)) + zabs(Hl(j, j + 1));
+            tol = fmax(st.ulp * tol, st.smlnum);
+            if (zabs(Hl(j, j)) <= tol) {
+                const int k = l * (n + 2) + (n + 1 - j);
+                if (k < key) key = k;
+            }
+        }
+        redi[t] = key;
+    }
+    PSD_SYNC();
+    int key = 0x7fffffff;
+    for (int t = 0; t < NT; ++t)
+        if (redi[t] < key) key = redi[t];
+    PSD_SYNC();
+    return key;
+}
+
+// generalized.jl:302-449,741-806
+PSD_D void psd_zgq_check(const psd_zgparams& P, psd_zgstate& st, int* redi) {
+    const int n = st.n, p = st.p;
+    const int NT = PSD_NTHREADS;
+    st.jiter += 1;
+    if (st.jiter > st.maxit) {
+        st.info = st.ilast;
+        st.phase = PSD_GPH_DONE;
+        return;
+    }
+    const psd_mat<psd_z> H1 = psd_zgfac(P, n, 1);
+    const int ilast = st.ilast;
+    bool split = false;
+    int jlo = 1;
+    if (ilast == 1) {
+        split = true;
+    } else {
+        PSD_SYNC();
+        PSD_PAR_FOR(t, NT) {
+            int best = 0;
+            for (int j = ilast - t; j >= 2; j -= NT) {
+                double tol = zabs(H1(j - 1, j - 1)) + zabs(H1(j, j));
+                if (tol == 0) {
+                    for (int cc = 1; cc <= j; ++cc) {
+                        double cs = 0.0;
+                        const int rmax = (cc + 1 < j) ? (cc + 1) : j;
+                        for (int rr = 1; rr <= rmax; ++rr) cs += zabs(H1(rr, cc));
+                        tol = fmax(tol, cs);
+                    }
+                }
+                tol = fmax(st.ulp * tol, st.smlnum);
+                if (zabs(H1(j, j - 1)) <= tol) {
+                    best = j;
+                    break;
+                }
+            }
+            redi[t] = best;
+        }
+        PSD_SYNC();
+        int jfound = 0;
+        for (int t = 0; t < NT; ++t)
+            if (redi[t] > jfound) jfound = redi[t];
+        PSD_SYNC();
+        if (jfound > 0) {
+            PSD_ONE { H1(jfound, jfound - 1) = zmk(0.0, 0.0); }
+            PSD_SYNC();
+            jlo = jfound;
+            if (jfound == ilast) split = true;
+        }
+    }
+    if (split) {
+        psd_z a;
+        double b;
+        int sc;
+        psd_zg_safeprod(P, n, p, ilast, a, b, sc);
+        PSD_ONE {
+            P.alpha[ilast - 1] = a;
+            P.beta[ilast - 1] = b;
+            P.ascale[ilast - 1] = sc;
+        }
+        st.nsplit += 1;
+        st.ilast -= 1;
+        if (st.ilast < 1) {
+            st.phase = PSD_GPH_DONE;
+            return;
+        }
+        st.iiter = 0;
+        if (st.ziter != -1) st.ziter = 0;
+        if (!st.wantT) {
+            st.ilastm = st.ilast;
+            if (st.ifirstm > st.ilast) st.ifirstm = 1;
+        }
+        return;
+    }
+    st.jlo = jlo;
+    const int key2 = psd_zgq_scan_diag(P, st, redi, jlo, true);
+    const int key3 = (key2 == 0x7fffffff) ? psd_zgq_scan_diag(P, st, redi, jlo, false) : 0x7fffffff;
+    if (st.ziter >= 7 || st.ziter < 0) {  // test 4 first; a pending zero is found again afterwards
+        st.phase = PSD_GPH_ZSHIFT;
+        st.kcur = jlo;
+        st.zflag = 0;
+        st.nzshift += 1;
+        psd_zglog(P, st, 4, jlo, ilast);
+        return;
+    }
+    if (key2 != 0x7fffffff || key3 != 0x7fffffff) {
+        const int key = (key2 != 0x7fffffff) ? key2 : key3;
+        const int l = key / (n + 2), j = (n + 1) - key % (n + 2);
+        PSD_ONE { psd_zgfac(P, n, l)(j, j) = zmk(0.0, 0.0); }
+        PSD_SYNC();
+        if (key2 != 0x7fffffff) psd_zgq_case2(P, st, l, j);
+        else psd_zgq_case3(P, st, l, j);
+        return;
+    }
+    // QZ step (:763-806)
+    st.ifirst = jlo;
+    st.iiter += 1;
+    st.ziter += 1;
+    if (!st.wantT) st.ifirstm = st.ifirst;
+    double c;
+    psd_z s, r;
+    PSD_SYNC();
+    if (st.iiter % 10 == 0) {
+        psd_zgivens(zmk(0.35, 0.62), zmk(0.81, 0.27), c, s, r);  // the reference draws rand(T, 2) (:782)
+    } else {
+        const int ifirst = st.ifirst;
+        psd_zgivens(zmk(1.0, 0.0), zmk(1.0, 0.0), c, s, r);
+        for (int l = p; l >= 2; --l) {
+            const psd_mat<psd_z> Hl = psd_zgfac(P, n, l);
+            if (psd_zgsig(P, l)) {
+                psd_zgivens(zscal(c, Hl(ifirst, ifirst)), zmul(Hl(ilast, ilast), zconj(s)), c, s, r);
+            } else {
+                psd_zgivens(zscal(c, Hl(ilast, ilast)), zneg(zmul(Hl(ifirst, ifirst), zconj(s))), c, s, r);
+                s = zneg(s);
+            }
+        }
+        psd_zgivens(zsub(zscal(c, H1(ifirst, ifirst)), zmul(H1(ilast, ilast), zconj(s))),
+                    zscal(c, H1(ifirst + 1, ifirst)), c, s, r);
+    }
+    st.c0 = c;
+    st.s0 = s;
+    st.phase = PSD_GPH_SWEEP;
+    st.kcur = st.ifirst;
+    st.nsweeps += 1;
+    psd_zglog(P, st, 0, st.ifirst, ilast);
+}
+
+PSD_KERNEL_B(PSD_STEP_NT) psd_zgq_step(psd_zgparams P) {
+    PSD_LDS_DECL;
+    psd_zgstate st = *P.st;
+    if (st.phase == PSD_GPH_DONE) {
+        PSD_ONE { P.desc->active = 0; P.desc->defer_run = 0; }
+        return;
+    }
+    const int NT = PSD_NTHREADS;
+    psd_z* ldsz = (psd_z*)psd_lds;
+    const size_t winb = (size_t)st.p * st.W * (st.W + 1);
+    psd_z* side = ldsz + winb;  // NT/2 complex = NT doubles
+    int* redi = (int*)((double*)side + NT);
+    int* lcnt = redi + 2 * NT;
+    PSD_ONE { P.desc->active = 0; P.desc->defer_run = 0; }
+    const long long tk0 = psd_clock(), tw0 = psd_wallclock();
+    bool emitted = false;
+    int guard = 0;
+    while (!emitted && st.phase != PSD_GPH_DONE && guard < 64) {
+        ++guard;
+        if (st.phase == PSD_GPH_CHECK) {
+            const int nc = st.ncase2 + st.ncase3;
+            psd_zgq_check(P, st, redi);
+            if (st.ncase2 + st.ncase3 != nc) break;
+        } else if (st.phase == PSD_GPH_SWEEP) {
+            psd_zgq_sweep_window(P, st, ldsz, lcnt);
+            emitted = true;
+        } else if (st.phase == PSD_GPH_ZSHIFT) {
+            psd_zgq_zshift_window(P, st, ldsz, lcnt);
+            emitted = true;
+        } else if (st.phase == PSD_GPH_HESS) {
+            psd_zgq_hess_window(P, st, ldsz, side, lcnt);
+            emitted = true;
+        } else {
+            st.phase = PSD_GPH_DONE;
+        }
+    }
+    st.cyc[4] += psd_clock() - tk0;
+    st.cyc[5] += psd_wallclock() - tw0;
+    PSD_SYNC();
+    PSD_ONE { *P.st = st; }
+}
+
+// Bulk application of one window's rotation lists, by factor: grid = (tiles, p factors, 3 roles); tiles 64 wide
+PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zgq_apply(psd_zgparams P, int n, int p) {
+    PSD_LDS_DECL;
+    const psd_gapply_desc d = *P.desc;
+    if (!d.active) return;
+    const int l = PSD_BLOCK_Y + 1;
+    const int role = PSD_BLOCK_Z;
+    const int own = (role == 0) ? psd_zgrowner(P, l, p) : (role == 1) ? psd_zgcowner(P, l, p) : l;
+    const int cnt = P.cnt[own - 1] < PSD_GTR_CAP ? P.cnt[own - 1] : PSD_GTR_CAP;
+    if (cnt <= 0) return;
+    const int T = PSD_ZAPPLY_NT;
+    const int S = d.phi - d.plo + 1;
+    psd_ztr* ltr = (psd_ztr*)psd_lds;
+    psd_z* tile = (psd_z*)(psd_lds + sizeof(psd_ztr) * PSD_GTR_CAP);
+    const bool h1x = d.h1mode == 1 && l == 1;
+    if (role == 0) {
+        const int c0 = (h1x ? d.h1c0 : d.lc0) + PSD_BLOCK_X * T;
+        if (c0 > d.lc1) return;
+        const int nc = (d.lc1 - c0 + 1 < T) ? (d.lc1 - c0 + 1) : T;
+        if (h1x && c0 >= d.plo && c0 + nc - 1 <= d.phi) return;
+        const psd_mat<psd_z> M = psd_zgfac(P, n, l);
+        const int ldt = T + 1;
+        PSD_PAR_FOR(e, cnt) { ltr[e] = P.tr[(size_t)(own - 1) * PSD_GTR_CAP + e]; }
+        PSD_PAR_FOR(t, S * nc) {
+            const int r = t % S, c = t / S;
+            tile[r * ldt + c] = M(d.plo + r, c0 + c);
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(c, nc) {
+            if (h1x && c0 + c >= d.plo && c0 + c <= d.phi) continue;
+            for (int e = 0; e < cnt; ++e) {
+                const psd_ztr tr = ltr[e];
+                const int r = tr.pos - d.plo;
+                psd_z a1 = tile[r * ldt + c], a2 = tile[(r + 1) * ldt + c];
+                psd_zrot_left(tr.c, tr.s, a1, a2);
+                tile[r * ldt + c] = a1;
+                tile[(r + 1) * ldt + c] = a2;
+            }
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(t, S * nc) {
+            const int r = t % S, c = t / S;
+            if (h1x && c0 + c >= d.plo && c0 + c <= d.phi) continue;
+            M(d.plo + r, c0 + c) = tile[r * ldt + c];
+        }
+    } else {
+        if (role == 1 && d.defer_h1 == 1 && l == 1) return;
+        const bool h1r = h1x && role == 1;
+        const int lo = (role == 1) ? (h1r ? 1 : d.rr0) : d.zr0;
+        const int hi = (role == 1) ? (h1r ? n : d.rr1) : d.zr1;
+        const int r0 = lo + PSD_BLOCK_X * T;
+        if (r0 > hi) return;
+        const int nr = (hi - r0 + 1 < T) ? (hi - r0 + 1) : T;
+        psd_z* base = (role == 1) ? P.H : P.Z;
+        const psd_mat<psd_z> M = psd_mat<psd_z>{base + (size_t)(l - 1) * n * n, n};
+        PSD_PAR_FOR(e, cnt) { ltr[e] = P.tr[(size_t)(own - 1) * PSD_GTR_CAP + e]; }
+        PSD_PAR_FOR(t, S * nr) {
+            const int r = t % nr, c = t / nr;
+            tile[c * T + r] = M(r0 + r, d.plo + c);
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(r, nr) {
+            if (h1r && r0 + r >= d.plo && r0 + r <= d.phi) continue;
+            for (int e = 0; e < cnt; ++e) {
+                const psd_ztr tr = ltr[e];
+                const int c = tr.pos - d.plo;
+                psd_z a1 = tile[c * T + r], a2 = tile[(c + 1) * T + r];
+                psd_zrot_right_adj(tr.c, tr.s, a1, a2);
+                tile[c * T + r] = a1;
+                tile[(c + 1) * T + r] = a2;
+            }
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(t, S * nr) {
+            const int r = t % nr, c = t / nr;
+            if (h1r && r0 + r >= d.plo && r0 + r <= d.phi) continue;
+            M(r0 + r, d.plo + c) = tile[c * T + r];
+        }
+    }
+}
+
+// Deferred right side of H_1 after a zero-shift pass (generalized.jl:436-444)
+PSD_KERNEL psd_zgq_defer(psd_zgparams P, int n) {
+    const psd_gapply_desc d = *P.desc;
+    if (!d.active || d.defer_run != 1) return;
+    const psd_mat<psd_z> H1 = psd_mat<psd_z>{P.H, n};
+    const int NT = PSD_NTHREADS;
+    const int rbase = d.drow0 + PSD_BLOCK_X * NT;
+    PSD_PAR_FOR(t, NT) {
+        const int r = rbase + t;
+        if (r <= d.djhi + 1 && d.djhi >= d.djlo) {
+            int j = (r - 1 > d.djlo) ? (r - 1) : d.djlo;
+            psd_z a1 = H1(r, j);
+            for (; j <= d.djhi; ++j) {
+                const psd_ztr g = P.dG[j];
+                psd_z a2 = H1(r, j + 1);
+                psd_zrot_right_adj(g.c, g.s, a1, a2);
+                H1(r, j) = a1;
+                a1 = a2;
+            }
+            H1(r, d.djhi + 1) = a1;
+        }
+    }
+}
+
+PSD_KERNEL psd_zgq_init(psd_zgparams P, int n, int p, int wantT, int wantZ, int W, int maxitfac, int maxlog,
+                        int hessmode) {
+    const psd_mat<psd_z> H1 = psd_mat<psd_z>{P.H, n};
+    if (!hessmode) PSD_PAR_FOR(c, n) {
+        for (int r = c + 3; r <= n; ++r) H1(r, c + 1) = zmk(0.0, 0.0);  // _gethess!
+    }
+    PSD_ONE {
+        psd_zgstate st;
+        st.n = n; st.p = p; st.wantT = wantT; st.wantZ = wantZ; st.W = W;
+        st.phase = PSD_GPH_CHECK; st.info = 0;
+        st.ilast = n; st.ifirst = 1; st.ifirstm = 1; st.ilastm = n; st.iiter = 1;
+        st.ziter = (p >= 20) ? -1 : 0;
+        st.jiter = 0; st.maxit = maxitfac * n;
+        st.jlo = 1; st.kcur = 0; st.zflag = 0; st.hj = 0;
+        st.nsweeps = st.nzshift = st.nsplit = st.ncase2 = st.ncase3 = st.nwindows = st.nlog = 0;
+        st.maxlog = maxlog;
+        st.c0 = 1.0; st.s0 = zmk(0.0, 0.0);
+        st.ulp = PSD_DBL_EPS;
+        st.safmin = PSD_DBL_MIN;
+        st.smlnum = PSD_DBL_MIN * ((double)n / PSD_DBL_EPS);
+        for (int q = 0; q < 6; ++q) st.cyc[q] = 0;
+        if (n == 0) st.phase = PSD_GPH_DONE;
+        if (hessmode) {
+            st.phase = (n >= 3) ? PSD_GPH_HESS : PSD_GPH_DONE;
+            st.hj = 1;
+            st.kcur = n - 1;
+            st.wantT = 1;
+        }
+        *P.st = st;
+        P.desc->active = 0;
+        P.desc->defer_run = 0;
+    }
+}
+
+// generalized.jl:860-908 with a signature, factor l (launched for l = p..2): diag(T_l) real >= 0; the phases go into
+// row j (S[l]) or column j (!S[l]) of T_l, column j of Z_l and column j (S[l-1]) or row j (!S[l-1]) of T_{l-1}.
+// grid = n blocks (one per j)
+PSD_KERNEL psd_zgq_phase(psd_zgparams P, int n, int l, int wantZ) {
+    PSD_LDS_DECL;
+    psd_z* zs = (psd_z*)psd_lds;
+    const int j = PSD_BLOCK_X + 1;
+    const psd_mat<psd_z> Hl = psd_zgfac(P, n, l);
+    const psd_mat<psd_z> Hm = psd_zgfac(P, n, l - 1);
+    const bool sl = psd_zgsig(P, l), sm = psd_zgsig(P, l - 1);
+    PSD_ONE {
+        const psd_z d = Hl(j, j);
+        const double abst = zabs(d);
+        psd_z z = zmk(1.0, 0.0);
+        if (abst > PSD_DBL_MIN) {
+            z = zconj(zmk(d.re / abst, d.im / abst));
+            Hl(j, j) = zmk(abst, 0.0);
+        }
+        zs[0] = z;
+    }
+    PSD_SYNC();
+    const psd_z z = zs[0];
+    if (z.re == 1.0 && z.im == 0.0) return;
+    // sf[j] = z (S[l]) or conj(z) (!S[l]);  Z_l[:, j] *= conj(sf);  T_{l-1}: column j *= conj(sf) (S) / row j *= sf (!S)
+    const psd_z sf = sl ? z : zconj(z);
+    const psd_z sfc = zconj(sf);
+    if (sl) {
+        PSD_PAR_FOR(t, n - j) { Hl(j, j + 1 + t) = zmul(Hl(j, j + 1 + t), z); }
+    } else {
+        PSD_PAR_FOR(t, j - 1) { Hl(t + 1, j) = zmul(Hl(t + 1, j), z); }
+    }
+    if (wantZ) {
+        const psd_mat<psd_z> Zl = psd_mat<psd_z>{P.Z + (size_t)(l - 1) * n * n, n};
+        PSD_PAR_FOR(r, n) { Zl(r + 1, j) = zmul(Zl(r + 1, j), sfc); }
+    }
+    if (sm) {
+        PSD_PAR_FOR(r, j) { Hm(r + 1, j) = zmul(Hm(r + 1, j), sfc); }
+    } else {
+        PSD_PAR_FOR(t, n - j + 1) { Hm(j, j + t) = zmul(Hm(j, j + t), sf); }
+    }
+}
+
+// ---- stage 1 helpers of the complex signed Hessenberg reduction ------------------------------------------------------
+// in place B(r, c) = conj(A(n+1-c, n+1-r)).  grid = n (columns)
+PSD_KERNEL psd_zantitranspose(psd_z* A, int n) {
+    const psd_mat<psd_z> M = psd_mat<psd_z>{A, n};
+    const int c = PSD_BLOCK_X + 1;
+    PSD_PAR_FOR(t, n) {
+        const int r = t + 1;
+        const int r2 = n + 1 - c, c2 = n + 1 - r;
+        if (r + c < n + 1) {
+            const psd_z x = M(r, c);
+            M(r, c) = zconj(M(r2, c2));
+            M(r2, c2) = zconj(x);
+        } else if (r + c == n + 1) {
+            M(r, c) = zconj(M(r, c));
+        }
+    }
+}
+PSD_KERNEL psd_zflip(psd_z* A, int n, int rows) {
+    const psd_mat<psd_z> M = psd_mat<psd_z>{A, n};
+    const int k = PSD_BLOCK_X + 1;
+    if (rows == 0) {
+        if (k > n / 2) return;
+        PSD_PAR_FOR(t, n) {
+            const psd_z x = M(t + 1, k);
+            M(t + 1, k) = M(t + 1, n + 1 - k);
+            M(t + 1, n + 1 - k) = x;
+        }
+    } else {
+        PSD_PAR_FOR(t, n / 2) {
+            const psd_z x = M(t + 1, k);
+            M(t + 1, k) = M(n - t, k);
+            M(n - t, k) = x;
+        }
+    }
+}
+PSD_KERNEL psd_ztril_zero(psd_z* A, int n) {
+    const psd_mat<psd_z> M = psd_mat<psd_z>{A, n};
+    const int c = PSD_BLOCK_X + 1;
+    PSD_PAR_FOR(t, n) {
+        if (t + 1 > c) M(t + 1, c) = zmk(0.0, 0.0);
+    }
+}

@@ -671,3 +671,112 @@ def case_rg_full_sizes(eng, sizes):
         pt.rgpschur_check(A, S, ps, tol=100 * max(1.0, np.sqrt(n / 32)), qtol=10 * max(1.0, np.sqrt(n / 32)))
         po = pt.oracle_gpschur(A, S, lr)
         assert pt.match_eigs(po.values, ps.values) < 1e-8 * max(1.0, abs(po.values).max())
+
+
+# ---- complex generalized (signed) path: generalized.jl with S containing false; test/generalized.jl complex parts ----
+def _zg_run(eng, A, S, tol=100, **kw):
+    ps = eng.zpschur_hess_(A[0].copy(order="F"), [a.copy(order="F") for a in A[1:]], S, **kw)
+    pt.gpschur_check(A, S, ps, tol=tol)
+    return ps
+
+
+def _zg_match_oracle(A, S, ps, rtol=1e-9):
+    po = pt.oracle_zpschur_hess(A[0], A[1:], S)
+    assert po.info == 0
+    fin = np.isfinite(po.values)
+    assert fin.sum() == np.isfinite(ps.values).sum()
+    if fin.any():
+        assert pt.match_eigs(po.values[fin], ps.values[np.isfinite(ps.values)]) < rtol * max(1.0, abs(po.values[fin]).max())
+    return po
+
+
+def case_zg_hess_ut(eng, p):
+    # test/generalized.jl:67-76 (ComplexF64)
+    S = [True, False] + [True] * (p - 2)
+    for seed in range(3):
+        A = zhess_ut(5, p, 1800 + 10 * p + seed)
+        ps = _zg_run(eng, A, S)
+        _zg_match_oracle(A, S, ps)
+    A = zhess_ut(5, p, 1831 + p)
+    pr = eng.zpschur_hess_(A[0].copy(order="F"), [a.copy(order="F") for a in A[1:]], S, rev=True)
+    assert pr.orientation == "L" and pr.schurindex == p and pr.S == S[::-1]
+    pt.gpschur_check(A[1:][::-1] + [A[0]], S[::-1], pr)
+
+
+def case_zg_holes(eng):
+    """test/generalized.jl:77-152 (ComplexF64) and :165-174 (n = 32, p = 4, S = [T,F,T,F], A[2][3,3] = 0)."""
+    for (S, l, j) in RG_HOLES:
+        A = zhess_ut(5, 5, 1900)
+        A[l - 1][j - 1, j - 1] = 0.0
+        ps = _zg_run(eng, A, S)
+        po = _zg_match_oracle(A, S, ps)
+        c2, c3 = ps.stats.reserved % 1000, ps.stats.reserved // 1000
+        assert (c2, c3) == ((po.sweeplog[:, 0] == 2).sum(), (po.sweeplog[:, 0] == 3).sum())
+        assert c2 + c3 >= 1
+    for (n, p, S, l, j) in [(32, 4, [True, False, True, False], 2, 3), (40, 4, [True, True, False, True], 3, 30),
+                            (40, 4, [True, False, True, True], 2, 8), (30, 21, None, 5, 11)]:
+        if S is None:
+            S = [True] + [bool((q * 5 + 1) % 3) for q in range(1, p)]
+        A = zhess_ut(n, p, 140 + n + p)
+        A = [np.asfortranarray(a + 2 * np.eye(n)) if k > 0 else a for k, a in enumerate(A)]
+        A[l - 1][j - 1, j - 1] = 0.0
+        ps = _zg_run(eng, A, S, tol=100 * max(1, n / 32))
+        _zg_match_oracle(A, S, ps, rtol=1e-8)
+
+
+def case_zg_windows(eng, sizes):
+    for (n, p, pat) in sizes:
+        if pat == "alt":
+            S = [True] + [bool(q % 2 == 0) for q in range(1, p)]
+        elif pat == "neg":
+            S = [True] + [False] * (p - 1)
+        else:
+            S = [True] + [bool((q * 7 + n) % 3) for q in range(1, p)]
+            if all(S):
+                S[-1] = False
+        A = zhess_ut(n, p, 1300 + n + p)
+        A = [np.asfortranarray(a + 1.0 * np.eye(n)) if k > 0 else a for k, a in enumerate(A)]
+        ps = _zg_run(eng, A, S, tol=100 * max(1, np.sqrt(n / 32)))
+        _zg_match_oracle(A, S, ps, rtol=1e-8)
+        assert ps.stats.nsweeps > 0
+        fast = eng.zpschur_hess_(A[0].copy(order="F"), [a.copy(order="F") for a in A[1:]], S, wantZ=False, wantT=False)
+        assert pt.match_eigs(ps.values, fast.values) < 1e-8 * abs(ps.values).max()
+
+
+def case_zg_phessenberg(eng, p):
+    # test/generalized.jl:1-40 (ComplexF64)
+    n = 5
+    S = [True]
+    for _ in range(1, p):
+        S.append(not S[-1])
+    A = pt.rand_uniform_zfactors(n, p, seed=1700 + p)
+    Hs, Qs = eng.gphessenberg_([a.copy(order="F") for a in A], S)
+    pt.sg_hess_check(A, S, Hs, Qs)
+    for (n2, p2, S2) in [(9, 6, [True, True, False, False, True, False]), (33, 4, [True, False, False, False]),
+                         (40, 3, [True, False, True])]:
+        A = pt.bench_factors(n2, p2, seed=3 + n2, dtype=np.complex128)
+        Hs, Qs = eng.gphessenberg_([a.copy(order="F") for a in A], S2)
+        pt.sg_hess_check(A, S2, Hs, Qs, tol=20 * max(1, n2 / 8), qtol=10 * max(1, n2 / 16))
+
+
+def case_zg_full(eng, lr):
+    # test/generalized.jl:188-232
+    n, p = 5, 4
+    S = [True, False, True, False] if lr == "R" else [False, True, False, True]
+    for seed in range(3):
+        A = pt.rand_uniform_zfactors(n, p, 1970 + seed)
+        ps = eng.pschur_([a.copy(order="F") for a in A], lr, S=S)
+        assert ps.schurindex == (1 if lr == "R" else p) and ps.orientation == lr
+        pt.gpschur_check(A, S, ps)
+        po = pt.oracle_gpschur(A, S, lr)
+        assert pt.match_eigs(po.values, ps.values) < 1e-9 * max(1.0, abs(po.values).max())
+    for (n2, p2) in [(24, 3), (40, 6)]:
+        S2 = [bool((q * 7 + n2) % 3) for q in range(p2)]
+        S2[p2 - 1 if lr == "L" else 0] = True
+        if all(S2):
+            S2[1] = False
+        A = pt.bench_factors(n2, p2, seed=n2 + p2, dtype=np.complex128)
+        ps = eng.pschur_([a.copy(order="F") for a in A], lr, S=S2)
+        pt.gpschur_check(A, S2, ps, tol=100 * max(1.0, np.sqrt(n2 / 32)), qtol=10 * max(1.0, np.sqrt(n2 / 32)))
+        po = pt.oracle_gpschur(A, S2, lr)
+        assert pt.match_eigs(po.values, ps.values) < 1e-8 * max(1.0, abs(po.values).max())

@@ -68,3 +68,27 @@ def test_rg_config4_full(gpu_engine):
     po = pt.oracle_gpschur(A, S, "R")
     assert po.info == 0
     assert pt.match_eigs(po.values, ps.values) < 1e-8 * abs(po.values).max()
+
+
+# ---- complex signed path (csrc/psd_zgz.h) ----
+@pytest.mark.parametrize("p", [2, 3, 5])
+def test_zg_hess_ut(gpu_engine, p):
+    ec.case_zg_hess_ut(gpu_engine, p)
+
+
+def test_zg_holes(gpu_engine):
+    ec.case_zg_holes(gpu_engine)
+
+
+def test_zg_windows(gpu_engine):
+    ec.case_zg_windows(gpu_engine, [(40, 3, "alt"), (45, 6, "mix"), (33, 5, "neg"), (30, 22, "mix"), (130, 8, "alt")])
+
+
+@pytest.mark.parametrize("p", [2, 5])
+def test_zg_phessenberg(gpu_engine, p):
+    ec.case_zg_phessenberg(gpu_engine, p)
+
+
+@pytest.mark.parametrize("lr", ["R", "L"])
+def test_zg_full(gpu_engine, lr):
+    ec.case_zg_full(gpu_engine, lr)

@@ -39,3 +39,27 @@ def test_rg_full(sim_engine, lr):
 
 def test_rg_full_sizes(sim_engine):
     ec.case_rg_full_sizes(sim_engine, [(24, 3, "R", "mix"), (40, 6, "L", "mix"), (30, 4, "R", "true"), (33, 21, "L", "mix")])
+
+
+# ---- complex signed path (csrc/psd_zgz.h) ----
+@pytest.mark.parametrize("p", [2, 3, 5])
+def test_zg_hess_ut(sim_engine, p):
+    ec.case_zg_hess_ut(sim_engine, p)
+
+
+def test_zg_holes(sim_engine):
+    ec.case_zg_holes(sim_engine)
+
+
+def test_zg_windows(sim_engine):
+    ec.case_zg_windows(sim_engine, [(40, 3, "alt"), (45, 6, "mix"), (33, 5, "neg"), (30, 22, "mix")])
+
+
+@pytest.mark.parametrize("p", [2, 5])
+def test_zg_phessenberg(sim_engine, p):
+    ec.case_zg_phessenberg(sim_engine, p)
+
+
+@pytest.mark.parametrize("lr", ["R", "L"])
+def test_zg_full(sim_engine, lr):
+    ec.case_zg_full(sim_engine, lr)
