@@ -227,18 +227,118 @@ PSD_D void psd_gdesc_write(const psd_gparams& P, const psd_gstate& st, const int
 //             (H_l[q+1,q+1], -H_l[q+1,q])  (:993-1004, :906-920).  A "backwards" Givens(q+1, q, c, s') of the
 //             zero-shift / Case II text (:294-300) is the same rotation.
 // Returns the new rotation in (c, s); it acts on the rows (cols_in) or columns (!cols_in) of H_l.
-PSD_D void psd_g_link(const psd_gwin& w, int l, int q, bool cols_in, double& c, double& s, int rlo, int chi) {
+// One fused pass: every operand is loaded once into a lane register (row lanes hold (H[r,q], H[r,q+1]), column
+// lanes hold (H[q,cc], H[q+1,cc])), the 2x2 corner travels by v_readlane, one wave-level sync.
+// If slot >= 0 the new rotation is also stored as entry `slot` of owner `own`'s list (lane 0, no counter round trip).
+PSD_D void psd_g_link(const psd_gwin& w, int l, int q, bool cols_in, double& c, double& s, int rlo, int chi,
+                      psd_gtr* trbase = nullptr, int own = 0, int slot = -1) {
+    const int r0 = (rlo > w.bs) ? rlo : w.bs;
+    const int c1 = (chi < w.be) ? chi : w.be;
+    double* base = w.b + (l - 1) * w.bsz;
+    PSD_LANEVAR(double, x1);
+    PSD_LANEVAR(double, x2);
+    PSD_LANEVAR(int, off);
+    PSD_LANEVAR(int, str);
     double r;
     if (cols_in) {
-        psd_gwin_right(w, l, q, c, s, rlo, q + 1);
-        psd_givens(w.at(l, q, q), w.at(l, q + 1, q), c, s, r);
-        psd_gwin_set2(w, l, q, q, r, q + 1, q, 0.0);
-        psd_gwin_left(w, l, q, c, s, q + 1, chi);
+        const int nr = q + 2 - r0, nl = c1 - q;  // rows r0..q+1 ; columns q+1..c1
+        PSD_PAR_ONCE(t, nr + nl) {
+            if (t < nr) {
+                PSD_LV(off) = (q - w.bs) * w.ld + (r0 + t - w.bs);
+                PSD_LV(str) = w.ld;
+            } else {
+                PSD_LV(off) = (q + 1 + (t - nr) - w.bs) * w.ld + (q - w.bs);
+                PSD_LV(str) = 1;
+            }
+            const double a1 = base[PSD_LV(off)], a2 = base[PSD_LV(off) + PSD_LV(str)];
+            if (t < nr) {
+                PSD_LV(x1) = c * a1 + s * a2;
+                PSD_LV(x2) = c * a2 - s * a1;
+            } else {
+                PSD_LV(x1) = a1;
+                PSD_LV(x2) = a2;
+            }
+        }
+        const double f = PSD_BCAST(x1, nr - 2), g = PSD_BCAST(x1, nr - 1);
+        const double top = PSD_BCAST(x2, nr - 2), bot = PSD_BCAST(x2, nr - 1);
+        psd_givens(f, g, c, s, r);
+        PSD_PAR_ONCE(t, nr + nl) {
+            double* qp = base + PSD_LV(off);
+            if (t < nr) {
+                if (t >= nr - 2) {  // rows q, q+1: column q becomes (r, 0); their column q+1 belongs to the row pass
+                    qp[0] = (t == nr - 2) ? r : 0.0;
+                } else {
+                    qp[0] = PSD_LV(x1);
+                    qp[PSD_LV(str)] = PSD_LV(x2);
+                }
+            } else {
+                const double a1 = (t == nr) ? top : PSD_LV(x1), a2 = (t == nr) ? bot : PSD_LV(x2);
+                qp[0] = c * a1 + s * a2;
+                qp[1] = c * a2 - s * a1;
+            }
+        }
     } else {
-        psd_gwin_left(w, l, q, c, s, q, chi);
-        psd_givens(w.at(l, q + 1, q + 1), -w.at(l, q + 1, q), c, s, r);
-        psd_gwin_set2(w, l, q + 1, q + 1, r, q + 1, q, 0.0);
-        psd_gwin_right(w, l, q, c, s, rlo, q);
+        const int nl = c1 - q + 1, nr = q - r0;  // columns q..c1 ; rows r0..q-1
+        PSD_PAR_ONCE(t, nl + nr) {
+            if (t < nl) {
+                PSD_LV(off) = (q + t - w.bs) * w.ld + (q - w.bs);
+                PSD_LV(str) = 1;
+            } else {
+                PSD_LV(off) = (q - w.bs) * w.ld + (r0 + (t - nl) - w.bs);
+                PSD_LV(str) = w.ld;
+            }
+            const double a1 = base[PSD_LV(off)], a2 = base[PSD_LV(off) + PSD_LV(str)];
+            if (t < nl) {
+                PSD_LV(x1) = c * a1 + s * a2;
+                PSD_LV(x2) = c * a2 - s * a1;
+            } else {
+                PSD_LV(x1) = a1;
+                PSD_LV(x2) = a2;
+            }
+        }
+        // 2x2 corner after the row rotation: column q in lane 0, column q+1 in lane 1
+        const double p00 = PSD_BCAST(x1, 0), p10 = PSD_BCAST(x2, 0), p01 = PSD_BCAST(x1, 1), p11 = PSD_BCAST(x2, 1);
+        psd_givens(p11, -p10, c, s, r);
+        PSD_PAR_ONCE(t, nl + nr) {
+            double* qp = base + PSD_LV(off);
+            if (t == 0) {
+                qp[0] = c * p00 + s * p01;
+                qp[1] = 0.0;
+            } else if (t == 1) {
+                qp[0] = c * p01 - s * p00;
+                qp[1] = r;
+            } else if (t < nl) {
+                qp[0] = PSD_LV(x1);
+                qp[1] = PSD_LV(x2);
+            } else {
+                const double a1 = PSD_LV(x1), a2 = PSD_LV(x2);
+                qp[0] = c * a1 + s * a2;
+                qp[PSD_LV(str)] = c * a2 - s * a1;
+            }
+        }
+    }
+    if (slot >= 0 && slot < PSD_GTR_CAP) {
+        PSD_ONE {
+            psd_gtr tr;
+            tr.pos = q;
+            tr.pad = 0;
+            tr.c = c;
+            tr.s = s;
+            trbase[(size_t)(own - 1) * PSD_GTR_CAP + slot] = tr;
+        }
+    }
+    PSD_WAVE_SYNC();
+}
+PSD_D void psd_gstore_tr(const psd_gparams& P, int own, int slot, int pos, double c, double s) {
+    if (slot < PSD_GTR_CAP) {
+        PSD_ONE {
+            psd_gtr tr;
+            tr.pos = pos;
+            tr.pad = 0;
+            tr.c = c;
+            tr.s = s;
+            P.tr[(size_t)(own - 1) * PSD_GTR_CAP + slot] = tr;
+        }
     }
 }
 
@@ -870,7 +970,7 @@ PSD_D void psd_gq_case3(const psd_gparams& P, psd_gstate& st, int ldeflate, int 
 // window.  mode 0: generated from column j-1 of H_1 (tail of a sweep); mode 1: (c, s) given (perfect-shift rotation
 // of a 2x2 deflation, :717-742); mode 2: generated from `side` = column hj of H_1 outside the window (stage 2 of the
 // signed Hessenberg reduction, generalized.jl:1036-1044).
-PSD_D void psd_gq_tail(const psd_gparams& P, const psd_gstate& st, const psd_gwin& w, int* lcnt, int j, int mode,
+PSD_D void psd_gq_tail(const psd_gparams& P, const psd_gstate& st, const psd_gwin& w, int slot, int j, int mode,
                        double c, double s, double* side) {
     const int p = st.p;
     if (mode == 0) {
@@ -889,11 +989,9 @@ PSD_D void psd_gq_tail(const psd_gparams& P, const psd_gstate& st, const psd_gwi
     }
     // (stage 2: A_1 is still full to the left of the position, the rows take the rotation on every window column)
     psd_gwin_left(w, 1, j, c, s, (mode == 2) ? w.bs : j, st.ilastm);
-    psd_grecord(P, lcnt, 1, j, c, s);
-    for (int l = p; l >= 2; --l) {
-        psd_g_link(w, l, j, psd_gsig(P, l), c, s, st.ifirstm, st.ilastm);
-        psd_grecord(P, lcnt, l, j, c, s);  // rows owner of l if S[l], columns owner of l if !S[l]: both are l
-    }
+    psd_gstore_tr(P, 1, slot, j, c, s);
+    for (int l = p; l >= 2; --l)  // owner: rows owner of l if S[l], columns owner of l if !S[l]: both are l
+        psd_g_link(w, l, j, psd_gsig(P, l), c, s, st.ifirstm, st.ilastm, P.tr, l, slot);
     psd_gwin_right(w, 1, j, c, s, st.ifirstm, st.ilastm);
 }
 
@@ -916,7 +1014,9 @@ PSD_D void psd_gq_hess_window(const psd_gparams& P, psd_gstate& st, double* ldsd
     PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
     PSD_PAR_FOR(t, w.be - w.bs + 1) { side[t] = A1(w.bs + t, hj); }
     psd_gwin_load(P, w, n, p);
-    for (int q = qe; q >= qs; --q) psd_gq_tail(P, st, w, lcnt, q, 2, 0.0, 0.0, side);
+    for (int q = qe; q >= qs; --q) psd_gq_tail(P, st, w, qe - q, q, 2, 0.0, 0.0, side);
+    PSD_WAVE_SYNC();
+    PSD_PAR_FOR(m, p) { lcnt[m] = qe - qs + 1; }
     psd_gwin_store(P, w, n, p);
     PSD_PAR_FOR(t, w.be - w.bs + 1) { A1(w.bs + t, hj) = side[t]; }
     psd_gdesc_write(P, st, lcnt, w.bs, w.be, w.be + 1, n, 1, w.bs - 1, 0, 0, 0, 0, 1, hj + 1);
@@ -948,6 +1048,7 @@ PSD_D void psd_gq_sweep_window(const psd_gparams& P, psd_gstate& st, double* lds
     psd_gwin_load(P, w, n, p);
     const long long tc1 = psd_clock();
     int jstart = ks;
+    int slot = 0;  // every owner receives the same number of list entries: 2 (initial pass), 2 per position, 1 (tail)
     if (first && p > 1) {
         // initial transformation (:890-943): the shift rotations enter H_1 from the right and travel forward
         const int j = ifirst;
@@ -955,19 +1056,18 @@ PSD_D void psd_gq_sweep_window(const psd_gparams& P, psd_gstate& st, double* lds
         const int own = psd_gnext(1, p);
         psd_gwin_right(w, 1, j + 1, c2, s2, ifirstm, ilast);
         psd_gwin_right(w, 1, j, c1, s1, ifirstm, ilast);
-        psd_grecord(P, lcnt, own, j + 1, c2, s2);
-        psd_grecord(P, lcnt, own, j, c1, s1);
+        psd_gstore_tr(P, own, 0, j + 1, c2, s2);
+        psd_gstore_tr(P, own, 1, j, c1, s1);
         for (int l = 2; l <= p; ++l) {
             const bool sg = psd_gsig(P, l);
             const int ownl = psd_gnext(l, p);
-            psd_g_link(w, l, j + 1, !sg, c2, s2, ifirstm, ilastm);
-            psd_grecord(P, lcnt, ownl, j + 1, c2, s2);
-            psd_g_link(w, l, j, !sg, c1, s1, ifirstm, ilastm);
-            psd_grecord(P, lcnt, ownl, j, c1, s1);
+            psd_g_link(w, l, j + 1, !sg, c2, s2, ifirstm, ilastm, P.tr, ownl, 0);
+            psd_g_link(w, l, j, !sg, c1, s1, ifirstm, ilastm, P.tr, ownl, 1);
         }
         psd_gwin_left(w, 1, j + 1, c2, s2, ifirst, ilastm);
         psd_gwin_left(w, 1, j, c1, s1, ifirst, ilastm);
         jstart = ifirst + 1;
+        slot = 2;
     }
     for (int j = jstart; j <= ke; ++j) {
         double c1, s1, c2, s2;
@@ -987,21 +1087,25 @@ PSD_D void psd_gq_sweep_window(const psd_gparams& P, psd_gstate& st, double* lds
         }
         psd_gwin_left(w, 1, j + 1, c2, s2, j, ilastm);
         psd_gwin_left(w, 1, j, c1, s1, j, ilastm);
-        psd_grecord(P, lcnt, 1, j + 1, c2, s2);
-        psd_grecord(P, lcnt, 1, j, c1, s1);
+        psd_gstore_tr(P, 1, slot, j + 1, c2, s2);
+        psd_gstore_tr(P, 1, slot + 1, j, c1, s1);
         for (int l = p; l >= 2; --l) {
             const bool sg = psd_gsig(P, l);
-            psd_g_link(w, l, j + 1, sg, c2, s2, ifirstm, ilastm);
-            psd_grecord(P, lcnt, l, j + 1, c2, s2);
-            psd_g_link(w, l, j, sg, c1, s1, ifirstm, ilastm);
-            psd_grecord(P, lcnt, l, j, c1, s1);
+            psd_g_link(w, l, j + 1, sg, c2, s2, ifirstm, ilastm, P.tr, l, slot);
+            psd_g_link(w, l, j, sg, c1, s1, ifirstm, ilastm, P.tr, l, slot + 1);
         }
         const int lm = (j + 3 < ilastm) ? (j + 3) : ilastm;
         psd_gwin_right(w, 1, j + 1, c2, s2, ifirstm, lm);
         psd_gwin_right(w, 1, j, c1, s1, ifirstm, lm);
+        slot += 2;
     }
     const bool last = ke >= ilast - 2;
-    if (last) psd_gq_tail(P, st, w, lcnt, ilast - 1, 0, 0.0, 0.0, nullptr);
+    if (last) {
+        psd_gq_tail(P, st, w, slot, ilast - 1, 0, 0.0, 0.0, nullptr);
+        slot += 1;
+    }
+    PSD_WAVE_SYNC();
+    PSD_PAR_FOR(m, p) { lcnt[m] = slot; }
     const long long tc2 = psd_clock();
     psd_gwin_store(P, w, n, p);
     st.cyc[1] += tc1 - tc0;
@@ -1290,7 +1394,9 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
             w.be = ilast;
             PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
             psd_gwin_load(P, w, n, p);
-            psd_gq_tail(P, st, w, lcnt, j, 1, r1, r2, nullptr);
+            psd_gq_tail(P, st, w, 0, j, 1, r1, r2, nullptr);
+            PSD_WAVE_SYNC();
+            PSD_PAR_FOR(m, p) { lcnt[m] = 1; }
             psd_gwin_store(P, w, n, p);
             psd_gdesc_write(P, st, lcnt, w.bs, w.be, w.be + 1, st.ilastm, st.ifirstm, w.bs - 1, 0, 0, 0, 0);
             st.nwindows += 1;

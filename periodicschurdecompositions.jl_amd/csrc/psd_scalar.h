@@ -142,8 +142,11 @@ PSD_HD void psd_givens(double f, double g, double& cs, double& sn, double& r) {
             cs = f1 / r; sn = g1 / r;
             for (int q = 0; q < count; ++q) r *= safmn2;
         } else {
-            r = sqrt(f1 * f1 + g1 * g1);
-            cs = f1 / r; sn = g1 / r;
+            // common case: rsqrt + Newton pair instead of the IEEE sqrt and two divisions (the argument is in
+            // (2^-970, 2^970), far from the range limits)
+            double rinv;
+            psd_sqrt_pair_fast(f1 * f1 + g1 * g1, r, rinv);
+            cs = f1 * rinv; sn = g1 * rinv;
         }
         if (fabs(f) > fabs(g) && cs < 0.0) {
             cs = -cs; sn = -sn; r = -r;
