@@ -95,6 +95,11 @@ struct psd_ctx {
     int* log = nullptr;
     int logcap = 0;
     size_t step_lds_set = 0, zstep_lds_set = 0, rostep_lds_set = 0;
+    psd_hess_args* hargs = nullptr;  // device argument block of the graph-replayed Hessenberg reduction
+#ifndef PSD_HOSTSIM
+    hipGraphExec_t hess_exec = nullptr;
+    int hess_graph_n = 0, hess_graph_p = 0;
+#endif
     psd_rostate* rost = nullptr;
     psd_tq* rotq = nullptr;
     unsigned char* rosel = nullptr;
@@ -185,6 +190,13 @@ struct psd_ctx {
     }
 
     void release() {
+        if (hargs) psd_rt_free(hargs);
+        hargs = nullptr;
+#ifndef PSD_HOSTSIM
+        if (hess_exec) (void)hipGraphExecDestroy(hess_exec);
+        hess_exec = nullptr;
+        hess_graph_n = hess_graph_p = 0;
+#endif
         void* ptrs[] = {dH, dZ, tau, vbuf, hdiag, hsub, hsup, Pd, Pe, Pf, hnorms, wr, wi, st, desc, tr, cnt, log};
         for (void* q : ptrs)
             if (q) psd_rt_free(q);
@@ -311,32 +323,55 @@ void fill_bytes(psd_stats* s, int n, int p, int wantT, int wantZ, const std::vec
 
 // PSD.jl:213-259 on device: dH [p][n][n] internal order, overwritten LAPACK-style; tau [p][n]
 int hessenberg_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
-    const size_t nn = (size_t)n * n;
     PSD_CHECK(psd_rt_memset(dtau, 0, sizeof(double) * (size_t)n * p, c->stream));
     const size_t lds_refl = PSD_HESS_NT * 8;
     const size_t lds_apply = (PSD_HESS_NT + (size_t)n + 8) * 8;
-    for (int i = 1; i <= n - 1; ++i) {
+    if (n < 2) return 0;
+    if (!c->hargs) PSD_CHECK(psd_rt_malloc((void**)&c->hargs, sizeof(psd_hess_args)));
+    psd_hess_args ha;
+    ha.H = dH;
+    ha.tau = dtau;
+    ha.vbuf = c->vbuf;
+    ha.i = 1;
+    ha.p = p;
+    PSD_CHECK(psd_rt_h2d(c->hargs, &ha, sizeof(ha), c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));  // (ha lives on the stack)
+    const int nLmax = (n - 2 + 1 + 3) / 4;  // lc0 = 2
+    const int nR = (n + 31) / 32;
+    auto column = [&]() {  // the launches of one column i = hargs->i  (PSD.jl:229-247)
         for (int j = p; j >= 1; --j) {
-            const int r0 = (j == 1) ? (i + 1) : i;  // first row of the reflector
-            if (n - r0 + 1 < 2) continue;
-            double* Aj = dH + (size_t)(j - 1) * nn;
-            double* Ajm1 = dH + (size_t)((j == 1 ? p : j - 1) - 1) * nn;
-            PSD_LAUNCH(psd_hess_refl, psd_dim3(1), PSD_HESS_NT, lds_refl, c->stream, Aj, n, r0, i, c->vbuf,
-                       dtau + (size_t)(j - 1) * n + (i - 1));
-            const int lc0 = i + 1;
-            const int nL = (n - lc0 + 1 + 3) / 4;
-            const int nR = (n + 31) / 32;
-            if (Aj != Ajm1) {
-                PSD_LAUNCH(psd_hess_apply, psd_dim3(nL + nR), PSD_HESS_NT, lds_apply, c->stream, Aj, Ajm1, n, r0, lc0,
-                           (const double*)c->vbuf, nL);
+            PSD_LAUNCH(psd_hess_refl_g, psd_dim3(1), PSD_HESS_NT, lds_refl, c->stream, (const psd_hess_args*)c->hargs, n, j);
+            if (p > 1) {
+                PSD_LAUNCH(psd_hess_apply_g, psd_dim3(nLmax + nR), PSD_HESS_NT, lds_apply, c->stream,
+                           (const psd_hess_args*)c->hargs, n, j, nLmax, 0);
             } else {  // p == 1: same matrix, left then right (PSD.jl:245-246)
-                PSD_LAUNCH(psd_hess_apply, psd_dim3(nL), PSD_HESS_NT, lds_apply, c->stream, Aj, (double*)nullptr, n, r0,
-                           lc0, (const double*)c->vbuf, nL);
-                PSD_LAUNCH(psd_hess_apply, psd_dim3(nR), PSD_HESS_NT, lds_apply, c->stream, (double*)nullptr, Ajm1, n, r0,
-                           lc0, (const double*)c->vbuf, 0);
+                PSD_LAUNCH(psd_hess_apply_g, psd_dim3(nLmax + nR), PSD_HESS_NT, lds_apply, c->stream,
+                           (const psd_hess_args*)c->hargs, n, j, nLmax, 1);
+                PSD_LAUNCH(psd_hess_apply_g, psd_dim3(nLmax + nR), PSD_HESS_NT, lds_apply, c->stream,
+                           (const psd_hess_args*)c->hargs, n, j, nLmax, 2);
             }
         }
+        PSD_LAUNCH(psd_hess_next, psd_dim3(1), 64, 0, c->stream, c->hargs);
+    };
+#ifdef PSD_HOSTSIM
+    for (int i = 1; i <= n - 1; ++i) column();
+#else
+    if (c->hess_exec == nullptr || c->hess_graph_n != n || c->hess_graph_p != p) {
+        if (c->hess_exec) {
+            (void)hipGraphExecDestroy(c->hess_exec);
+            c->hess_exec = nullptr;
+        }
+        hipGraph_t graph = nullptr;
+        PSD_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        column();
+        PSD_CHECK(hipStreamEndCapture(c->stream, &graph));
+        PSD_CHECK(hipGraphInstantiate(&c->hess_exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        c->hess_graph_n = n;
+        c->hess_graph_p = p;
     }
+    for (int i = 1; i <= n - 1; ++i) PSD_CHECK(hipGraphLaunch(c->hess_exec, c->stream));
+#endif
     return 0;
 }
 

@@ -38,7 +38,7 @@ PSD_D double psd_block_sum(double* red, int NT) {
 }
 
 // x = A[r0:n, c]  ->  (beta, v);  vbuf[0] = tau, vbuf[1..m-1] = v (v0 = 1 implicit); tau_out = tau
-PSD_KERNEL psd_hess_refl(double* A, int n, int r0, int c, double* vbuf, double* tau_out) {
+PSD_D void psd_hess_refl_body(double* A, int n, int r0, int c, double* vbuf, double* tau_out) {
     PSD_LDS_DECL;
     double* red = (double*)psd_lds;
     const int NT = PSD_NTHREADS;
@@ -118,7 +118,7 @@ PSD_KERNEL psd_hess_refl(double* A, int n, int r0, int c, double* vbuf, double* 
 // H = I - tau [1;v][1;v]' of length m = n - r0 + 1.
 //   blocks [0, nL):   AL[r0:n, lc0:n] <- H' AL[r0:n, lc0:n]      (PSD.jl:238,245)
 //   blocks [nL, ..):  AR[:, r0:n]     <- AR[:, r0:n] H           (PSD.jl:239,246)
-PSD_KERNEL psd_hess_apply(double* AL, double* AR, int n, int r0, int lc0, const double* vbuf, int nL) {
+PSD_D void psd_hess_apply_body(double* AL, double* AR, int n, int r0, int lc0, const double* vbuf, int nL, int b) {
     PSD_LDS_DECL;
     const int NT = PSD_NTHREADS;  // 256
     const int m = n - r0 + 1;
@@ -126,7 +126,6 @@ PSD_KERNEL psd_hess_apply(double* AL, double* AR, int n, int r0, int lc0, const 
     if (tau == 0.0) return;
     double* red = (double*)psd_lds;  // NT doubles
     double* vs = red + NT;           // m doubles (v0 = 1)
-    const int b = PSD_BLOCK_X;
     if (b < nL) {
         if (!AL) return;
         const psd_mat<double> M = psd_mat<double>{AL, n};
@@ -183,6 +182,53 @@ PSD_KERNEL psd_hess_apply(double* AL, double* AR, int n, int r0, int lc0, const 
             }
         }
     }
+}
+
+PSD_KERNEL psd_hess_refl(double* A, int n, int r0, int c, double* vbuf, double* tau_out) {
+    psd_hess_refl_body(A, n, r0, c, vbuf, tau_out);
+}
+PSD_KERNEL psd_hess_apply(double* AL, double* AR, int n, int r0, int lc0, const double* vbuf, int nL) {
+    psd_hess_apply_body(AL, AR, n, r0, lc0, vbuf, nL, PSD_BLOCK_X);
+}
+
+// Graph-replay form of one column of the reduction.  The reduction is n-1 columns x p links x 2 launches of small
+// kernels, and issuing them one by one leaves the GPU idle two thirds of the time (host launch rate).  The launch
+// sequence of ONE column is captured into a hipGraph whose kernels take everything that changes from column to
+// column (the column index i, and the operand pointers of this call) from a small argument block in device memory;
+// the graph is then replayed n-1 times, psd_hess_next advancing i on the device.
+struct psd_hess_args {
+    double* H;
+    double* tau;
+    double* vbuf;
+    int i, p;
+};
+PSD_KERNEL psd_hess_refl_g(const psd_hess_args* G, int n, int j) {
+    const int i = G->i;
+    const int r0 = (j == 1) ? (i + 1) : i;
+    if (i > n - 1 || n - r0 + 1 < 2) return;
+    psd_hess_refl_body(G->H + (size_t)(j - 1) * n * n, n, r0, i, G->vbuf, G->tau + (size_t)(j - 1) * n + (i - 1));
+}
+// grid = nLmax + nR blocks; mode 0: left on A_j and right on A_{j-1}; 1: left only; 2: right only (p == 1)
+PSD_KERNEL psd_hess_apply_g(const psd_hess_args* G, int n, int j, int nLmax, int mode) {
+    const int i = G->i;
+    const int r0 = (j == 1) ? (i + 1) : i;
+    if (i > n - 1 || n - r0 + 1 < 2) return;
+    const int lc0 = i + 1;
+    const int nL = (n - lc0 + 1 + 3) / 4;
+    const int b = PSD_BLOCK_X;
+    const int jm1 = (j == 1) ? G->p : (j - 1);
+    double* Aj = G->H + (size_t)(j - 1) * n * n;
+    double* Am = G->H + (size_t)(jm1 - 1) * n * n;
+    if (b < nLmax) {
+        if (b >= nL || mode == 2) return;
+        psd_hess_apply_body(Aj, nullptr, n, r0, lc0, G->vbuf, nL, b);
+    } else {
+        if (mode == 1) return;
+        psd_hess_apply_body(nullptr, Am, n, r0, lc0, G->vbuf, nL, nL + (b - nLmax));
+    }
+}
+PSD_KERNEL psd_hess_next(psd_hess_args* G) {
+    PSD_ONE { G->i += 1; }
 }
 
 // Q <- I for all p factors.  grid = (n, p)
