@@ -294,6 +294,47 @@ int psdo_sg_phessenberg(int n, int p, int is_complex, double* A, const uint8_t* 
     return 0;
 }
 
+// ordschur!(P::GeneralizedPeriodicSchur, select) by 1x1 swaps (ordschur.jl:11-96, sylswap.jl:638-764).  T/Z [p][n][n]
+// in user order (T1 at `schurindex`), S user-order signature; eigenvalues recomputed in scaled form.
+int psdo_gordschur(int n, int p, int is_complex, double* Td, double* Zd, const uint8_t* S, char orient, int schurindex,
+                   const uint8_t* select, int wantZ, double* alpha, double* beta, int32_t* ascale, int64_t* nswaps) {
+    std::vector<char> Su(p + 1, 1);
+    for (int l = 1; l <= p; ++l) Su[l] = S[l - 1] ? 1 : 0;
+    cplx* al = reinterpret_cast<cplx*>(alpha);
+    std::vector<cplx> v(p);
+    int info;
+    if (is_complex) {
+        std::vector<MatT<cplx>> Tu(p + 1), Zu(p + 1);
+        for (int l = 1; l <= p; ++l) {
+            Tu[l] = MatT<cplx>{reinterpret_cast<cplx*>(Td) + (size_t)(l - 1) * n * n, n};
+            Zu[l] = MatT<cplx>{Zd ? reinterpret_cast<cplx*>(Zd) + (size_t)(l - 1) * n * n : nullptr, n};
+        }
+        info = gordschur1x1<cplx>(n, p, Tu, Zu, Su, wantZ != 0 && Zd, orient, schurindex, select, nswaps);
+        if (info != 0) return info;
+        for (int j = 1; j <= n; ++j) {  // ordschur.jl:75-96: user order, _safeprod(P, v4ev) with P.S
+            for (int l = 2; l <= p; ++l) v[l - 2] = Tu[l](j, j);
+            int sc;
+            safeprod(Su, p, Tu[1](j, j), v.data(), al[j - 1], beta[j - 1], sc);
+            ascale[j - 1] = sc;
+        }
+    } else {
+        std::vector<MatT<double>> Tu(p + 1), Zu(p + 1);
+        for (int l = 1; l <= p; ++l) {
+            Tu[l] = MatT<double>{Td + (size_t)(l - 1) * n * n, n};
+            Zu[l] = MatT<double>{Zd ? Zd + (size_t)(l - 1) * n * n : nullptr, n};
+        }
+        info = gordschur1x1<double>(n, p, Tu, Zu, Su, wantZ != 0 && Zd, orient, schurindex, select, nswaps);
+        if (info != 0) return info;
+        for (int j = 1; j <= n; ++j) {
+            for (int l = 2; l <= p; ++l) v[l - 2] = cplx(Tu[l](j, j));
+            int sc;
+            safeprod(Su, p, cplx(Tu[1](j, j)), v.data(), al[j - 1], beta[j - 1], sc);
+            ascale[j - 1] = sc;
+        }
+    }
+    return 0;
+}
+
 // pschur!(H1, Hs, S; wantT, wantZ, Q, maxitfac) for Float64 — rgeneralized.jl:49-1083.  H, Z [p][n][n]; Z holds Q on
 // entry (identity for Q = nothing).  alpha is complex (2n doubles).  counters[8]: niter, sweeps, zero-shift passes,
 // Case II, Case III, 2x2 real deflations, 2x2 complex blocks, iwarn.

@@ -137,6 +137,8 @@ def oracle_lib():
     lib.psdo_d_ordschur.argtypes = [C.c_int, C.c_int, dp, dp, C.c_char, C.c_int, u8p, C.c_int, dp, dp, i64p]
     lib.psdo_sg_phessenberg.argtypes = [C.c_int, C.c_int, C.c_int, dp, u8p, dp]
     i32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    lib.psdo_gordschur.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, u8p, C.c_char, C.c_int, u8p, C.c_int, dp, dp,
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     lib.psdo_d_gpschur_hess.argtypes = [C.c_int, C.c_int, dp, u8p, dp, C.c_int, C.c_int, C.c_int, dp, dp, i32p, i64p]
     lib.psdo_gpschur.argtypes = [C.c_int, C.c_int, C.c_int, dp, u8p, C.c_char, C.c_int, C.c_int, C.c_int, dp, dp, dp,
                                  i32p, C.POINTER(C.c_int), i64p]
@@ -421,6 +423,52 @@ def rgpschur_check(As, S, ps, qtol=10, tol=100, lam_check=True):
             k = int(np.argmin(d))
             assert d[k] <= max(1e-8 * abs(z), 100 * scale), (z, ref[k], d[k], scale)
             used[k] = True
+
+
+def oracle_gordschur(ps, select, wantZ=True):
+    """CPU restatement of ordschur!(P::GeneralizedPeriodicSchur, select) by 1x1 swaps (ordschur.jl:11-96,
+    sylswap.jl:638-764).  Returns a new GPSD record and the number of swaps."""
+    lib = oracle_lib()
+    p = len(ps.Ts)
+    n = ps.Ts[0].shape[0]
+    cplx = np.iscomplexobj(ps.Ts[0])
+    dt = np.complex128 if cplx else np.float64
+    T = pack(ps.Ts, dt)
+    Z = pack(ps.Z, dt) if wantZ else None
+    ptr = _zp if cplx else _dp
+    sel = (C.c_uint8 * n)(*[1 if x else 0 for x in select])
+    Sarr = (C.c_uint8 * p)(*[1 if x else 0 for x in ps.S])
+    alpha = np.zeros(n, dtype=np.complex128)
+    beta = np.zeros(n)
+    sc = np.zeros(n, dtype=np.int32)
+    nsw = C.c_int64(0)
+    info = lib.psdo_gordschur(n, p, int(cplx), ptr(T), ptr(Z) if wantZ else None, Sarr, ps.orientation.encode()[0:1],
+                              ps.schurindex, sel, int(wantZ), _zp(alpha), _dp(beta),
+                              sc.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nsw))
+    out = GPSD(ps.S, unpack(T), unpack(Z) if wantZ else [], alpha, beta, sc, ps.orientation, ps.schurindex, info)
+    out.nswaps = nsw.value
+    return out
+
+
+def gord_test_factors(n, p, S, seed, cplx):
+    """test/ordschur.jl:167-190: well separated real spectrum 4^j spread over the factors with signature S, hidden by
+    random unitary equivalences."""
+    rng = np.random.default_rng(seed)
+    def rnd(shape):
+        x = rng.random(shape)
+        return x + 1j * rng.random(shape) if cplx else x
+    A = [0.01 * np.triu(rnd((n, n))) for _ in range(p)]
+    for j in range(n):
+        mu = 2.0 ** (2 * (j + 1) / p)
+        for l in range(p):
+            A[l][j, j] = mu if S[l] else 1.0 / mu
+    for l in range(p):
+        g = rng.standard_normal((n, n)) + (1j * rng.standard_normal((n, n)) if cplx else 0)
+        q, _ = np.linalg.qr(g)
+        A[l] = q @ A[l] if S[l] else A[l] @ q.conj().T
+        l1 = (l + 1) % p
+        A[l1] = A[l1] @ q.conj().T if S[l1] else q @ A[l1]
+    return [np.asfortranarray(a) for a in A]
 
 
 def rand_uniform_zfactors(n, p, seed):

@@ -113,3 +113,41 @@ def test_zgen_full(built, lr):
         ps = pt.oracle_gpschur(A, S, lr)
         assert ps.info == 0
         pt.gpschur_check(A, S, ps)
+
+
+# test/ordschur.jl:165-222 "gen. ordschur: distinct real" for Float64 and ComplexF64
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("lr", ["L", "R"])
+def test_gordschur_distinct_real(built, cplx, lr):
+    p, n, nsel = 5, 7, 2
+    S = [True] * p
+    for l in range(0, p - 1, 2):
+        S[l] = False
+    A = pt.gord_test_factors(n, p, S, seed=31, cplx=cplx)
+    if lr == "R":  # the same problem seen from the right: reversed sequence and signature
+        A, S = A[::-1], S[::-1]
+    ps0 = pt.oracle_gpschur(A, S, lr)
+    assert ps0.info == 0
+    check = pt.gpschur_check if cplx else pt.rgpschur_check
+    check(A, S, ps0)
+    lam0 = ps0.values
+    for rev in (False, True):
+        idx = np.argsort(-np.abs(lam0) if rev else np.abs(lam0))
+        select = np.zeros(n, dtype=bool)
+        select[idx[:nsel]] = True
+        ps1 = pt.oracle_gordschur(ps0, select)
+        assert ps1.info == 0
+        check(A, S, ps1)
+        for j in range(nsel):
+            assert np.any(np.isclose(ps1.values[:nsel], lam0[idx[j]], rtol=1e-8))
+    # all-true signature: the signed swap must agree with the plain one
+    St = [True] * p
+    At = pt.gord_test_factors(n, p, St, seed=5, cplx=cplx)
+    if lr == "R":
+        At = At[::-1]
+    pg = pt.oracle_gpschur(At, St, lr)
+    select = np.zeros(n, dtype=bool)
+    select[[2, 5]] = True
+    g1 = pt.oracle_gordschur(pg, select)
+    assert g1.info == 0 and g1.nswaps > 0
+    check(At, St, g1)
