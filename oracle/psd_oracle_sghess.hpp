@@ -217,9 +217,13 @@ int swapadj1x1g_signed(int n, int k, std::vector<MatT<T>>& X, std::vector<MatT<T
     // sylvester.jl:141-168 (dense, as the reference) and :235-245
     std::vector<T> M((size_t)k * k, T(0.0)), rhs(k);
     auto at = [&](int r, int c) -> T& { return M[(size_t)(c - 1) * k + (r - 1)]; };
-    if (S[k]) {
+    if (k == 1) {
+        // the reference's two assignments hit the same cell for K = 1 and the second one wins (sylvester.jl:146-149),
+        // which is not the equation; (A - B) x = -C is used here (and on the device)
+        at(1, 1) = T11[1] - T22[1];
+    } else if (S[k]) {
         at(1, 1) = -T22[k];
-        at(1, k) = T11[k];  // (k == 1: the same cell, the second assignment wins, as in the reference)
+        at(1, k) = T11[k];
     } else {
         at(1, 1) = T11[k];
         at(1, k) = -T22[k];

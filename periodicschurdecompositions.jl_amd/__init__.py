@@ -171,6 +171,9 @@ class Engine:
                                          C.c_void_p, dp, dp, i32p, ip, C.POINTER(Stats), i32p, C.c_int64, ip]
         lib.psd_z_ordschur.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, dpp, C.c_char, C.c_int, C.POINTER(C.c_uint8),
                                        C.c_int, dp, dp, i32p, C.POINTER(Stats), ip]
+        lib.psd_z_gordschur.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, dpp, C.POINTER(C.c_uint8), C.c_char, C.c_int,
+                                        C.POINTER(C.c_uint8), C.c_int, dp, dp, i32p, C.POINTER(Stats), ip]
+        lib.psd_d_gordschur.argtypes = lib.psd_z_gordschur.argtypes
         lib.psd_d_ordschur.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, dpp, C.c_char, C.c_int, C.POINTER(C.c_uint8),
                                        C.c_int, dp, dp, C.POINTER(Stats), ip]
         self.ctx = C.c_void_p()
@@ -488,6 +491,8 @@ class Engine:
         p = len(P.Ts)
         if len(select) != n:
             raise DimensionMismatch("select must have one entry per eigenvalue")
+        if isinstance(P, GeneralizedPeriodicSchur) and not all(P.S):
+            return self._gordschur_(P, select, wantZ)
         if not np.iscomplexobj(P.Ts[0]):
             return self._rordschur_(P, select, wantZ)
         if P.schurindex not in (1, p):
@@ -517,6 +522,43 @@ class Engine:
             P.values = alpha / beta * np.exp2(sc.astype(np.float64))
         if isinstance(P, GeneralizedPeriodicSchur):
             P.alpha, P.beta, P.alphascale = alpha, beta, sc
+        P.stats = st
+        return P
+
+    def _gordschur_(self, P, select, wantZ):
+        """ordschur!(P::GeneralizedPeriodicSchur, select; wantZ) with a signed S — src/ordschur.jl:11-96,323-328,
+        src/sylswap.jl:638-764 (1x1 swaps; a Float64 decomposition needs a real spectrum in this build)."""
+        n = P.Ts[0].shape[0]
+        p = len(P.Ts)
+        if P.schurindex not in (1, p):
+            raise ValueError("only implemented for schurindex in (1,p)")  # src/ordschur.jl:32
+        cplx = np.iscomplexobj(P.Ts[0])
+        dt = np.complex128 if cplx else np.float64
+        self._as_work(P.Ts, dt)
+        wantZ = wantZ and len(P.Z) > 0
+        if wantZ:
+            self._as_work(P.Z, dt)
+        sel = (C.c_uint8 * n)(*[1 if x else 0 for x in select])
+        Sarr = (C.c_uint8 * p)(*[1 if x else 0 for x in P.S])
+        alpha = np.zeros(n, dtype=np.complex128)
+        beta = np.zeros(n)
+        sc = np.zeros(n, dtype=np.int32)
+        st = Stats()
+        info = C.c_int(0)
+        dp = C.POINTER(C.c_double)
+        fn = self.lib.psd_z_gordschur if cplx else self.lib.psd_d_gordschur
+        fn(self.ctx, n, p, self._ptrs(P.Ts), self._ptrs(P.Z) if wantZ else None, Sarr, P.orientation.encode(),
+           P.schurindex, sel, int(wantZ), alpha.view(np.float64).ctypes.data_as(dp), beta.ctypes.data_as(dp),
+           sc.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(st), C.byref(info))
+        iv = info.value
+        if iv == 3000:
+            raise SingularException()
+        if 2000 <= iv < 3000:
+            raise IllConditionedException(iv - 2000)
+        self._raise(iv)
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            P.values = alpha / beta * np.exp2(sc.astype(np.float64))
+        P.alpha, P.beta, P.alphascale = alpha, beta, sc
         P.stats = st
         return P
 

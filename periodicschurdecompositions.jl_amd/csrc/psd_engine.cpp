@@ -9,6 +9,7 @@
 #include "psd_rord.h"
 #include "psd_rgz.h"
 #include "psd_zgz.h"
+#include "psd_zgord.h"
 
 #include "../../include/psd_mi355x.h"
 
@@ -134,7 +135,7 @@ struct psd_ctx {
     psd_ztr *zgtr = nullptr, *zgdG = nullptr;
     unsigned char* zgS = nullptr;
     int* zgcnt = nullptr;
-    size_t zgstep_lds_set = 0;
+    size_t zgstep_lds_set = 0, zgostep_lds_set = 0;
 
     void zgrelease() {
         void* ptrs[] = {zgst, zgdesc, zgtr, zgdG, zgS, zgcnt};
@@ -1924,6 +1925,210 @@ int psd_d_gpschur_hess(psd_ctx* c, int n, int p, double* const* H, const uint8_t
     if (wantZ)
         for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(Q[j], c->dZ + j * nn, nn * 8, c->stream));
     PSD_CHECK(psd_rt_sync(c->stream));
+    return rc;
+}
+
+}  // extern "C"
+
+
+// =================================================================================================
+// ordschur! for GeneralizedPeriodicSchur (1x1 swaps)
+namespace {
+
+size_t zgord_lds_bytes(int p, int W) {
+    size_t b = (size_t)p * W * (W + 1) * 16 + (size_t)15 * p * 16 + ((size_t)p + 2) * 8 + (size_t)p * 4 + 64;
+    return (b + 15) & ~(size_t)15;
+}
+
+// dH/dZ in the internal right order, S internal signature
+int zgordschur_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t* S, const uint8_t* select, int wantZ,
+                   double* alpha, double* beta, int32_t* ascale, psd_stats* stats, int* info) {
+    int W = 0;
+    {
+        const int cand[] = {32, 24, 20, 16, 12, 10, 8, 6, 4};
+        for (int Wc : cand)
+            if (zgord_lds_bytes(p, Wc) <= 155 * 1024) {
+                W = Wc;
+                break;
+            }
+    }
+    if (W == 0) return *info = PSD_INFO_NOTIMPL;
+    PSD_CHECK(psd_rt_h2d(c->osel, select, (size_t)n, c->stream));
+    std::vector<unsigned char> hS(p, 1);
+    for (int l = 0; l < p; ++l) hS[l] = S[l] ? 1 : 0;
+    PSD_CHECK(psd_rt_h2d(c->zgS, hS.data(), (size_t)p, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    psd_zgoparams O;
+    O.z.H = dH;
+    O.z.Z = wantZ ? dZ : nullptr;
+    O.z.S = c->zgS;
+    O.z.st = c->zgst;
+    O.z.desc = c->zgdesc;
+    O.z.tr = c->zgtr;
+    O.z.cnt = c->zgcnt;
+    O.z.dG = c->zgdG;
+    O.z.alpha = c->zalpha;
+    O.z.beta = c->zbeta;
+    O.z.ascale = c->zascale;
+    O.z.log = c->zlog;
+    O.st = c->ost;
+    O.select = c->osel;
+    const size_t lds_step = zgord_lds_bytes(p, W);
+#ifndef PSD_HOSTSIM
+    if (lds_step > c->zgostep_lds_set) {
+        PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_zgord_step),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
+        c->zgostep_lds_set = lds_step;
+    }
+#endif
+    PSD_LAUNCH(psd_zgord_init, psd_dim3(1), 64, 0, c->stream, O, n, p, wantZ, W);
+    const size_t lds_apply = sizeof(psd_ztr) * PSD_GTR_CAP + (size_t)32 * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
+    const int tiles = (n + PSD_ZAPPLY_NT - 1) / PSD_ZAPPLY_NT;
+    psd_ostate hst;
+    memset(&hst, 0, sizeof(hst));
+    long long launched = 0;
+    const long long cap = (long long)n * ((long long)n / (W > 1 ? W - 1 : 1) + 2) + 1024;
+    Timer t;
+    t.start(c->stream);
+    for (;;) {
+        for (int b = 0; b < 32; ++b) {
+            PSD_LAUNCH(psd_zgord_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, O);
+            PSD_LAUNCH(psd_zgq_apply, psd_dim3(tiles, p, 3), PSD_ZAPPLY_NT, lds_apply, c->stream, O.z, n, p);
+            ++launched;
+        }
+        PSD_CHECK(psd_rt_d2h(&hst, c->ost, sizeof(hst), c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+        if (hst.phase == PSD_OPH_DONE) break;
+        if (launched > cap) return *info = PSD_INFO_RUNTIME + 0xfffb;
+    }
+    if (hst.info == 0) {
+        PSD_LAUNCH(psd_zgord_values, psd_dim3((n + 255) / 256), 256, 0, c->stream, O.z, n, p);
+        PSD_CHECK(psd_rt_d2h(alpha, c->zalpha, sizeof(psd_z) * n, c->stream));
+        PSD_CHECK(psd_rt_d2h(beta, c->zbeta, sizeof(double) * n, c->stream));
+        std::vector<int> hsc(n, 0);
+        PSD_CHECK(psd_rt_d2h(hsc.data(), c->zascale, sizeof(int) * n, c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+        for (int q = 0; q < n; ++q) ascale[q] = hsc[q];
+    }
+    const double ms = t.stop(c->stream);
+    PSD_CHECK(psd_rt_last_error());
+    if (stats) {
+        stats->ms_iter = stats->ms_total = ms;
+        stats->nsweeps = hst.nswaps;
+        stats->nwindows = hst.nwindows;
+        stats->nlaunch_step = (int32_t)launched;
+        stats->window = W;
+    }
+    return *info = hst.info;
+}
+
+// host entry shared by the complex and the (promoted) real case; Tz/Zz: p host matrices of n*n complex
+int gordschur_host(psd_ctx* c, int n, int p, std::vector<std::vector<psd_z>>& Tz, std::vector<std::vector<psd_z>>& Zz,
+                   const uint8_t* S, char orient, int schurindex, const uint8_t* select, int wantZ, double* alpha,
+                   double* beta, int32_t* ascale, psd_stats* stats, int* info) {
+    if (!((orient == 'R' && schurindex == 1) || (orient == 'L' && schurindex == p))) {
+        if (schurindex != 1 && schurindex != p) return *info = -7;  // ArgumentError, ordschur.jl:32
+        return *info = PSD_INFO_NOTIMPL;
+    }
+    if ((*info = c->zreserve(n, p, true, 16)) != 0) return *info;
+    if ((*info = c->zgreserve(n, p)) != 0) return *info;
+    const size_t nn = (size_t)n * n;
+    const bool left = orient == 'L';
+    auto slotA = [&](int j) { return left ? (p + 1 - j) : j; };               // internal j <- user slot
+    auto slotZ = [&](int j) { return (!left || j == 1) ? j : (p + 2 - j); };
+    std::vector<uint8_t> Sint(p, 1);
+    for (int j = 1; j <= p; ++j) Sint[j - 1] = S[slotA(j) - 1] ? 1 : 0;
+    if (!Sint[0]) return *info = -5;
+    for (int j = 1; j <= p; ++j)
+        PSD_CHECK(psd_rt_h2d(c->zH + (size_t)(j - 1) * nn, Tz[slotA(j) - 1].data(), nn * 16, c->stream));
+    if (wantZ)
+        for (int j = 1; j <= p; ++j)
+            PSD_CHECK(psd_rt_h2d(c->zZ + (size_t)(j - 1) * nn, Zz[slotZ(j) - 1].data(), nn * 16, c->stream));
+    int rc = zgordschur_dev(c, n, p, c->zH, c->zZ, Sint.data(), select, wantZ, alpha, beta, ascale, stats, info);
+    if (rc < 0 || rc >= PSD_INFO_NOTIMPL) return rc;
+    for (int j = 1; j <= p; ++j)
+        PSD_CHECK(psd_rt_d2h(Tz[slotA(j) - 1].data(), c->zH + (size_t)(j - 1) * nn, nn * 16, c->stream));
+    if (wantZ)
+        for (int j = 1; j <= p; ++j)
+            PSD_CHECK(psd_rt_d2h(Zz[slotZ(j) - 1].data(), c->zZ + (size_t)(j - 1) * nn, nn * 16, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    return rc;
+}
+
+int gord_check_args(psd_ctx* c, int n, int p, const void* T, const void* Z, const uint8_t* S, char orient,
+                    const uint8_t* select, int wantZ, int* info) {
+    if (!c) return *info = -1;
+    if ((*info = check_dims(n, p)) != 0) return *info;
+    if (!T) return *info = -4;
+    if (wantZ && !Z) return *info = -5;
+    if (!S) return *info = -5;
+    if (orient != 'R' && orient != 'L') return *info = -6;
+    if (!select) return *info = -8;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int psd_z_gordschur(psd_ctx* c, int n, int p, double* const* T, double* const* Z, const uint8_t* S, char orient,
+                    int schurindex, const uint8_t* select, int wantZ, double* alpha, double* beta, int32_t* ascale,
+                    psd_stats* stats, int* info) {
+    int dummy;
+    if (!info) info = &dummy;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (gord_check_args(c, n, p, T, Z, S, orient, select, wantZ, info) != 0) return *info;
+    const size_t nn = (size_t)n * n;
+    std::vector<std::vector<psd_z>> Tz(p), Zz(wantZ ? p : 0);
+    for (int j = 0; j < p; ++j) {
+        Tz[j].resize(nn);
+        memcpy(Tz[j].data(), T[j], nn * 16);
+        if (wantZ) {
+            Zz[j].resize(nn);
+            memcpy(Zz[j].data(), Z[j], nn * 16);
+        }
+    }
+    int rc = gordschur_host(c, n, p, Tz, Zz, S, orient, schurindex, select, wantZ, alpha, beta, ascale, stats, info);
+    if (rc < 0 || rc >= PSD_INFO_NOTIMPL) return rc;
+    for (int j = 0; j < p; ++j) {
+        memcpy(T[j], Tz[j].data(), nn * 16);
+        if (wantZ) memcpy(Z[j], Zz[j].data(), nn * 16);
+    }
+    return rc;
+}
+
+// Float64 with a real spectrum (T1 triangular): promoted to the complex kernel, whose rotations stay real on real data.
+// A 2x2 block in T1 (conjugate pair) needs the signed block swap of sylswap.jl:197-538: PSD_INFO_NOTIMPL.
+int psd_d_gordschur(psd_ctx* c, int n, int p, double* const* T, double* const* Z, const uint8_t* S, char orient,
+                    int schurindex, const uint8_t* select, int wantZ, double* alpha, double* beta, int32_t* ascale,
+                    psd_stats* stats, int* info) {
+    int dummy;
+    if (!info) info = &dummy;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (gord_check_args(c, n, p, T, Z, S, orient, select, wantZ, info) != 0) return *info;
+    if (schurindex < 1 || schurindex > p) return *info = -7;
+    const size_t nn = (size_t)n * n;
+    {
+        const double* T1 = T[schurindex - 1];
+        for (int j = 0; j + 1 < n; ++j)
+            if (T1[(size_t)j * n + (j + 1)] != 0.0) return *info = PSD_INFO_NOTIMPL;
+    }
+    std::vector<std::vector<psd_z>> Tz(p), Zz(wantZ ? p : 0);
+    for (int j = 0; j < p; ++j) {
+        Tz[j].resize(nn);
+        for (size_t q = 0; q < nn; ++q) Tz[j][q] = zmk(T[j][q], 0.0);
+        if (wantZ) {
+            Zz[j].resize(nn);
+            for (size_t q = 0; q < nn; ++q) Zz[j][q] = zmk(Z[j][q], 0.0);
+        }
+    }
+    int rc = gordschur_host(c, n, p, Tz, Zz, S, orient, schurindex, select, wantZ, alpha, beta, ascale, stats, info);
+    if (rc < 0 || rc >= PSD_INFO_NOTIMPL) return rc;
+    for (int j = 0; j < p; ++j) {
+        for (size_t q = 0; q < nn; ++q) T[j][q] = Tz[j][q].re;
+        if (wantZ)
+            for (size_t q = 0; q < nn; ++q) Z[j][q] = Zz[j][q].re;
+    }
     return rc;
 }
 

@@ -780,3 +780,60 @@ def case_zg_full(eng, lr):
         pt.gpschur_check(A, S2, ps, tol=100 * max(1.0, np.sqrt(n2 / 32)), qtol=10 * max(1.0, np.sqrt(n2 / 32)))
         po = pt.oracle_gpschur(A, S2, lr)
         assert pt.match_eigs(po.values, ps.values) < 1e-8 * max(1.0, abs(po.values).max())
+
+
+# ---- ordschur! for GeneralizedPeriodicSchur (signed 1x1 swaps): test/ordschur.jl:165-222 ----
+def case_gordschur_reference(eng, cplx, lr):
+    import psd_amd
+
+    p, n, nsel = 5, 7, 2
+    S = [True] * p
+    for l in range(0, p - 1, 2):
+        S[l] = False
+    A = pt.gord_test_factors(n, p, S, seed=31, cplx=cplx)
+    if lr == "R":
+        A, S = A[::-1], S[::-1]
+    ps0 = eng.pschur_([a.copy(order="F") for a in A], lr, S=S)
+    check = pt.gpschur_check if cplx else pt.rgpschur_check
+    check(A, S, ps0)
+    lam0 = ps0.values.copy()
+    po0 = pt.GPSD(S, [t.copy() for t in ps0.Ts], [z.copy() for z in ps0.Z], ps0.alpha, ps0.beta, ps0.alphascale, lr,
+                  ps0.schurindex)
+    for rev in (False, True):
+        idx = np.argsort(-np.abs(lam0) if rev else np.abs(lam0))
+        select = np.zeros(n, dtype=bool)
+        select[idx[:nsel]] = True
+        P1 = psd_amd.GeneralizedPeriodicSchur(S, [t.copy(order="F") for t in ps0.Ts], [z.copy(order="F") for z in ps0.Z],
+                                              ps0.alpha.copy(), ps0.beta.copy(), ps0.alphascale.copy(), lr, ps0.schurindex)
+        ps1 = eng.ordschur_(P1, select)
+        check(A, S, ps1)
+        for j in range(nsel):
+            assert np.any(np.isclose(ps1.values[:nsel], lam0[idx[j]], rtol=1e-8))
+        po = pt.oracle_gordschur(po0, select)
+        assert po.info == 0 and po.nswaps == ps1.stats.nsweeps
+        assert pt.match_eigs(po.values, ps1.values) < 1e-9 * abs(po.values).max()
+
+
+def case_gordschur_windows(eng, sizes):
+    """larger signed problems: several windows, every signature class, with and without Z"""
+    import psd_amd
+
+    for (n, p, cplx, lr) in sizes:
+        S = [bool((q * 7 + n) % 3) for q in range(p)]
+        if all(S):
+            S[p // 2] = False
+        S[p - 1 if lr == "R" else 0] = True  # (after the reversal below the leftmost working entry is true)
+        A = pt.gord_test_factors(n, p, S if lr == "L" else S, seed=n + p, cplx=cplx)
+        if lr == "R":
+            A, S = A[::-1], S[::-1]
+        ps0 = eng.pschur_([a.copy(order="F") for a in A], lr, S=S)
+        lam0 = ps0.values.copy()
+        order = np.argsort(np.abs(lam0))
+        select = np.zeros(n, dtype=bool)
+        select[order[: n // 2]] = True
+        check = pt.gpschur_check if cplx else pt.rgpschur_check
+        ps1 = eng.ordschur_(ps0, select)
+        assert ps1.stats.nsweeps > 0
+        check(A, S, ps1, tol=100 * max(1.0, np.sqrt(n / 32)), qtol=10 * max(1.0, np.sqrt(n / 32)))
+        m = int(select.sum())
+        assert pt.match_eigs(lam0[select], ps1.values[:m]) < 1e-7 * abs(lam0).max()

@@ -92,3 +92,15 @@ def test_zg_phessenberg(gpu_engine, p):
 @pytest.mark.parametrize("lr", ["R", "L"])
 def test_zg_full(gpu_engine, lr):
     ec.case_zg_full(gpu_engine, lr)
+
+
+# ---- ordschur! of a GeneralizedPeriodicSchur (csrc/psd_zgord.h) ----
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("lr", ["L", "R"])
+def test_gordschur_reference(gpu_engine, cplx, lr):
+    ec.case_gordschur_reference(gpu_engine, cplx, lr)
+
+
+def test_gordschur_windows(gpu_engine):
+    ec.case_gordschur_windows(gpu_engine, [(12, 3, True, "L"), (12, 4, False, "R"), (40, 3, True, "R"),
+                                           (36, 21, True, "L"), (90, 6, True, "L"), (64, 5, False, "R")])
