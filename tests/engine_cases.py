@@ -274,17 +274,12 @@ def case_zexpsplit(eng, p):
 def case_zedge(eng):
     import psd_amd
 
-    try:
-        A = zhess_ut(5, 3, 91)
-        eng.zpschur_hess_(A[0].copy(order="F"), [a.copy(order="F") for a in A[1:]], [True, False, True])
-        raise AssertionError("negative signatures are not in this build")
-    except psd_amd.NotImplementedPSD:
-        pass
-    try:
-        eng.pschur(pt.rand_uniform_zfactors(4, 2, 5), S=[True, False])
-        raise AssertionError("signed complex case is not in this build")
-    except psd_amd.NotImplementedPSD:
-        pass
+    # negative signatures dispatch to the signed engine (generalized.jl:138-146)
+    A = zhess_ut(5, 3, 91)
+    pt.gpschur_check(A, [True, False, True],
+                     eng.zpschur_hess_(A[0].copy(order="F"), [a.copy(order="F") for a in A[1:]], [True, False, True]))
+    A2 = pt.rand_uniform_zfactors(4, 2, 5)
+    pt.gpschur_check(A2, [True, False], eng.pschur(A2, S=[True, False]))
     try:
         eng.pschur(pt.rand_uniform_zfactors(4, 2, 5), S=[False, True])
         raise AssertionError("leftmost S must be true")
