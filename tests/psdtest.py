@@ -459,7 +459,8 @@ def gord_test_factors(n, p, S, seed, cplx):
         return x + 1j * rng.random(shape) if cplx else x
     A = [0.01 * np.triu(rnd((n, n))) for _ in range(p)]
     for j in range(n):
-        mu = 2.0 ** (2 * (j + 1) / p)
+        # the reference's n = 7 spectrum 4^j; for larger n the same range [4, 4^7] is kept (well conditioned factors)
+        mu = 2.0 ** (2 * (j + 1) / p) if n <= 7 else 2.0 ** (2 * (1 + 6 * j / (n - 1)) / p)
         for l in range(p):
             A[l][j, j] = mu if S[l] else 1.0 / mu
     for l in range(p):
