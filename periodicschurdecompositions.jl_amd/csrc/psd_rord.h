@@ -10,8 +10,10 @@
 // MI355X structure (as psd_zord.h): a block travelling upwards is a chase; one wavefront keeps the
 // diagonal window of all p factors in LDS, performs as many adjacent swaps as fit, and emits one
 // dense m x m (m <= 4) orthogonal block transform per factor and swap; psd_rord_apply updates the
-// off-window rows of T_m, columns of T_{m-1} and Z_m at bandwidth.  The O(p) small dense algebra of
-// a swap (block-cyclic QR, 2x2 Hessenberg repair, stability test) runs on one lane out of LDS.
+// off-window rows of T_m, columns of T_{m-1} and Z_m at bandwidth.  The small dense algebra of a swap runs out of
+// LDS: the block-cyclic QR of the Sylvester system and the 2x2 Hessenberg repair are chains over the factors (the QR
+// itself spread over the lanes by columns, compile-time sized so that it stays in registers), everything else
+// (Q formation, block products, stability test) runs one factor per lane.
 #pragma once
 #include "psd_real_qr.h"
 #include "psd_zord.h"
@@ -61,52 +63,7 @@ PSD_D psd_rparams P_as_r(const psd_roparams& P) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// tiny dense helpers (column-major, explicit leading dimension), executed by one lane
-
-// Householder QR of the first nc columns of the nr x ncols matrix S (ld), applied to all columns.
-// Returns false if a diagonal entry of R is exactly zero.
-PSD_D bool psd_sm_qr(double* S, int ld, int nr, int ncols, int nc) {
-    bool ok = true;
-    for (int k = 0; k < nc; ++k) {
-        double nrm = 0.0;
-        for (int i = k; i < nr; ++i) nrm = hypot(nrm, S[k * ld + i]);
-        if (nrm == 0.0) {
-            ok = false;
-            continue;
-        }
-        const double alpha = S[k * ld + k];
-        const double beta = -copysign(nrm, alpha);
-        double v[8];
-        v[k] = alpha - beta;
-        double vn2 = v[k] * v[k];
-        for (int i = k + 1; i < nr; ++i) {
-            v[i] = S[k * ld + i];
-            vn2 += v[i] * v[i];
-        }
-        if (vn2 == 0.0) continue;
-        const double tau2 = 2.0 / vn2;
-        for (int c = k; c < ncols; ++c) {
-            double d = 0.0;
-            for (int i = k; i < nr; ++i) d += v[i] * S[c * ld + i];
-            d *= tau2;
-            for (int i = k; i < nr; ++i) S[c * ld + i] -= d * v[i];
-        }
-        S[k * ld + k] = beta;
-        for (int i = k + 1; i < nr; ++i) S[k * ld + i] = 0.0;
-    }
-    for (int k = 0; k < nc; ++k)
-        if (S[k * ld + k] == 0.0) ok = false;
-    return ok;
-}
-
-// solve R x = b, R pp x pp upper triangular (ld)
-PSD_D void psd_sm_trsv(const double* R, int ld, int pp, double* b) {
-    for (int k = pp - 1; k >= 0; --k) {
-        double s = b[k];
-        for (int c = k + 1; c < pp; ++c) s -= R[c * ld + k] * b[c];
-        b[k] = s / R[k * ld + k];
-    }
-}
+// tiny dense helpers (column-major, explicit leading dimension)
 
 // full m x m Q of the Householder QR of the m x nc matrix Xi (ld 4): Q' Xi = [R; 0].  Q is written as a full
 // 4 x 4 matrix, identity outside m x m (so that fixed-size 4 x 4 products need no masks).  Fixed trip counts and
