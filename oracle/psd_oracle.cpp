@@ -7,6 +7,7 @@
 #include "psd_oracle_rord.hpp"
 #include "psd_oracle_sghess.hpp"
 #include "psd_oracle_rgen.hpp"
+#include "psd_oracle_grord.hpp"
 
 #include <chrono>
 
@@ -323,14 +324,9 @@ int psdo_gordschur(int n, int p, int is_complex, double* Td, double* Zd, const u
             Tu[l] = MatT<double>{Td + (size_t)(l - 1) * n * n, n};
             Zu[l] = MatT<double>{Zd ? Zd + (size_t)(l - 1) * n * n : nullptr, n};
         }
-        info = gordschur1x1<double>(n, p, Tu, Zu, Su, wantZ != 0 && Zd, orient, schurindex, select, nswaps);
+        // 1x1 and 2x2 blocks, signed swaps (rordschur.jl + sylswap.jl:197-538,638-764)
+        info = grordschur(n, p, Tu, Zu, Su, wantZ != 0 && Zd, orient, schurindex, select, al, beta, ascale, nswaps);
         if (info != 0) return info;
-        for (int j = 1; j <= n; ++j) {
-            for (int l = 2; l <= p; ++l) v[l - 2] = cplx(Tu[l](j, j));
-            int sc;
-            safeprod(Su, p, cplx(Tu[1](j, j)), v.data(), al[j - 1], beta[j - 1], sc);
-            ascale[j - 1] = sc;
-        }
     }
     return 0;
 }

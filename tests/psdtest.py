@@ -531,7 +531,7 @@ def ord_test_factors(n, p, seed, dtype=np.float64):
     return A
 
 
-def mkrps(n, p, jcs, seed, nnfac=1e-2):
+def mkrps(n, p, jcs, seed, nnfac=1e-2, alt=False):
     """test/ordschur.jl:62-125 `mkrps` (alt = false, tri = false): a left-oriented real periodic Schur decomposition
     with schurindex p and conjugate pairs 4^jj (1 +- i) in the (1-based) rows jcs, jcs+1.  Returns (PSD, As)."""
     T1 = np.triu(nnfac * rand_uniform_factors(n, 1, seed)[0])
@@ -561,6 +561,15 @@ def mkrps(n, p, jcs, seed, nnfac=1e-2):
         As = [Zs[l + 1] @ Ts[l] @ Zs[l].T for l in range(p - 1)] + [Zs[0] @ T1 @ Zs[p - 1].T]
     else:
         As = [Zs[0] @ T1 @ Zs[0].T]
+    if alt:  # test/ordschur.jl:108-118: every other factor enters inverted
+        S = [True] * p
+        for l in range(0, p - 1, 2):
+            S[l] = False
+            Ts[l] = np.linalg.inv(Ts[l])
+            As[l] = Zs[l] @ Ts[l] @ Zs[l + 1].T
+        full = [np.asfortranarray(t) for t in Ts] + [np.asfortranarray(T1)]
+        ps = GPSD(S, full, [np.asfortranarray(z) for z in Zs], lam.copy(), np.ones(n), np.zeros(n, dtype=np.int32), "L", p)
+        return ps, [np.asfortranarray(a) for a in As]
     full = [np.asfortranarray(t) for t in Ts] + [np.asfortranarray(T1)]
     ps = PSD(full, [np.asfortranarray(z) for z in Zs], lam, "L", p)
     return ps, [np.asfortranarray(a) for a in As]

@@ -151,3 +151,43 @@ def test_gordschur_distinct_real(built, cplx, lr):
     g1 = pt.oracle_gordschur(pg, select)
     assert g1.info == 0 and g1.nswaps > 0
     check(At, St, g1)
+
+
+# test/ordschur.jl:226-275 "gen. ordschur Float64: conjugate pair(s)" (mkrps with alt = true) + random decompositions
+def test_gordschur_pairs_reference(built):
+    n, p = 7, 5
+    ps0, A = pt.mkrps(n, p, [3, 6], seed=905, alt=True)
+    pt.rgpschur_check(A, ps0.S, ps0)
+    lam0 = ps0.values
+    for selset in ([6, 7], [3, 4], [1, 2, 5], [1, 3, 4], [1, 2, 6, 7], [5]):
+        select = np.zeros(n, dtype=bool)
+        select[[j - 1 for j in selset]] = True
+        ps1 = pt.oracle_gordschur(ps0, select)
+        assert ps1.info == 0, ps1.info
+        pt.rgpschur_check(A, ps0.S, ps1, tol=400)
+        nsel = len(selset)
+        for j in selset:
+            assert np.any(np.isclose(ps1.values[:nsel], lam0[j - 1], rtol=1e-7)), (selset, ps1.values, lam0)
+
+
+@pytest.mark.parametrize("lr", ["L", "R"])
+def test_gordschur_pairs_random(built, lr):
+    for (n, p, seed) in [(10, 3, 1), (14, 4, 2), (16, 5, 3)]:
+        S = [bool((q * 7 + n) % 3) for q in range(p)]
+        if all(S):
+            S[1] = False
+        S[p - 1 if lr == "L" else 0] = True
+        A = pt.bench_factors(n, p, seed=seed + 40)
+        ps0 = pt.oracle_gpschur(A, S, lr)
+        assert ps0.info == 0
+        lam0 = ps0.values.copy()
+        assert np.any(lam0.imag != 0)
+        thr = np.sort(np.abs(lam0))[n // 2]
+        select = np.abs(lam0) <= thr
+        ps1 = pt.oracle_gordschur(ps0, select)
+        assert ps1.info == 0 and ps1.nswaps > 0
+        pt.rgpschur_check(A, S, ps1, tol=400)
+        m = int(select.sum())
+        sc = abs(lam0).max()
+        assert pt.match_eigs(lam0[select], ps1.values[:m]) < 1e-8 * sc
+        assert pt.match_eigs(lam0[~select], ps1.values[m:]) < 1e-8 * sc
