@@ -166,8 +166,9 @@ int psd_d_ordschur(psd_ctx* ctx, int n, int p, double* const* T, double* const* 
 /* LinearAlgebra.ordschur!(P::GeneralizedPeriodicSchur, select; wantZ) by adjacent 1x1 swaps — ordschur.jl:11-96,
  * 323-328, signed swap sylswap.jl:638-764.  T/Z: p matrices in the user order of the decomposition (T1 at
  * `schurindex`), S the user-order signature; eigenvalues are recomputed in the scaled form.  info as psd_z_ordschur.
- * psd_d_gordschur (Float64) requires a real spectrum (T1 triangular); a conjugate pair needs the signed block swap of
- * sylswap.jl:197-538 and returns PSD_INFO_NOTIMPL in this build. */
+ * psd_d_gordschur (Float64): rordschur.jl:3-132,141-268 with the signed block swap sylswap.jl:197-538 for 2x2 blocks
+ * (conjugate pairs; `select` is completed to pairs) and ordschur.jl:206-314 for the eigenvalues; a decomposition with
+ * a real spectrum (T1 triangular) goes through the 1x1 kernel. */
 int psd_z_gordschur(psd_ctx* ctx, int n, int p, double* const* T, double* const* Z, const uint8_t* S, char orient,
                     int schurindex, const uint8_t* select, int wantZ, double* alpha, double* beta, int32_t* ascale,
                     psd_stats* stats, int* info);

@@ -10,6 +10,7 @@
 #include "psd_rgz.h"
 #include "psd_zgz.h"
 #include "psd_zgord.h"
+#include "psd_grord.h"
 
 #include "../../include/psd_mi355x.h"
 
@@ -1464,7 +1465,7 @@ int psd_z_ordschur(psd_ctx* c, int n, int p, double* const* T, double* const* Z,
 namespace {
 
 size_t rord_lds_bytes(int p, int W) {
-    size_t b = ((size_t)p * W * (W + 1) + (size_t)p * (PSD_RORD_SCR + 52) + 4 + 192) * 8 + (size_t)p * 4 + 64;
+    size_t b = ((size_t)p * W * (W + 1) + (size_t)p * (PSD_RORD_SCR + 52) + 4 + 192) * 8 + (size_t)p * 5 + 80;
     return (b + 15) & ~(size_t)15;
 }
 int choose_window_rord(int p) {
@@ -1474,11 +1475,20 @@ int choose_window_rord(int p) {
     return 0;
 }
 
+// Sint != nullptr: GeneralizedPeriodicSchur (signed swaps), eigenvalues returned in the scaled form (alpha complex)
 int rordschur_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t* select, int wantZ, double* wr,
-                  double* wi, psd_stats* stats, int* info) {
+                  double* wi, psd_stats* stats, int* info, const uint8_t* Sint = nullptr, double* alpha = nullptr,
+                  double* beta = nullptr, int32_t* ascale = nullptr) {
     const int W = choose_window_rord(p);
     if (W == 0) return *info = PSD_INFO_NOTIMPL;
     if ((*info = c->roreserve(n, p)) != 0) return *info;
+    if (Sint) {
+        if ((*info = c->greserve(n, p, 16)) != 0) return *info;
+        std::vector<unsigned char> hS(p, 1);
+        for (int l = 0; l < p; ++l) hS[l] = Sint[l] ? 1 : 0;
+        PSD_CHECK(psd_rt_h2d(c->gS, hS.data(), (size_t)p, c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+    }
     PSD_CHECK(psd_rt_h2d(c->rosel, select, (size_t)n, c->stream));
     psd_roparams P;
     P.H = dH;
@@ -1491,6 +1501,10 @@ int rordschur_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_
     P.wr = c->wr;
     P.wi = c->wi;
     P.xscr = c->roxscr;
+    P.S = Sint ? c->gS : nullptr;
+    P.alpha = Sint ? c->galpha : nullptr;
+    P.beta = Sint ? c->gbeta : nullptr;
+    P.ascale = Sint ? c->gascale : nullptr;
     const size_t lds_step = rord_lds_bytes(p, W);
 #ifndef PSD_HOSTSIM
     if (lds_step > c->rostep_lds_set) {
@@ -1519,7 +1533,16 @@ int rordschur_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_
         if (hst.phase == PSD_ROPH_DONE) break;
         if (launched > cap) return *info = PSD_INFO_RUNTIME + 0xfffc;
     }
-    if (hst.info == 0) {
+    if (hst.info == 0 && Sint) {
+        PSD_LAUNCH(psd_grord_values, psd_dim3((n + 63) / 64), 64, 0, c->stream, P, n, p);
+        PSD_LAUNCH(psd_grord_cleanup, psd_dim3(n), 64, 0, c->stream, P, n);
+        PSD_CHECK(psd_rt_d2h(alpha, c->galpha, sizeof(psd_z) * n, c->stream));
+        PSD_CHECK(psd_rt_d2h(beta, c->gbeta, sizeof(double) * n, c->stream));
+        std::vector<int> hsc(n, 0);
+        PSD_CHECK(psd_rt_d2h(hsc.data(), c->gascale, sizeof(int) * n, c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+        for (int q = 0; q < n; ++q) ascale[q] = hsc[q];
+    } else if (hst.info == 0) {
         PSD_LAUNCH(psd_rord_values, psd_dim3((n + 63) / 64), 64, 0, c->stream, P, n, p);
         PSD_LAUNCH(psd_rord_cleanup, psd_dim3(n), 64, 0, c->stream, P, n);
         PSD_CHECK(psd_rt_d2h(wr, c->wr, sizeof(double) * n, c->stream));
@@ -2108,10 +2131,37 @@ int psd_d_gordschur(psd_ctx* c, int n, int p, double* const* T, double* const* Z
     if (gord_check_args(c, n, p, T, Z, S, orient, select, wantZ, info) != 0) return *info;
     if (schurindex < 1 || schurindex > p) return *info = -7;
     const size_t nn = (size_t)n * n;
+    bool pairs = false;
     {
         const double* T1 = T[schurindex - 1];
         for (int j = 0; j + 1 < n; ++j)
-            if (T1[(size_t)j * n + (j + 1)] != 0.0) return *info = PSD_INFO_NOTIMPL;
+            if (T1[(size_t)j * n + (j + 1)] != 0.0) pairs = true;
+    }
+    if (pairs) {  // 2x2 blocks: signed block swaps in real arithmetic (sylswap.jl:197-538)
+        if (!((orient == 'R' && schurindex == 1) || (orient == 'L' && schurindex == p))) {
+            if (schurindex != 1 && schurindex != p) return *info = -7;
+            return *info = PSD_INFO_NOTIMPL;
+        }
+        if ((*info = c->reserve(n, p, true, 16)) != 0) return *info;
+        const bool left = orient == 'L';
+        auto slotA = [&](int j) { return left ? (p + 1 - j) : j; };
+        auto slotZ = [&](int j) { return (!left || j == 1) ? j : (p + 2 - j); };
+        std::vector<uint8_t> Sint(p, 1);
+        for (int j = 1; j <= p; ++j) Sint[j - 1] = S[slotA(j) - 1] ? 1 : 0;
+        if (!Sint[0]) return *info = -5;
+        for (int j = 1; j <= p; ++j) PSD_CHECK(psd_rt_h2d(c->dH + (size_t)(j - 1) * nn, T[slotA(j) - 1], nn * 8, c->stream));
+        if (wantZ)
+            for (int j = 1; j <= p; ++j)
+                PSD_CHECK(psd_rt_h2d(c->dZ + (size_t)(j - 1) * nn, Z[slotZ(j) - 1], nn * 8, c->stream));
+        int rc = rordschur_dev(c, n, p, c->dH, c->dZ, select, wantZ, nullptr, nullptr, stats, info, Sint.data(), alpha, beta,
+                               ascale);
+        if (rc < 0 || rc >= PSD_INFO_NOTIMPL) return rc;
+        for (int j = 1; j <= p; ++j) PSD_CHECK(psd_rt_d2h(T[slotA(j) - 1], c->dH + (size_t)(j - 1) * nn, nn * 8, c->stream));
+        if (wantZ)
+            for (int j = 1; j <= p; ++j)
+                PSD_CHECK(psd_rt_d2h(Z[slotZ(j) - 1], c->dZ + (size_t)(j - 1) * nn, nn * 8, c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+        return rc;
     }
     std::vector<std::vector<psd_z>> Tz(p), Zz(wantZ ? p : 0);
     for (int j = 0; j < p; ++j) {

@@ -50,7 +50,14 @@ struct psd_roparams {
     double* wr;
     double* wi;
     double* xscr;  // [n][p][8] scratch for _rpeigvals2x2
+    // GeneralizedPeriodicSchur (signed swaps, sylswap.jl:197-538): signature of the internal right-order factors
+    // (nullptr: all true) and the scaled eigenvalue outputs of ordschur.jl:206-314
+    const unsigned char* S;
+    psd_z* alpha;
+    double* beta;
+    int* ascale;
 };
+PSD_HD bool psd_rosig(const psd_roparams& P, int j) { return P.S == nullptr || P.S[j - 1] != 0; }
 
 PSD_D psd_rparams P_as_r(const psd_roparams& P) {
     psd_rparams R;
@@ -228,7 +235,9 @@ PSD_D bool psd_sm_qr_par(double* S, int nr, int ncols, int pp) {
 // blocks, then back substitution.  Per-factor scratch layout (ld 2 blocks): scr[l] + 0: T11, +4: T12,
 // +8: T22, +12: X.  wk: K x 52 doubles (D 16, E 16, F 16, rhs 4); ws: 192 doubles of LDS work space
 // (S 8 x 13, Lo, Hi, rb, x).  Whole wavefront, uniform control.  Returns false if singular.
-PSD_D bool psd_rord_psylsolve(int K, int p1, int p2, double* scr, double* wk, double* ws) {
+// SL[k] (k = 0..K-1): signature of the left-sequence factor k+1 (sylvester.jl:53-87): equation k is
+//   SL[k]:  A_k X_k - X_{k+1} B_k = -C_k        !SL[k]:  A_k X_{k+1} - X_k B_k = -C_k
+PSD_D bool psd_rord_psylsolve(int K, int p1, int p2, double* scr, double* wk, double* ws, const unsigned char* SL) {
     const int pp = p1 * p2;
     double* S = ws;          // 8 x 13
     double* Lo = ws + 104;   // 16
@@ -259,8 +268,13 @@ PSD_D bool psd_rord_psylsolve(int K, int p1, int p2, double* scr, double* wk, do
     PSD_SYNC();
     PSD_PAR_FOR(k, K) {
         double* w = wk + k * 52;
-        fillA(scr + k * PSD_RORD_SCR + 0, w);        // D_k = kron(I, A_k)
-        fillB(scr + k * PSD_RORD_SCR + 8, w + 16);   // E_k = kron(B_k^T, -I)
+        if (SL[k]) {
+            fillA(scr + k * PSD_RORD_SCR + 0, w);        // D_k = kron(I, A_k) multiplies x_k
+            fillB(scr + k * PSD_RORD_SCR + 8, w + 16);   // E_k = kron(B_k^T, -I) multiplies x_{k+1}
+        } else {
+            fillB(scr + k * PSD_RORD_SCR + 8, w);
+            fillA(scr + k * PSD_RORD_SCR + 0, w + 16);
+        }
         for (int q = 0; q < 16; ++q) w[32 + q] = 0.0;
         rhsC(scr + k * PSD_RORD_SCR + 4, w + 48);
     }
@@ -407,40 +421,82 @@ PSD_D bool psd_rord_psylsolve(int K, int p1, int p2, double* scr, double* wk, do
 // sequence X_l): +0 T11, +4 T12, +8 T22, +12 X (ld 2); +16 Q, +32 Txx, +48 Ws, +64 Qfin (ld 4); +80 orig block
 // (ld 4).  Whole wavefront: the cyclic solve and the 2x2 Hessenberg repair are chains over the factors, everything
 // else runs one factor per lane.  Returns (uniformly) 0 ok, 1 rejected (strong test), 2 singular.
-PSD_D int psd_rord_swap_scalar(int K, int p1, int p2, double* scr, double* wk, double* ws, double tnrm, long long* cyc) {
+PSD_D int psd_rord_swap_scalar(int K, int p1, int p2, double* scr, double* wk, double* ws, double tnrm, long long* cyc,
+                                const unsigned char* SL, bool gen) {
     const int m = p1 + p2;
     const long long tq0 = psd_clock();
-    const bool solved = psd_rord_psylsolve(K, p1, p2, scr, wk, ws);
+    const bool solved = psd_rord_psylsolve(K, p1, p2, scr, wk, ws, SL);
     cyc[2] += psd_clock() - tq0;
     if (!solved) return 2;
     const double thresh = fmax(PSD_DBL_MIN, 100.0 * PSD_DBL_EPS * tnrm);
     PSD_SYNC();
     PSD_PAR_FOR(l, K) {
         double* s = scr + l * PSD_RORD_SCR;
-        double Xi[16];  // [X; I] (m x p2), ld 4
+        const int lp = (l == 0) ? (K - 1) : (l - 1);
+        if (SL[lp]) {  // Q_l from the QR of [X; I] (sylswap.jl:58-66, 243-256)
+            double Xi[16];  // [X; I] (m x p2), ld 4
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int c = q >> 2, r = q & 3;
-            double x = 0.0;
-            if (c < p2) {
-                if (r < p1) x = s[12 + (c & 1) * 2 + (r & 1)];
-                else if (r == p1 + c) x = 1.0;
+            for (int q = 0; q < 16; ++q) {
+                const int c = q >> 2, r = q & 3;
+                double x = 0.0;
+                if (c < p2) {
+                    if (r < p1) x = s[12 + (c & 1) * 2 + (r & 1)];
+                    else if (r == p1 + c) x = 1.0;
+                }
+                Xi[q] = x;
             }
-            Xi[q] = x;
+            psd_sm_fullq(Xi, m, p2, s + 16);
+        } else {
+            // Q_l = q' from the RQ of [I -X] = [0 R] q (sylswap.jl:258-268): q = J Qb' J with Qb from the QR of
+            // B = J [I -X]' J (m x p1), so Q_l = J Qb J
+            double Bm[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int c = q >> 2, r = q & 3;  // B(r, c) = Xi(p1-1-c, m-1-r),  Xi(a, b) = (b < p1) ? (a == b) : -X(a, b-p1)
+                double x = 0.0;
+                if (c < p1 && r < m) {
+                    const int a = p1 - 1 - c, b = m - 1 - r;
+                    if (b < p1) x = (a == b) ? 1.0 : 0.0;
+                    else x = -s[12 + ((b - p1) & 1) * 2 + (a & 1)];
+                }
+                Bm[q] = x;
+            }
+            psd_sm_fullq(Bm, m, p1, s + 64);  // (the Qfin slot is free until the end of the swap)
+            for (int q = 0; q < 16; ++q) {
+                const int c = q >> 2, r = q & 3;
+                s[16 + q] = (r < m && c < m) ? s[64 + (m - 1 - c) * 4 + (m - 1 - r)] : ((r == c) ? 1.0 : 0.0);
+            }
         }
-        psd_sm_fullq(Xi, m, p2, s + 16);
         for (int q = 0; q < 16; ++q) s[32 + q] = s[80 + q];  // Txx <- original [T11 T12; 0 T22]
         for (int c = 0; c < 4; ++c)
             for (int r = 0; r < 4; ++r) s[48 + c * 4 + r] = (r == c) ? 1.0 : 0.0;
-        psd_sm_mul(s + 32, false, s + 16, false, m, s + 32);  // Txx[l] <- Txx[l] q_l
+        // X_l:  SL[l] ? Txx[l] Q_l : Q_l' Txx[l]
+        if (SL[l]) psd_sm_mul(s + 32, false, s + 16, false, m, s + 32);
+        else psd_sm_mul(s + 16, true, s + 32, false, m, s + 32);
     }
     PSD_SYNC();
-    PSD_PAR_FOR(l, K) {  // Txx[l-1] <- q_l' Txx[l-1]
+    PSD_PAR_FOR(l, K) {  // X_{l-1}:  SL[l-1] ? Q_l' Txx[l-1] : Txx[l-1] Q_l
         double* s = scr + l * PSD_RORD_SCR;
-        double* sp = scr + ((l == 0) ? (K - 1) : (l - 1)) * PSD_RORD_SCR;
-        psd_sm_mul(s + 16, true, sp + 32, false, m, sp + 32);
+        const int lp = (l == 0) ? (K - 1) : (l - 1);
+        double* sp = scr + lp * PSD_RORD_SCR;
+        if (SL[lp]) psd_sm_mul(s + 16, true, sp + 32, false, m, sp + 32);
+        else psd_sm_mul(sp + 32, false, s + 16, false, m, sp + 32);
     }
     PSD_SYNC();
+    bool weak_ok = true;
+    if (gen) {  // weak test of the signed swap (sylswap.jl:303-313)
+        double wsmax = 0.0;
+        for (int l = 0; l < K; ++l) {
+            double ssq = 0.0;
+            for (int a = p2; a < m; ++a)
+                for (int b = 0; b < p2; ++b) {
+                    const double x = scr[l * PSD_RORD_SCR + 32 + b * 4 + a];
+                    ssq += x * x;
+                }
+            wsmax = fmax(wsmax, sqrt(ssq));
+        }
+        weak_ok = !(wsmax > thresh);
+    }
     bool fill1 = false, fill2 = false;
     if (p2 > 1)
         for (int l = 0; l < K; ++l) fill1 |= fabs(scr[l * PSD_RORD_SCR + 32 + 0 * 4 + 1]) > thresh;
@@ -465,26 +521,32 @@ PSD_D int psd_rord_swap_scalar(int K, int p1, int p2, double* scr, double* wk, d
             Hq[0] = 1.0; Hq[1] = 0.0; Hq[2] = 0.0; Hq[3] = 1.0;
         }
         PSD_SYNC();
-        PSD_ONE {
+        PSD_ONE {  // rpschur2x2.jl:326-359 with the signature
             for (int l = 2; l <= K; ++l) {
-                double* Al = wk + (l - 1) * 52;
+                double* Al = wk + (l - 1) * 52;  // [a(0,0) a(1,0) a(0,1) a(1,1)]
                 const int lp = (l % K) + 1;
                 double* Ap = wk + (lp - 1) * 52;
-                double x0 = Al[0], x1 = Al[1];
-                double tau;
-                {
-                    double xv[2] = {x0, x1};
+                double v1, v2, tau;
+                if (SL[l - 1]) {
+                    double xv[2] = {Al[0], Al[1]};
                     tau = psd_reflector_small(xv, 2);
-                    x0 = xv[0];
-                    x1 = xv[1];
-                }
-                Al[0] = x0;
-                Al[1] = 0.0;
-                const double v1 = 1.0, v2 = x1;
-                {  // lmul!(hr', Al[:, 2])
-                    const double sdot = v1 * Al[2] + v2 * Al[3];
+                    Al[0] = xv[0];
+                    Al[1] = 0.0;
+                    v1 = 1.0;
+                    v2 = xv[1];
+                    const double sdot = v1 * Al[2] + v2 * Al[3];  // lmul!(hr', Al[:, 2])
                     Al[2] -= sdot * tau * v1;
                     Al[3] -= sdot * tau * v2;
+                } else {
+                    double xv[2] = {Al[3], Al[1]};  // (a(1,1), a(1,0))
+                    tau = psd_reflector_small(xv, 2);
+                    Al[1] = 0.0;
+                    Al[3] = xv[0];
+                    v1 = xv[1];
+                    v2 = 1.0;
+                    const double sdot = Al[0] * v1 + Al[2] * v2;  // rmul!(Al[1:1, :], hr)
+                    Al[0] -= sdot * tau * v1;
+                    Al[2] -= sdot * tau * v2;
                 }
                 {  // Qs[lp] <- hr' Qs[lp]
                     double* Q = wk + (lp - 1) * 52 + 4;
@@ -494,30 +556,53 @@ PSD_D int psd_rord_swap_scalar(int K, int p1, int p2, double* scr, double* wk, d
                         Q[c * 2 + 1] -= sdot * tau * v2;
                     }
                 }
-                for (int r = 0; r < 2; ++r) {  // rmul!(Ap, hr)
-                    const double sdot = Ap[0 * 2 + r] * v1 + Ap[1 * 2 + r] * v2;
-                    Ap[0 * 2 + r] -= sdot * tau * v1;
-                    Ap[1 * 2 + r] -= sdot * tau * v2;
+                if (SL[lp - 1]) {
+                    for (int r = 0; r < 2; ++r) {  // rmul!(Ap, hr)
+                        const double sdot = Ap[0 * 2 + r] * v1 + Ap[1 * 2 + r] * v2;
+                        Ap[0 * 2 + r] -= sdot * tau * v1;
+                        Ap[1 * 2 + r] -= sdot * tau * v2;
+                    }
+                } else {
+                    for (int c = 0; c < 2; ++c) {  // lmul!(hr', Ap)
+                        const double sdot = v1 * Ap[c * 2 + 0] + v2 * Ap[c * 2 + 1];
+                        Ap[c * 2 + 0] -= sdot * tau * v1;
+                        Ap[c * 2 + 1] -= sdot * tau * v2;
+                    }
                 }
             }
         }
         PSD_SYNC();
-        PSD_PAR_FOR(t, K) {
+        PSD_PAR_FOR(t, K) {  // sylswap.jl:166-190
             const int l = t + 1;
             const int lp = (l % K) + 1;
             const double* q = wk + (l - 1) * 52 + 4;
             const double* qp = wk + (lp - 1) * 52 + 4;
             double* Tl = scr + (l - 1) * PSD_RORD_SCR + 32;
             double* W = scr + (l - 1) * PSD_RORD_SCR + 48;
-            for (int r = 0; r < m; ++r) {
-                const double a = Tl[j0 * 4 + r], b = Tl[j1 * 4 + r];
-                Tl[j0 * 4 + r] = a * q[0] + b * q[1];
-                Tl[j1 * 4 + r] = a * q[2] + b * q[3];
-            }
-            for (int c = 0; c < m; ++c) {
-                const double a = Tl[c * 4 + j0], b = Tl[c * 4 + j1];
-                Tl[c * 4 + j0] = qp[0] * a + qp[1] * b;
-                Tl[c * 4 + j1] = qp[2] * a + qp[3] * b;
+            const double* qc = SL[l - 1] ? q : qp;  // acts on the columns j0:j1
+            const double* qr = SL[l - 1] ? qp : q;  // its transpose acts on the rows j0:j1
+            if (SL[l - 1]) {
+                for (int r = 0; r < m; ++r) {
+                    const double a = Tl[j0 * 4 + r], b = Tl[j1 * 4 + r];
+                    Tl[j0 * 4 + r] = a * qc[0] + b * qc[1];
+                    Tl[j1 * 4 + r] = a * qc[2] + b * qc[3];
+                }
+                for (int c = 0; c < m; ++c) {
+                    const double a = Tl[c * 4 + j0], b = Tl[c * 4 + j1];
+                    Tl[c * 4 + j0] = qr[0] * a + qr[1] * b;
+                    Tl[c * 4 + j1] = qr[2] * a + qr[3] * b;
+                }
+            } else {
+                for (int c = 0; c < m; ++c) {
+                    const double a = Tl[c * 4 + j0], b = Tl[c * 4 + j1];
+                    Tl[c * 4 + j0] = qr[0] * a + qr[1] * b;
+                    Tl[c * 4 + j1] = qr[2] * a + qr[3] * b;
+                }
+                for (int r = 0; r < m; ++r) {
+                    const double a = Tl[j0 * 4 + r], b = Tl[j1 * 4 + r];
+                    Tl[j0 * 4 + r] = a * qc[0] + b * qc[1];
+                    Tl[j1 * 4 + r] = a * qc[2] + b * qc[3];
+                }
             }
             for (int r = 0; r < m; ++r) {
                 const double a = W[j0 * 4 + r], b = W[j1 * 4 + r];
@@ -539,8 +624,13 @@ PSD_D int psd_rord_swap_scalar(int K, int p1, int p2, double* scr, double* wk, d
     PSD_PAR_FOR(l, K) {
         const int l1 = (l + 1) % K;
         double* Tt = wk + l * 52 + 16;  // (the E block of the solver is free again)
-        psd_sm_mul(scr + l1 * PSD_RORD_SCR + 64, false, scr + l * PSD_RORD_SCR + 32, false, m, Tt);
-        psd_sm_mul(Tt, false, scr + l * PSD_RORD_SCR + 64, true, m, Tt);
+        if (SL[l]) {  // Qfin_{l+1} Txx[l] Qfin_l'
+            psd_sm_mul(scr + l1 * PSD_RORD_SCR + 64, false, scr + l * PSD_RORD_SCR + 32, false, m, Tt);
+            psd_sm_mul(Tt, false, scr + l * PSD_RORD_SCR + 64, true, m, Tt);
+        } else {  // Qfin_l Txx[l] Qfin_{l+1}'  (sylswap.jl:355-366)
+            psd_sm_mul(scr + l * PSD_RORD_SCR + 64, false, scr + l * PSD_RORD_SCR + 32, false, m, Tt);
+            psd_sm_mul(Tt, false, scr + l1 * PSD_RORD_SCR + 64, true, m, Tt);
+        }
         double d = 0.0;
         for (int c = 0; c < m; ++c)
             for (int r = 0; r < m; ++r) {
@@ -550,7 +640,7 @@ PSD_D int psd_rord_swap_scalar(int K, int p1, int p2, double* scr, double* wk, d
         wk[l * 52 + 12] = (sqrt(d) > thresh) ? 1.0 : 0.0;
     }
     PSD_SYNC();
-    bool ok = true;
+    bool ok = weak_ok;
     for (int l = 0; l < K; ++l)
         if (wk[l * 52 + 12] != 0.0) ok = false;
     PSD_SYNC();
@@ -558,15 +648,17 @@ PSD_D int psd_rord_swap_scalar(int K, int p1, int p2, double* scr, double* wk, d
 }
 
 // ------------------------------------------------------------------------------------------------
-// in-window application of the block transform Q (m x m, ld 4) of sequence index l:
-// right on the columns i1.. of X_l = T_{sg}, left (Q') on the rows i1.. of X_{l-1} = T_{own}
-PSD_D void psd_rord_win_apply_lane(const psd_win& w, int sg, int own, int i1, int m, const double* q, int t,
-                                   int nrow) {
+// in-window application of the block transform Q (m x m, ld 4) of sequence index l to X_l = T_{sg} and
+// X_{l-1} = T_{own}.  Unsigned (and S true): right on the columns i1.. of T_sg, left (Q') on the rows i1.. of T_own;
+// a negative signature of a factor flips its side (sylswap.jl:396-445).
+// lane t < nA works on T_sg, the others on T_own; `right`: row r = bs + k gets  row <- row Q  on the columns i1..;
+// otherwise column c = i1 + k gets  column <- Q' column  on the rows i1..
+PSD_D void psd_rord_win_apply_one(const psd_win& w, int fac, bool right, int i1, int m, const double* q, int k) {
     double a[4], b[4];
-    if (t < nrow) {
-        const int r = w.bs + t;
+    if (right) {
+        const int r = w.bs + k;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] = (e < m) ? w.at(sg, r, i1 + e) : 0.0;
+        for (int e = 0; e < 4; ++e) a[e] = (e < m) ? w.at(fac, r, i1 + e) : 0.0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             double sum = 0.0;
@@ -576,11 +668,11 @@ PSD_D void psd_rord_win_apply_lane(const psd_win& w, int sg, int own, int i1, in
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (e < m) w.at(sg, r, i1 + e) = b[e];
+            if (e < m) w.at(fac, r, i1 + e) = b[e];
     } else {
-        const int c = i1 + (t - nrow);
+        const int c = i1 + k;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] = (e < m) ? w.at(own, i1 + e, c) : 0.0;
+        for (int e = 0; e < 4; ++e) a[e] = (e < m) ? w.at(fac, i1 + e, c) : 0.0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             double sum = 0.0;
@@ -590,29 +682,35 @@ PSD_D void psd_rord_win_apply_lane(const psd_win& w, int sg, int own, int i1, in
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (e < m) w.at(own, i1 + e, c) = b[e];
+            if (e < m) w.at(fac, i1 + e, c) = b[e];
     }
 }
-PSD_D void psd_rord_win_apply(const psd_win& w, int sg, int own, int i1, int m, const double* Q) {
-    const int nrow = (i1 + m - 1) - w.bs + 1;  // rows bs..i1+m-1 of T_sg
-    const int ncol = w.be - i1 + 1;            // columns i1..be of T_own
+PSD_D void psd_rord_win_apply(const psd_win& w, int sg, int own, int i1, int m, const double* Q, bool ssg, bool sown) {
+    const int nrow = (i1 + m - 1) - w.bs + 1;  // rows bs..i1+m-1
+    const int ncol = w.be - i1 + 1;            // columns i1..be
+    const bool rightA = ssg, rightB = !sown;   // T_sg: columns if S[sg]; T_own: rows if S[own]
+    const int nA = rightA ? nrow : ncol, nB = rightB ? nrow : ncol;
     double q[16];  // identity-padded 4 x 4
 #pragma unroll
     for (int e = 0; e < 16; ++e) q[e] = Q[e];
     if (sg != own) {
-        PSD_PAR_FOR(t, nrow + ncol) { psd_rord_win_apply_lane(w, sg, own, i1, m, q, t, nrow); }
+        PSD_PAR_FOR(t, nA + nB) {
+            if (t < nA) psd_rord_win_apply_one(w, sg, rightA, i1, m, q, t);
+            else psd_rord_win_apply_one(w, own, rightB, i1, m, q, t - nA);
+        }
     } else {
         // p == 1: both sides act on the same factor and overlap in the diagonal block -> two ordered passes
-        PSD_PAR_FOR(t, nrow) { psd_rord_win_apply_lane(w, sg, own, i1, m, q, t, nrow); }
+        PSD_PAR_FOR(t, nA) { psd_rord_win_apply_one(w, sg, rightA, i1, m, q, t); }
         PSD_SYNC();
-        PSD_PAR_FOR(t, ncol) { psd_rord_win_apply_lane(w, sg, own, i1, m, q, nrow + t, nrow); }
+        PSD_PAR_FOR(t, nB) { psd_rord_win_apply_one(w, own, rightB, i1, m, q, t); }
     }
     PSD_SYNC();
 }
 
 // one swap inside the window; returns 0 ok / 1 rejected / 2 singular
 PSD_D int psd_rord_swap(const psd_roparams& P, const psd_rostate& st, const psd_win& w, double* scr, double* wk,
-                        double* ws, double* flagbuf, int* lcnt, int i1, int p1, int p2, long long* cyc) {
+                        double* ws, double* flagbuf, int* lcnt, int i1, int p1, int p2, long long* cyc,
+                        const unsigned char* SL) {
     const int p = st.p, m = p1 + p2;
     PSD_SYNC();
     PSD_PAR_FOR(t, p) {
@@ -647,7 +745,7 @@ PSD_D int psd_rord_swap(const psd_roparams& P, const psd_rostate& st, const psd_
     tn = sqrt(tn);
     PSD_SYNC();
     const long long ts0 = psd_clock();
-    const int flag0 = psd_rord_swap_scalar(p, p1, p2, scr, wk, ws, tn, cyc);
+    const int flag0 = psd_rord_swap_scalar(p, p1, p2, scr, wk, ws, tn, cyc, SL, P.S != nullptr);
     cyc[3] += psd_clock() - ts0;
     const long long ta0 = psd_clock();
     PSD_ONE { flagbuf[0] = (double)flag0; }
@@ -657,7 +755,7 @@ PSD_D int psd_rord_swap(const psd_roparams& P, const psd_rostate& st, const psd_
     for (int l = 1; l <= p; ++l) {
         const int own = psd_ord_owner(p, l), sg = psd_ord_sigma(p, l);
         const double* Q = scr + (l - 1) * PSD_RORD_SCR + 64;
-        psd_rord_win_apply(w, sg, own, i1, m, Q);
+        psd_rord_win_apply(w, sg, own, i1, m, Q, psd_rosig(P, sg), psd_rosig(P, own));
         {
             const int q = lcnt[own - 1];
             PSD_SYNC();
@@ -705,6 +803,9 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rord_step(psd_roparams P) {
     double* flagbuf = wk + (size_t)p * 52;
     double* ws = flagbuf + 4;
     int* lcnt = (int*)(ws + 192);
+    unsigned char* SL = (unsigned char*)(lcnt + p);  // signature of the left-oriented sequence X_l = T_{sigma(l)}
+    PSD_PAR_FOR(t, p) { SL[t] = psd_rosig(P, psd_ord_sigma(p, t + 1)) ? 1 : 0; }
+    PSD_SYNC();
     // driver scan: rordschur.jl:77-110
     while (st.phase == PSD_ROPH_SCAN) {
         st.j += 1;
@@ -767,7 +868,7 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rord_step(psd_roparams P) {
         // rordschur.jl:181-247 restricted to the blocks that fit the window
         while (here > st.jtarget && !fail) {
             if (st.pend1x1) {  // second 1x1 of a split pair follows its partner (rordschur.jl:207-215)
-                fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here, 1, 1, cyc);
+                fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here, 1, 1, cyc, SL);
                 if (fail) break;
                 st.nswaps += 1;
                 st.pend1x1 = 0;
@@ -782,13 +883,13 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rord_step(psd_roparams P) {
             }
             if (here - nbnext < w.bs) break;
             if (!st.splitsrc) {
-                fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - nbnext, nbnext, st.nbsrc, cyc);
+                fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - nbnext, nbnext, st.nbsrc, cyc, SL);
                 if (fail) break;
                 st.nswaps += 1;
                 here -= nbnext;
                 if (st.nbsrc == 2 && w.at(1, here + 1, here) == 0) st.splitsrc = 1;
             } else {
-                fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - nbnext, nbnext, 1, cyc);
+                fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - nbnext, nbnext, 1, cyc, SL);
                 if (fail) break;
                 st.nswaps += 1;
                 if (nbnext == 1) {
@@ -796,15 +897,15 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rord_step(psd_roparams P) {
                 } else {
                     if (w.at(1, here, here - 1) == 0) nbnext = 1;
                     if (nbnext == 2) {
-                        fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - 1, 2, 1, cyc);
+                        fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - 1, 2, 1, cyc, SL);
                         if (fail) break;
                         st.nswaps += 1;
                         here -= 2;
                     } else {
-                        fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here, 1, 1, cyc);
+                        fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here, 1, 1, cyc, SL);
                         if (fail) break;
                         st.nswaps += 1;
-                        fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - 1, 1, 1, cyc);
+                        fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - 1, 1, 1, cyc, SL);
                         if (fail) break;
                         st.nswaps += 1;
                         here -= 2;
@@ -879,11 +980,16 @@ PSD_KERNEL_B(PSD_APPLY_NT) psd_rord_apply(psd_roparams P, int n, int p) {
     psd_tq* ltr = (psd_tq*)psd_lds;
     double* tile = (double*)(psd_lds + sizeof(psd_tq) * PSD_RORD_CAP);
     PSD_PAR_FOR(e, cnt) { ltr[e] = P.tq[(size_t)(m - 1) * PSD_RORD_CAP + e]; }
-    if (role == 0) {
+    // owner m acts on T_m from the left if S[m] (else from the right), on T_{m-1} from the right if S[m-1] (else
+    // from the left), on Z_m from the right
+    const int mm1 = (m == 1) ? p : (m - 1);
+    const int fac = (role == 0) ? m : ((role == 1) ? mm1 : m);
+    const bool left = (role == 0) ? psd_rosig(P, m) : ((role == 1) ? !psd_rosig(P, mm1) : false);
+    if (left) {
         const int c0 = d.lc0 + PSD_BLOCK_X * T;
         if (c0 > d.lc1) return;
         const int nc = (d.lc1 - c0 + 1 < T) ? (d.lc1 - c0 + 1) : T;
-        const psd_mat<double> M = psd_mat<double>{P.H + (size_t)(m - 1) * n * n, n};
+        const psd_mat<double> M = psd_mat<double>{P.H + (size_t)(fac - 1) * n * n, n};
         const int ldt = T + 1;
         PSD_PAR_FOR(t, S * nc) {
             const int r = t % S, c = t / S;
@@ -910,14 +1016,13 @@ PSD_KERNEL_B(PSD_APPLY_NT) psd_rord_apply(psd_roparams P, int n, int p) {
             M(d.plo + r, c0 + c) = tile[r * ldt + c];
         }
     } else {
-        const int lo = (role == 1) ? d.rr0 : d.zr0;
-        const int hi = (role == 1) ? d.rr1 : d.zr1;
+        const int lo = (role == 2) ? d.zr0 : d.rr0;
+        const int hi = (role == 2) ? d.zr1 : d.rr1;
         const int r0 = lo + PSD_BLOCK_X * T;
         if (r0 > hi) return;
         const int nr = (hi - r0 + 1 < T) ? (hi - r0 + 1) : T;
-        const int jm = (role == 1) ? ((m == 1) ? p : (m - 1)) : m;
-        double* base = (role == 1) ? P.H : P.Z;
-        const psd_mat<double> M = psd_mat<double>{base + (size_t)(jm - 1) * n * n, n};
+        double* base = (role == 2) ? P.Z : P.H;
+        const psd_mat<double> M = psd_mat<double>{base + (size_t)(fac - 1) * n * n, n};
         PSD_PAR_FOR(t, S * nr) {
             const int r = t % nr, c = t / nr;
             tile[c * T + r] = M(r0 + r, d.plo + c);

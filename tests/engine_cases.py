@@ -832,3 +832,47 @@ def case_gordschur_windows(eng, sizes):
         check(A, S, ps1, tol=100 * max(1.0, np.sqrt(n / 32)), qtol=10 * max(1.0, np.sqrt(n / 32)))
         m = int(select.sum())
         assert pt.match_eigs(lam0[select], ps1.values[:m]) < 1e-7 * abs(lam0).max()
+
+
+def case_gordschur_pairs_reference(eng):
+    """test/ordschur.jl:226-275 "gen. ordschur Float64: conjugate pair(s)" (mkrps, alt = true)"""
+    import psd_amd
+
+    n, p = 7, 5
+    ps0, A = pt.mkrps(n, p, [3, 6], seed=905, alt=True)
+    lam0 = ps0.values
+    for selset in ([6, 7], [3, 4], [1, 2, 5], [1, 3, 4], [1, 2, 6, 7], [5]):
+        select = np.zeros(n, dtype=bool)
+        select[[j - 1 for j in selset]] = True
+        P1 = psd_amd.GeneralizedPeriodicSchur(ps0.S, [t.copy(order="F") for t in ps0.Ts], [z.copy(order="F") for z in ps0.Z],
+                                              ps0.alpha.copy(), ps0.beta.copy(), ps0.ascale.copy(), "L", p)
+        ps1 = eng.ordschur_(P1, select)
+        pt.rgpschur_check(A, ps0.S, ps1, tol=400)
+        nsel = len(selset)
+        for j in selset:
+            assert np.any(np.isclose(ps1.values[:nsel], lam0[j - 1], rtol=1e-7)), (selset, ps1.values)
+        po = pt.oracle_gordschur(ps0, select)
+        assert po.info == 0 and po.nswaps == ps1.stats.nsweeps
+        assert pt.match_eigs(po.values, ps1.values) < 1e-9 * abs(po.values).max()
+
+
+def case_gordschur_pairs_random(eng, sizes):
+    """real signed decompositions with conjugate pairs from pschur!(A, S, lr); smaller half selected"""
+    for (n, p, lr, seed) in sizes:
+        S = [bool((q * 7 + n) % 3) for q in range(p)]
+        if all(S):
+            S[1] = False
+        S[p - 1 if lr == "L" else 0] = True
+        A = pt.bench_factors(n, p, seed=seed + 40)
+        ps0 = eng.pschur_([a.copy(order="F") for a in A], lr, S=S)
+        lam0 = ps0.values.copy()
+        assert np.any(lam0.imag != 0)
+        thr = np.sort(np.abs(lam0))[n // 2]
+        select = np.abs(lam0) <= thr
+        ps1 = eng.ordschur_(ps0, select)
+        assert ps1.stats.nsweeps > 0
+        pt.rgpschur_check(A, S, ps1, tol=400 * max(1.0, np.sqrt(n / 32)), qtol=10 * max(1.0, np.sqrt(n / 32)))
+        m = int(select.sum())
+        sc = abs(lam0).max()
+        assert pt.match_eigs(lam0[select], ps1.values[:m]) < 1e-8 * sc
+        assert pt.match_eigs(lam0[~select], ps1.values[m:]) < 1e-8 * sc

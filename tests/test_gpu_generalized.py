@@ -104,3 +104,12 @@ def test_gordschur_reference(gpu_engine, cplx, lr):
 def test_gordschur_windows(gpu_engine):
     ec.case_gordschur_windows(gpu_engine, [(12, 3, True, "L"), (12, 4, False, "R"), (40, 3, True, "R"),
                                            (36, 21, True, "L"), (90, 6, True, "L"), (64, 5, False, "R")])
+
+
+def test_gordschur_pairs_reference(gpu_engine):
+    ec.case_gordschur_pairs_reference(gpu_engine)
+
+
+def test_gordschur_pairs_random(gpu_engine):
+    ec.case_gordschur_pairs_random(gpu_engine, [(10, 3, "L", 1), (14, 4, "R", 2), (16, 5, "L", 3), (40, 3, "R", 4),
+                                                (30, 21, "L", 5), (96, 6, "R", 6), (128, 8, "L", 7)])

@@ -74,3 +74,11 @@ def test_gordschur_reference(sim_engine, cplx, lr):
 
 def test_gordschur_windows(sim_engine):
     ec.case_gordschur_windows(sim_engine, [(12, 3, True, "L"), (12, 4, False, "R"), (40, 3, True, "R"), (36, 21, True, "L")])
+
+
+def test_gordschur_pairs_reference(sim_engine):
+    ec.case_gordschur_pairs_reference(sim_engine)
+
+
+def test_gordschur_pairs_random(sim_engine):
+    ec.case_gordschur_pairs_random(sim_engine, [(10, 3, "L", 1), (14, 4, "R", 2), (16, 5, "L", 3), (40, 3, "R", 4), (30, 21, "L", 5)])
