@@ -1465,7 +1465,8 @@ int psd_z_ordschur(psd_ctx* c, int n, int p, double* const* T, double* const* Z,
 namespace {
 
 size_t rord_lds_bytes(int p, int W) {
-    size_t b = ((size_t)p * W * (W + 1) + (size_t)p * (PSD_RORD_SCR + 52) + 4 + 192) * 8 + (size_t)p * 5 + 80;
+    size_t b = ((size_t)p * W * (W + 1) + (size_t)p * (PSD_RORD_SCR + 52) + 4 + 192 + psd_rord_tree_doubles(p)) * 8 +
+               (size_t)p * 5 + 80;
     return (b + 15) & ~(size_t)15;
 }
 int choose_window_rord(int p) {

@@ -11,9 +11,9 @@
 // diagonal window of all p factors in LDS, performs as many adjacent swaps as fit, and emits one
 // dense m x m (m <= 4) orthogonal block transform per factor and swap; psd_rord_apply updates the
 // off-window rows of T_m, columns of T_{m-1} and Z_m at bandwidth.  The small dense algebra of a swap runs out of
-// LDS: the block-cyclic QR of the Sylvester system and the 2x2 Hessenberg repair are chains over the factors (the QR
-// itself spread over the lanes by columns, compile-time sized so that it stays in registers), everything else
-// (Q formation, block products, stability test) runs one factor per lane.
+// LDS: the periodic Sylvester system is reduced by a tree of stacked-pair Householder QRs (log2 p levels, see
+// psd_rord_psylsolve_tree; the sequential block-cyclic QR remains for p < 4), the 2x2 Hessenberg repair is a chain
+// over the factors, everything else (Q formation, block products, stability test) runs one factor per lane.
 #pragma once
 #include "psd_real_qr.h"
 #include "psd_zord.h"
@@ -416,6 +416,281 @@ PSD_D bool psd_rord_psylsolve(int K, int p1, int p2, double* scr, double* wk, do
     return ok;
 }
 
+// Tree (cyclic-reduction) form of the same solve: the cyclic block-bidiagonal system
+//     D_i x_self(i) + E_i x_next(i) = r_i ,   i = 0..m-1
+// is reduced level by level: rows (2q, 2q+1) are stacked with the shared unknown first,
+//     [ E_a  D_a  0    | r_a ]        columns: x_mid | x_left | x_right | rhs
+//     [ D_b  0    E_b  | r_b ]
+// a Householder QR of the first block column leaves [R a b | s] (kept for the back substitution) on top and the
+// reduced row  c x_left + d x_right = s'  below; an odd last row is carried over.  All pairs of a level are independent,
+// four of them are factored per pass (16 lanes per pair, one column per lane), so the chain is log2(K) levels deep
+// instead of K-1 steps.  Orthogonal transformations only, as the reference's structured QR (babd.jl:17-96).
+// tw: LDS work area of psd_rord_tree_doubles(K) doubles.
+// (rows over all levels: m + ceil(m/2) + ... <= 2 K + log2 K)
+PSD_HD int psd_rord_tree_doubles(int K) { return (2 * K + 8) * 36 + 4 * 104 + 4 * 12 + (7 * K + 16 + 32 + 1) / 2 + 8; }
+
+template <int PP>
+PSD_D bool psd_rord_tree_level_qr(double* SR, double* vb, int nact) {
+    // nact (<= 4) stacked matrices of 2 PP x (3 PP + 1), ld 8, at SR + g * 104; QR of the first PP columns of each
+    constexpr int NR = 2 * PP, NCOL = 3 * PP + 1;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < PP; ++k) {
+        PSD_WAVE_SYNC();
+        PSD_PAR_FOR(g, nact) {  // reflector of column k of matrix g
+            const double* col = SR + g * 104 + k * 8;
+            double v[NR];
+            double amax = 0.0;
+#pragma unroll
+            for (int i = k; i < NR; ++i) {
+                v[i] = col[i];
+                amax = fmax(amax, fabs(v[i]));
+            }
+            double* o = vb + g * 12;
+            if (amax == 0.0) {
+                o[10] = 0.0;  // singular
+                o[8] = 0.0;   // tau2 = 0: no update
+                o[9] = 0.0;
+            } else {
+                int ex;
+                (void)frexp(amax, &ex);
+                double ssq = 0.0;
+#pragma unroll
+                for (int i = k; i < NR; ++i) {
+                    v[i] = ldexp(v[i], -ex);
+                    ssq += v[i] * v[i];
+                }
+                const double alpha = v[k];
+                double nrm, rnrm;
+                psd_sqrt_pair_fast(ssq, nrm, rnrm);
+                const double beta = -copysign(nrm, alpha);
+                v[k] = alpha - beta;
+#pragma unroll
+                for (int i = k; i < NR; ++i) o[i] = v[i];
+                o[8] = psd_rcp_fast(nrm * (nrm + fabs(alpha)));
+                o[9] = ldexp(beta, ex);
+                o[10] = 1.0;
+            }
+        }
+        PSD_WAVE_SYNC();
+        PSD_PAR_FOR(t, 64) {
+            const int g = t >> 4, c = t & 15;
+            if (g < nact && c >= k && c < NCOL) {
+                const double* o = vb + g * 12;
+                double* col = SR + g * 104 + c * 8;
+                if (o[10] != 0.0) {
+                    if (c == k) {
+                        col[k] = o[9];
+#pragma unroll
+                        for (int i = k + 1; i < NR; ++i) col[i] = 0.0;
+                    } else {
+                        double x[NR];
+                        double d = 0.0;
+#pragma unroll
+                        for (int i = k; i < NR; ++i) {
+                            x[i] = col[i];
+                            d += o[i] * x[i];
+                        }
+                        d *= o[8];
+#pragma unroll
+                        for (int i = k; i < NR; ++i) col[i] = x[i] - d * o[i];
+                    }
+                }
+            }
+        }
+        PSD_WAVE_SYNC();
+        for (int g = 0; g < nact; ++g)
+            if (vb[g * 12 + 10] == 0.0) ok = false;
+    }
+    for (int g = 0; g < nact; ++g)
+        for (int k = 0; k < PP; ++k)
+            if (SR[g * 104 + k * 8 + k] == 0.0) ok = false;
+    return ok;
+}
+template <int PP>
+PSD_D bool psd_rord_psylsolve_tree_t(int K, int p1, int p2, double* scr, double* wk, double* tw, const unsigned char* SL) {
+    constexpr int pp = PP;
+    double* RW = tw;                      // [2K+8][36]: D 16 | E 16 | r 4
+    double* SR = RW + (2 * K + 8) * 36;   // [4][104]
+    double* vb = SR + 4 * 104;        // [4][12]
+    int* selfi = (int*)(vb + 4 * 12);  // [2K+8]
+    int* nexti = selfi + 2 * K + 8;    // [2K+8]
+    int* meta = nexti + 2 * K + 8;     // [K][3]: mid, left, right of every pair
+    int* lvl = meta + 3 * K;           // [32]: per level (npairs, first pair slot)
+    auto fillA = [&](const double* A, double* M) {
+        for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 4; ++r) M[c * 4 + r] = 0.0;
+        for (int j = 0; j < p2; ++j)
+            for (int i = 0; i < p1; ++i)
+                for (int k = 0; k < p1; ++k) M[(j * p1 + k) * 4 + (j * p1 + i)] = A[k * 2 + i];
+    };
+    auto fillB = [&](const double* B, double* M) {
+        for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 4; ++r) M[c * 4 + r] = 0.0;
+        for (int j = 0; j < p2; ++j)
+            for (int i = 0; i < p1; ++i)
+                for (int k = 0; k < p2; ++k) M[(k * p1 + i) * 4 + (j * p1 + i)] = -B[j * 2 + k];
+    };
+    PSD_WAVE_SYNC();
+    PSD_PAR_FOR(k, K) {  // level 0: equation k couples x_k (D) and x_{k+1} (E), sylvester.jl:53-87
+        double* w = RW + k * 36;
+        if (SL[k]) {
+            fillA(scr + k * PSD_RORD_SCR + 0, w);
+            fillB(scr + k * PSD_RORD_SCR + 8, w + 16);
+        } else {
+            fillB(scr + k * PSD_RORD_SCR + 8, w);
+            fillA(scr + k * PSD_RORD_SCR + 0, w + 16);
+        }
+        const double* C = scr + k * PSD_RORD_SCR + 4;
+        for (int q = 0; q < 4; ++q) w[32 + q] = 0.0;
+        for (int j = 0; j < p2; ++j)
+            for (int i = 0; i < p1; ++i) w[32 + j * p1 + i] = -C[j * 2 + i];
+        selfi[k] = k;
+        nexti[k] = (k + 1 == K) ? 0 : (k + 1);
+    }
+    PSD_WAVE_SYNC();
+    int m = K, rowbase = 0, pairslot = 0, nlev = 0;
+    bool ok = true;
+    while (m > 1) {
+        const int npairs = m / 2;
+        const int newbase = rowbase + m;
+        for (int b0 = 0; b0 < npairs; b0 += 4) {
+            const int nact = (npairs - b0 < 4) ? (npairs - b0) : 4;
+            PSD_WAVE_SYNC();
+            PSD_PAR_FOR(t, 64) {  // stack: lane = (pair g, column c)
+                const int g = t >> 4, c = t & 15;
+                if (g < nact && c <= 3 * pp) {
+                    const int q = b0 + g;
+                    const double* ra = RW + (rowbase + 2 * q) * 36;
+                    const double* rb = RW + (rowbase + 2 * q + 1) * 36;
+                    const bool merged = selfi[rowbase + 2 * q] == nexti[rowbase + 2 * q + 1];  // m == 2
+                    double* col = SR + g * 104 + c * 8;
+                    const int blk = (c == 3 * pp) ? 3 : (c / pp), cc = (c == 3 * pp) ? 0 : (c % pp);
+                    for (int i = 0; i < pp; ++i) {
+                        double top, bot;
+                        if (blk == 0) {         // x_mid: E_a over D_b
+                            top = ra[16 + cc * 4 + i];
+                            bot = rb[cc * 4 + i];
+                        } else if (blk == 1) {  // x_left: D_a over 0 (or E_b if left == right)
+                            top = ra[cc * 4 + i];
+                            bot = merged ? rb[16 + cc * 4 + i] : 0.0;
+                        } else if (blk == 2) {  // x_right: 0 over E_b
+                            top = 0.0;
+                            bot = merged ? 0.0 : rb[16 + cc * 4 + i];
+                        } else {
+                            top = ra[32 + i];
+                            bot = rb[32 + i];
+                        }
+                        col[i] = top;
+                        col[pp + i] = bot;
+                    }
+                }
+            }
+            if (!psd_rord_tree_level_qr<PP>(SR, vb, nact)) ok = false;
+            PSD_PAR_FOR(t, 64) {  // unstack
+                const int g = t >> 4, c = t & 15;
+                if (g < nact && c <= 3 * pp) {
+                    const int q = b0 + g;
+                    const double* col = SR + g * 104 + c * 8;
+                    double* top = wk + (pairslot + q) * 52;  // R 16 | a 16 | b 16 | s 4
+                    double* nr = RW + (newbase + q) * 36;
+                    const int blk = (c == 3 * pp) ? 3 : (c / pp), cc = (c == 3 * pp) ? 0 : (c % pp);
+                    for (int i = 0; i < pp; ++i) {
+                        if (blk < 3) top[blk * 16 + cc * 4 + i] = col[i];
+                        else top[48 + i] = col[i];
+                        if (blk == 1) nr[cc * 4 + i] = col[pp + i];
+                        else if (blk == 2) nr[16 + cc * 4 + i] = col[pp + i];
+                        else if (blk == 3) nr[32 + i] = col[pp + i];
+                    }
+                    if (c == 0) {
+                        const int ia = rowbase + 2 * q, ib = ia + 1;
+                        meta[3 * (pairslot + q) + 0] = nexti[ia];
+                        meta[3 * (pairslot + q) + 1] = selfi[ia];
+                        meta[3 * (pairslot + q) + 2] = nexti[ib];
+                        selfi[newbase + q] = selfi[ia];
+                        nexti[newbase + q] = nexti[ib];
+                    }
+                }
+            }
+            PSD_WAVE_SYNC();
+        }
+        if (m & 1) {  // odd: the last row is carried over
+            PSD_PAR_FOR(t, 36) { RW[(newbase + npairs) * 36 + t] = RW[(rowbase + m - 1) * 36 + t]; }
+            PSD_ONE {
+                selfi[newbase + npairs] = selfi[rowbase + m - 1];
+                nexti[newbase + npairs] = nexti[rowbase + m - 1];
+            }
+            PSD_WAVE_SYNC();
+        }
+        PSD_ONE {
+            lvl[2 * nlev] = npairs;
+            lvl[2 * nlev + 1] = pairslot;
+        }
+        nlev += 1;
+        pairslot += npairs;
+        rowbase = newbase;
+        m = (m + 1) / 2;
+    }
+    if (!ok) return false;
+    // one row left: (D + E) x = r
+    {
+        const double* w = RW + rowbase * 36;
+        PSD_WAVE_SYNC();
+        PSD_PAR_FOR(t, 16) {
+            const int c = t >> 2, r = t & 3;
+            if (c < pp && r < pp) SR[c * 8 + r] = w[c * 4 + r] + w[16 + c * 4 + r];
+            if (c == 0 && r < pp) SR[pp * 8 + r] = w[32 + r];
+        }
+        PSD_WAVE_SYNC();
+        if (!psd_sm_qr_par(SR, pp, pp + 1, pp)) return false;
+        double y[4];
+        for (int k = pp - 1; k >= 0; --k) {
+            double sum = SR[pp * 8 + k];
+            for (int c = k + 1; c < pp; ++c) sum -= SR[c * 8 + k] * y[c];
+            y[k] = sum / SR[k * 8 + k];
+        }
+        const int u = selfi[rowbase];
+        PSD_WAVE_SYNC();
+        PSD_ONE {
+            for (int q = 0; q < pp; ++q) scr[u * PSD_RORD_SCR + 12 + (q / p1) * 2 + (q % p1)] = y[q];
+        }
+        PSD_WAVE_SYNC();
+    }
+    // back substitution, level by level:  R x_mid = s - a x_left - b x_right
+    for (int L = nlev - 1; L >= 0; --L) {
+        const int npairs = lvl[2 * L], ps = lvl[2 * L + 1];
+        PSD_PAR_FOR(q, npairs) {
+            const double* top = wk + (ps + q) * 52;
+            const int um = meta[3 * (ps + q) + 0], ul = meta[3 * (ps + q) + 1], ur = meta[3 * (ps + q) + 2];
+            double xl[4], xr[4], y[4];
+            for (int e = 0; e < 4; ++e) {
+                xl[e] = (e < pp) ? scr[ul * PSD_RORD_SCR + 12 + (e / p1) * 2 + (e % p1)] : 0.0;
+                xr[e] = (e < pp) ? scr[ur * PSD_RORD_SCR + 12 + (e / p1) * 2 + (e % p1)] : 0.0;
+            }
+            for (int r = 0; r < pp; ++r) {
+                double sum = top[48 + r];
+                for (int c = 0; c < pp; ++c) sum -= top[16 + c * 4 + r] * xl[c] + top[32 + c * 4 + r] * xr[c];
+                y[r] = sum;
+            }
+            for (int k = pp - 1; k >= 0; --k) {
+                double sum = y[k];
+                for (int c = k + 1; c < pp; ++c) sum -= top[c * 4 + k] * y[c];
+                y[k] = sum / top[k * 4 + k];
+            }
+            for (int e = 0; e < pp; ++e) scr[um * PSD_RORD_SCR + 12 + (e / p1) * 2 + (e % p1)] = y[e];
+        }
+        PSD_WAVE_SYNC();
+    }
+    return true;
+}
+
+PSD_D bool psd_rord_psylsolve_tree(int K, int p1, int p2, double* scr, double* wk, double* tw, const unsigned char* SL) {
+    const int pp = p1 * p2;
+    if (pp == 4) return psd_rord_psylsolve_tree_t<4>(K, p1, p2, scr, wk, tw, SL);
+    if (pp == 2) return psd_rord_psylsolve_tree_t<2>(K, p1, p2, scr, wk, tw, SL);
+    return psd_rord_psylsolve_tree_t<1>(K, p1, p2, scr, wk, tw, SL);
+}
+
 // The small dense part of one swap of adjacent blocks (p1, p2) — sylswap.jl:14-129 (and :542-617 via the same
 // machinery for p1 = p2 = 1).  Per-factor scratch (index = position l-1 in the reference's left-oriented
 // sequence X_l): +0 T11, +4 T12, +8 T22, +12 X (ld 2); +16 Q, +32 Txx, +48 Ws, +64 Qfin (ld 4); +80 orig block
@@ -425,7 +700,8 @@ PSD_D int psd_rord_swap_scalar(int K, int p1, int p2, double* scr, double* wk, d
                                 const unsigned char* SL, bool gen) {
     const int m = p1 + p2;
     const long long tq0 = psd_clock();
-    const bool solved = psd_rord_psylsolve(K, p1, p2, scr, wk, ws, SL);
+    const bool solved = (K >= 4) ? psd_rord_psylsolve_tree(K, p1, p2, scr, wk, ws + 192, SL)
+                                 : psd_rord_psylsolve(K, p1, p2, scr, wk, ws, SL);
     cyc[2] += psd_clock() - tq0;
     if (!solved) return 2;
     const double thresh = fmax(PSD_DBL_MIN, 100.0 * PSD_DBL_EPS * tnrm);
@@ -802,7 +1078,7 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rord_step(psd_roparams P) {
     double* wk = scr + (size_t)p * PSD_RORD_SCR;
     double* flagbuf = wk + (size_t)p * 52;
     double* ws = flagbuf + 4;
-    int* lcnt = (int*)(ws + 192);
+    int* lcnt = (int*)(ws + 192 + psd_rord_tree_doubles(p));
     unsigned char* SL = (unsigned char*)(lcnt + p);  // signature of the left-oriented sequence X_l = T_{sigma(l)}
     PSD_PAR_FOR(t, p) { SL[t] = psd_rosig(P, psd_ord_sigma(p, t + 1)) ? 1 : 0; }
     PSD_SYNC();
