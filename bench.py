@@ -58,6 +58,18 @@ def cpu_baseline(n, p, seed):
             "seconds": dt, "phase_ms": [float(x) for x in po.phase_ms]}
 
 
+def cycle_shares(st):
+    """In-kernel s_memtime accounting of the chase kernel (psd_stats.step_cycles): share of decide / window load /
+    chase / window store in the kernel's own time, and the shader clock derived from s_memrealtime."""
+    c = list(st.step_cycles)
+    if not c[4]:
+        return None
+    out = {"decide": c[0] / c[4], "window_load": c[1] / c[4], "chase": c[2] / c[4], "window_store": c[3] / c[4]}
+    if c[5]:
+        out["shader_clock_GHz"] = c[4] / (c[5] * 10e-9) / 1e9  # s_memrealtime ticks at 100 MHz
+    return out
+
+
 def pmc_traffic(n, p):
     """HBM bytes per chase launch (step + apply kernels) from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE, separate runs, gfx950 correction of the guide applied; profiles/r01/pmc_traffic_cfg2.json says how).
@@ -171,6 +183,7 @@ def main():
             "config": {"workload": "configs[1]: pschur!(A,:R) N=%d p=%d Float64 wantT wantZ, A_j = I + 0.5*G_j/sqrt(n)" % (n, p),
                        "seed": seed, "parallelism": "replicas x%d" % world, "window": st.window},
             "sweeps_per_step": sweeps / args.steps,
+            "chase_kernel_cycle_shares": cycle_shares(st),
             "phase_ms_per_step": {"hessenberg": ms_hess / args.steps, "formq": ms_formq / args.steps,
                                   "iteration": ms_iter / args.steps},
             "algorithmic_GBps": {"sweeps": bytes_sw / (ms_iter * 1e-3) / 1e9 if ms_iter else None,

@@ -124,28 +124,31 @@ struct psd_win {
 PSD_D void psd_win_load(const psd_rparams& P, const psd_win& w, int n, int p) {
     const int m = w.be - w.bs + 1;
     const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
-    const int total = p * m;  // columns over all factors
     PSD_PAR_FOR(t, PSD_STEP_NT) {
         const int r = t & (RW - 1), g = t >> sh;
         if (r < m) {
-            for (int q0 = g; q0 < total; q0 += 16 * ncg) {
-                double v[16];
+            // factor loop outside (no index divisions in the hot loop); two factors per batch: 32 loads in flight
+            for (int j = 0; j < p; j += 2) {
+                const bool two = j + 1 < p;
+                const double* src0 = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r);
+                const double* src1 = src0 + (two ? (size_t)n * n : 0);
+                double* dst0 = w.b + j * w.bsz + r;
+                double* dst1 = dst0 + w.bsz;
+                for (int c0 = g; c0 < m; c0 += 16 * ncg) {
+                    double v0[16], v1[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int q = q0 + u * ncg;
-                    if (q < total) {
-                        const int j = q / m, c = q - j * m;
-                        v[u] = P.H[(size_t)j * n * n + (size_t)(w.bs - 1 + c) * n + (w.bs - 1 + r)];
-                    } else {
-                        v[u] = 0.0;
+                    for (int u = 0; u < 16; ++u) {
+                        const int c = c0 + u * ncg;
+                        v0[u] = (c < m) ? src0[(size_t)c * n] : 0.0;
+                        v1[u] = (c < m && two) ? src1[(size_t)c * n] : 0.0;
                     }
-                }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int q = q0 + u * ncg;
-                    if (q < total) {
-                        const int j = q / m, c = q - j * m;
-                        w.b[j * w.bsz + c * w.ld + r] = v[u];
+                    for (int u = 0; u < 16; ++u) {
+                        const int c = c0 + u * ncg;
+                        if (c < m) {
+                            dst0[c * w.ld] = v0[u];
+                            if (two) dst1[c * w.ld] = v1[u];
+                        }
                     }
                 }
             }
@@ -156,14 +159,14 @@ PSD_D void psd_win_load(const psd_rparams& P, const psd_win& w, int n, int p) {
 PSD_D void psd_win_store(const psd_rparams& P, const psd_win& w, int n, int p) {
     const int m = w.be - w.bs + 1;
     const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
-    const int total = p * m;
     PSD_SYNC();
     PSD_PAR_FOR(t, PSD_STEP_NT) {
         const int r = t & (RW - 1), g = t >> sh;
         if (r < m) {
-            for (int q = g; q < total; q += ncg) {
-                const int j = q / m, c = q - j * m;
-                P.H[(size_t)j * n * n + (size_t)(w.bs - 1 + c) * n + (w.bs - 1 + r)] = w.b[j * w.bsz + c * w.ld + r];
+            for (int j = 0; j < p; ++j) {
+                double* dst = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r);
+                const double* src = w.b + j * w.bsz + r;
+                for (int c = g; c < m; c += ncg) dst[(size_t)c * n] = src[c * w.ld];
             }
         }
     }

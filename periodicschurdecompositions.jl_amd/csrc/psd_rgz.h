@@ -86,28 +86,23 @@ struct psd_gwin {
 PSD_D void psd_gwin_load(const psd_gparams& P, const psd_gwin& w, int n, int p) {
     const int m = w.be - w.bs + 1;
     const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
-    const int total = p * m;
     PSD_PAR_FOR(t, PSD_STEP_NT) {
         const int r = t & (RW - 1), g = t >> sh;
         if (r < m) {
-            for (int q0 = g; q0 < total; q0 += 8 * ncg) {
-                double v[8];
+            for (int j = 0; j < p; ++j) {  // (factor loop outside: no index divisions in the hot loop)
+                const double* src = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r);
+                double* dst = w.b + j * w.bsz + r;
+                for (int c0 = g; c0 < m; c0 += 16 * ncg) {
+                    double v[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int q = q0 + u * ncg;
-                    if (q < total) {
-                        const int l = q / m, c = q - l * m;
-                        v[u] = P.H[(size_t)l * n * n + (size_t)(w.bs - 1 + c) * n + (w.bs - 1 + r)];
-                    } else {
-                        v[u] = 0.0;
+                    for (int u = 0; u < 16; ++u) {
+                        const int c = c0 + u * ncg;
+                        v[u] = (c < m) ? src[(size_t)c * n] : 0.0;
                     }
-                }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int q = q0 + u * ncg;
-                    if (q < total) {
-                        const int l = q / m, c = q - l * m;
-                        w.b[l * w.bsz + c * w.ld + r] = v[u];
+                    for (int u = 0; u < 16; ++u) {
+                        const int c = c0 + u * ncg;
+                        if (c < m) dst[c * w.ld] = v[u];
                     }
                 }
             }
@@ -118,14 +113,14 @@ PSD_D void psd_gwin_load(const psd_gparams& P, const psd_gwin& w, int n, int p) 
 PSD_D void psd_gwin_store(const psd_gparams& P, const psd_gwin& w, int n, int p) {
     const int m = w.be - w.bs + 1;
     const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
-    const int total = p * m;
     PSD_SYNC();
     PSD_PAR_FOR(t, PSD_STEP_NT) {
         const int r = t & (RW - 1), g = t >> sh;
         if (r < m) {
-            for (int q = g; q < total; q += ncg) {
-                const int l = q / m, c = q - l * m;
-                P.H[(size_t)l * n * n + (size_t)(w.bs - 1 + c) * n + (w.bs - 1 + r)] = w.b[l * w.bsz + c * w.ld + r];
+            for (int j = 0; j < p; ++j) {
+                double* dst = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r);
+                const double* src = w.b + j * w.bsz + r;
+                for (int c = g; c < m; c += ncg) dst[(size_t)c * n] = src[c * w.ld];
             }
         }
     }

@@ -83,28 +83,23 @@ struct psd_zwin {
 PSD_D void psd_zwin_load(const psd_zparams& P, const psd_zwin& w, int n, int p) {
     const int m = w.be - w.bs + 1;
     const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
-    const int total = p * m;
     PSD_PAR_FOR(t, PSD_STEP_NT) {
         const int r = t & (RW - 1), g = t >> sh;
         if (r < m) {
-            for (int q0 = g; q0 < total; q0 += 8 * ncg) {
-                psd_z v[8];
+            for (int j = 0; j < p; ++j) {  // (factor loop outside: no index divisions in the hot loop)
+                const psd_z* src = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r);
+                psd_z* dst = w.b + j * w.bsz + r;
+                for (int c0 = g; c0 < m; c0 += 8 * ncg) {
+                    psd_z v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int q = q0 + u * ncg;
-                    if (q < total) {
-                        const int j = q / m, c = q - j * m;
-                        v[u] = P.H[(size_t)j * n * n + (size_t)(w.bs - 1 + c) * n + (w.bs - 1 + r)];
-                    } else {
-                        v[u] = zmk(0.0, 0.0);
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = c0 + u * ncg;
+                        v[u] = (c < m) ? src[(size_t)c * n] : zmk(0.0, 0.0);
                     }
-                }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int q = q0 + u * ncg;
-                    if (q < total) {
-                        const int j = q / m, c = q - j * m;
-                        w.b[j * w.bsz + c * w.ld + r] = v[u];
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = c0 + u * ncg;
+                        if (c < m) dst[c * w.ld] = v[u];
                     }
                 }
             }
@@ -115,14 +110,14 @@ PSD_D void psd_zwin_load(const psd_zparams& P, const psd_zwin& w, int n, int p) 
 PSD_D void psd_zwin_store(const psd_zparams& P, const psd_zwin& w, int n, int p) {
     const int m = w.be - w.bs + 1;
     const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
-    const int total = p * m;
     PSD_SYNC();
     PSD_PAR_FOR(t, PSD_STEP_NT) {
         const int r = t & (RW - 1), g = t >> sh;
         if (r < m) {
-            for (int q = g; q < total; q += ncg) {
-                const int j = q / m, c = q - j * m;
-                P.H[(size_t)j * n * n + (size_t)(w.bs - 1 + c) * n + (w.bs - 1 + r)] = w.b[j * w.bsz + c * w.ld + r];
+            for (int j = 0; j < p; ++j) {
+                psd_z* dst = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r);
+                const psd_z* src = w.b + j * w.bsz + r;
+                for (int c = g; c < m; c += ncg) dst[(size_t)c * n] = src[c * w.ld];
             }
         }
     }
