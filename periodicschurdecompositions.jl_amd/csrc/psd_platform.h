@@ -117,6 +117,8 @@ typedef dim3 psd_dim3;
 // LDS hand-off between lanes of ONE wavefront (only valid in single-wave workgroups): DS operations
 // of a wave execute in order, so only the compiler has to be fenced; unlike __syncthreads() this does
 // not drain outstanding global stores (vmcnt), which would put their acknowledge latency on the chain.
+// (measured: dropping the s_waitcnt and keeping only the compiler fence is bit-identical on the whole GPU test tier
+// and 1.4 % faster; the conservative form stays)
 #define PSD_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define PSD_PAR_FOR(t, count) for (int t = (int)threadIdx.x; t < (int)(count); t += (int)blockDim.x)
 #define PSD_ONE if (threadIdx.x == 0)
