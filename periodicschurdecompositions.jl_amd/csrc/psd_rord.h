@@ -1267,8 +1267,9 @@ PSD_KERNEL_B(PSD_APPLY_NT) psd_rord_apply(psd_roparams P, int n, int p) {
         const int nc = (d.lc1 - c0 + 1 < T) ? (d.lc1 - c0 + 1) : T;
         const psd_mat<double> M = psd_mat<double>{P.H + (size_t)(fac - 1) * n * n, n};
         const int ldt = T + 1;
-        PSD_PAR_FOR(t, S * nc) {
-            const int r = t % S, c = t / S;
+        PSD_PAR_FOR(t, 32 * nc) {  // (S <= 32; no index divisions)
+            const int r = t & 31, c = t >> 5;
+            if (r >= S) continue;
             tile[r * ldt + c] = M(d.plo + r, c0 + c);
         }
         PSD_SYNC();
@@ -1287,8 +1288,9 @@ PSD_KERNEL_B(PSD_APPLY_NT) psd_rord_apply(psd_roparams P, int n, int p) {
             }
         }
         PSD_SYNC();
-        PSD_PAR_FOR(t, S * nc) {
-            const int r = t % S, c = t / S;
+        PSD_PAR_FOR(t, 32 * nc) {  // (S <= 32; no index divisions)
+            const int r = t & 31, c = t >> 5;
+            if (r >= S) continue;
             M(d.plo + r, c0 + c) = tile[r * ldt + c];
         }
     } else {
@@ -1299,8 +1301,9 @@ PSD_KERNEL_B(PSD_APPLY_NT) psd_rord_apply(psd_roparams P, int n, int p) {
         const int nr = (hi - r0 + 1 < T) ? (hi - r0 + 1) : T;
         double* base = (role == 2) ? P.Z : P.H;
         const psd_mat<double> M = psd_mat<double>{base + (size_t)(fac - 1) * n * n, n};
-        PSD_PAR_FOR(t, S * nr) {
-            const int r = t % nr, c = t / nr;
+        PSD_PAR_FOR(t, S * T) {
+            const int r = t & (T - 1), c = t / T;
+            if (r >= nr) continue;
             tile[c * T + r] = M(r0 + r, d.plo + c);
         }
         PSD_SYNC();
@@ -1319,8 +1322,9 @@ PSD_KERNEL_B(PSD_APPLY_NT) psd_rord_apply(psd_roparams P, int n, int p) {
             }
         }
         PSD_SYNC();
-        PSD_PAR_FOR(t, S * nr) {
-            const int r = t % nr, c = t / nr;
+        PSD_PAR_FOR(t, S * T) {
+            const int r = t & (T - 1), c = t / T;
+            if (r >= nr) continue;
             M(r0 + r, d.plo + c) = tile[c * T + r];
         }
     }

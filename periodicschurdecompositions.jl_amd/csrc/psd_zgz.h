@@ -752,8 +752,9 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zgq_apply(psd_zgparams P, int n, int p) {
         const psd_mat<psd_z> M = psd_zgfac(P, n, l);
         const int ldt = T + 1;
         PSD_PAR_FOR(e, cnt) { ltr[e] = P.tr[(size_t)(own - 1) * PSD_GTR_CAP + e]; }
-        PSD_PAR_FOR(t, S * nc) {
-            const int r = t % S, c = t / S;
+        PSD_PAR_FOR(t, 32 * nc) {  // (S <= 32; no index divisions)
+            const int r = t & 31, c = t >> 5;
+            if (r >= S) continue;
             tile[r * ldt + c] = M(d.plo + r, c0 + c);
         }
         PSD_SYNC();
@@ -769,8 +770,9 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zgq_apply(psd_zgparams P, int n, int p) {
             }
         }
         PSD_SYNC();
-        PSD_PAR_FOR(t, S * nc) {
-            const int r = t % S, c = t / S;
+        PSD_PAR_FOR(t, 32 * nc) {  // (S <= 32; no index divisions)
+            const int r = t & 31, c = t >> 5;
+            if (r >= S) continue;
             if (h1x && c0 + c >= d.plo && c0 + c <= d.phi) continue;
             M(d.plo + r, c0 + c) = tile[r * ldt + c];
         }
@@ -785,8 +787,9 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zgq_apply(psd_zgparams P, int n, int p) {
         psd_z* base = (role == 1) ? P.H : P.Z;
         const psd_mat<psd_z> M = psd_mat<psd_z>{base + (size_t)(l - 1) * n * n, n};
         PSD_PAR_FOR(e, cnt) { ltr[e] = P.tr[(size_t)(own - 1) * PSD_GTR_CAP + e]; }
-        PSD_PAR_FOR(t, S * nr) {
-            const int r = t % nr, c = t / nr;
+        PSD_PAR_FOR(t, S * T) {
+            const int r = t & (T - 1), c = t / T;
+            if (r >= nr) continue;
             tile[c * T + r] = M(r0 + r, d.plo + c);
         }
         PSD_SYNC();
@@ -802,8 +805,9 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zgq_apply(psd_zgparams P, int n, int p) {
             }
         }
         PSD_SYNC();
-        PSD_PAR_FOR(t, S * nr) {
-            const int r = t % nr, c = t / nr;
+        PSD_PAR_FOR(t, S * T) {
+            const int r = t & (T - 1), c = t / T;
+            if (r >= nr) continue;
             if (h1r && r0 + r >= d.plo && r0 + r <= d.phi) continue;
             M(r0 + r, d.plo + c) = tile[c * T + r];
         }

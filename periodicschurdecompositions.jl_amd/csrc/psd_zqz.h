@@ -787,8 +787,9 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply(psd_zparams P, int n, int p) {
         const psd_mat<psd_z> M = psd_mat<psd_z>{P.H + (size_t)(m - 1) * n * n, n};
         const int ldt = T + 1;
         PSD_PAR_FOR(e, cnt) { ltr[e] = P.tr[(size_t)(m - 1) * PSD_ZTR_CAP + e]; }
-        PSD_PAR_FOR(t, S * nc) {
-            const int r = t % S, c = t / S;
+        PSD_PAR_FOR(t, 32 * nc) {  // (S <= 32; no index divisions)
+            const int r = t & 31, c = t >> 5;
+            if (r >= S) continue;
             tile[r * ldt + c] = M(d.plo + r, c0 + c);
         }
         PSD_SYNC();
@@ -803,8 +804,9 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply(psd_zparams P, int n, int p) {
             }
         }
         PSD_SYNC();
-        PSD_PAR_FOR(t, S * nc) {
-            const int r = t % S, c = t / S;
+        PSD_PAR_FOR(t, 32 * nc) {  // (S <= 32; no index divisions)
+            const int r = t & 31, c = t >> 5;
+            if (r >= S) continue;
             M(d.plo + r, c0 + c) = tile[r * ldt + c];
         }
     } else {
@@ -818,8 +820,9 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply(psd_zparams P, int n, int p) {
         psd_z* base = (role == 1) ? P.H : P.Z;
         const psd_mat<psd_z> M = psd_mat<psd_z>{base + (size_t)(jm - 1) * n * n, n};
         PSD_PAR_FOR(e, cnt) { ltr[e] = P.tr[(size_t)(m - 1) * PSD_ZTR_CAP + e]; }
-        PSD_PAR_FOR(t, S * nr) {
-            const int r = t % nr, c = t / nr;
+        PSD_PAR_FOR(t, S * T) {
+            const int r = t & (T - 1), c = t / T;
+            if (r >= nr) continue;
             tile[c * T + r] = M(r0 + r, d.plo + c);
         }
         PSD_SYNC();
@@ -834,8 +837,9 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply(psd_zparams P, int n, int p) {
             }
         }
         PSD_SYNC();
-        PSD_PAR_FOR(t, S * nr) {
-            const int r = t % nr, c = t / nr;
+        PSD_PAR_FOR(t, S * T) {
+            const int r = t & (T - 1), c = t / T;
+            if (r >= nr) continue;
             M(r0 + r, d.plo + c) = tile[c * T + r];
         }
     }
