@@ -493,7 +493,12 @@ PSD_D void psd_desc_write(const psd_rparams& P, const psd_rstate& st, const int*
 // offset inside a factor block / stride, lane_adj: 0 for column lanes, bsz for row lanes.
 PSD_D void psd_qr_micro3(const psd_rparams& P, const psd_win& w, int j, int nl, int cnt, int lk, int k,
                          PSD_LANEVAR_REF(int, lane_off), PSD_LANEVAR_REF(int, lane_str),
-                         PSD_LANEVAR_REF(int, lane_adj), double& x0, double& x1, double& x2, int slot) {
+                         PSD_LANEVAR_REF(int, lane_adj), double& x0, double& x1, double& x2, double& tau_io,
+                         bool more, int slot) {
+    // (x0, x1, x2, tau_io) in: the 3-reflector of this factor, already generated: (beta, v2, v3, tau);
+    // out (if `more`): the 3-reflector of the next factor, generated here from H_{j-1}[k..k+2, k] while the
+    // 2-reflector of this factor is being generated and applied — two independent dependency chains in one
+    // basic block, which the scheduler interleaves (a lone wavefront is otherwise stalled on each chain's latency)
     PSD_LANEVAR(double, a1);
     PSD_LANEVAR(double, a2);
     PSD_LANEVAR(double, a3);
@@ -505,7 +510,7 @@ PSD_D void psd_qr_micro3(const psd_rparams& P, const psd_win& w, int j, int nl, 
         PSD_LV(a2) = q[sd];
         PSD_LV(a3) = q[2 * sd];
     }
-    const double tau = psd_refl3(x0, x1, x2);
+    const double tau = tau_io;
     const double beta = x0, v2 = x1, v3 = x2;
     PSD_PAR_ONCE(t, cnt) {
         const double x = tau * (PSD_LV(a1) + v2 * PSD_LV(a2) + v3 * PSD_LV(a3));
@@ -517,7 +522,8 @@ PSD_D void psd_qr_micro3(const psd_rparams& P, const psd_win& w, int j, int nl, 
     x0 = PSD_BCAST(a1, lk);                               // H_{j-1}[k..k+2, k] for the next factor
     x1 = PSD_BCAST(a1, lk + 1);
     x2 = PSD_BCAST(a1, lk + 2);
-    const double tau2 = psd_refl2(y0, y1);
+    double tau2;
+    psd_refl32_pair(x0, x1, x2, tau_io, y0, y1, tau2);  // (for the last factor the 3-reflector is simply not used)
     const double beta2 = y0, w2 = y1;
     PSD_PAR_ONCE(t, cnt) {
         const double x = tau2 * (PSD_LV(a2) + w2 * PSD_LV(a3));
@@ -739,8 +745,9 @@ PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
                 }
             }
             const int lk = nl + (k - r0);
+            double tau3 = psd_refl3(x0, x1, x2);  // reflector of factor p; each micro-step generates the next one
             for (int j = p; j >= 2; --j)
-                psd_qr_micro3(P, w, j, nl, cnt, lk, k, lane_off, lane_str, lane_adj, x0, x1, x2, nj);
+                psd_qr_micro3(P, w, j, nl, cnt, lk, k, lane_off, lane_str, lane_adj, x0, x1, x2, tau3, j > 2, nj);
         } else {
             double tau = (nr == 3) ? psd_refl3(x0, x1, x2) : psd_refl2(x0, x1);
             if (p > 1) {

@@ -108,6 +108,39 @@ PSD_HD double psd_refl2(double& x0, double& x1) {
     return tau;
 }
 
+// psd_refl3 on (x0, x1, x2) and psd_refl2 on (y0, y1) at once: the two fast paths are evaluated in ONE straight-line
+// block (no control flow between them), so that the instruction scheduler interleaves the two independent dependency
+// chains; the range checks come afterwards and send the rare cases to the individual routines.
+PSD_HD void psd_refl32_pair(double& x0, double& x1, double& x2, double& tau3, double& y0, double& y1, double& tau2) {
+    const double tx = fmax(fabs(x1), fabs(x2)), bx = fmax(tx, fabs(x0));
+    const double ty = fabs(y1), by = fmax(ty, fabs(y0));
+    const bool fx = (bx < 1e140) && (tx > 1e-140);
+    const bool fy = (by < 1e140) && (ty > 1e-140);
+    double nx, rnx, ny, rny;
+    psd_sqrt_pair_fast(fx ? (x0 * x0 + (x1 * x1 + x2 * x2)) : 1.0, nx, rnx);
+    psd_sqrt_pair_fast(fy ? (y0 * y0 + y1 * y1) : 1.0, ny, rny);
+    const double ax = fabs(x0), ay = fabs(y0);
+    const double t3 = 1.0 + ax * rnx, t2 = 1.0 + ay * rny;
+    const double sx = psd_rcp_fast(copysign(ax + nx, x0)), sy = psd_rcp_fast(copysign(ay + ny, y0));
+    const double fx1 = x1 * sx, fx2 = x2 * sx, fx0 = -copysign(nx, x0);
+    const double fy1 = y1 * sy, fy0 = -copysign(ny, y0);
+    if (fx) {
+        x0 = fx0;
+        x1 = fx1;
+        x2 = fx2;
+        tau3 = t3;
+    } else {
+        tau3 = psd_refl3(x0, x1, x2);
+    }
+    if (fy) {
+        y0 = fy0;
+        y1 = fy1;
+        tau2 = t2;
+    } else {
+        tau2 = psd_refl2(y0, y1);
+    }
+}
+
 // stdlib LinearAlgebra.givensAlgorithm(f::Float64, g::Float64) (imported by the reference at
 // PSD.jl:9): (c, s, r) with [c s; -s c][f; g] = [r; 0].
 PSD_HD void psd_givens(double f, double g, double& cs, double& sn, double& r) {
