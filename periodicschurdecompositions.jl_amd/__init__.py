@@ -380,6 +380,23 @@ class Engine:
         Atmp = [np.array(a, dtype=dt, order="F", copy=True) for a in A]
         return self.pschur_(Atmp, lr, **kw)
 
+    def gpschur(self, As, Bs, **kw):
+        """gpschur(As, Bs) — src/generalized.jl:1191-1211: generalized periodic Schur decomposition for the formal
+        product B_p^-1 A_p ... B_1^-1 A_1 of paired series in left operator order.  As the reference, the arguments are
+        complexified and interleaved by `_mkpsargs` (:1198-1211) and handed to pschur!(Cs, Ss)."""
+        ph = len(As)
+        if len(Bs) != ph:
+            raise DimensionMismatch("As and Bs must have the same length")
+        cz = lambda m: np.array(m, dtype=np.complex128, order="F", copy=True)  # noqa: E731
+        ib = 0 if ph == 1 else ph - 2
+        Cs, Ss = [cz(As[ph - 1]), cz(Bs[ib])], [True, False]
+        for j in range(ph - 1, 0, -1):  # j = ph-1 .. 1 (1-based)
+            Cs.append(cz(As[j - 1]))
+            jx = ph if j == 1 else j - 1
+            Cs.append(cz(Bs[jx - 1]))
+            Ss += [True, False]
+        return self.pschur_(Cs, "R", S=Ss, **kw)
+
     def zpschur_hess_(self, H1, Hs, S=None, Q=None, wantT=True, wantZ=True, maxitfac=30, rev=False):
         """pschur!(H1, Hs, S; wantT, wantZ, Q, maxitfac, rev) for ComplexF64 — src/generalized.jl:166-175."""
         H = [H1] + list(Hs)

@@ -876,3 +876,21 @@ def case_gordschur_pairs_random(eng, sizes):
         sc = abs(lam0).max()
         assert pt.match_eigs(lam0[select], ps1.values[:m]) < 1e-8 * sc
         assert pt.match_eigs(lam0[~select], ps1.values[m:]) < 1e-8 * sc
+
+
+def case_gpschur_pairs(eng):
+    """gpschur(As, Bs) (generalized.jl:1191-1211): eigenvalues of B_p^-1 A_p ... B_1^-1 A_1"""
+    for (n, ph, seed) in [(5, 1, 1), (6, 2, 2), (7, 3, 3), (20, 4, 4)]:
+        As = pt.bench_factors(n, ph, seed=seed + 70)
+        Bs = pt.bench_factors(n, ph, seed=seed + 170)
+        ps = eng.gpschur(As, Bs)
+        assert len(ps.Ts) == 2 * ph and ps.S == [True, False] * ph
+        Cs = [np.asarray(As[ph - 1], dtype=complex), np.asarray(Bs[0 if ph == 1 else ph - 2], dtype=complex)]
+        for j in range(ph - 1, 0, -1):
+            Cs += [np.asarray(As[j - 1], dtype=complex), np.asarray(Bs[(ph if j == 1 else j - 1) - 1], dtype=complex)]
+        pt.gpschur_check(Cs, ps.S, ps, tol=100 * max(1.0, n / 8))
+        P = np.eye(n, dtype=complex)
+        for j in range(ph):  # left operator order: factor j+1 applied after factor j
+            P = np.linalg.solve(Bs[j], As[j] @ P)
+        lam = np.linalg.eigvals(P)
+        assert pt.match_eigs(lam, ps.values) < 1e-8 * abs(lam).max()

@@ -113,3 +113,7 @@ def test_gordschur_pairs_reference(gpu_engine):
 def test_gordschur_pairs_random(gpu_engine):
     ec.case_gordschur_pairs_random(gpu_engine, [(10, 3, "L", 1), (14, 4, "R", 2), (16, 5, "L", 3), (40, 3, "R", 4),
                                                 (30, 21, "L", 5), (96, 6, "R", 6), (128, 8, "L", 7)])
+
+
+def test_gpschur_pairs(gpu_engine):
+    ec.case_gpschur_pairs(gpu_engine)

@@ -82,3 +82,7 @@ def test_gordschur_pairs_reference(sim_engine):
 
 def test_gordschur_pairs_random(sim_engine):
     ec.case_gordschur_pairs_random(sim_engine, [(10, 3, "L", 1), (14, 4, "R", 2), (16, 5, "L", 3), (40, 3, "R", 4), (30, 21, "L", 5)])
+
+
+def test_gpschur_pairs(sim_engine):
+    ec.case_gpschur_pairs(sim_engine)
