@@ -339,7 +339,7 @@ int hessenberg_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
     PSD_CHECK(psd_rt_h2d(c->hargs, &ha, sizeof(ha), c->stream));
     PSD_CHECK(psd_rt_sync(c->stream));  // (ha lives on the stack)
     const int nLmax = (n - 2 + 1 + 3) / 4;  // lc0 = 2
-    const int nR = (n + 31) / 32;
+    const int nR = (n + PSD_HESS_RS - 1) / PSD_HESS_RS;
     auto column = [&]() {  // the launches of one column i = hargs->i  (PSD.jl:229-247)
         for (int j = p; j >= 1; --j) {
             PSD_LAUNCH(psd_hess_refl_g, psd_dim3(1), PSD_HESS_NT, lds_refl, c->stream, (const psd_hess_args*)c->hargs, n, j);
@@ -757,7 +757,7 @@ int zhessenberg_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dtau) {
                        dtau + (size_t)(j - 1) * n + (i - 1));
             const int lc0 = i + 1;
             const int nL = (n - lc0 + 1 + 3) / 4;
-            const int nR = (n + 31) / 32;
+            const int nR = (n + PSD_HESS_RS - 1) / PSD_HESS_RS;
             if (Aj != Ajm1) {
                 PSD_LAUNCH(psd_zhess_apply, psd_dim3(nL + nR), PSD_HESS_NT, lds_apply, c->stream, Aj, Ajm1, n, r0, lc0,
                            (const psd_z*)c->zvbuf, nL);
@@ -1043,7 +1043,7 @@ int zsghess_dev(psd_ctx* c, int n, int p, psd_z* dA, psd_z* dQ, const uint8_t* S
         for (int i = 1; i <= n - 1; ++i) {
             PSD_LAUNCH(psd_zhess_refl, psd_dim3(1), PSD_HESS_NT, lds_refl, c->stream, Al, n, i, i, c->zvbuf, (psd_z*)nullptr);
             const int nL = (n - i + 3) / 4;
-            const int nR = (n + 31) / 32;
+            const int nR = (n + PSD_HESS_RS - 1) / PSD_HESS_RS;
             PSD_LAUNCH(psd_zhess_apply, psd_dim3(nL + (Ql ? nR : 0)), PSD_HESS_NT, lds_apply, c->stream, Al, Ql, n, i,
                        i + 1, (const psd_z*)c->zvbuf, nL);
             if (mrows == 0) {
@@ -1788,7 +1788,7 @@ int sghess_dev(psd_ctx* c, int n, int p, double* dA, double* dQ, const uint8_t* 
             PSD_LAUNCH(psd_hess_refl, psd_dim3(1), PSD_HESS_NT, lds_refl, c->stream, Al, n, i, i, c->vbuf,
                        (double*)nullptr);
             const int nL = (n - i + 3) / 4;   // columns i+1..n of A_l
-            const int nR = (n + 31) / 32;
+            const int nR = (n + PSD_HESS_RS - 1) / PSD_HESS_RS;
             PSD_LAUNCH(psd_hess_apply, psd_dim3(nL + (Ql ? nR : 0)), PSD_HESS_NT, lds_apply, c->stream, Al, Ql, n, i,
                        i + 1, (const double*)c->vbuf, nL);
             if (mrows == 0) {

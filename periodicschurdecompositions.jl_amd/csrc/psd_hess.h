@@ -11,12 +11,14 @@
 //                   vector for the update kernel;
 //   psd_hess_apply  wide kernel: blocks [0,nL) apply H' from the left to A_j (one wavefront per
 //                   column, lanes down the column: coalesced), blocks [nL,..) apply H from the
-//                   right to A_{j-1} (32-row strips, 8 column phases, v staged in LDS).
+//                   right to A_{j-1} (8-row strips, 32 column phases, v staged in LDS: many short strips
+//                   keep all compute units busy).
 // Q_j are formed afterwards by backward accumulation, all p factors per launch.
 #pragma once
 #include "psd_scalar.h"
 
 #define PSD_HESS_NT 256
+#define PSD_HESS_RS 8  // rows per strip of the right-hand update (NT / RS column phases per strip)
 
 PSD_D double psd_block_max(double* red, int NT) {
     for (int s = NT / 2; s > 0; s >>= 1) {
@@ -156,29 +158,29 @@ PSD_D void psd_hess_apply_body(double* AL, double* AR, int n, int r0, int lc0, c
     } else {
         if (!AR) return;
         const psd_mat<double> M = psd_mat<double>{AR, n};
-        const int rbase = 1 + 32 * (b - nL);
+        const int rbase = 1 + PSD_HESS_RS * (b - nL);
         if (rbase > n) return;
         PSD_PAR_FOR(q, m) { vs[q] = (q == 0) ? 1.0 : vbuf[q]; }
         PSD_SYNC();
         PSD_PAR_FOR(t, NT) {
-            const int ph = t >> 5, r = rbase + (t & 31);
+            const int ph = t / PSD_HESS_RS, r = rbase + (t & (PSD_HESS_RS - 1));
             double s = 0.0;
             if (r <= n)
-                for (int q = ph; q < m; q += 8) s += M(r, r0 + q) * vs[q];
+                for (int q = ph; q < m; q += PSD_HESS_NT / PSD_HESS_RS) s += M(r, r0 + q) * vs[q];
             red[t] = s;
         }
         PSD_SYNC();
-        PSD_PAR_FOR(t, 32) {
+        PSD_PAR_FOR(t, PSD_HESS_RS) {
             double s = 0.0;
-            for (int ph = 0; ph < 8; ++ph) s += red[ph * 32 + t];
+            for (int ph = 0; ph < PSD_HESS_NT / PSD_HESS_RS; ++ph) s += red[ph * PSD_HESS_RS + t];
             red[t] = tau * s;
         }
         PSD_SYNC();
         PSD_PAR_FOR(t, NT) {
-            const int ph = t >> 5, r = rbase + (t & 31);
+            const int ph = t / PSD_HESS_RS, r = rbase + (t & (PSD_HESS_RS - 1));
             if (r <= n) {
-                const double x = red[t & 31];
-                for (int q = ph; q < m; q += 8) M(r, r0 + q) -= x * vs[q];
+                const double x = red[t & (PSD_HESS_RS - 1)];
+                for (int q = ph; q < m; q += PSD_HESS_NT / PSD_HESS_RS) M(r, r0 + q) -= x * vs[q];
             }
         }
     }

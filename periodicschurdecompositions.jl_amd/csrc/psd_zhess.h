@@ -131,29 +131,29 @@ PSD_KERNEL psd_zhess_apply(psd_z* AL, psd_z* AR, int n, int r0, int lc0, const p
     } else {
         if (!AR) return;
         const psd_mat<psd_z> M = psd_mat<psd_z>{AR, n};
-        const int rbase = 1 + 32 * (b - nL);
+        const int rbase = 1 + PSD_HESS_RS * (b - nL);
         if (rbase > n) return;
         PSD_PAR_FOR(q, m) { vs[q] = (q == 0) ? zmk(1.0, 0.0) : vbuf[q]; }
         PSD_SYNC();
         PSD_PAR_FOR(t, NT) {
-            const int ph = t >> 5, r = rbase + (t & 31);
+            const int ph = t / PSD_HESS_RS, r = rbase + (t & (PSD_HESS_RS - 1));
             psd_z s = zmk(0.0, 0.0);
             if (r <= n)
-                for (int q = ph; q < m; q += 8) s = zadd(s, zmul(M(r, r0 + q), vs[q]));
+                for (int q = ph; q < m; q += PSD_HESS_NT / PSD_HESS_RS) s = zadd(s, zmul(M(r, r0 + q), vs[q]));
             red[t] = s;
         }
         PSD_SYNC();
-        PSD_PAR_FOR(t, 32) {
+        PSD_PAR_FOR(t, PSD_HESS_RS) {
             psd_z s = zmk(0.0, 0.0);
-            for (int ph = 0; ph < 8; ++ph) s = zadd(s, red[ph * 32 + t]);
+            for (int ph = 0; ph < PSD_HESS_NT / PSD_HESS_RS; ++ph) s = zadd(s, red[ph * PSD_HESS_RS + t]);
             red[t] = zmul(tau, s);
         }
         PSD_SYNC();
         PSD_PAR_FOR(t, NT) {
-            const int ph = t >> 5, r = rbase + (t & 31);
+            const int ph = t / PSD_HESS_RS, r = rbase + (t & (PSD_HESS_RS - 1));
             if (r <= n) {
-                const psd_z x = red[t & 31];
-                for (int q = ph; q < m; q += 8) M(r, r0 + q) = zsub(M(r, r0 + q), zmul(x, zconj(vs[q])));
+                const psd_z x = red[t & (PSD_HESS_RS - 1)];
+                for (int q = ph; q < m; q += PSD_HESS_NT / PSD_HESS_RS) M(r, r0 + q) = zsub(M(r, r0 + q), zmul(x, zconj(vs[q])));
             }
         }
     }
