@@ -61,21 +61,24 @@ struct Timer {
 #endif
 };
 
+size_t step_lds_bytes(int p, int W, int esize);
 int choose_window(int p, int esize = 8) {
-    // largest W with p blocks of W x (W+1) elements (+ scratch) inside the 160 KiB LDS of one CU
-    const size_t budget = 150 * 1024;
-    const int cand[] = {32, 24, 20, 16, 12, 10, 8, 6};
-    for (int W : cand) {
-        size_t need = (size_t)p * W * (W + 1) * esize + PSD_STEP_NT * 8 + 2 * PSD_STEP_NT * 4 + (size_t)p * 4 + 64;
-        if (need <= budget) return W;
+    // largest W <= 32 with p blocks of W x (W+1) elements (+ scratch) inside the 160 KiB LDS of one CU;
+    // PSD_WINDOW (test hook) lowers it
+    int cap = 32;
+    if (const char* e = getenv("PSD_WINDOW")) {
+        const int w = atoi(e);
+        if (w >= 6 && w < cap) cap = w;
     }
+    for (int W = cap; W >= 6; --W)
+        if (step_lds_bytes(p, W, esize) <= (size_t)160 * 1024) return W;
     return 0;
 }
 size_t step_lds_bytes(int p, int W, int esize = 8) {
     size_t b = (size_t)p * W * (W + 1) * esize + PSD_STEP_NT * 8 + (2 * PSD_STEP_NT + (size_t)p) * 4;
     return (b + 15) & ~(size_t)15;
 }
-size_t apply_lds_bytes() { return sizeof(psd_tr) * PSD_TR_CAP + (size_t)32 * (PSD_APPLY_NT + 1) * 8; }
+size_t apply_lds_bytes() { return PSD_TR_LDS_BYTES + (size_t)32 * (PSD_APPLY_NT + 1) * 8; }
 
 }  // namespace
 

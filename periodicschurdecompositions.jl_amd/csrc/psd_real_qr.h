@@ -1104,6 +1104,52 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rq_step(psd_rparams P) {
 //   role 1: right on H_{m-1}, rows [rr0,rr1] x columns [plo,phi]
 //   role 2: right on Z_m, rows [zr0,zr1] x columns [plo,phi]
 // Every element of the panel is read once and written once; the sequence runs out of LDS.
+// Sweep and RQ-pass lists visit their positions monotonically (ascending resp. descending), so one line (a column of
+// the rows panel, a row of the columns panel; at most 32 elements) stays in registers through the whole list: the loop
+// over positions is fully unrolled (static register indices) and the list is read ahead from LDS, with two sentinel
+// records behind its end.
+#define PSD_TR_LDS_RECS (PSD_TR_CAP + 2)
+#define PSD_TR_LDS_BYTES (sizeof(psd_tr) * PSD_TR_LDS_RECS + 16)
+template <bool UP>
+PSD_D void psd_tr_regline(const psd_tr* ltr, int plo, double (&a)[34]) {
+    int e = 0;
+    psd_tr cur = ltr[0], nxt = ltr[1];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        const int b = UP ? q : 31 - q;
+        while (cur.pos - plo == b) {
+            psd_tr_apply(cur, a[b], a[b + 1], a[b + 2]);
+            cur = nxt;
+            ++e;
+            nxt = ltr[e + 1 < PSD_TR_LDS_RECS ? e + 1 : PSD_TR_LDS_RECS - 1];
+        }
+    }
+}
+// Stages the owner's list (plus sentinels) in LDS and classifies its order: +1 ascending, -1 descending, 0 neither.
+// Contains block synchronisations; every thread of the block calls it.
+PSD_D int psd_tr_stage(const psd_tr* gtr, int cnt, psd_tr* ltr, int* flags) {
+    PSD_PAR_FOR(e, PSD_TR_LDS_RECS) {
+        psd_tr tr;
+        if (e < cnt) {
+            tr = gtr[e];
+        } else {
+            tr.pos = 0x3fffffff;
+            tr.kind = PSD_TR_G;
+            tr.c0 = 1.0;
+            tr.c1 = tr.c2 = 0.0;
+        }
+        ltr[e] = tr;
+    }
+    PSD_ONE { flags[0] = flags[1] = 0; }
+    PSD_SYNC();
+    PSD_PAR_FOR(e, cnt - 1) {
+        if (ltr[e + 1].pos < ltr[e].pos) flags[0] = 1;
+        if (ltr[e + 1].pos > ltr[e].pos) flags[1] = 1;
+    }
+    PSD_SYNC();
+    return !flags[0] ? 1 : (!flags[1] ? -1 : 0);
+}
+
 PSD_KERNEL_B(PSD_APPLY_NT) psd_rq_apply(psd_rparams P, int n, int p) {
     PSD_LDS_DECL;
     const psd_apply_desc d = *P.desc;
@@ -1115,21 +1161,43 @@ PSD_KERNEL_B(PSD_APPLY_NT) psd_rq_apply(psd_rparams P, int n, int p) {
     const int T = PSD_APPLY_NT;
     const int S = d.phi - d.plo + 1;
     psd_tr* ltr = (psd_tr*)psd_lds;
-    double* tile = (double*)(psd_lds + sizeof(psd_tr) * PSD_TR_CAP);
+    int* flags = (int*)(psd_lds + sizeof(psd_tr) * PSD_TR_LDS_RECS);
+    double* tile = (double*)(psd_lds + PSD_TR_LDS_BYTES);
+    const psd_tr* gtr = P.tr + (size_t)(m - 1) * PSD_TR_CAP;
     if (role == 0) {
         const int c0 = d.lc0 + PSD_BLOCK_X * T;
         if (c0 > d.lc1) return;
         const int nc = (d.lc1 - c0 + 1 < T) ? (d.lc1 - c0 + 1) : T;
         const psd_mat<double> M = psd_mat<double>{P.H + (size_t)(m - 1) * n * n, n};
         const int ldt = T + 1;
-        PSD_PAR_FOR(e, cnt) { ltr[e] = P.tr[(size_t)(m - 1) * PSD_TR_CAP + e]; }
-        PSD_PAR_FOR(t, 32 * nc) {  // (S <= 32; no index divisions)
-            const int r = t & 31, c = t >> 5;
+        // rows panel -> LDS (transposed access: a thread owns a column); eight loads in flight per thread
+        PSD_PAR_FOR(t0, 32 * 4) {  // (S <= 32; thread t0 covers row t0 & 31 of the columns (t0 >> 5) + 4 k)
+            const int r = t0 & 31, cb = t0 >> 5;
             if (r >= S) continue;
-            tile[r * ldt + c] = M(d.plo + r, c0 + c);
+            for (int k0 = 0; k0 < T / 4; k0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = cb + 4 * (k0 + u);
+                    v[u] = (c < nc) ? M(d.plo + r, c0 + c) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tile[r * ldt + cb + 4 * (k0 + u)] = v[u];
+            }
         }
-        PSD_SYNC();
+        const int order = psd_tr_stage(gtr, cnt, ltr, flags);
         PSD_PAR_FOR(c, nc) {
+            if (order != 0) {
+                double a[34];
+#pragma unroll
+                for (int r = 0; r < 34; ++r) a[r] = (r < S) ? tile[r * ldt + c] : 0.0;
+                if (order > 0) psd_tr_regline<true>(ltr, d.plo, a);
+                else psd_tr_regline<false>(ltr, d.plo, a);
+#pragma unroll
+                for (int r = 0; r < 32; ++r)
+                    if (r < S) tile[r * ldt + c] = a[r];
+                continue;
+            }
             for (int e = 0; e < cnt; ++e) {
                 const psd_tr tr = ltr[e];
                 const int r = tr.pos - d.plo;
@@ -1142,10 +1210,19 @@ PSD_KERNEL_B(PSD_APPLY_NT) psd_rq_apply(psd_rparams P, int n, int p) {
             }
         }
         PSD_SYNC();
-        PSD_PAR_FOR(t, 32 * nc) {  // (S <= 32; no index divisions)
-            const int r = t & 31, c = t >> 5;
+        PSD_PAR_FOR(t0, 32 * 4) {
+            const int r = t0 & 31, cb = t0 >> 5;
             if (r >= S) continue;
-            M(d.plo + r, c0 + c) = tile[r * ldt + c];
+            for (int k0 = 0; k0 < T / 4; k0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = tile[r * ldt + cb + 4 * (k0 + u)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = cb + 4 * (k0 + u);
+                    if (c < nc) M(d.plo + r, c0 + c) = v[u];
+                }
+            }
         }
     } else {
         const int lo = (role == 1) ? d.rr0 : d.zr0;
@@ -1156,7 +1233,21 @@ PSD_KERNEL_B(PSD_APPLY_NT) psd_rq_apply(psd_rparams P, int n, int p) {
         const int jm = (role == 1) ? ((m == 1) ? p : (m - 1)) : m;
         double* base = (role == 1) ? P.H : P.Z;
         const psd_mat<double> M = psd_mat<double>{base + (size_t)(jm - 1) * n * n, n};
-        PSD_PAR_FOR(e, cnt) { ltr[e] = P.tr[(size_t)(m - 1) * PSD_TR_CAP + e]; }
+        const int order = psd_tr_stage(gtr, cnt, ltr, flags);
+        if (order != 0) {
+            // a thread owns a row of the columns panel: coalesced loads straight into registers, no LDS tile
+            PSD_PAR_FOR(r, nr) {
+                double a[34];
+#pragma unroll
+                for (int c = 0; c < 34; ++c) a[c] = (c < S) ? M(r0 + r, d.plo + c) : 0.0;
+                if (order > 0) psd_tr_regline<true>(ltr, d.plo, a);
+                else psd_tr_regline<false>(ltr, d.plo, a);
+#pragma unroll
+                for (int c = 0; c < 32; ++c)
+                    if (c < S) M(r0 + r, d.plo + c) = a[c];
+            }
+            return;
+        }
         PSD_PAR_FOR(t, S * T) {
             const int r = t & (T - 1), c = t / T;
             if (r >= nr) continue;

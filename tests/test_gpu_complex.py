@@ -48,11 +48,11 @@ def test_zwindow_widths(gpu_engine):
 
 def test_config3_shape_reduced(gpu_engine):
     """BASELINE config 3 is n=1024, p=64 ComplexF64 (2 GiB; minutes on one GPU).  Same code path, same window width
-    (p = 64 -> W = 10), reduced order: eigenvalues vs numpy's eigvals of the explicit product + invariants."""
+    (p = 64 -> W = 12), reduced order: eigenvalues vs numpy's eigvals of the explicit product + invariants."""
     n, p = 128, 64
     As = pt.bench_factors(n, p, seed=1234 + 3, dtype=np.complex128)
     ps = gpu_engine.pschur(As, "R")
-    assert ps.stats.window == 10
+    assert ps.stats.window == ec.expected_window(p, 16) == 12
     ok, err = pt.checkpsd(ps, As, thresh=100 * np.sqrt(n / 32))
     assert ok, err
     P = pt.product(As)
