@@ -119,35 +119,69 @@ struct psd_win {
     PSD_HD double& at(int j, int r, int c) const { return b[(j - 1) * bsz + (c - bs) * ld + (r - bs)]; }
 };
 
-// Window <-> HBM: 64 lanes, lane = (row, column group); 16 independent 8-byte accesses in flight per
-// lane and batch, column segments contiguous in memory.
+// Window <-> HBM: 64 lanes, lane = (row pair, column group of 4); a lane moves two consecutive rows of a column as
+// one 16-byte access (8-byte aligned: global_load/store_dwordx4 accept that), two factors per batch = 16 accesses of
+// 16 bytes in flight per lane.  A single wavefront is bounded by the number of outstanding accesses, not by bandwidth,
+// so the bytes per access are what counts.  The odd last row travels with the row above it (no access beyond the
+// window's rows, which at the bottom of the matrix would leave the allocation).
+struct alignas(8) psd_pair {
+    double a, b;
+};
+#ifdef PSD_HOSTSIM
+PSD_D psd_pair psd_pair_load(const double* q) { return *(const psd_pair*)q; }
+PSD_D void psd_pair_store(double* q, const psd_pair& x) { *(psd_pair*)q = x; }
+#else
+typedef double psd_v2u __attribute__((ext_vector_type(2), aligned(8)));
+PSD_D psd_pair psd_pair_load(const double* q) {
+    const psd_v2u v = *(const psd_v2u*)q;
+    psd_pair x;
+    x.a = v.x;
+    x.b = v.y;
+    return x;
+}
+PSD_D void psd_pair_store(double* q, const psd_pair& x) {
+    psd_v2u v;
+    v.x = x.a;
+    v.y = x.b;
+    *(psd_v2u*)q = v;
+}
+#endif
 PSD_D void psd_win_load(const psd_rparams& P, const psd_win& w, int n, int p) {
     const int m = w.be - w.bs + 1;
-    const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
     PSD_PAR_FOR(t, PSD_STEP_NT) {
-        const int r = t & (RW - 1), g = t >> sh;
+        const int r = 2 * (t & 15), g = t >> 4;
         if (r < m) {
-            // factor loop outside (no index divisions in the hot loop); two factors per batch: 32 loads in flight
+            const bool pair = r + 1 < m;
+            const int back = (pair || r == 0) ? 0 : 1;  // (m == 1: the single element twice, second copy dropped)
+            const bool one = !pair && r == 0;
             for (int j = 0; j < p; j += 2) {
-                const bool two = j + 1 < p;
-                const double* src0 = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r);
-                const double* src1 = src0 + (two ? (size_t)n * n : 0);
-                double* dst0 = w.b + j * w.bsz + r;
-                double* dst1 = dst0 + w.bsz;
-                for (int c0 = g; c0 < m; c0 += 16 * ncg) {
-                    double v0[16], v1[16];
+                const double* src = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r - back);
+                double* dst = w.b + j * w.bsz + r;
+                psd_pair v[2][8];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int c = c0 + u * ncg;
-                        v0[u] = (c < m) ? src0[(size_t)c * n] : 0.0;
-                        v1[u] = (c < m && two) ? src1[(size_t)c * n] : 0.0;
+                for (int f = 0; f < 2; ++f) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = g + 4 * u;
+                        const double* q = src + (size_t)f * n * n + (size_t)c * n;
+                        psd_pair x;
+                        x.a = x.b = 0.0;
+                        if (c < m && j + f < p) {
+                            if (one) x.a = q[0];
+                            else x = psd_pair_load(q);
+                        }
+                        v[f][u] = x;
                     }
+                }
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int c = c0 + u * ncg;
-                        if (c < m) {
-                            dst0[c * w.ld] = v0[u];
-                            if (two) dst1[c * w.ld] = v1[u];
+                for (int f = 0; f < 2; ++f) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = g + 4 * u;
+                        if (c < m && j + f < p) {
+                            double* q = dst + f * w.bsz + c * w.ld;
+                            q[0] = back ? v[f][u].b : v[f][u].a;
+                            if (pair) q[1] = v[f][u].b;
                         }
                     }
                 }
@@ -158,15 +192,28 @@ PSD_D void psd_win_load(const psd_rparams& P, const psd_win& w, int n, int p) {
 }
 PSD_D void psd_win_store(const psd_rparams& P, const psd_win& w, int n, int p) {
     const int m = w.be - w.bs + 1;
-    const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
     PSD_SYNC();
     PSD_PAR_FOR(t, PSD_STEP_NT) {
-        const int r = t & (RW - 1), g = t >> sh;
+        const int r = 2 * (t & 15), g = t >> 4;
         if (r < m) {
+            const bool pair = r + 1 < m;
             for (int j = 0; j < p; ++j) {
                 double* dst = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r);
                 const double* src = w.b + j * w.bsz + r;
-                for (int c = g; c < m; c += ncg) dst[(size_t)c * n] = src[c * w.ld];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = g + 4 * u;
+                    if (c < m) {
+                        if (pair) {
+                            psd_pair x;
+                            x.a = src[c * w.ld];
+                            x.b = src[c * w.ld + 1];
+                            psd_pair_store(dst + (size_t)c * n, x);
+                        } else {
+                            dst[(size_t)c * n] = src[c * w.ld];
+                        }
+                    }
+                }
             }
         }
     }
