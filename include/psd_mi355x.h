@@ -148,7 +148,8 @@ int psd_z_pschur_dev(psd_ctx* ctx, int n, int p, double* dA, char orient, int wa
 /* LinearAlgebra.ordschur!(P::PeriodicSchur{ComplexF64}, select; wantZ) — ordschur.jl:11-73: move the selected
  * eigenvalues (select[j] != 0) and their subspace to the top by adjacent swaps (sylswap.jl:542-635).
  * T: p pointers, the full user-order factor list with T1 at position `schurindex`; Z: p pointers (or NULL with
- * !wantZ); both updated in place.  Supported alignments: ('R', 1) and ('L', p) — what pschur! returns.
+ * !wantZ); both updated in place.  schurindex must be 1 or p (info -7 otherwise, ordschur.jl:32); all four
+ * alignments of the reference (utils.jl:6-85: _rev_alias, _circshift) are mapped onto the same working form.
  * Eigenvalues are recomputed from the diagonals (ordschur.jl:97-120) in scaled form.
  * info: 0; PSD_INFO_ILLCOND + j  IllConditionedException(j) (ordschur.jl:61); PSD_INFO_SINGULAR (utils.jl:128). */
 #define PSD_INFO_ILLCOND 2000

@@ -78,6 +78,24 @@ size_t step_lds_bytes(int p, int W, int esize = 8) {
     size_t b = (size_t)p * W * (W + 1) * esize + PSD_STEP_NT * 8 + (2 * PSD_STEP_NT + (size_t)p) * 4;
     return (b + 15) & ~(size_t)15;
 }
+// ordschur! alignments (ordschur.jl:20-33, rordschur.jl:15-27, utils.jl:6-85): the swap kernels work on the right-
+// oriented form with the quasi-triangular factor first.  slotA[j] / slotZ[j] (0-based) = user slot of the internal
+// factor / transformation j: 'R' with schurindex p is a circular shift by one (_circshift), 'L' is the reversal
+// (_rev_alias) — with schurindex 1 followed by that shift.  false: schurindex not in (1, p).
+bool ord_slots(char orient, int schurindex, int p, std::vector<int>& slotA, std::vector<int>& slotZ) {
+    if (schurindex != 1 && schurindex != p) return false;
+    slotA.assign(p, 0);
+    slotZ.assign(p, 0);
+    const bool left = orient == 'L';
+    const bool shift = p > 1 && ((!left && schurindex == p) || (left && schurindex == 1));
+    for (int j = 0; j < p; ++j) {
+        const int q = shift ? (j + p - 1) % p : j;  // position before the shift
+        slotA[j] = left ? (p - 1 - q) : q;
+        slotZ[j] = (!left || q == 0) ? q : (p - q);
+    }
+    return true;
+}
+
 size_t apply_lds_bytes() { return PSD_TR_LDS_BYTES + (size_t)32 * (PSD_APPLY_NT + 1) * 8; }
 
 }  // namespace
@@ -1429,34 +1447,18 @@ int psd_z_ordschur(psd_ctx* c, int n, int p, double* const* T, double* const* Z,
     if (wantZ && !Z) return *info = -5;
     if (orient != 'R' && orient != 'L') return *info = -6;
     if (!select) return *info = -8;
-    // alignments produced by pschur!: ('R', 1) and ('L', p); the reference also accepts ('R', p) and ('L', 1)
-    // (ordschur.jl:26-33) — not in this build
-    if (!((orient == 'R' && schurindex == 1) || (orient == 'L' && schurindex == p))) {
-        if (schurindex != 1 && schurindex != p) return *info = -7;  // ArgumentError, ordschur.jl:32
-        return *info = PSD_INFO_NOTIMPL;
-    }
+    std::vector<int> slotA, slotZ;
+    if (!ord_slots(orient, schurindex, p, slotA, slotZ)) return *info = -7;  // ArgumentError, ordschur.jl:32
     if ((*info = c->zreserve(n, p, true, 16)) != 0) return *info;
     const size_t nn = (size_t)n * n;
-    const bool left = orient == 'L';
-    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->zH + j * nn, T[j], nn * 16, c->stream));
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->zH + j * nn, T[slotA[j]], nn * 16, c->stream));
     if (wantZ)
-        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->zZ + j * nn, Z[j], nn * 16, c->stream));
-    double* dA_ = reinterpret_cast<double*>(c->zH);
-    double* dZ_ = reinterpret_cast<double*>(c->zZ);
-    auto flip = [&]() {  // user 'L' order <-> internal right order (as in psd_z_pschur_dev)
-        if (left && p > 1) {
-            PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, p / 2), 64, 0, c->stream, dA_, 2 * n, n, 0, p);
-            if (wantZ && p > 2)
-                PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, (p - 1) / 2), 64, 0, c->stream, dZ_, 2 * n, n, 1, p - 1);
-        }
-    };
-    flip();
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->zZ + j * nn, Z[slotZ[j]], nn * 16, c->stream));
     int rc = zordschur_dev(c, n, p, c->zH, c->zZ, select, wantZ, alpha, beta, ascale, stats, info);
-    flip();
     if (rc < 0 || rc >= PSD_INFO_NOTIMPL) return rc;
-    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(T[j], c->zH + j * nn, nn * 16, c->stream));
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(T[slotA[j]], c->zH + j * nn, nn * 16, c->stream));
     if (wantZ)
-        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(Z[j], c->zZ + j * nn, nn * 16, c->stream));
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(Z[slotZ[j]], c->zZ + j * nn, nn * 16, c->stream));
     PSD_CHECK(psd_rt_sync(c->stream));
     return rc;
 }
@@ -1581,30 +1583,18 @@ int psd_d_ordschur(psd_ctx* c, int n, int p, double* const* T, double* const* Z,
     if (wantZ && !Z) return *info = -5;
     if (orient != 'R' && orient != 'L') return *info = -6;
     if (!select) return *info = -8;
-    if (!((orient == 'R' && schurindex == 1) || (orient == 'L' && schurindex == p))) {
-        if (schurindex != 1 && schurindex != p) return *info = -7;  // rordschur.jl:25
-        return *info = PSD_INFO_NOTIMPL;
-    }
+    std::vector<int> slotA, slotZ;
+    if (!ord_slots(orient, schurindex, p, slotA, slotZ)) return *info = -7;  // rordschur.jl:25
     if ((*info = c->reserve(n, p, true, 16)) != 0) return *info;
     const size_t nn = (size_t)n * n;
-    const bool left = orient == 'L';
-    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->dH + j * nn, T[j], nn * 8, c->stream));
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->dH + j * nn, T[slotA[j]], nn * 8, c->stream));
     if (wantZ)
-        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->dZ + j * nn, Z[j], nn * 8, c->stream));
-    auto flip = [&]() {
-        if (left && p > 1) {
-            PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, p / 2), 64, 0, c->stream, c->dH, n, n, 0, p);
-            if (wantZ && p > 2)
-                PSD_LAUNCH(psd_reverse_blocks, psd_dim3(n, (p - 1) / 2), 64, 0, c->stream, c->dZ, n, n, 1, p - 1);
-        }
-    };
-    flip();
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_h2d(c->dZ + j * nn, Z[slotZ[j]], nn * 8, c->stream));
     int rc = rordschur_dev(c, n, p, c->dH, c->dZ, select, wantZ, wr, wi, stats, info);
-    flip();
     if (rc < 0 || rc >= PSD_INFO_NOTIMPL) return rc;
-    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(T[j], c->dH + j * nn, nn * 8, c->stream));
+    for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(T[slotA[j]], c->dH + j * nn, nn * 8, c->stream));
     if (wantZ)
-        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(Z[j], c->dZ + j * nn, nn * 8, c->stream));
+        for (int j = 0; j < p; ++j) PSD_CHECK(psd_rt_d2h(Z[slotZ[j]], c->dZ + j * nn, nn * 8, c->stream));
     PSD_CHECK(psd_rt_sync(c->stream));
     return rc;
 }
@@ -2053,16 +2043,13 @@ int zgordschur_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t
 int gordschur_host(psd_ctx* c, int n, int p, std::vector<std::vector<psd_z>>& Tz, std::vector<std::vector<psd_z>>& Zz,
                    const uint8_t* S, char orient, int schurindex, const uint8_t* select, int wantZ, double* alpha,
                    double* beta, int32_t* ascale, psd_stats* stats, int* info) {
-    if (!((orient == 'R' && schurindex == 1) || (orient == 'L' && schurindex == p))) {
-        if (schurindex != 1 && schurindex != p) return *info = -7;  // ArgumentError, ordschur.jl:32
-        return *info = PSD_INFO_NOTIMPL;
-    }
+    std::vector<int> sA, sZ;
+    if (!ord_slots(orient, schurindex, p, sA, sZ)) return *info = -7;  // ArgumentError, ordschur.jl:32
     if ((*info = c->zreserve(n, p, true, 16)) != 0) return *info;
     if ((*info = c->zgreserve(n, p)) != 0) return *info;
     const size_t nn = (size_t)n * n;
-    const bool left = orient == 'L';
-    auto slotA = [&](int j) { return left ? (p + 1 - j) : j; };               // internal j <- user slot
-    auto slotZ = [&](int j) { return (!left || j == 1) ? j : (p + 2 - j); };
+    auto slotA = [&](int j) { return sA[j - 1] + 1; };  // internal j <- user slot (1-based)
+    auto slotZ = [&](int j) { return sZ[j - 1] + 1; };
     std::vector<uint8_t> Sint(p, 1);
     for (int j = 1; j <= p; ++j) Sint[j - 1] = S[slotA(j) - 1] ? 1 : 0;
     if (!Sint[0]) return *info = -5;
@@ -2142,14 +2129,11 @@ int psd_d_gordschur(psd_ctx* c, int n, int p, double* const* T, double* const* Z
             if (T1[(size_t)j * n + (j + 1)] != 0.0) pairs = true;
     }
     if (pairs) {  // 2x2 blocks: signed block swaps in real arithmetic (sylswap.jl:197-538)
-        if (!((orient == 'R' && schurindex == 1) || (orient == 'L' && schurindex == p))) {
-            if (schurindex != 1 && schurindex != p) return *info = -7;
-            return *info = PSD_INFO_NOTIMPL;
-        }
+        std::vector<int> sA, sZ;
+        if (!ord_slots(orient, schurindex, p, sA, sZ)) return *info = -7;
         if ((*info = c->reserve(n, p, true, 16)) != 0) return *info;
-        const bool left = orient == 'L';
-        auto slotA = [&](int j) { return left ? (p + 1 - j) : j; };
-        auto slotZ = [&](int j) { return (!left || j == 1) ? j : (p + 2 - j); };
+        auto slotA = [&](int j) { return sA[j - 1] + 1; };
+        auto slotZ = [&](int j) { return sZ[j - 1] + 1; };
         std::vector<uint8_t> Sint(p, 1);
         for (int j = 1; j <= p; ++j) Sint[j - 1] = S[slotA(j) - 1] ? 1 : 0;
         if (!Sint[0]) return *info = -5;

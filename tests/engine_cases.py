@@ -915,3 +915,69 @@ def case_gpschur_pairs(eng):
             P = np.linalg.solve(Bs[j], As[j] @ P)
         lam = np.linalg.eigvals(P)
         assert pt.match_eigs(lam, ps.values) < 1e-8 * abs(lam).max()
+
+
+# ------------------------------------------------------------------------------------------------
+# ordschur! alignments: the reference accepts schurindex 1 or p in either orientation (ordschur.jl:20-33,
+# rordschur.jl:15-27: _rev_alias for 'R', _circshift(P, 1) for schurindex p).  A decomposition with the quasi-triangular
+# factor at the other end of the list is the circular shift by one of all lists (utils.jl:6-40); it maps to the same
+# working arrays, so the reordered factors must agree bit for bit with those of the natural alignment.
+def _shifted(lst, lr):
+    lst = list(lst)
+    return (lst[1:] + lst[:1]) if lr == "R" else (lst[-1:] + lst[:-1])
+
+
+def case_ordschur_alignments(eng):
+    import psd_amd
+
+    n, p = 9, 4
+    for cplx in (True, False):
+        for signed in (False, True):
+            for lr in "RL":
+                S = [True] * p
+                if signed:
+                    S[1] = S[2] = False
+                    if lr == "L":
+                        S = S[::-1]
+                A = pt.bench_factors(n, p, seed=77 + p, dtype=np.complex128 if cplx else np.float64)
+                A = [np.asfortranarray(a) for a in A]
+                ps0 = eng.pschur_([a.copy(order="F") for a in A], lr, S=S) if signed else eng.pschur(A, lr)
+                k0 = ps0.schurindex
+                assert k0 == (1 if lr == "R" else p)
+                lam0 = ps0.values.copy()
+                thr = np.sort(np.abs(lam0))[n // 2]
+                select = np.abs(lam0) <= thr
+                k1 = p if lr == "R" else 1
+
+                def build(Ts, Zs, k, Sx):
+                    Ts = [t.copy(order="F") for t in Ts]
+                    Zs = [z.copy(order="F") for z in Zs]
+                    if signed:
+                        return psd_amd.GeneralizedPeriodicSchur(Sx, Ts, Zs, ps0.alpha.copy(), ps0.beta.copy(),
+                                                                ps0.alphascale.copy(), lr, k)
+                    return psd_amd.PeriodicSchur(Ts, Zs, lam0.copy(), lr, k)
+
+                P_nat = eng.ordschur_(build(ps0.Ts, ps0.Z, k0, S), select)
+                As, Ss = _shifted(A, lr), _shifted(S, lr)
+                P_sh0 = build(_shifted(ps0.Ts, lr), _shifted(ps0.Z, lr), k1, Ss)
+                ok, err = pt.checkpsd(P_sh0, As, S=Ss, strict=False)
+                assert ok, ("shifted input is not a decomposition", cplx, signed, lr, err)
+                P_sh = eng.ordschur_(P_sh0, select)
+                assert P_sh.stats.nsweeps == P_nat.stats.nsweeps > 0
+                for a, b in zip(_shifted(P_nat.Ts, lr), P_sh.Ts):
+                    assert np.array_equal(a, b), (cplx, signed, lr)
+                for a, b in zip(_shifted(P_nat.Z, lr), P_sh.Z):
+                    assert np.array_equal(a, b), (cplx, signed, lr)
+                assert np.array_equal(P_nat.values, P_sh.values)
+                ok, err = pt.checkpsd(P_sh, As, S=Ss, strict=False, thresh=400)
+                assert ok, (cplx, signed, lr, err)
+                m = int(select.sum())
+                assert pt.match_eigs(lam0[select], P_sh.values[:m]) < 1e-8 * abs(lam0).max()
+    # a schurindex strictly inside the period is an ArgumentError (ordschur.jl:32)
+    ps0 = eng.pschur(pt.bench_factors(5, 3, seed=5), "R")
+    bad = psd_amd.PeriodicSchur(ps0.Ts, ps0.Z, ps0.values, "R", 2)
+    try:
+        eng.ordschur_(bad, np.array([False, True, False, False, False]))
+        raise AssertionError("schurindex 2 of 3 must be rejected")
+    except ValueError:
+        pass

@@ -99,3 +99,7 @@ def test_zordschur_windows(gpu_engine):
 
 def test_zordschur_edge(gpu_engine):
     ec.case_zordschur_edge(gpu_engine)
+
+
+def test_ordschur_alignments(gpu_engine):
+    ec.case_ordschur_alignments(gpu_engine)

@@ -53,3 +53,7 @@ def test_zordschur_windows(sim_engine):
 
 def test_zordschur_edge(sim_engine):
     ec.case_zordschur_edge(sim_engine)
+
+
+def test_ordschur_alignments(sim_engine):
+    ec.case_ordschur_alignments(sim_engine)
