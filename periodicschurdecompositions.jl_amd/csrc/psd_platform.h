@@ -19,6 +19,7 @@
 #define PSD_HD inline
 #define PSD_D inline
 #define PSD_D_NOINLINE inline
+#define PSD_KEEP(x) ((void)0)
 struct psd_dim3 {
     int x, y, z;
     psd_dim3(int x_ = 1, int y_ = 1, int z_ = 1) : x(x_), y(y_), z(z_) {}
@@ -106,6 +107,9 @@ static inline int psd_rt_last_error() { return 0; }
 #define PSD_HD __host__ __device__ __forceinline__
 #define PSD_D __device__ __forceinline__
 #define PSD_D_NOINLINE __device__ __attribute__((noinline))
+// pins the value at this point of the instruction stream (keeps the optimiser from sinking its computation into a
+// later branch)
+#define PSD_KEEP(x) asm volatile("" : "+v"(x))
 typedef dim3 psd_dim3;
 #define PSD_KERNEL __global__ void
 #define PSD_KERNEL_B(nt) __global__ void __launch_bounds__(nt)

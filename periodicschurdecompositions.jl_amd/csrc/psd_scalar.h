@@ -112,31 +112,38 @@ PSD_HD double psd_refl2(double& x0, double& x1) {
 // block (no control flow between them), so that the instruction scheduler interleaves the two independent dependency
 // chains; the range checks come afterwards and send the rare cases to the individual routines.
 PSD_HD void psd_refl32_pair(double& x0, double& x1, double& x2, double& tau3, double& y0, double& y1, double& tau2) {
-    const double tx = fmax(fabs(x1), fabs(x2)), bx = fmax(tx, fabs(x0));
-    const double ty = fabs(y1), by = fmax(ty, fabs(y0));
-    const bool fx = (bx < 1e140) && (tx > 1e-140);
-    const bool fy = (by < 1e140) && (ty > 1e-140);
+    // Both fast paths are evaluated unconditionally (on out-of-range data they produce values nobody uses) and ONE
+    // combined range test follows: with a test per reflector the compiler branches between the two chains and they
+    // run one after the other.  The test is on the sums of squares: finite and < 1e280 means no square overflowed,
+    // tail sum > 1e-280 means the tail is neither zero (H = I, tau = 0: dlarfg path) nor lost to underflow.
+    const double tx2 = x1 * x1 + x2 * x2, nx2 = x0 * x0 + tx2;
+    const double ty2 = y1 * y1, ny2 = y0 * y0 + ty2;
     double nx, rnx, ny, rny;
-    psd_sqrt_pair_fast(fx ? (x0 * x0 + (x1 * x1 + x2 * x2)) : 1.0, nx, rnx);
-    psd_sqrt_pair_fast(fy ? (y0 * y0 + y1 * y1) : 1.0, ny, rny);
+    psd_sqrt_pair_fast(nx2, nx, rnx);
+    psd_sqrt_pair_fast(ny2, ny, rny);
     const double ax = fabs(x0), ay = fabs(y0);
-    const double t3 = 1.0 + ax * rnx, t2 = 1.0 + ay * rny;
+    double t3 = 1.0 + ax * rnx, t2 = 1.0 + ay * rny;
     const double sx = psd_rcp_fast(copysign(ax + nx, x0)), sy = psd_rcp_fast(copysign(ay + ny, y0));
-    const double fx1 = x1 * sx, fx2 = x2 * sx, fx0 = -copysign(nx, x0);
-    const double fy1 = y1 * sy, fy0 = -copysign(ny, y0);
-    if (fx) {
+    double fx1 = x1 * sx, fx2 = x2 * sx, fx0 = -copysign(nx, x0);
+    double fy1 = y1 * sy, fy0 = -copysign(ny, y0);
+#if defined(__HIP_DEVICE_COMPILE__)
+    PSD_KEEP(fx1);
+    PSD_KEEP(fx2);
+    PSD_KEEP(t3);
+    PSD_KEEP(fy1);
+    PSD_KEEP(t2);
+#endif
+    const bool ok = (nx2 < 1e280) & (tx2 > 1e-280) & (ny2 < 1e280) & (ty2 > 1e-280);
+    if (ok) {
         x0 = fx0;
         x1 = fx1;
         x2 = fx2;
         tau3 = t3;
-    } else {
-        tau3 = psd_refl3(x0, x1, x2);
-    }
-    if (fy) {
         y0 = fy0;
         y1 = fy1;
         tau2 = t2;
     } else {
+        tau3 = psd_refl3(x0, x1, x2);
         tau2 = psd_refl2(y0, y1);
     }
 }

@@ -1,4 +1,4 @@
-"""BASELINE config 4 at full size on one GPU: pschur!(A, S, :R) for n = 256, p = 8, Float64, alternating signature.
+"""BASELINE config 4 at full size on one GPU: pschur!(A, S, :R), Float64; usage: gpu_config4.py n p [alternating|random25].
 Prints one JSON line with phase timings, the oracle's (CPU, 1 thread) time for the same input and the invariants."""
 import json
 import os
@@ -17,7 +17,12 @@ import psdtest as pt  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 p = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-S = [True] + [bool(q % 2 == 0) for q in range(1, p)]
+kind = sys.argv[3] if len(sys.argv) > 3 else "alternating"
+if kind == "random25":  # second run with ~25 % of the factors inverted, at random (seeded)
+    rs = np.random.RandomState(1234 + 4)
+    S = [True] + [bool(x) for x in (rs.rand(p - 1) >= 0.25)]
+else:
+    S = [True] + [bool(q % 2 == 0) for q in range(1, p)]
 A = pt.bench_factors(n, p, seed=4)
 eng = psd_amd.Engine()
 eng.pschur_([a.copy(order="F") for a in pt.bench_factors(32, p, seed=1)], "R", S=S)  # warm-up
@@ -35,7 +40,7 @@ except AssertionError as e:
     ok = str(e)
 err = pt.match_eigs(po.values, ps.values) / abs(po.values).max()
 print(json.dumps({
-    "config": f"pschur!(A, S, :R) n={n} p={p} Float64 alternating signature", "wall_s": wall,
+    "config": f"pschur!(A, S, :R) n={n} p={p} Float64 {kind} signature ({p - sum(S)} of {p} inverted)", "wall_s": wall,
     "ms": {"hessenberg_total": st.ms_hess, "hessenberg_stage1": st.ms_formq, "iteration": st.ms_iter, "total": st.ms_total},
     "sweeps": st.nsweeps, "zero_shift_passes": st.nrqpass, "blocks2x2": st.ndefl2, "windows": st.nwindows,
     "step_launches": st.nlaunch_step, "window": st.window, "oracle_cpu_s": cpu, "oracle_counters": po.counters,
