@@ -149,7 +149,7 @@ struct psd_ctx {
     psd_z* galpha = nullptr;
     double *gbeta = nullptr, *gxscr = nullptr;
     int *gascale = nullptr, *gcnt = nullptr, *glog = nullptr;
-    size_t gstep_lds_set = 0;
+    size_t gstep_lds_set = 0, ghess_lds_set = 0;
     // complex generalized path (shares zalpha/zbeta/zascale/zlog/zvbuf with the complex path)
     int zgcap_n = 0, zgcap_p = 0;
     psd_zgstate* zgst = nullptr;
@@ -1638,6 +1638,19 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
         c->gstep_lds_set = lds_step;
     }
 #endif
+    // stage 2 of the signed Hessenberg reduction runs as a pipeline over the factors (psd_gq_hess_step) when its LDS
+    // (window + mailboxes) fits; PSD_HESS_SERIAL=1 (test hook) keeps the single-wave chase
+    const size_t lds_hess = psd_ghess_lds_bytes(p, W);
+    const int hess_links = psd_ghess_links(p), hess_waves = psd_ghess_waves(p);
+    const char* hserial = getenv("PSD_HESS_SERIAL");
+    const bool hess_pipe = hessmode && lds_hess <= (size_t)160 * 1024 && !(hserial && hserial[0] == '1');
+#ifndef PSD_HOSTSIM
+    if (hess_pipe && lds_hess > c->ghess_lds_set) {
+        PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_gq_hess_step),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hess));
+        c->ghess_lds_set = lds_hess;
+    }
+#endif
     PSD_LAUNCH(psd_gq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, hessmode);
     const size_t lds_apply = sizeof(psd_gtr) * PSD_GTR_CAP + (size_t)32 * (PSD_GAPPLY_NT + 1) * sizeof(double);
     const int tiles = (n + PSD_GAPPLY_NT - 1) / PSD_GAPPLY_NT;
@@ -1664,7 +1677,10 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
                 (void)hipEventRecord(ev0, c->stream);
             }
 #endif
-            PSD_LAUNCH(psd_gq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
+            if (hess_pipe)
+                PSD_LAUNCH(psd_gq_hess_step, psd_dim3(1), 64 * hess_waves, lds_hess, c->stream, P, hess_links);
+            else
+                PSD_LAUNCH(psd_gq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
 #ifndef PSD_HOSTSIM
             if (sample) {
                 (void)hipEventRecord(ev1, c->stream);
@@ -1672,7 +1688,7 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
             }
 #endif
             PSD_LAUNCH(psd_gq_apply, psd_dim3(tiles, p, 3), PSD_GAPPLY_NT, lds_apply, c->stream, P, n, p);
-            PSD_LAUNCH(psd_gq_defer, psd_dim3(dtiles), 256, 0, c->stream, P, n);
+            if (!hess_pipe) PSD_LAUNCH(psd_gq_defer, psd_dim3(dtiles), 256, 0, c->stream, P, n);
             ++launched;
         }
         PSD_CHECK(psd_rt_d2h(&hst, c->gst, sizeof(hst), c->stream));

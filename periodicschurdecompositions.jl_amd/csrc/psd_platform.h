@@ -47,6 +47,8 @@ extern psd_simctx psd_sim;  // the block currently being simulated (serial)
 // regions and can be broadcast from a given lane (v_readlane on the GPU, array slot here).
 #define PSD_MAXLANES 64
 #define PSD_PAR_ONCE(t, count) for (int t = 0; t < (int)(count); ++t)
+// the wavefronts of a workgroup as independent workers (serial here; they touch disjoint data between two PSD_SYNCs)
+#define PSD_WAVES_FOR(g, G) for (int g = 0; g < (int)(G); ++g)
 #define PSD_LANEVAR(type, name) type name[PSD_MAXLANES]
 #define PSD_LANEVAR_REF(type, name) type* name
 #define PSD_LV(name) name[t]
@@ -126,10 +128,21 @@ typedef dim3 psd_dim3;
 // (measured: dropping the s_waitcnt and keeping only the compiler fence is bit-identical on the whole GPU test tier
 // and 1.4 % faster; the conservative form stays)
 #define PSD_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define PSD_PAR_FOR(t, count) for (int t = (int)threadIdx.x; t < (int)(count); t += (int)blockDim.x)
-#define PSD_ONE if (threadIdx.x == 0)
+// PSD_TID / PSD_TSTRIDE: the thread index the data-parallel macros run over.  Default: the workgroup.  A header that
+// is included a second time with PSD_TID = lane of the wavefront, PSD_TSTRIDE = 64 yields wave-scoped copies of its
+// functions, which the wavefronts of a multi-wave workgroup call independently (psd_rgz.h, namespace psd_wv).
+#define PSD_TID_BLOCK ((int)threadIdx.x)
+#define PSD_TSTRIDE_BLOCK ((int)blockDim.x)
+#define PSD_TID_WAVE ((int)threadIdx.x & 63)
+#define PSD_TSTRIDE_WAVE 64
+#define PSD_TID PSD_TID_BLOCK
+#define PSD_TSTRIDE PSD_TSTRIDE_BLOCK
+#define PSD_PAR_FOR(t, count) for (int t = PSD_TID; t < (int)(count); t += PSD_TSTRIDE)
+#define PSD_ONE if (PSD_TID == 0)
 #define PSD_MAXLANES 64
-#define PSD_PAR_ONCE(t, count) if (const int t = (int)threadIdx.x; t < (int)(count))
+#define PSD_PAR_ONCE(t, count) if (const int t = PSD_TID; t < (int)(count))
+// the wavefronts of a workgroup as independent workers: g = wave index, runs for g < G
+#define PSD_WAVES_FOR(g, G) if (const int g = (int)threadIdx.x >> 6; g < (int)(G))
 #define PSD_LANEVAR(type, name) type name = type()
 #define PSD_LANEVAR_REF(type, name) type name
 #define PSD_LV(name) name

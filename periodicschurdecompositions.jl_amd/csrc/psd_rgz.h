@@ -83,82 +83,7 @@ struct psd_gwin {
     PSD_HD double& at(int l, int r, int c) const { return b[(l - 1) * bsz + (c - bs) * ld + (r - bs)]; }
 };
 
-PSD_D void psd_gwin_load(const psd_gparams& P, const psd_gwin& w, int n, int p) {
-    const int m = w.be - w.bs + 1;
-    const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
-    PSD_PAR_FOR(t, PSD_STEP_NT) {
-        const int r = t & (RW - 1), g = t >> sh;
-        if (r < m) {
-            for (int j = 0; j < p; ++j) {  // (factor loop outside: no index divisions in the hot loop)
-                const double* src = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r);
-                double* dst = w.b + j * w.bsz + r;
-                for (int c0 = g; c0 < m; c0 += 16 * ncg) {
-                    double v[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int c = c0 + u * ncg;
-                        v[u] = (c < m) ? src[(size_t)c * n] : 0.0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int c = c0 + u * ncg;
-                        if (c < m) dst[c * w.ld] = v[u];
-                    }
-                }
-            }
-        }
-    }
-    PSD_SYNC();
-}
-PSD_D void psd_gwin_store(const psd_gparams& P, const psd_gwin& w, int n, int p) {
-    const int m = w.be - w.bs + 1;
-    const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
-    PSD_SYNC();
-    PSD_PAR_FOR(t, PSD_STEP_NT) {
-        const int r = t & (RW - 1), g = t >> sh;
-        if (r < m) {
-            for (int j = 0; j < p; ++j) {
-                double* dst = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r);
-                const double* src = w.b + j * w.bsz + r;
-                for (int c = g; c < m; c += ncg) dst[(size_t)c * n] = src[c * w.ld];
-            }
-        }
-    }
-    PSD_SYNC();
-}
-
-// in-window rmul!(view(H_l, r0:r1, :), G') on columns (j, j+1)
-PSD_D void psd_gwin_right(const psd_gwin& w, int l, int j, double c, double s, int r0, int r1) {
-    if (r0 < w.bs) r0 = w.bs;
-    if (r1 > w.be) r1 = w.be;
-    PSD_PAR_FOR(t, r1 - r0 + 1) {
-        const int r = r0 + t;
-        const double a1 = w.at(l, r, j), a2 = w.at(l, r, j + 1);
-        w.at(l, r, j) = c * a1 + s * a2;
-        w.at(l, r, j + 1) = c * a2 - s * a1;
-    }
-    PSD_WAVE_SYNC();
-}
-// in-window lmul!(G, view(H_l, :, c0:c1)) on rows (j, j+1)
-PSD_D void psd_gwin_left(const psd_gwin& w, int l, int j, double c, double s, int c0, int c1) {
-    if (c0 < w.bs) c0 = w.bs;
-    if (c1 > w.be) c1 = w.be;
-    PSD_PAR_FOR(t, c1 - c0 + 1) {
-        const int cc = c0 + t;
-        const double a1 = w.at(l, j, cc), a2 = w.at(l, j + 1, cc);
-        w.at(l, j, cc) = c * a1 + s * a2;
-        w.at(l, j + 1, cc) = c * a2 - s * a1;
-    }
-    PSD_WAVE_SYNC();
-}
-PSD_D void psd_gwin_set2(const psd_gwin& w, int l, int r1, int c1, double v1, int r2, int c2, double v2) {
-    PSD_WAVE_SYNC();
-    PSD_ONE {
-        w.at(l, r1, c1) = v1;
-        w.at(l, r2, c2) = v2;
-    }
-    PSD_WAVE_SYNC();
-}
+#include "psd_rgz_chain.inl"
 
 PSD_D void psd_grecord(const psd_gparams& P, int* lcnt, int m, int pos, double c, double s) {
     PSD_ONE {
@@ -213,128 +138,6 @@ PSD_D void psd_gdesc_write(const psd_gparams& P, const psd_gstate& st, const int
         *P.desc = d;
     }
     PSD_SYNC();
-}
-
-// One factor of a rotation chain inside the window.  Incoming rotation (c, s) at (q, q+1):
-//   cols_in:  it acts on the columns of H_l; the fill H_l[q+1,q] is removed by a new row rotation
-//             (rgeneralized.jl:980-991 for S[l] in the downward chain, :922-933 for !S[l] in the forward chain)
-//   !cols_in: it acts on the rows; the fill is removed by a new column rotation generated from
-//             (H_l[q+1,q+1], -H_l[q+1,q])  (:993-1004, :906-920).  A "backwards" Givens(q+1, q, c, s') of the
-//             zero-shift / Case II text (:294-300) is the same rotation.
-// Returns the new rotation in (c, s); it acts on the rows (cols_in) or columns (!cols_in) of H_l.
-// One fused pass: every operand is loaded once into a lane register (row lanes hold (H[r,q], H[r,q+1]), column
-// lanes hold (H[q,cc], H[q+1,cc])), the 2x2 corner travels by v_readlane, one wave-level sync.
-// If slot >= 0 the new rotation is also stored as entry `slot` of owner `own`'s list (lane 0, no counter round trip).
-PSD_D void psd_g_link(const psd_gwin& w, int l, int q, bool cols_in, double& c, double& s, int rlo, int chi,
-                      psd_gtr* trbase = nullptr, int own = 0, int slot = -1) {
-    const int r0 = (rlo > w.bs) ? rlo : w.bs;
-    const int c1 = (chi < w.be) ? chi : w.be;
-    double* base = w.b + (l - 1) * w.bsz;
-    PSD_LANEVAR(double, x1);
-    PSD_LANEVAR(double, x2);
-    PSD_LANEVAR(int, off);
-    PSD_LANEVAR(int, str);
-    double r;
-    if (cols_in) {
-        const int nr = q + 2 - r0, nl = c1 - q;  // rows r0..q+1 ; columns q+1..c1
-        PSD_PAR_ONCE(t, nr + nl) {
-            if (t < nr) {
-                PSD_LV(off) = (q - w.bs) * w.ld + (r0 + t - w.bs);
-                PSD_LV(str) = w.ld;
-            } else {
-                PSD_LV(off) = (q + 1 + (t - nr) - w.bs) * w.ld + (q - w.bs);
-                PSD_LV(str) = 1;
-            }
-            const double a1 = base[PSD_LV(off)], a2 = base[PSD_LV(off) + PSD_LV(str)];
-            if (t < nr) {
-                PSD_LV(x1) = c * a1 + s * a2;
-                PSD_LV(x2) = c * a2 - s * a1;
-            } else {
-                PSD_LV(x1) = a1;
-                PSD_LV(x2) = a2;
-            }
-        }
-        const double f = PSD_BCAST(x1, nr - 2), g = PSD_BCAST(x1, nr - 1);
-        const double top = PSD_BCAST(x2, nr - 2), bot = PSD_BCAST(x2, nr - 1);
-        psd_givens(f, g, c, s, r);
-        PSD_PAR_ONCE(t, nr + nl) {
-            double* qp = base + PSD_LV(off);
-            if (t < nr) {
-                if (t >= nr - 2) {  // rows q, q+1: column q becomes (r, 0); their column q+1 belongs to the row pass
-                    qp[0] = (t == nr - 2) ? r : 0.0;
-                } else {
-                    qp[0] = PSD_LV(x1);
-                    qp[PSD_LV(str)] = PSD_LV(x2);
-                }
-            } else {
-                const double a1 = (t == nr) ? top : PSD_LV(x1), a2 = (t == nr) ? bot : PSD_LV(x2);
-                qp[0] = c * a1 + s * a2;
-                qp[1] = c * a2 - s * a1;
-            }
-        }
-    } else {
-        const int nl = c1 - q + 1, nr = q - r0;  // columns q..c1 ; rows r0..q-1
-        PSD_PAR_ONCE(t, nl + nr) {
-            if (t < nl) {
-                PSD_LV(off) = (q + t - w.bs) * w.ld + (q - w.bs);
-                PSD_LV(str) = 1;
-            } else {
-                PSD_LV(off) = (q - w.bs) * w.ld + (r0 + (t - nl) - w.bs);
-                PSD_LV(str) = w.ld;
-            }
-            const double a1 = base[PSD_LV(off)], a2 = base[PSD_LV(off) + PSD_LV(str)];
-            if (t < nl) {
-                PSD_LV(x1) = c * a1 + s * a2;
-                PSD_LV(x2) = c * a2 - s * a1;
-            } else {
-                PSD_LV(x1) = a1;
-                PSD_LV(x2) = a2;
-            }
-        }
-        // 2x2 corner after the row rotation: column q in lane 0, column q+1 in lane 1
-        const double p00 = PSD_BCAST(x1, 0), p10 = PSD_BCAST(x2, 0), p01 = PSD_BCAST(x1, 1), p11 = PSD_BCAST(x2, 1);
-        psd_givens(p11, -p10, c, s, r);
-        PSD_PAR_ONCE(t, nl + nr) {
-            double* qp = base + PSD_LV(off);
-            if (t == 0) {
-                qp[0] = c * p00 + s * p01;
-                qp[1] = 0.0;
-            } else if (t == 1) {
-                qp[0] = c * p01 - s * p00;
-                qp[1] = r;
-            } else if (t < nl) {
-                qp[0] = PSD_LV(x1);
-                qp[1] = PSD_LV(x2);
-            } else {
-                const double a1 = PSD_LV(x1), a2 = PSD_LV(x2);
-                qp[0] = c * a1 + s * a2;
-                qp[PSD_LV(str)] = c * a2 - s * a1;
-            }
-        }
-    }
-    if (slot >= 0 && slot < PSD_GTR_CAP) {
-        PSD_ONE {
-            psd_gtr tr;
-            tr.pos = q;
-            tr.pad = 0;
-            tr.c = c;
-            tr.s = s;
-            trbase[(size_t)(own - 1) * PSD_GTR_CAP + slot] = tr;
-        }
-    }
-    PSD_WAVE_SYNC();
-}
-PSD_D void psd_gstore_tr(const psd_gparams& P, int own, int slot, int pos, double c, double s) {
-    if (slot < PSD_GTR_CAP) {
-        PSD_ONE {
-            psd_gtr tr;
-            tr.pos = pos;
-            tr.pad = 0;
-            tr.c = c;
-            tr.s = s;
-            P.tr[(size_t)(own - 1) * PSD_GTR_CAP + slot] = tr;
-        }
-    }
 }
 
 // rgeneralized.jl:1140-1359 `_qzrots` (MB03AF 'Double'): starting rotations of an implicit double-shift sweep
@@ -1022,6 +825,156 @@ PSD_D void psd_gq_hess_window(const psd_gparams& P, psd_gstate& st, double* ldsd
         st.kcur = n - 1;
         if (st.hj > n - 2) st.phase = PSD_GPH_DONE;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 2 of the signed Hessenberg reduction as a pipeline over the factors.
+// Within one column hj the rotation at position q only depends on the rotation at q+1 THROUGH THE SAME FACTOR (they
+// share index q+1); its starting values come from column hj of A_1, which the lap-closing column rotation of A_1
+// (columns q, q+1 >= hj+1) never touches.  So the laps of consecutive positions overlap: the factors of the lap
+// (A_1 rows, A_p, ..., A_2, A_1 columns) are dealt out to the G wavefronts of one workgroup, wave g works on rotation
+// b - g in beat b, the rotation (c, s) moves to the next wave through an LDS mailbox, one barrier per beat.  Wave 0
+// owns A_1: it generates the rotation, applies it to the rows, and applies the column rotation that closes the lap
+// G beats later (a fixed delay, so the result does not depend on timing; left and right multiplications commute).
+// A window of K positions takes K + G beats of L links instead of K (p + 1) links.
+#define PSD_GHESS_MAXWAVES 16
+PSD_HD int psd_ghess_n0(int L, int p) {  // links of wave 0 next to its two A_1 updates
+    int n0 = L - 2;
+    if (n0 < 0) n0 = 0;
+    if (n0 > p - 1) n0 = p - 1;
+    return n0;
+}
+PSD_HD int psd_ghess_links(int p) { return (p + 1 + PSD_GHESS_MAXWAVES - 1) / PSD_GHESS_MAXWAVES; }
+PSD_HD int psd_ghess_waves(int p) {
+    const int L = psd_ghess_links(p), rest = p - 1 - psd_ghess_n0(L, p);
+    return 1 + (rest + L - 1) / L;
+}
+
+namespace psd_wv {
+#ifndef PSD_HOSTSIM
+#undef PSD_TID
+#undef PSD_TSTRIDE
+#define PSD_TID PSD_TID_WAVE
+#define PSD_TSTRIDE PSD_TSTRIDE_WAVE
+#endif
+#include "psd_rgz_chain.inl"
+
+// one beat of wave g (called by all lanes of that wave); mail: [(G + 1)][2 parities][c, s]
+PSD_D void psd_ghess_beat(const psd_gparams& P, const psd_gstate& st, const psd_gwin& w, double* side, double* mail, int g,
+                          int G, int b, int K, int L, int qe) {
+    const int p = st.p;
+    const int n0 = psd_ghess_n0(L, p);
+    if (g == 0) {
+        const int kc = b - G;  // the lap that closes on the columns of A_1 in this beat
+        if (kc >= 0 && kc < K) {
+            const double* m = mail + (size_t)(G * 2 + (kc & 1)) * 2;
+            psd_wv::psd_gwin_right(w, 1, qe - kc, m[0], m[1], st.ifirstm, st.ilastm);
+        }
+        if (b < K) {
+            const int q = qe - b;
+            double c, s, r;
+            psd_givens(side[q - w.bs], side[q + 1 - w.bs], c, s, r);
+            PSD_WAVE_SYNC();
+            PSD_ONE {
+                side[q - w.bs] = r;
+                side[q + 1 - w.bs] = 0.0;
+            }
+            PSD_WAVE_SYNC();
+            psd_wv::psd_gwin_left(w, 1, q, c, s, w.bs, st.ilastm);
+            psd_wv::psd_gstore_tr(P, 1, b, q, c, s);
+            for (int i = 0; i < n0; ++i) {
+                const int l = p - i;
+                psd_wv::psd_g_link(w, l, q, psd_gsig(P, l), c, s, st.ifirstm, st.ilastm, P.tr, l, b);
+            }
+            double* m = mail + (size_t)(1 * 2 + (b & 1)) * 2;
+            PSD_ONE {
+                m[0] = c;
+                m[1] = s;
+            }
+            PSD_WAVE_SYNC();
+        }
+    } else {
+        const int k = b - g;
+        if (k >= 0 && k < K) {
+            const double* mi = mail + (size_t)(g * 2 + (k & 1)) * 2;
+            double c = mi[0], s = mi[1];
+            const int q = qe - k;
+            const int i0 = n0 + (g - 1) * L;
+            const int i1 = (i0 + L < p - 1) ? (i0 + L) : (p - 1);
+            for (int i = i0; i < i1; ++i) {
+                const int l = p - i;
+                psd_wv::psd_g_link(w, l, q, psd_gsig(P, l), c, s, st.ifirstm, st.ilastm, P.tr, l, k);
+            }
+            double* mo = mail + (size_t)((g + 1) * 2 + (k & 1)) * 2;
+            PSD_ONE {
+                mo[0] = c;
+                mo[1] = s;
+            }
+            PSD_WAVE_SYNC();
+        }
+    }
+}
+#ifndef PSD_HOSTSIM
+#undef PSD_TID
+#undef PSD_TSTRIDE
+#define PSD_TID PSD_TID_BLOCK
+#define PSD_TSTRIDE PSD_TSTRIDE_BLOCK
+#endif
+}  // namespace psd_wv
+
+// LDS of the pipelined kernel: window blocks, column hj of A_1 (<= 64 entries), mailboxes, list lengths
+PSD_HD size_t psd_ghess_lds_bytes(int p, int W) {
+    size_t b = (size_t)p * W * (W + 1) * 8 + 64 * 8 + (size_t)4 * (PSD_GHESS_MAXWAVES + 1) * 8 + (size_t)p * 4;
+    return (b + 15) & ~(size_t)15;
+}
+
+// One window (positions qs..qe of column hj, processed downwards) of stage 2; blockDim = 64 G, L links per wave
+// (psd_ghess_waves / psd_ghess_links).  Same state, lists and descriptor as psd_gq_hess_window.
+PSD_KERNEL_B(64 * PSD_GHESS_MAXWAVES) psd_gq_hess_step(psd_gparams P, int L) {
+    PSD_LDS_DECL;
+    psd_gstate st = *P.st;
+    PSD_ONE { P.desc->active = 0; P.desc->defer_run = 0; }
+    if (st.phase != PSD_GPH_HESS) return;
+    const long long tk0 = psd_clock(), tw0 = psd_wallclock();
+    const int G = PSD_NTHREADS >> 6;
+    const int n = st.n, p = st.p, hj = st.hj;
+    double* ldsd = (double*)psd_lds;
+    double* side = ldsd + (size_t)p * st.W * (st.W + 1);
+    double* mail = side + 64;
+    int* lcnt = (int*)(mail + 4 * (PSD_GHESS_MAXWAVES + 1));
+    const int nb = st.W - 1;
+    const int qe = st.kcur;
+    const int qs = (qe - nb + 1 > hj + 1) ? (qe - nb + 1) : (hj + 1);
+    const int K = qe - qs + 1;
+    psd_gwin w;
+    w.b = ldsd;
+    w.W = st.W;
+    w.ld = st.W + 1;
+    w.bsz = st.W * (st.W + 1);
+    w.bs = qs;
+    w.be = qe + 1;
+    const psd_mat<double> A1 = psd_gfac(P, n, 1);
+    PSD_PAR_FOR(m, p) { lcnt[m] = K; }
+    PSD_PAR_FOR(t, w.be - w.bs + 1) { side[t] = A1(w.bs + t, hj); }
+    PSD_WAVES_FOR(g, G) { psd_wv::psd_gwin_load(P, w, n, p, g, G); }
+    for (int b = 0; b < K + G; ++b) {
+        PSD_WAVES_FOR(g, G) { psd_wv::psd_ghess_beat(P, st, w, side, mail, g, G, b, K, L, qe); }
+        PSD_SYNC();
+    }
+    PSD_WAVES_FOR(g, G) { psd_wv::psd_gwin_store(P, w, n, p, g, G); }
+    PSD_PAR_FOR(t, w.be - w.bs + 1) { A1(w.bs + t, hj) = side[t]; }
+    psd_gdesc_write(P, st, lcnt, w.bs, w.be, w.be + 1, n, 1, w.bs - 1, 0, 0, 0, 0, 1, hj + 1);
+    st.nwindows += 1;
+    st.kcur = qs - 1;
+    if (st.kcur < hj + 1) {
+        st.hj = hj + 1;
+        st.kcur = n - 1;
+        if (st.hj > n - 2) st.phase = PSD_GPH_DONE;
+    }
+    st.cyc[4] += psd_clock() - tk0;
+    st.cyc[5] += psd_wallclock() - tw0;
+    PSD_SYNC();
+    PSD_ONE { *P.st = st; }
 }
 
 // rgeneralized.jl:890-1054: one window of the implicit double-shift sweep
