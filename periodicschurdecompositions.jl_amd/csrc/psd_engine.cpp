@@ -157,7 +157,7 @@ struct psd_ctx {
     psd_ztr *zgtr = nullptr, *zgdG = nullptr;
     unsigned char* zgS = nullptr;
     int* zgcnt = nullptr;
-    size_t zgstep_lds_set = 0, zgostep_lds_set = 0;
+    size_t zgstep_lds_set = 0, zgostep_lds_set = 0, zghess_lds_set = 0;
 
     void zgrelease() {
         void* ptrs[] = {zgst, zgdesc, zgtr, zgdG, zgS, zgcnt};
@@ -979,6 +979,18 @@ int zgiterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
         c->zgstep_lds_set = lds_step;
     }
 #endif
+    // stage 2 of the signed Hessenberg reduction: pipeline over the factors (see giterate_dev)
+    const size_t lds_hess = psd_zghess_lds_bytes(p, W);
+    const int hess_links = psd_ghess_links(p), hess_waves = psd_ghess_waves(p);
+    const char* hserial = getenv("PSD_HESS_SERIAL");
+    const bool hess_pipe = hessmode && lds_hess <= (size_t)160 * 1024 && !(hserial && hserial[0] == '1');
+#ifndef PSD_HOSTSIM
+    if (hess_pipe && lds_hess > c->zghess_lds_set) {
+        PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_zgq_hess_step),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hess));
+        c->zghess_lds_set = lds_hess;
+    }
+#endif
     PSD_LAUNCH(psd_zgq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, hessmode);
     const size_t lds_apply = sizeof(psd_ztr) * PSD_GTR_CAP + (size_t)32 * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
     const int tiles = (n + PSD_ZAPPLY_NT - 1) / PSD_ZAPPLY_NT;
@@ -991,9 +1003,12 @@ int zgiterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
     const long long cap = (long long)maxitfac * n * ((long long)n / nbmin + 8) + 8LL * n + 1024 + (hessmode ? (long long)n * n : 0);
     for (;;) {
         for (int b = 0; b < batch; ++b) {
-            PSD_LAUNCH(psd_zgq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
+            if (hess_pipe)
+                PSD_LAUNCH(psd_zgq_hess_step, psd_dim3(1), 64 * hess_waves, lds_hess, c->stream, P, hess_links);
+            else
+                PSD_LAUNCH(psd_zgq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
             PSD_LAUNCH(psd_zgq_apply, psd_dim3(tiles, p, 3), PSD_ZAPPLY_NT, lds_apply, c->stream, P, n, p);
-            PSD_LAUNCH(psd_zgq_defer, psd_dim3(dtiles), 256, 0, c->stream, P, n);
+            if (!hess_pipe) PSD_LAUNCH(psd_zgq_defer, psd_dim3(dtiles), 256, 0, c->stream, P, n);
             ++launched;
         }
         PSD_CHECK(psd_rt_d2h(&hst, c->zgst, sizeof(hst), c->stream));

@@ -48,39 +48,10 @@ PSD_HD bool psd_zgsig(const psd_zgparams& P, int l) { return P.S[l - 1] != 0; }
 PSD_HD int psd_zgrowner(const psd_zgparams& P, int l, int p) { return psd_zgsig(P, l) ? l : psd_gnext(l, p); }
 PSD_HD int psd_zgcowner(const psd_zgparams& P, int l, int p) { return psd_zgsig(P, l) ? psd_gnext(l, p) : l; }
 
-PSD_D void psd_zgwin_load(const psd_zgparams& P, const psd_zwin& w, int n, int p) {
-    psd_zparams Q;
-    Q.H = P.H;
-    psd_zwin_load(Q, w, n, p);
-}
-PSD_D void psd_zgwin_store(const psd_zgparams& P, const psd_zwin& w, int n, int p) {
-    psd_zparams Q;
-    Q.H = P.H;
-    psd_zwin_store(Q, w, n, p);
-}
-PSD_D void psd_zgwin_set2(const psd_zwin& w, int l, int r1, int c1, psd_z v1, int r2, int c2, psd_z v2) {
-    PSD_WAVE_SYNC();
-    PSD_ONE {
-        w.at(l, r1, c1) = v1;
-        w.at(l, r2, c2) = v2;
-    }
-    PSD_WAVE_SYNC();
-}
-PSD_D void psd_zgrecord(const psd_zgparams& P, int* lcnt, int m, int pos, double c, psd_z s) {
-    PSD_ONE {
-        const int q = lcnt[m - 1];
-        if (q < PSD_GTR_CAP) {
-            psd_ztr tr;
-            tr.pos = pos;
-            tr.pad = 0;
-            tr.c = c;
-            tr.s = s;
-            P.tr[(size_t)(m - 1) * PSD_GTR_CAP + q] = tr;
-        }
-        lcnt[m - 1] = q + 1;
-    }
-    PSD_WAVE_SYNC();
-}
+#define PSD_NS ::
+#include "psd_zgz_chain.inl"
+#undef PSD_NS
+
 PSD_D void psd_zglog(const psd_zgparams& P, psd_zgstate& st, int kind, int lo, int hi) {
     PSD_ONE {
         if (st.nlog < st.maxlog) {
@@ -117,25 +88,6 @@ PSD_D void psd_zgdesc_write(const psd_zgparams& P, const psd_zgstate& st, const 
         *P.desc = d;
     }
     PSD_SYNC();
-}
-
-// One factor of a rotation chain inside the window (see psd_g_link): incoming (c, s) at (q, q+1);
-//   cols_in:  right on the columns, new row rotation from (H[q,q], H[q+1,q])          (generalized.jl:823-832)
-//   !cols_in: left on the rows, new column rotation from (H[q+1,q+1], H[q+1,q]): the reference's backwards
-//             Givens(q+1, q, c, s') is the standard rotation (q, q+1; c, -s)            (:833-845)
-PSD_D void psd_zg_link(const psd_zwin& w, int l, int q, bool cols_in, double& c, psd_z& s, int rlo, int chi) {
-    psd_z r;
-    if (cols_in) {
-        psd_zwin_right(w, l, q, c, s, rlo, q + 1);
-        psd_zgivens(w.at(l, q, q), w.at(l, q + 1, q), c, s, r);
-        psd_zgwin_set2(w, l, q, q, r, q + 1, q, zmk(0.0, 0.0));
-        psd_zwin_left(w, l, q, c, s, q + 1, chi);
-    } else {
-        psd_zwin_left(w, l, q, c, s, q, chi);
-        psd_zgivens(w.at(l, q + 1, q + 1), zneg(w.at(l, q + 1, q)), c, s, r);
-        psd_zgwin_set2(w, l, q + 1, q + 1, r, q + 1, q, zmk(0.0, 0.0));
-        psd_zwin_right(w, l, q, c, s, rlo, q);
-    }
 }
 
 // generalized.jl:939-976 `_safeprod` with a signature
@@ -527,6 +479,140 @@ PSD_D void psd_zgq_hess_window(const psd_zgparams& P, psd_zgstate& st, psd_z* ld
         st.kcur = n - 1;
         if (st.hj > n - 2) st.phase = PSD_GPH_DONE;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 2 as a pipeline over the factors (see psd_gq_hess_step in psd_rgz.h for the argument): wave-scoped copies of
+// the window helpers and of the chain link, one beat function, one multi-wave kernel.
+namespace psd_wv {
+#ifndef PSD_HOSTSIM
+#undef PSD_TID
+#undef PSD_TSTRIDE
+#define PSD_TID PSD_TID_WAVE
+#define PSD_TSTRIDE PSD_TSTRIDE_WAVE
+#endif
+#include "psd_zqz_win.inl"
+#define PSD_NS psd_wv::
+#include "psd_zgz_chain.inl"
+#undef PSD_NS
+
+// one beat of wave g; mail: [(G + 1)][2 parities][c, s.re, s.im, -]
+PSD_D void psd_zghess_beat(const psd_zgparams& P, const psd_zgstate& st, const psd_zwin& w, psd_z* side, double* mail,
+                           int* lcnt, int g, int G, int b, int K, int L, int qe) {
+    const int p = st.p;
+    const int n0 = psd_ghess_n0(L, p);
+    const psd_z z0 = zmk(0.0, 0.0);
+    if (g == 0) {
+        const int kc = b - G;
+        if (kc >= 0 && kc < K) {
+            const double* m = mail + (size_t)(G * 2 + (kc & 1)) * 4;
+            psd_wv::psd_zwin_right(w, 1, qe - kc, m[0], zmk(m[1], m[2]), st.ifirstm, st.n);
+        }
+        if (b < K) {
+            const int q = qe - b;
+            double c;
+            psd_z s, r;
+            psd_zgivens(side[q - w.bs], side[q + 1 - w.bs], c, s, r);
+            PSD_WAVE_SYNC();
+            PSD_ONE {
+                side[q - w.bs] = r;
+                side[q + 1 - w.bs] = z0;
+            }
+            PSD_WAVE_SYNC();
+            psd_wv::psd_zwin_left(w, 1, q, c, s, w.bs, st.ilastm);
+            psd_wv::psd_zgrecord(P, lcnt, 1, q, c, s);
+            for (int i = 0; i < n0; ++i) {
+                const int l = p - i;
+                psd_wv::psd_zg_link(w, l, q, psd_zgsig(P, l), c, s, st.ifirstm, st.ilastm);
+                psd_wv::psd_zgrecord(P, lcnt, l, q, c, s);
+            }
+            double* m = mail + (size_t)(1 * 2 + (b & 1)) * 4;
+            PSD_ONE {
+                m[0] = c;
+                m[1] = s.re;
+                m[2] = s.im;
+            }
+            PSD_WAVE_SYNC();
+        }
+    } else {
+        const int k = b - g;
+        if (k >= 0 && k < K) {
+            const double* mi = mail + (size_t)(g * 2 + (k & 1)) * 4;
+            double c = mi[0];
+            psd_z s = zmk(mi[1], mi[2]);
+            const int q = qe - k;
+            const int i0 = n0 + (g - 1) * L;
+            const int i1 = (i0 + L < p - 1) ? (i0 + L) : (p - 1);
+            for (int i = i0; i < i1; ++i) {
+                const int l = p - i;
+                psd_wv::psd_zg_link(w, l, q, psd_zgsig(P, l), c, s, st.ifirstm, st.ilastm);
+                psd_wv::psd_zgrecord(P, lcnt, l, q, c, s);
+            }
+            double* mo = mail + (size_t)((g + 1) * 2 + (k & 1)) * 4;
+            PSD_ONE {
+                mo[0] = c;
+                mo[1] = s.re;
+                mo[2] = s.im;
+            }
+            PSD_WAVE_SYNC();
+        }
+    }
+}
+#ifndef PSD_HOSTSIM
+#undef PSD_TID
+#undef PSD_TSTRIDE
+#define PSD_TID PSD_TID_BLOCK
+#define PSD_TSTRIDE PSD_TSTRIDE_BLOCK
+#endif
+}  // namespace psd_wv
+
+PSD_HD size_t psd_zghess_lds_bytes(int p, int W) {
+    size_t b = (size_t)p * W * (W + 1) * 16 + 64 * 16 + (size_t)8 * (PSD_GHESS_MAXWAVES + 1) * 8 + (size_t)p * 4;
+    return (b + 15) & ~(size_t)15;
+}
+
+PSD_KERNEL_B(64 * PSD_GHESS_MAXWAVES) psd_zgq_hess_step(psd_zgparams P, int L) {
+    PSD_LDS_DECL;
+    psd_zgstate st = *P.st;
+    PSD_ONE { P.desc->active = 0; P.desc->defer_run = 0; }
+    if (st.phase != PSD_GPH_HESS) return;
+    const int G = PSD_NTHREADS >> 6;
+    const int n = st.n, p = st.p, hj = st.hj;
+    psd_z* ldsz = (psd_z*)psd_lds;
+    psd_z* side = ldsz + (size_t)p * st.W * (st.W + 1);
+    double* mail = (double*)(side + 64);
+    int* lcnt = (int*)(mail + 8 * (PSD_GHESS_MAXWAVES + 1));
+    const int nb = st.W - 1;
+    const int qe = st.kcur;
+    const int qs = (qe - nb + 1 > hj + 1) ? (qe - nb + 1) : (hj + 1);
+    const int K = qe - qs + 1;
+    psd_zwin w;
+    w.b = ldsz;
+    w.W = st.W;
+    w.ld = st.W + 1;
+    w.bsz = st.W * (st.W + 1);
+    w.bs = qs;
+    w.be = qe + 1;
+    const psd_mat<psd_z> A1 = psd_zgfac(P, n, 1);
+    PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
+    PSD_PAR_FOR(t, w.be - w.bs + 1) { side[t] = A1(w.bs + t, hj); }
+    PSD_WAVES_FOR(g, G) { psd_wv::psd_zgwin_load(P, w, n, p, g, G); }
+    for (int b = 0; b < K + G; ++b) {
+        PSD_WAVES_FOR(g, G) { psd_wv::psd_zghess_beat(P, st, w, side, mail, lcnt, g, G, b, K, L, qe); }
+        PSD_SYNC();
+    }
+    PSD_WAVES_FOR(g, G) { psd_wv::psd_zgwin_store(P, w, n, p, g, G); }
+    PSD_PAR_FOR(t, w.be - w.bs + 1) { A1(w.bs + t, hj) = side[t]; }
+    psd_zgdesc_write(P, st, lcnt, w.bs, w.be, w.be + 1, n, 1, w.bs - 1, 0, 0, 0, 0, 1, hj + 1);
+    st.nwindows += 1;
+    st.kcur = qs - 1;
+    if (st.kcur < hj + 1) {
+        st.hj = hj + 1;
+        st.kcur = n - 1;
+        if (st.hj > n - 2) st.phase = PSD_GPH_DONE;
+    }
+    PSD_SYNC();
+    PSD_ONE { *P.st = st; }
 }
 
 PSD_D int psd_zgq_scan_diag(const psd_zgparams& P, const psd_zgstate& st, int* redi, int jlo, bool sign) {

@@ -80,76 +80,7 @@ struct psd_zwin {
     PSD_HD psd_z& at(int j, int r, int c) const { return b[(j - 1) * bsz + (c - bs) * ld + (r - bs)]; }
 };
 
-PSD_D void psd_zwin_load(const psd_zparams& P, const psd_zwin& w, int n, int p) {
-    const int m = w.be - w.bs + 1;
-    const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
-    PSD_PAR_FOR(t, PSD_STEP_NT) {
-        const int r = t & (RW - 1), g = t >> sh;
-        if (r < m) {
-            for (int j = 0; j < p; ++j) {  // (factor loop outside: no index divisions in the hot loop)
-                const psd_z* src = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r);
-                psd_z* dst = w.b + j * w.bsz + r;
-                for (int c0 = g; c0 < m; c0 += 8 * ncg) {
-                    psd_z v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int c = c0 + u * ncg;
-                        v[u] = (c < m) ? src[(size_t)c * n] : zmk(0.0, 0.0);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int c = c0 + u * ncg;
-                        if (c < m) dst[c * w.ld] = v[u];
-                    }
-                }
-            }
-        }
-    }
-    PSD_SYNC();
-}
-PSD_D void psd_zwin_store(const psd_zparams& P, const psd_zwin& w, int n, int p) {
-    const int m = w.be - w.bs + 1;
-    const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
-    PSD_SYNC();
-    PSD_PAR_FOR(t, PSD_STEP_NT) {
-        const int r = t & (RW - 1), g = t >> sh;
-        if (r < m) {
-            for (int j = 0; j < p; ++j) {
-                psd_z* dst = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r);
-                const psd_z* src = w.b + j * w.bsz + r;
-                for (int c = g; c < m; c += ncg) dst[(size_t)c * n] = src[c * w.ld];
-            }
-        }
-    }
-    PSD_SYNC();
-}
-
-// in-window: rmul!(view(H_l, r0:r1, :), G') on columns (j, j+1)
-PSD_D void psd_zwin_right(const psd_zwin& w, int l, int j, double c, psd_z s, int r0, int r1) {
-    if (r0 < w.bs) r0 = w.bs;
-    if (r1 > w.be) r1 = w.be;
-    PSD_PAR_FOR(t, r1 - r0 + 1) {
-        const int r = r0 + t;
-        psd_z a1 = w.at(l, r, j), a2 = w.at(l, r, j + 1);
-        psd_zrot_right_adj(c, s, a1, a2);
-        w.at(l, r, j) = a1;
-        w.at(l, r, j + 1) = a2;
-    }
-    PSD_WAVE_SYNC();
-}
-// in-window: lmul!(G, view(H_l, :, c0:c1)) on rows (j, j+1)
-PSD_D void psd_zwin_left(const psd_zwin& w, int l, int j, double c, psd_z s, int c0, int c1) {
-    if (c0 < w.bs) c0 = w.bs;
-    if (c1 > w.be) c1 = w.be;
-    PSD_PAR_FOR(t, c1 - c0 + 1) {
-        const int cc = c0 + t;
-        psd_z a1 = w.at(l, j, cc), a2 = w.at(l, j + 1, cc);
-        psd_zrot_left(c, s, a1, a2);
-        w.at(l, j, cc) = a1;
-        w.at(l, j + 1, cc) = a2;
-    }
-    PSD_WAVE_SYNC();
-}
+#include "psd_zqz_win.inl"
 
 PSD_D void psd_zrecord(const psd_zparams& P, int* lcnt, int m, int pos, double c, psd_z s) {
     PSD_ONE {

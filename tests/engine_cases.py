@@ -769,7 +769,9 @@ def case_zg_phessenberg(eng, p):
     Hs, Qs = eng.gphessenberg_([a.copy(order="F") for a in A], S)
     pt.sg_hess_check(A, S, Hs, Qs)
     for (n2, p2, S2) in [(9, 6, [True, True, False, False, True, False]), (33, 4, [True, False, False, False]),
-                         (40, 3, [True, False, True])]:
+                         (40, 3, [True, False, True]), (30, 22, None)]:
+        if S2 is None:
+            S2 = [True] + [bool((q * 5) % 3) for q in range(1, p2)]
         A = pt.bench_factors(n2, p2, seed=3 + n2, dtype=np.complex128)
         Hs, Qs = eng.gphessenberg_([a.copy(order="F") for a in A], S2)
         pt.sg_hess_check(A, S2, Hs, Qs, tol=20 * max(1, n2 / 8), qtol=10 * max(1, n2 / 16))
