@@ -104,6 +104,11 @@ struct psd_ctx {
     int device = 0;
     psd_stream_t stream = 0;
     int profile = 0;
+#ifndef PSD_HOSTSIM
+    // state polling without draining the stream: two pinned slots and events (iterate_dev)
+    void* pin[2] = {nullptr, nullptr};
+    hipEvent_t pev[2] = {nullptr, nullptr};
+#endif
     // workspace (grown on demand)
     int cap_n = 0, cap_p = 0;
     bool cap_mats = false;
@@ -452,6 +457,21 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
 #ifndef PSD_HOSTSIM
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pend;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pend_prev;
+    int slot = 0;
+    bool have_prev = false;
+    auto harvest = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>>& v) {
+        for (auto& pr : v) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                sample_ms += ms;
+                ++samples;
+            }
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        v.clear();
+    };
 #endif
     for (;;) {
         for (int b = 0; b < batch; ++b) {
@@ -473,19 +493,28 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
             PSD_LAUNCH(psd_rq_apply, psd_dim3(tiles, p, 3), PSD_APPLY_NT, lds_apply, c->stream, P, n, p);
             ++launched;
         }
+#ifdef PSD_HOSTSIM
         PSD_CHECK(psd_rt_d2h(&hst, c->st, sizeof(hst), c->stream));
         PSD_CHECK(psd_rt_sync(c->stream));
-#ifndef PSD_HOSTSIM
-        for (auto& pr : pend) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
-                sample_ms += ms;
-                ++samples;
-            }
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
+#else
+        // The state of this batch is copied to a pinned slot behind it; the host looks at the PREVIOUS batch's state
+        // while this one runs, so the stream never drains between batches (a drained poll costs ~70 us).  The batch
+        // that is in flight when DONE is seen consists of launches that return at once.
+        static_assert(sizeof(psd_rstate) <= 4096, "pinned poll slot too small");
+        PSD_CHECK(psd_rt_d2h(c->pin[slot], c->st, sizeof(hst), c->stream));
+        PSD_CHECK((int)hipEventRecord(c->pev[slot], c->stream));
+        if (!have_prev) {  // first batch: drained poll (small problems end here)
+            PSD_CHECK((int)hipEventSynchronize(c->pev[slot]));
+            memcpy(&hst, c->pin[slot], sizeof(hst));
+            harvest(pend);
+            have_prev = true;
+        } else {
+            PSD_CHECK((int)hipEventSynchronize(c->pev[slot ^ 1]));
+            memcpy(&hst, c->pin[slot ^ 1], sizeof(hst));
+            harvest(pend_prev);
         }
-        pend.clear();
+        pend_prev.swap(pend);
+        slot ^= 1;
 #endif
         if (hst.phase == PSD_PH_DONE) break;
         if (launched > cap) {
@@ -493,6 +522,11 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
             return PSD_INFO_RUNTIME + 0xfffe;
         }
     }
+#ifndef PSD_HOSTSIM
+    PSD_CHECK(psd_rt_sync(c->stream));  // (the batch behind the one that reported DONE)
+    harvest(pend_prev);
+    harvest(pend);
+#endif
     PSD_CHECK(psd_rt_last_error());
     *st_out = hst;
     if (stats) {
@@ -582,6 +616,13 @@ int psd_create(psd_ctx** ctx, int device) {
         delete c;
         return PSD_INFO_RUNTIME + 4;
     }
+    for (int q = 0; q < 2; ++q) {
+        if (hipHostMalloc(&c->pin[q], 4096, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&c->pev[q], hipEventDisableTiming) != hipSuccess) {
+            psd_destroy(c);
+            return PSD_INFO_RUNTIME + 5;
+        }
+    }
 #endif
     *ctx = c;
     return 0;
@@ -595,6 +636,10 @@ int psd_destroy(psd_ctx* c) {
     c->zrelease();
     c->rorelease();
 #ifndef PSD_HOSTSIM
+    for (int q = 0; q < 2; ++q) {
+        if (c->pev[q]) (void)hipEventDestroy(c->pev[q]);
+        if (c->pin[q]) (void)hipHostFree(c->pin[q]);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
 #endif
     delete c;

@@ -983,3 +983,26 @@ def case_ordschur_alignments(eng):
         raise AssertionError("schurindex 2 of 3 must be rejected")
     except ValueError:
         pass
+
+
+# ------------------------------------------------------------------------------------------------
+# Stage 2 of the signed Hessenberg reduction: the pipelined multi-wave kernel against the single-wave chase
+# (PSD_HESS_SERIAL=1).  Same rotations up to the order in which A_1 takes its row and column updates, so the factors
+# agree to rounding and both satisfy the invariants of test/generalized.jl:1-40.
+def case_hess_pipeline_vs_serial(eng):
+    for (n, p, cplx) in [(40, 7, False), (36, 19, False), (28, 6, True), (24, 18, True), (12, 1, False), (10, 2, True)]:
+        S = [True] + [bool((q * 5 + n) % 3) for q in range(1, p)]
+        A = pt.bench_factors(n, p, seed=11 + n, dtype=np.complex128 if cplx else np.float64)
+        old = os.environ.pop("PSD_HESS_SERIAL", None)
+        try:
+            Hp, Qp = eng.gphessenberg_([a.copy(order="F") for a in A], S)
+            os.environ["PSD_HESS_SERIAL"] = "1"
+            Hs, Qs = eng.gphessenberg_([a.copy(order="F") for a in A], S)
+        finally:
+            os.environ.pop("PSD_HESS_SERIAL", None)
+            if old is not None:
+                os.environ["PSD_HESS_SERIAL"] = old
+        pt.sg_hess_check(A, S, Hp, Qp, tol=20 * max(1, n / 8), qtol=10 * max(1, n / 16))
+        pt.sg_hess_check(A, S, Hs, Qs, tol=20 * max(1, n / 8), qtol=10 * max(1, n / 16))
+        for a, b in zip(Hp, Hs):
+            assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max()), (n, p, cplx, np.abs(a - b).max())

@@ -117,3 +117,7 @@ def test_gordschur_pairs_random(gpu_engine):
 
 def test_gpschur_pairs(gpu_engine):
     ec.case_gpschur_pairs(gpu_engine)
+
+
+def test_hess_pipeline_vs_serial(gpu_engine):
+    ec.case_hess_pipeline_vs_serial(gpu_engine)

@@ -86,3 +86,7 @@ def test_gordschur_pairs_random(sim_engine):
 
 def test_gpschur_pairs(sim_engine):
     ec.case_gpschur_pairs(sim_engine)
+
+
+def test_hess_pipeline_vs_serial(sim_engine):
+    ec.case_hess_pipeline_vs_serial(sim_engine)
