@@ -1712,7 +1712,7 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
     }
 #endif
     PSD_LAUNCH(psd_gq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, hessmode);
-    const size_t lds_apply = sizeof(psd_gtr) * PSD_GTR_CAP + (size_t)32 * (PSD_GAPPLY_NT + 1) * sizeof(double);
+    const size_t lds_apply = PSD_GTR_LDS_BYTES + (size_t)32 * (PSD_GAPPLY_NT + 1) * sizeof(double);
     const int tiles = (n + PSD_GAPPLY_NT - 1) / PSD_GAPPLY_NT;
     const int dtiles = (n + 255) / 256;
     const int batch = 32;

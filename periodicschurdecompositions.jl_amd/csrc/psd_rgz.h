@@ -1420,6 +1420,53 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_gq_step(psd_gparams P) {
 }
 
 // Bulk application of one window's rotation lists, by factor: grid = (tiles, p factors, 3 roles).
+// As in psd_rq_apply a thread keeps its line (<= 32 elements) in registers through the whole list when the list visits
+// its positions monotonically (sweeps ascending, Hessenberg stage 2 descending): fully unrolled position loop with
+// static register indices, list read ahead from LDS behind two sentinel records.
+#define PSD_GTR_LDS_RECS (PSD_GTR_CAP + 2)
+#define PSD_GTR_LDS_BYTES (sizeof(psd_gtr) * PSD_GTR_LDS_RECS + 16)
+template <bool UP>
+PSD_D void psd_gtr_regline(const psd_gtr* ltr, int plo, double (&a)[33]) {
+    int e = 0;
+    psd_gtr cur = ltr[0], nxt = ltr[1];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        const int b = UP ? q : 31 - q;
+        while (cur.pos - plo == b) {
+            const double a1 = a[b], a2 = a[b + 1];
+            a[b] = cur.c * a1 + cur.s * a2;
+            a[b + 1] = cur.c * a2 - cur.s * a1;
+            cur = nxt;
+            ++e;
+            nxt = ltr[e + 1 < PSD_GTR_LDS_RECS ? e + 1 : PSD_GTR_LDS_RECS - 1];
+        }
+    }
+}
+// stages the list (plus sentinels) in LDS and classifies its order: +1 ascending, -1 descending, 0 neither; contains
+// block synchronisations
+PSD_D int psd_gtr_stage(const psd_gtr* gtr, int cnt, psd_gtr* ltr, int* flags) {
+    PSD_PAR_FOR(e, PSD_GTR_LDS_RECS) {
+        psd_gtr tr;
+        if (e < cnt) {
+            tr = gtr[e];
+        } else {
+            tr.pos = 0x3fffffff;
+            tr.pad = 0;
+            tr.c = 1.0;
+            tr.s = 0.0;
+        }
+        ltr[e] = tr;
+    }
+    PSD_ONE { flags[0] = flags[1] = 0; }
+    PSD_SYNC();
+    PSD_PAR_FOR(e, cnt - 1) {
+        if (ltr[e + 1].pos < ltr[e].pos) flags[0] = 1;
+        if (ltr[e + 1].pos > ltr[e].pos) flags[1] = 1;
+    }
+    PSD_SYNC();
+    return !flags[0] ? 1 : (!flags[1] ? -1 : 0);
+}
+
 PSD_KERNEL_B(PSD_GAPPLY_NT) psd_gq_apply(psd_gparams P, int n, int p) {
     PSD_LDS_DECL;
     const psd_gapply_desc d = *P.desc;
@@ -1432,7 +1479,9 @@ PSD_KERNEL_B(PSD_GAPPLY_NT) psd_gq_apply(psd_gparams P, int n, int p) {
     const int T = PSD_GAPPLY_NT;
     const int S = d.phi - d.plo + 1;
     psd_gtr* ltr = (psd_gtr*)psd_lds;
-    double* tile = (double*)(psd_lds + sizeof(psd_gtr) * PSD_GTR_CAP);
+    int* flags = (int*)(psd_lds + sizeof(psd_gtr) * PSD_GTR_LDS_RECS);
+    double* tile = (double*)(psd_lds + PSD_GTR_LDS_BYTES);
+    const psd_gtr* gtr = P.tr + (size_t)(own - 1) * PSD_GTR_CAP;
     const bool h1x = d.h1mode == 1 && l == 1;  // stage 2 of the signed Hessenberg reduction: H_1 outside the window
     if (role == 0) {
         const int c0 = (h1x ? d.h1c0 : d.lc0) + PSD_BLOCK_X * T;
@@ -1441,15 +1490,35 @@ PSD_KERNEL_B(PSD_GAPPLY_NT) psd_gq_apply(psd_gparams P, int n, int p) {
         if (h1x && c0 >= d.plo && c0 + nc - 1 <= d.phi) return;
         const psd_mat<double> M = psd_gfac(P, n, l);
         const int ldt = T + 1;
-        PSD_PAR_FOR(e, cnt) { ltr[e] = P.tr[(size_t)(own - 1) * PSD_GTR_CAP + e]; }
-        PSD_PAR_FOR(t, 32 * nc) {  // (S <= 32; no index divisions)
-            const int r = t & 31, c = t >> 5;
+        // rows panel -> LDS (a thread owns a column); eight loads in flight per thread
+        PSD_PAR_FOR(t0, 32 * 4) {  // (S <= 32; thread t0 covers row t0 & 31 of the columns (t0 >> 5) + 4 k)
+            const int r = t0 & 31, cb = t0 >> 5;
             if (r >= S) continue;
-            tile[r * ldt + c] = M(d.plo + r, c0 + c);
+            for (int k0 = 0; k0 < T / 4; k0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = cb + 4 * (k0 + u);
+                    v[u] = (c < nc) ? M(d.plo + r, c0 + c) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tile[r * ldt + cb + 4 * (k0 + u)] = v[u];
+            }
         }
-        PSD_SYNC();
+        const int order = psd_gtr_stage(gtr, cnt, ltr, flags);
         PSD_PAR_FOR(c, nc) {
             if (h1x && c0 + c >= d.plo && c0 + c <= d.phi) continue;
+            if (order != 0) {
+                double a[33];
+#pragma unroll
+                for (int r = 0; r < 33; ++r) a[r] = (r < S) ? tile[r * ldt + c] : 0.0;
+                if (order > 0) psd_gtr_regline<true>(ltr, d.plo, a);
+                else psd_gtr_regline<false>(ltr, d.plo, a);
+#pragma unroll
+                for (int r = 0; r < 32; ++r)
+                    if (r < S) tile[r * ldt + c] = a[r];
+                continue;
+            }
             for (int e = 0; e < cnt; ++e) {
                 const psd_gtr tr = ltr[e];
                 const int r = tr.pos - d.plo;
@@ -1459,11 +1528,19 @@ PSD_KERNEL_B(PSD_GAPPLY_NT) psd_gq_apply(psd_gparams P, int n, int p) {
             }
         }
         PSD_SYNC();
-        PSD_PAR_FOR(t, 32 * nc) {  // (S <= 32; no index divisions)
-            const int r = t & 31, c = t >> 5;
+        PSD_PAR_FOR(t0, 32 * 4) {
+            const int r = t0 & 31, cb = t0 >> 5;
             if (r >= S) continue;
-            if (h1x && c0 + c >= d.plo && c0 + c <= d.phi) continue;
-            M(d.plo + r, c0 + c) = tile[r * ldt + c];
+            for (int k0 = 0; k0 < T / 4; k0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = tile[r * ldt + cb + 4 * (k0 + u)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = cb + 4 * (k0 + u);
+                    if (c < nc && !(h1x && c0 + c >= d.plo && c0 + c <= d.phi)) M(d.plo + r, c0 + c) = v[u];
+                }
+            }
         }
     } else {
         if (role == 1 && d.defer_h1 == 1 && l == 1) return;  // H_1's column updates are deferred (zero-shift pass)
@@ -1475,7 +1552,22 @@ PSD_KERNEL_B(PSD_GAPPLY_NT) psd_gq_apply(psd_gparams P, int n, int p) {
         const int nr = (hi - r0 + 1 < T) ? (hi - r0 + 1) : T;
         double* base = (role == 1) ? P.H : P.Z;
         const psd_mat<double> M = psd_mat<double>{base + (size_t)(l - 1) * n * n, n};
-        PSD_PAR_FOR(e, cnt) { ltr[e] = P.tr[(size_t)(own - 1) * PSD_GTR_CAP + e]; }
+        const int order = psd_gtr_stage(gtr, cnt, ltr, flags);
+        if (order != 0) {
+            // a thread owns a row of the columns panel: coalesced loads straight into registers, no LDS tile
+            PSD_PAR_FOR(r, nr) {
+                if (h1r && r0 + r >= d.plo && r0 + r <= d.phi) continue;
+                double a[33];
+#pragma unroll
+                for (int c = 0; c < 33; ++c) a[c] = (c < S) ? M(r0 + r, d.plo + c) : 0.0;
+                if (order > 0) psd_gtr_regline<true>(ltr, d.plo, a);
+                else psd_gtr_regline<false>(ltr, d.plo, a);
+#pragma unroll
+                for (int c = 0; c < 32; ++c)
+                    if (c < S) M(r0 + r, d.plo + c) = a[c];
+            }
+            return;
+        }
         PSD_PAR_FOR(t, S * T) {
             const int r = t & (T - 1), c = t / T;
             if (r >= nr) continue;
