@@ -1,5 +1,7 @@
 """GPU tier (MI355X): parity of the complex HIP path through the C ABI (same cases as the simulated tier, plus
 larger sizes and the device-resident entry)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -52,7 +54,8 @@ def test_config3_shape_reduced(gpu_engine):
     n, p = 128, 64
     As = pt.bench_factors(n, p, seed=1234 + 3, dtype=np.complex128)
     ps = gpu_engine.pschur(As, "R")
-    assert ps.stats.window == ec.expected_window(p, 16) == 12
+    assert ps.stats.window == ec.expected_window(p, 16)
+    assert ps.stats.window == 12 or "PSD_WINDOW" in os.environ
     ok, err = pt.checkpsd(ps, As, thresh=100 * np.sqrt(n / 32))
     assert ok, err
     P = pt.product(As)
