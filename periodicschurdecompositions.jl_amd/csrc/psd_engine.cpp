@@ -874,7 +874,7 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
     }
 #endif
     PSD_LAUNCH(psd_zq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog);
-    const size_t lds_apply = sizeof(psd_ztr) * PSD_ZTR_CAP + (size_t)32 * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
+    const size_t lds_apply = PSD_ZTR_LDS_BYTES + (size_t)32 * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
     const int tiles = (n + PSD_ZAPPLY_NT - 1) / PSD_ZAPPLY_NT;
     const int dtiles = (n + 255) / 256;
     const int batch = 32;
@@ -1451,7 +1451,7 @@ int zordschur_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
     }
 #endif
     PSD_LAUNCH(psd_zord_init, psd_dim3(1), 64, 0, c->stream, O, n, p, wantZ, W);
-    const size_t lds_apply = sizeof(psd_ztr) * PSD_ZTR_CAP + (size_t)32 * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
+    const size_t lds_apply = PSD_ZTR_LDS_BYTES + (size_t)32 * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
     const int tiles = (n + PSD_ZAPPLY_NT - 1) / PSD_ZAPPLY_NT;
     psd_ostate hst;
     memset(&hst, 0, sizeof(hst));

@@ -698,6 +698,49 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_zq_step(psd_zparams P) {
 // Bulk application of one window's rotation lists.  grid = (tiles, p owners, 3 roles) as in the
 // real path; tiles are 64 wide (16-byte elements).
 #define PSD_ZAPPLY_NT 64
+// As in psd_rq_apply: a thread keeps its line (<= 32 complex elements) in registers through the whole list when the list
+// visits its positions monotonically; fully unrolled position loop, list read ahead from LDS behind two sentinels.
+#define PSD_ZTR_LDS_RECS (PSD_ZTR_CAP + 2)
+#define PSD_ZTR_LDS_BYTES (sizeof(psd_ztr) * PSD_ZTR_LDS_RECS + 16)
+template <bool UP, bool LEFT>
+PSD_D void psd_ztr_regline(const psd_ztr* ltr, int plo, psd_z (&a)[33]) {
+    int e = 0;
+    psd_ztr cur = ltr[0], nxt = ltr[1];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        const int b = UP ? q : 31 - q;
+        while (cur.pos - plo == b) {
+            if (LEFT) psd_zrot_left(cur.c, cur.s, a[b], a[b + 1]);
+            else psd_zrot_right_adj(cur.c, cur.s, a[b], a[b + 1]);
+            cur = nxt;
+            ++e;
+            nxt = ltr[e + 1 < PSD_ZTR_LDS_RECS ? e + 1 : PSD_ZTR_LDS_RECS - 1];
+        }
+    }
+}
+PSD_D int psd_ztr_stage(const psd_ztr* gtr, int cnt, psd_ztr* ltr, int* flags) {
+    PSD_PAR_FOR(e, PSD_ZTR_LDS_RECS) {
+        psd_ztr tr;
+        if (e < cnt) {
+            tr = gtr[e];
+        } else {
+            tr.pos = 0x3fffffff;
+            tr.pad = 0;
+            tr.c = 1.0;
+            tr.s = zmk(0.0, 0.0);
+        }
+        ltr[e] = tr;
+    }
+    PSD_ONE { flags[0] = flags[1] = 0; }
+    PSD_SYNC();
+    PSD_PAR_FOR(e, cnt - 1) {
+        if (ltr[e + 1].pos < ltr[e].pos) flags[0] = 1;
+        if (ltr[e + 1].pos > ltr[e].pos) flags[1] = 1;
+    }
+    PSD_SYNC();
+    return !flags[0] ? 1 : (!flags[1] ? -1 : 0);
+}
+
 PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply(psd_zparams P, int n, int p) {
     PSD_LDS_DECL;
     const psd_zapply_desc d = *P.desc;
@@ -709,7 +752,10 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply(psd_zparams P, int n, int p) {
     const int T = PSD_ZAPPLY_NT;
     const int S = d.phi - d.plo + 1;
     psd_ztr* ltr = (psd_ztr*)psd_lds;
-    psd_z* tile = (psd_z*)(psd_lds + sizeof(psd_ztr) * PSD_ZTR_CAP);
+    int* flags = (int*)(psd_lds + sizeof(psd_ztr) * PSD_ZTR_LDS_RECS);
+    psd_z* tile = (psd_z*)(psd_lds + PSD_ZTR_LDS_BYTES);
+    const psd_ztr* gtr = P.tr + (size_t)(m - 1) * PSD_ZTR_CAP;
+    const psd_z z0 = zmk(0.0, 0.0);
     if (role == 0) {
         if (d.defer_h1 == 2 && m == 1) return;  // H_1's left side is deferred (upward pass of Case II)
         const int c0 = d.lc0 + PSD_BLOCK_X * T;
@@ -717,14 +763,38 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply(psd_zparams P, int n, int p) {
         const int nc = (d.lc1 - c0 + 1 < T) ? (d.lc1 - c0 + 1) : T;
         const psd_mat<psd_z> M = psd_mat<psd_z>{P.H + (size_t)(m - 1) * n * n, n};
         const int ldt = T + 1;
-        PSD_PAR_FOR(e, cnt) { ltr[e] = P.tr[(size_t)(m - 1) * PSD_ZTR_CAP + e]; }
-        PSD_PAR_FOR(t, 32 * nc) {  // (S <= 32; no index divisions)
-            const int r = t & 31, c = t >> 5;
+        // rows panel -> LDS (a thread owns a column); eight loads in flight per thread
+        PSD_PAR_FOR(t0, 32 * 2) {  // (S <= 32; thread t0 covers row t0 & 31 of the columns (t0 >> 5) + 2 k)
+            const int r = t0 & 31, cb = t0 >> 5;
             if (r >= S) continue;
-            tile[r * ldt + c] = M(d.plo + r, c0 + c);
+            for (int k0 = 0; k0 < T / 2; k0 += 8) {
+                psd_z v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = cb + 2 * (k0 + u);
+                    v[u] = z0;
+                    if (c < nc) v[u] = M(d.plo + r, c0 + c);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tile[r * ldt + cb + 2 * (k0 + u)] = v[u];
+            }
         }
-        PSD_SYNC();
+        const int order = psd_ztr_stage(gtr, cnt, ltr, flags);
         PSD_PAR_FOR(c, nc) {
+            if (order != 0) {
+                psd_z a[33];
+#pragma unroll
+                for (int r = 0; r < 33; ++r) {
+                    a[r] = z0;
+                    if (r < S) a[r] = tile[r * ldt + c];
+                }
+                if (order > 0) psd_ztr_regline<true, true>(ltr, d.plo, a);
+                else psd_ztr_regline<false, true>(ltr, d.plo, a);
+#pragma unroll
+                for (int r = 0; r < 32; ++r)
+                    if (r < S) tile[r * ldt + c] = a[r];
+                continue;
+            }
             for (int e = 0; e < cnt; ++e) {
                 const psd_ztr tr = ltr[e];
                 const int r = tr.pos - d.plo;
@@ -735,10 +805,19 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply(psd_zparams P, int n, int p) {
             }
         }
         PSD_SYNC();
-        PSD_PAR_FOR(t, 32 * nc) {  // (S <= 32; no index divisions)
-            const int r = t & 31, c = t >> 5;
+        PSD_PAR_FOR(t0, 32 * 2) {
+            const int r = t0 & 31, cb = t0 >> 5;
             if (r >= S) continue;
-            M(d.plo + r, c0 + c) = tile[r * ldt + c];
+            for (int k0 = 0; k0 < T / 2; k0 += 8) {
+                psd_z v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = tile[r * ldt + cb + 2 * (k0 + u)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = cb + 2 * (k0 + u);
+                    if (c < nc) M(d.plo + r, c0 + c) = v[u];
+                }
+            }
         }
     } else {
         const int jm = (role == 1) ? ((m == 1) ? p : (m - 1)) : m;
@@ -750,7 +829,24 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply(psd_zparams P, int n, int p) {
         const int nr = (hi - r0 + 1 < T) ? (hi - r0 + 1) : T;
         psd_z* base = (role == 1) ? P.H : P.Z;
         const psd_mat<psd_z> M = psd_mat<psd_z>{base + (size_t)(jm - 1) * n * n, n};
-        PSD_PAR_FOR(e, cnt) { ltr[e] = P.tr[(size_t)(m - 1) * PSD_ZTR_CAP + e]; }
+        const int order = psd_ztr_stage(gtr, cnt, ltr, flags);
+        if (order != 0) {
+            // a thread owns a row of the columns panel: coalesced loads straight into registers, no LDS tile
+            PSD_PAR_FOR(r, nr) {
+                psd_z a[33];
+#pragma unroll
+                for (int c = 0; c < 33; ++c) {
+                    a[c] = z0;
+                    if (c < S) a[c] = M(r0 + r, d.plo + c);
+                }
+                if (order > 0) psd_ztr_regline<true, false>(ltr, d.plo, a);
+                else psd_ztr_regline<false, false>(ltr, d.plo, a);
+#pragma unroll
+                for (int c = 0; c < 32; ++c)
+                    if (c < S) M(r0 + r, d.plo + c) = a[c];
+            }
+            return;
+        }
         PSD_PAR_FOR(t, S * T) {
             const int r = t & (T - 1), c = t / T;
             if (r >= nr) continue;
