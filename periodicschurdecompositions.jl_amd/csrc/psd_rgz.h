@@ -18,6 +18,7 @@
 //  and is not reproduced; every sweep uses the implicit shift.  Cases II/III (exactly singular
 // factors) are rare and run directly on HBM from the step kernel instead of through windows.
 #pragma once
+#include "psd_real_qr.h"
 #include "psd_zqz.h"
 
 enum { PSD_GPH_CHECK = 0, PSD_GPH_SWEEP = 1, PSD_GPH_ZSHIFT = 2, PSD_GPH_HESS = 3, PSD_GPH_DONE = 7 };

@@ -3,27 +3,45 @@
 // namespace psd_wv with the data-parallel macros running over the lanes of ONE wavefront (the multi-wave pipelined
 // Hessenberg kernel).  No include guard on purpose.
 
-// factors j0, j0 + jstep, ... (0-based) only
+// factors j0, j0 + jstep, ... (0-based) only.  As psd_win_load (psd_real_qr.h): lane = (row pair, column group of 4),
+// two consecutive rows per 16-byte access, two factors per batch; the odd last row travels with the row above it.
 PSD_D void psd_gwin_load(const psd_gparams& P, const psd_gwin& w, int n, int p, int j0 = 0, int jstep = 1) {
     const int m = w.be - w.bs + 1;
-    const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
     PSD_PAR_FOR(t, PSD_STEP_NT) {
-        const int r = t & (RW - 1), g = t >> sh;
+        const int r = 2 * (t & 15), g = t >> 4;
         if (r < m) {
-            for (int j = j0; j < p; j += jstep) {  // (factor loop outside: no index divisions in the hot loop)
-                const double* src = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r);
+            const bool pair = r + 1 < m;
+            const int back = (pair || r == 0) ? 0 : 1;
+            const bool one = !pair && r == 0;
+            for (int j = j0; j < p; j += 2 * jstep) {
+                const double* src = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r - back);
                 double* dst = w.b + j * w.bsz + r;
-                for (int c0 = g; c0 < m; c0 += 16 * ncg) {
-                    double v[16];
+                psd_pair v[2][8];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int c = c0 + u * ncg;
-                        v[u] = (c < m) ? src[(size_t)c * n] : 0.0;
+                for (int f = 0; f < 2; ++f) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = g + 4 * u;
+                        const double* q = src + (size_t)f * jstep * n * n + (size_t)c * n;
+                        psd_pair x;
+                        x.a = x.b = 0.0;
+                        if (c < m && j + f * jstep < p) {
+                            if (one) x.a = q[0];
+                            else x = psd_pair_load(q);
+                        }
+                        v[f][u] = x;
                     }
+                }
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int c = c0 + u * ncg;
-                        if (c < m) dst[c * w.ld] = v[u];
+                for (int f = 0; f < 2; ++f) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = g + 4 * u;
+                        if (c < m && j + f * jstep < p) {
+                            double* q = dst + f * jstep * w.bsz + c * w.ld;
+                            q[0] = back ? v[f][u].b : v[f][u].a;
+                            if (pair) q[1] = v[f][u].b;
+                        }
                     }
                 }
             }
@@ -33,15 +51,28 @@ PSD_D void psd_gwin_load(const psd_gparams& P, const psd_gwin& w, int n, int p, 
 }
 PSD_D void psd_gwin_store(const psd_gparams& P, const psd_gwin& w, int n, int p, int j0 = 0, int jstep = 1) {
     const int m = w.be - w.bs + 1;
-    const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
     PSD_SYNC();
     PSD_PAR_FOR(t, PSD_STEP_NT) {
-        const int r = t & (RW - 1), g = t >> sh;
+        const int r = 2 * (t & 15), g = t >> 4;
         if (r < m) {
+            const bool pair = r + 1 < m;
             for (int j = j0; j < p; j += jstep) {
                 double* dst = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r);
                 const double* src = w.b + j * w.bsz + r;
-                for (int c = g; c < m; c += ncg) dst[(size_t)c * n] = src[c * w.ld];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = g + 4 * u;
+                    if (c < m) {
+                        if (pair) {
+                            psd_pair x;
+                            x.a = src[c * w.ld];
+                            x.b = src[c * w.ld + 1];
+                            psd_pair_store(dst + (size_t)c * n, x);
+                        } else {
+                            dst[(size_t)c * n] = src[c * w.ld];
+                        }
+                    }
+                }
             }
         }
     }

@@ -6,6 +6,39 @@
 PSD_D void psd_zwin_load(const psd_zparams& P, const psd_zwin& w, int n, int p, int j0 = 0, int jstep = 1) {
     const int m = w.be - w.bs + 1;
     const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
+    if (m <= 16) {
+        // narrow windows (many factors): 16 rows x 4 column groups, a lane has at most 4 elements per factor, so four
+        // factors go into one batch (16 loads in flight) -- a batch costs one memory round trip whatever its size
+        PSD_PAR_FOR(t, PSD_STEP_NT) {
+            const int r = t & 15, g = t >> 4;
+            if (r < m) {
+                for (int j = j0; j < p; j += 4 * jstep) {
+                    const psd_z* src = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r);
+                    psd_z* dst = w.b + j * w.bsz + r;
+                    psd_z v[4][4];
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int c = g + 4 * u;
+                            v[f][u] = zmk(0.0, 0.0);
+                            if (c < m && j + f * jstep < p) v[f][u] = src[(size_t)f * jstep * n * n + (size_t)c * n];
+                        }
+                    }
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int c = g + 4 * u;
+                            if (c < m && j + f * jstep < p) dst[f * jstep * w.bsz + c * w.ld] = v[f][u];
+                        }
+                    }
+                }
+            }
+        }
+        PSD_SYNC();
+        return;
+    }
     PSD_PAR_FOR(t, PSD_STEP_NT) {
         const int r = t & (RW - 1), g = t >> sh;
         if (r < m) {
