@@ -124,6 +124,10 @@ struct psd_win {
 // 16 bytes in flight per lane.  A single wavefront is bounded by the number of outstanding accesses, not by bandwidth,
 // so the bytes per access are what counts.  The odd last row travels with the row above it (no access beyond the
 // window's rows, which at the bottom of the matrix would leave the allocation).
+// Entries more than PSD_WIN_BAND below the diagonal of a window block are structural zeros that no window pass reads or
+// writes (Hessenberg / triangular factors plus a 3x3 bulge): they are neither loaded nor stored.  (The simulated tier
+// poisons LDS with NaNs, so a read outside the band would surface there.)
+#define PSD_WIN_BAND 3
 struct alignas(8) psd_pair {
     double a, b;
 };
@@ -166,7 +170,7 @@ PSD_D void psd_win_load(const psd_rparams& P, const psd_win& w, int n, int p) {
                         const double* q = src + (size_t)f * n * n + (size_t)c * n;
                         psd_pair x;
                         x.a = x.b = 0.0;
-                        if (c < m && j + f < p) {
+                        if (c < m && c + PSD_WIN_BAND >= r && j + f < p) {
                             if (one) x.a = q[0];
                             else x = psd_pair_load(q);
                         }
@@ -178,7 +182,7 @@ PSD_D void psd_win_load(const psd_rparams& P, const psd_win& w, int n, int p) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int c = g + 4 * u;
-                        if (c < m && j + f < p) {
+                        if (c < m && c + PSD_WIN_BAND >= r && j + f < p) {
                             double* q = dst + f * w.bsz + c * w.ld;
                             q[0] = back ? v[f][u].b : v[f][u].a;
                             if (pair) q[1] = v[f][u].b;
@@ -203,7 +207,7 @@ PSD_D void psd_win_store(const psd_rparams& P, const psd_win& w, int n, int p) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int c = g + 4 * u;
-                    if (c < m) {
+                    if (c < m && c + PSD_WIN_BAND >= r) {
                         if (pair) {
                             psd_pair x;
                             x.a = src[c * w.ld];
