@@ -334,6 +334,66 @@ struct psd_ctx {
     }
 };
 
+#ifndef PSD_HOSTSIM
+// State polling of the window drivers without draining the stream: the state of the batch just enqueued is copied to a
+// pinned slot behind it, and the host looks at the PREVIOUS batch's state while this one runs (a drained poll costs
+// ~70 us).  The batch in flight when DONE is seen consists of launches that return at once.  The first batch is polled
+// drained (small problems end there).  HIP-event samples of the chase kernel are read back one batch late as well.
+struct psd_poller {
+    typedef std::vector<std::pair<hipEvent_t, hipEvent_t>> evlist;
+    psd_ctx* c;
+    double& sample_ms;
+    int& samples;
+    int slot = 0;
+    bool have_prev = false;
+    evlist pend_prev;
+    psd_poller(psd_ctx* c_, double& ms, int& ns) : c(c_), sample_ms(ms), samples(ns) {}
+    ~psd_poller() {  // (error paths leave without finish())
+        for (auto& pr : pend_prev) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+    }
+    void harvest(evlist& v) {
+        for (auto& pr : v) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                sample_ms += ms;
+                ++samples;
+            }
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        v.clear();
+    }
+    int poll(void* hst, const void* dev, size_t bytes, evlist& pend) {
+        if (bytes > 4096) return PSD_INFO_RUNTIME + 6;
+        int rc = psd_rt_d2h(c->pin[slot], dev, bytes, c->stream);
+        if (rc) return rc;
+        if ((rc = (int)hipEventRecord(c->pev[slot], c->stream)) != 0) return rc;
+        if (!have_prev) {
+            if ((rc = (int)hipEventSynchronize(c->pev[slot])) != 0) return rc;
+            memcpy(hst, c->pin[slot], bytes);
+            harvest(pend);
+            have_prev = true;
+        } else {
+            if ((rc = (int)hipEventSynchronize(c->pev[slot ^ 1])) != 0) return rc;
+            memcpy(hst, c->pin[slot ^ 1], bytes);
+            harvest(pend_prev);
+        }
+        pend_prev.swap(pend);
+        slot ^= 1;
+        return 0;
+    }
+    int finish(evlist& pend) {  // the batch behind the one that reported DONE
+        const int rc = psd_rt_sync(c->stream);
+        harvest(pend_prev);
+        harvest(pend);
+        return rc;
+    }
+};
+#endif
+
 namespace {
 
 void fill_bytes(psd_stats* s, int n, int p, int wantT, int wantZ, const std::vector<int>& log) {
@@ -457,21 +517,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
 #ifndef PSD_HOSTSIM
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pend;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pend_prev;
-    int slot = 0;
-    bool have_prev = false;
-    auto harvest = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>>& v) {
-        for (auto& pr : v) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
-                sample_ms += ms;
-                ++samples;
-            }
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
-        }
-        v.clear();
-    };
+    psd_poller poller(c, sample_ms, samples);
 #endif
     for (;;) {
         for (int b = 0; b < batch; ++b) {
@@ -497,24 +543,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
         PSD_CHECK(psd_rt_d2h(&hst, c->st, sizeof(hst), c->stream));
         PSD_CHECK(psd_rt_sync(c->stream));
 #else
-        // The state of this batch is copied to a pinned slot behind it; the host looks at the PREVIOUS batch's state
-        // while this one runs, so the stream never drains between batches (a drained poll costs ~70 us).  The batch
-        // that is in flight when DONE is seen consists of launches that return at once.
-        static_assert(sizeof(psd_rstate) <= 4096, "pinned poll slot too small");
-        PSD_CHECK(psd_rt_d2h(c->pin[slot], c->st, sizeof(hst), c->stream));
-        PSD_CHECK((int)hipEventRecord(c->pev[slot], c->stream));
-        if (!have_prev) {  // first batch: drained poll (small problems end here)
-            PSD_CHECK((int)hipEventSynchronize(c->pev[slot]));
-            memcpy(&hst, c->pin[slot], sizeof(hst));
-            harvest(pend);
-            have_prev = true;
-        } else {
-            PSD_CHECK((int)hipEventSynchronize(c->pev[slot ^ 1]));
-            memcpy(&hst, c->pin[slot ^ 1], sizeof(hst));
-            harvest(pend_prev);
-        }
-        pend_prev.swap(pend);
-        slot ^= 1;
+        PSD_CHECK(poller.poll(&hst, c->st, sizeof(hst), pend));
 #endif
         if (hst.phase == PSD_PH_DONE) break;
         if (launched > cap) {
@@ -523,9 +552,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
         }
     }
 #ifndef PSD_HOSTSIM
-    PSD_CHECK(psd_rt_sync(c->stream));  // (the batch behind the one that reported DONE)
-    harvest(pend_prev);
-    harvest(pend);
+    PSD_CHECK(poller.finish(pend));
 #endif
     PSD_CHECK(psd_rt_last_error());
     *st_out = hst;
@@ -888,6 +915,7 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
 #ifndef PSD_HOSTSIM
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pend;
+    psd_poller poller(c, sample_ms, samples);
 #endif
     for (;;) {
         for (int b = 0; b < batch; ++b) {
@@ -910,19 +938,11 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
             PSD_LAUNCH(psd_zq_defer, psd_dim3(dtiles), 256, 0, c->stream, P, n);
             ++launched;
         }
+#ifdef PSD_HOSTSIM
         PSD_CHECK(psd_rt_d2h(&hst, c->zst, sizeof(hst), c->stream));
         PSD_CHECK(psd_rt_sync(c->stream));
-#ifndef PSD_HOSTSIM
-        for (auto& pr : pend) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
-                sample_ms += ms;
-                ++samples;
-            }
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
-        }
-        pend.clear();
+#else
+        PSD_CHECK(poller.poll(&hst, c->zst, sizeof(hst), pend));
 #endif
         if (hst.phase == PSD_ZPH_DONE) break;
         if (launched > cap) {
@@ -930,6 +950,9 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
             return PSD_INFO_RUNTIME + 0xfffe;
         }
     }
+#ifndef PSD_HOSTSIM
+    PSD_CHECK(poller.finish(pend));
+#endif
     if (hst.info == 0 && wantT) {  // generalized.jl:860-908
         for (int l = p; l >= 2; --l)
             PSD_LAUNCH(psd_zq_phase, psd_dim3(n), 64, 64, c->stream, P, n, l, wantZ);
@@ -1046,6 +1069,12 @@ int zgiterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
     long long launched = 0;
     const int nbmin = (W - 3 > 0) ? (W - 3) : 1;
     const long long cap = (long long)maxitfac * n * ((long long)n / nbmin + 8) + 8LL * n + 1024 + (hessmode ? (long long)n * n : 0);
+#ifndef PSD_HOSTSIM
+    double sample_ms = 0.0;
+    int samples = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pend;
+    psd_poller poller(c, sample_ms, samples);
+#endif
     for (;;) {
         for (int b = 0; b < batch; ++b) {
             if (hess_pipe)
@@ -1056,14 +1085,21 @@ int zgiterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
             if (!hess_pipe) PSD_LAUNCH(psd_zgq_defer, psd_dim3(dtiles), 256, 0, c->stream, P, n);
             ++launched;
         }
+#ifdef PSD_HOSTSIM
         PSD_CHECK(psd_rt_d2h(&hst, c->zgst, sizeof(hst), c->stream));
         PSD_CHECK(psd_rt_sync(c->stream));
+#else
+        PSD_CHECK(poller.poll(&hst, c->zgst, sizeof(hst), pend));
+#endif
         if (hst.phase == PSD_GPH_DONE) break;
         if (launched > cap) {
             *st_out = hst;
             return PSD_INFO_RUNTIME + 0xfffc;
         }
     }
+#ifndef PSD_HOSTSIM
+    PSD_CHECK(poller.finish(pend));
+#endif
     if (!hessmode && hst.info == 0 && wantT) {  // generalized.jl:860-908
         for (int l = p; l >= 2; --l) PSD_LAUNCH(psd_zgq_phase, psd_dim3(n), 64, 64, c->stream, P, n, l, wantZ);
     }
@@ -1726,6 +1762,7 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
 #ifndef PSD_HOSTSIM
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pend;
+    psd_poller poller(c, sample_ms, samples);
 #endif
     for (;;) {
         for (int b = 0; b < batch; ++b) {
@@ -1751,19 +1788,11 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
             if (!hess_pipe) PSD_LAUNCH(psd_gq_defer, psd_dim3(dtiles), 256, 0, c->stream, P, n);
             ++launched;
         }
+#ifdef PSD_HOSTSIM
         PSD_CHECK(psd_rt_d2h(&hst, c->gst, sizeof(hst), c->stream));
         PSD_CHECK(psd_rt_sync(c->stream));
-#ifndef PSD_HOSTSIM
-        for (auto& pr : pend) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
-                sample_ms += ms;
-                ++samples;
-            }
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
-        }
-        pend.clear();
+#else
+        PSD_CHECK(poller.poll(&hst, c->gst, sizeof(hst), pend));
 #endif
         if (hst.phase == PSD_GPH_DONE) break;
         if (launched > cap) {
@@ -1771,6 +1800,9 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
             return PSD_INFO_RUNTIME + 0xfffd;
         }
     }
+#ifndef PSD_HOSTSIM
+    PSD_CHECK(poller.finish(pend));
+#endif
     PSD_CHECK(psd_rt_last_error());
     *st_out = hst;
     if (stats) {
