@@ -522,7 +522,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     for (;;) {
         for (int b = 0; b < batch; ++b) {
 #ifndef PSD_HOSTSIM
-            const bool sample = c->profile && ((launched & 3) == 0);
+            const bool sample = c->profile && ((launched & 15) == 0);
             if (sample) {
                 (void)hipEventCreate(&ev0);
                 (void)hipEventCreate(&ev1);
@@ -920,7 +920,7 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
     for (;;) {
         for (int b = 0; b < batch; ++b) {
 #ifndef PSD_HOSTSIM
-            const bool sample = c->profile && ((launched & 3) == 0);
+            const bool sample = c->profile && ((launched & 15) == 0);
             if (sample) {
                 (void)hipEventCreate(&ev0);
                 (void)hipEventCreate(&ev1);
@@ -1767,7 +1767,7 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
     for (;;) {
         for (int b = 0; b < batch; ++b) {
 #ifndef PSD_HOSTSIM
-            const bool sample = c->profile && ((launched & 3) == 0);
+            const bool sample = c->profile && ((launched & 15) == 0);
             if (sample) {
                 (void)hipEventCreate(&ev0);
                 (void)hipEventCreate(&ev1);
