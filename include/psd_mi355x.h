@@ -177,6 +177,16 @@ int psd_d_gordschur(psd_ctx* ctx, int n, int p, double* const* T, double* const*
                     int schurindex, const uint8_t* select, int wantZ, double* alpha, double* beta, int32_t* ascale,
                     psd_stats* stats, int* info);
 
+/* _rphessenberg!(Ap, A, Q) — rhessx.jl:55-109 (called by the Krylov driver, krylov.jl:809): row-wise periodic Hessenberg
+ * reduction for the left orientation.  Ap: m x n column-major (ld m), m = n or n + 1 (info -2 otherwise, :62), reduced to
+ * upper Hessenberg form; A: p-1 pointers to n x n matrices, reduced to upper triangular; Q: p pointers to nq x nqc
+ * matrices (nqc >= n), post-multiplied by the accumulated reflectors, or NULL.  All updated in place.
+ * psd_z_*: ComplexF64 (interleaved). */
+int psd_d_rphessenberg(psd_ctx* ctx, int m, int n, int p, double* Ap, double* const* A, double* const* Q, int nq, int nqc,
+                       int* info);
+int psd_z_rphessenberg(psd_ctx* ctx, int m, int n, int p, double* Ap, double* const* A, double* const* Q, int nq, int nqc,
+                       int* info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,7 @@
 #include "psd_oracle_sghess.hpp"
 #include "psd_oracle_rgen.hpp"
 #include "psd_oracle_grord.hpp"
+#include "psd_oracle_rhessx.hpp"
 
 #include <chrono>
 
@@ -407,6 +408,28 @@ int psdo_gpschur(int n, int p, int is_complex, double* A, const uint8_t* S, char
     for (int q = 0; q < n; ++q) ascale[q] = sc[q];
     if (schurindex) *schurindex = left ? p : 1;
     return info;
+}
+
+// _rphessenberg!(Ap, A, Q) — rhessx.jl:55-109.  Ap: m x n (ld m); A: [p-1][n][n]; Q: [p][nq][nqc] (nqc >= n) or NULL.
+int psdo_rphessenberg(int m, int n, int p, int is_complex, double* Ap, double* A, double* Q, int nq, int nqc) {
+    if (is_complex) {
+        MatT<cplx> Apm{reinterpret_cast<cplx*>(Ap), m};
+        std::vector<MatT<cplx>> Av(p), Qv;
+        for (int l = 1; l <= p - 1; ++l) Av[l] = MatT<cplx>{reinterpret_cast<cplx*>(A) + (size_t)(l - 1) * n * n, n};
+        if (Q) {
+            Qv.resize(p + 1);
+            for (int l = 1; l <= p; ++l) Qv[l] = MatT<cplx>{reinterpret_cast<cplx*>(Q) + (size_t)(l - 1) * nq * nqc, nq};
+        }
+        return rphessenberg<cplx>(m, n, p, Apm, Av, Qv, nq);
+    }
+    MatT<double> Apm{Ap, m};
+    std::vector<MatT<double>> Av(p), Qv;
+    for (int l = 1; l <= p - 1; ++l) Av[l] = MatT<double>{A + (size_t)(l - 1) * n * n, n};
+    if (Q) {
+        Qv.resize(p + 1);
+        for (int l = 1; l <= p; ++l) Qv[l] = MatT<double>{Q + (size_t)(l - 1) * nq * nqc, nq};
+    }
+    return rphessenberg<double>(m, n, p, Apm, Av, Qv, nq);
 }
 
 }  // extern "C"

@@ -165,6 +165,8 @@ class Engine:
         lib.psd_d_gphessenberg.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, C.POINTER(C.c_uint8), dpp,
                                            C.POINTER(Stats), ip]
         lib.psd_z_gphessenberg.argtypes = lib.psd_d_gphessenberg.argtypes
+        lib.psd_d_rphessenberg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, dpp, dpp, C.c_int, C.c_int, ip]
+        lib.psd_z_rphessenberg.argtypes = lib.psd_d_rphessenberg.argtypes
         lib.psd_d_gpschur.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, C.POINTER(C.c_uint8), C.c_char, C.c_int,
                                       C.c_int, C.c_int, dpp, dp, dp, i32p, ip, C.POINTER(Stats), ip]
         lib.psd_z_pschur_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char, C.c_int, C.c_int, C.c_int,
@@ -335,6 +337,34 @@ class Engine:
         self._raise(info.value)
         self.last_stats = st
         return list(A), Q
+
+    def rphessenberg_(self, Ap, A, Q=None):
+        """_rphessenberg!(Ap, A, Q) — src/rhessx.jl:55-109 (Float64 / ComplexF64): row-wise periodic Hessenberg reduction
+        for the left orientation.  Ap: m x n with m in (n, n+1); A: p-1 matrices n x n; Q: p matrices with at least n
+        columns that are post-multiplied (or None).  Everything is overwritten; returns (Ap, A)."""
+        m, n = Ap.shape
+        if m not in (n, n + 1):
+            raise ValueError("only implemented for square or 1 extra row")  # src/rhessx.jl:62
+        p = len(A) + 1
+        for a in A:
+            if a.shape != (n, n):
+                raise DimensionMismatch("all factors must be n x n")  # src/rhessx.jl:66
+        cplx = np.iscomplexobj(Ap)
+        dt = np.complex128 if cplx else np.float64
+        self._as_work([Ap] + list(A) + (list(Q) if Q is not None else []), dt)
+        nq = nqc = 0
+        if Q is not None:
+            if len(Q) != p:
+                raise DimensionMismatch("one Q per factor")
+            nq, nqc = Q[0].shape
+            if nqc < n or any(q.shape != (nq, nqc) for q in Q):
+                raise DimensionMismatch("Q matrices must share a shape with at least n columns")
+        info = C.c_int(0)
+        fn = self.lib.psd_z_rphessenberg if cplx else self.lib.psd_d_rphessenberg
+        fn(self.ctx, m, n, p, Ap.ctypes.data, self._ptrs(A) if p > 1 else None, self._ptrs(Q) if Q is not None else None,
+           nq, nqc, C.byref(info))
+        self._raise(info.value)
+        return Ap, list(A)
 
     def _zpschur_(self, A, orient, S, wantZ, wantT, maxitfac):
         """pschur!(A::Vector{Matrix{ComplexF64}}[, S], lr) — src/PeriodicSchurDecompositions.jl:1106-1111,

@@ -11,6 +11,7 @@
 #include "psd_zgz.h"
 #include "psd_zgord.h"
 #include "psd_grord.h"
+#include "psd_rhessx.h"
 
 #include "../../include/psd_mi355x.h"
 
@@ -2278,4 +2279,54 @@ int psd_d_gordschur(psd_ctx* c, int n, int p, double* const* T, double* const* Z
     return rc;
 }
 
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// _rphessenberg!(Ap, A, Q) — rhessx.jl:55-109
+namespace {
+template <class O, int ES>
+int rphessenberg_host(psd_ctx* c, int m, int n, int p, double* Ap, double* const* A, double* const* Q, int nq, int nqc,
+                      int* info) {
+    typedef typename O::T T;
+    int dummy;
+    if (!info) info = &dummy;
+    if (!c) return *info = -1;
+    if (n < 1 || !(m == n || m == n + 1)) return *info = -2;  // ArgumentError, rhessx.jl:62
+    if (p < 1) return *info = -3;
+    if (!Ap) return *info = -4;
+    if (p > 1 && !A) return *info = -5;
+    if (Q && (nq < 1 || nqc < n)) return *info = -8;
+    const size_t nap = (size_t)m * n, nn = (size_t)n * n, nqq = (size_t)nq * nqc;
+    T *dAp = nullptr, *dA = nullptr, *dQ = nullptr;
+    PSD_CHECK(psd_rt_malloc((void**)&dAp, nap * ES));
+    PSD_CHECK(psd_rt_malloc((void**)&dA, (p > 1 ? (size_t)(p - 1) * nn : 1) * ES));
+    if (Q) PSD_CHECK(psd_rt_malloc((void**)&dQ, (size_t)p * nqq * ES));
+    PSD_CHECK(psd_rt_h2d(dAp, Ap, nap * ES, c->stream));
+    for (int l = 0; l + 1 < p; ++l) PSD_CHECK(psd_rt_h2d(dA + (size_t)l * nn, A[l], nn * ES, c->stream));
+    if (Q)
+        for (int l = 0; l < p; ++l) PSD_CHECK(psd_rt_h2d(dQ + (size_t)l * nqq, Q[l], nqq * ES, c->stream));
+    const size_t lds = sizeof(double) * PSD_RH_NT + (size_t)(n + 2) * ES;
+    PSD_LAUNCH(psd_rphess_kernel<O>, psd_dim3(1), PSD_RH_NT, lds, c->stream, dAp, dA, dQ, m, n, p, nq, nqc);
+    PSD_CHECK(psd_rt_d2h(Ap, dAp, nap * ES, c->stream));
+    for (int l = 0; l + 1 < p; ++l) PSD_CHECK(psd_rt_d2h(A[l], dA + (size_t)l * nn, nn * ES, c->stream));
+    if (Q)
+        for (int l = 0; l < p; ++l) PSD_CHECK(psd_rt_d2h(Q[l], dQ + (size_t)l * nqq, nqq * ES, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    PSD_CHECK(psd_rt_last_error());
+    psd_rt_free(dAp);
+    psd_rt_free(dA);
+    if (dQ) psd_rt_free(dQ);
+    return *info = 0;
+}
+}  // namespace
+
+extern "C" {
+int psd_d_rphessenberg(psd_ctx* c, int m, int n, int p, double* Ap, double* const* A, double* const* Q, int nq, int nqc,
+                       int* info) {
+    return rphessenberg_host<psd_rh_real, 8>(c, m, n, p, Ap, A, Q, nq, nqc, info);
+}
+int psd_z_rphessenberg(psd_ctx* c, int m, int n, int p, double* Ap, double* const* A, double* const* Q, int nq, int nqc,
+                       int* info) {
+    return rphessenberg_host<psd_rh_cplx, 16>(c, m, n, p, Ap, A, Q, nq, nqc, info);
+}
 }  // extern "C"

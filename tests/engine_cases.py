@@ -1006,3 +1006,43 @@ def case_hess_pipeline_vs_serial(eng):
         pt.sg_hess_check(A, S, Hs, Qs, tol=20 * max(1, n / 8), qtol=10 * max(1, n / 16))
         for a, b in zip(Hp, Hs):
             assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max()), (n, p, cplx, np.abs(a - b).max())
+
+
+# ------------------------------------------------------------------------------------------------
+# _rphessenberg! (rhessx.jl:55-109): invariants of the reduction and agreement with the
+# CPU restatement.  Shapes as the Krylov driver uses them (krylov.jl:801-809): Ap with one extra row, Q = I.
+def case_rphessenberg(eng):
+    import psd_amd
+
+    rs = np.random.RandomState(17)
+    for cplx in (False, True):
+        dt = np.complex128 if cplx else np.float64
+        for (m, n, p) in [(6, 6, 1), (7, 6, 1), (9, 8, 3), (8, 8, 3), (21, 20, 5), (3, 2, 2), (2, 2, 4), (41, 40, 2), (1, 1, 3)]:
+            def rnd(a, b):
+                x = rs.randn(a, b)
+                return np.asfortranarray((x + 1j * rs.randn(a, b)) if cplx else x).astype(dt, order="F")
+
+            Ap0 = rnd(m, n)
+            As0 = [rnd(n, n) for _ in range(p - 1)]
+            Ap = Ap0.copy(order="F")
+            As = [a.copy(order="F") for a in As0]
+            Qs = [np.asfortranarray(np.eye(n, dtype=dt)) for _ in range(p)]
+            eng.rphessenberg_(Ap, As, Qs)
+            pt.rphess_check(Ap0, As0, Ap, As, Qs)
+            Apo, Aso, Qso = pt.oracle_rphessenberg(Ap0, As0, [np.eye(n, dtype=dt) for _ in range(p)])
+            sc = max(1.0, np.abs(Apo).max())
+            assert np.abs(Ap - Apo).max() < 1e-11 * sc, (m, n, p, cplx, np.abs(Ap - Apo).max())
+            for a, b in zip(As, Aso):
+                assert np.abs(a - b).max() < 1e-11 * max(1.0, np.abs(b).max())
+            for a, b in zip(Qs, Qso):
+                assert np.abs(a - b).max() < 1e-11
+            # without Q: same factors
+            Ap2 = Ap0.copy(order="F")
+            As2 = [a.copy(order="F") for a in As0]
+            eng.rphessenberg_(Ap2, As2, None)
+            assert np.abs(Ap2 - Ap).max() < 1e-13 * sc
+    try:
+        eng.rphessenberg_(np.asfortranarray(np.zeros((5, 3))), [], None)
+        raise AssertionError("m = n + 2 must be rejected")
+    except ValueError:
+        pass

@@ -724,3 +724,51 @@ def checkpsd(ps, As, thresh=100, strict=True, S=None):
         if err[l] > thresh:
             ok = False
     return ok, err
+
+
+# ------------------------------------------------------------------------------------------------
+# _rphessenberg! (rhessx.jl:55-109): row-wise periodic Hessenberg reduction, left orientation
+def oracle_rphessenberg(Ap, As, Qs=None):
+    """CPU restatement.  Ap: m x n (m = n or n + 1); As: p-1 matrices n x n; Qs: p matrices nq x nqc (nqc >= n) that
+    are post-multiplied, or None.  Returns (Ap, As, Qs) reduced."""
+    lib = oracle_lib()
+    m, n = Ap.shape
+    p = len(As) + 1
+    cplx = np.iscomplexobj(Ap) or any(np.iscomplexobj(a) for a in As)
+    dt = np.complex128 if cplx else np.float64
+    ptr = _zp if cplx else _dp
+    apw = np.asfortranarray(Ap.astype(dt))
+    A = pack(As, dt) if p > 1 else np.zeros((1, 1, 1), dtype=dt)
+    if Qs is not None:
+        nq, nqc = Qs[0].shape
+        Q = pack(Qs, dt)
+        qp = ptr(Q)
+    else:
+        nq = nqc = 0
+        Q = None
+        qp = None
+    fa = apw.reshape(-1, order="F").copy()
+    info = lib.psdo_rphessenberg(m, n, p, int(cplx), ptr(fa), ptr(A), qp, nq, nqc)
+    assert info == 0
+    return fa.reshape((m, n), order="F"), (unpack(A) if p > 1 else []), (unpack(Q) if Q is not None else None)
+
+
+def rphess_check(Ap0, As0, Ap, As, Qs, tol=40):
+    """Invariants of the reduction started with Q_l = I_n: with U_l = Q_l (orthogonal),
+    A_l^new = U_{l+1}' A_l U_l (l < p), Ap^new = blockdiag(U_1, 1)' Ap U_p; Ap upper Hessenberg (an extra row keeps its
+    last entry only), A_l upper triangular."""
+    m, n = Ap0.shape
+    p = len(As0) + 1
+    assert np.all(np.tril(Ap, -2) == 0)
+    for l in range(p - 1):
+        assert np.all(np.tril(As[l], -1) == 0)
+    for l in range(p):
+        assert np.linalg.norm(Qs[l].conj().T @ Qs[l] - np.eye(n)) < tol * EPS * n
+    U1 = np.eye(m, dtype=Ap.dtype)
+    U1[:n, :n] = Qs[0]
+    sc = max(1.0, np.linalg.norm(Ap0, 1))
+    assert np.linalg.norm(U1.conj().T @ Ap0 @ Qs[p - 1] - Ap) < tol * EPS * n * sc, np.linalg.norm(U1.conj().T @ Ap0 @ Qs[p - 1] - Ap)
+    for l in range(p - 1):
+        sc = max(1.0, np.linalg.norm(As0[l], 1))
+        R = Qs[l + 1].conj().T @ As0[l] @ Qs[l] - As[l]
+        assert np.linalg.norm(R) < tol * EPS * n * sc, (l, np.linalg.norm(R))

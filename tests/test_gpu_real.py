@@ -141,3 +141,7 @@ def test_rordschur_windows(gpu_engine):
 
 def test_rordschur_edge(gpu_engine):
     ec.case_rordschur_edge(gpu_engine)
+
+
+def test_rphessenberg(gpu_engine):
+    ec.case_rphessenberg(gpu_engine)

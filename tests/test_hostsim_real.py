@@ -70,3 +70,7 @@ def test_rordschur_windows(sim_engine):
 
 def test_rordschur_edge(sim_engine):
     ec.case_rordschur_edge(sim_engine)
+
+
+def test_rphessenberg(sim_engine):
+    ec.case_rphessenberg(sim_engine)
