@@ -532,8 +532,21 @@ class Engine:
             return PeriodicSchur(Ts, Zr, lam, "L", p, st, slog)
         return PeriodicSchur(H, Z, lam, "R", 1, st, slog)
 
-    def ordschur_(self, P, select, wantZ=True):
-        """LinearAlgebra.ordschur!(P, select; wantZ) — src/ordschur.jl:11-73 (ComplexF64).  Mutates and returns P."""
+    def ordschur_(self, P, select, wantZ=True, Z=None):
+        """LinearAlgebra.ordschur!(P, select; wantZ, Z) — src/ordschur.jl:11-73 (ComplexF64).  Mutates and returns P.
+        `Z`: supplementary matrices that receive the transformations instead of P.Z (src/ordschur.jl:17,34-42; not for
+        the right orientation, :36-38)."""
+        if Z is not None and wantZ:
+            if P.orientation == "R":
+                raise NotImplementedPSD("no logic for reversing supplementary Z")  # src/ordschur.jl:37
+            if len(Z) != len(P.Ts):
+                raise DimensionMismatch("one supplementary Z per factor")
+            keep = P.Z
+            P.Z = list(Z)
+            try:
+                return self.ordschur_(P, select, wantZ=True)
+            finally:
+                P.Z = keep
         n = P.Ts[0].shape[0]
         p = len(P.Ts)
         if len(select) != n:

@@ -1046,3 +1046,28 @@ def case_rphessenberg(eng):
         raise AssertionError("m = n + 2 must be rejected")
     except ValueError:
         pass
+
+
+# ordschur!(P, select; Z = supplementary matrices) — ordschur.jl:17,34-42: the swaps act on Z instead of P.Z
+def case_ordschur_supplementary_z(eng):
+    import psd_amd
+
+    n, p = 8, 3
+    for cplx in (True, False):
+        A = pt.bench_factors(n, p, seed=91, dtype=np.complex128 if cplx else np.float64)
+        ps0 = eng.pschur(A, "L")
+        lam0 = ps0.values.copy()
+        select = np.abs(lam0) <= np.sort(np.abs(lam0))[n // 2]
+        ref = eng.ordschur_(_clone(ps0), select)
+        P = _clone(ps0)
+        Zkeep = [z.copy() for z in P.Z]
+        Zsup = [z.copy(order="F") for z in P.Z]
+        out = eng.ordschur_(P, select, Z=Zsup)
+        assert all(np.array_equal(a, b) for a, b in zip(out.Z, Zkeep))  # P.Z untouched
+        assert all(np.array_equal(a, b) for a, b in zip(Zsup, ref.Z))   # the supplementary set took the swaps
+        assert all(np.array_equal(a, b) for a, b in zip(out.Ts, ref.Ts))
+        try:
+            eng.ordschur_(_clone(eng.pschur(A, "R")), select, Z=Zsup)
+            raise AssertionError("supplementary Z with the right orientation must be rejected")
+        except psd_amd.NotImplementedPSD:
+            pass

@@ -106,3 +106,7 @@ def test_zordschur_edge(gpu_engine):
 
 def test_ordschur_alignments(gpu_engine):
     ec.case_ordschur_alignments(gpu_engine)
+
+
+def test_ordschur_supplementary_z(gpu_engine):
+    ec.case_ordschur_supplementary_z(gpu_engine)

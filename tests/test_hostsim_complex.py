@@ -57,3 +57,7 @@ def test_zordschur_edge(sim_engine):
 
 def test_ordschur_alignments(sim_engine):
     ec.case_ordschur_alignments(sim_engine)
+
+
+def test_ordschur_supplementary_z(sim_engine):
+    ec.case_ordschur_supplementary_z(sim_engine)
