@@ -186,6 +186,16 @@ class Engine:
     def version(self):
         return self.lib.psd_version().decode()
 
+    def set_train(self, bulges):
+        """Multishift trains of the real pschur! path (psd_set_train): bulges >= 2 (default 6) or 0 for the reference's
+        one-shift-one-sweep iteration."""
+        self.lib.psd_set_train.argtypes = [C.c_void_p, C.c_int]
+        self.lib.psd_set_train(self.ctx, int(bulges))
+
+    def get_train(self):
+        self.lib.psd_get_train.argtypes = [C.c_void_p]
+        return int(self.lib.psd_get_train(self.ctx))
+
     def set_profile(self, on):
         self.lib.psd_set_profile(self.ctx, int(on))
 

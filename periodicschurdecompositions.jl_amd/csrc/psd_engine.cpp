@@ -125,6 +125,34 @@ struct psd_ctx {
     int logcap = 0;
     size_t step_lds_set = 0, zstep_lds_set = 0, rostep_lds_set = 0;
     psd_hess_args* hargs = nullptr;  // device argument block of the graph-replayed Hessenberg reduction
+    // multishift trains (experimental): bulges per train (0/1 = off), per-cursor state / descriptor / lists
+    int train_m = 6;  // default: trains of up to six bulges (psd_set_train / PSD_TRAIN; 0 or 1 = the reference's iteration)
+    int tcap_p = 0;
+    psd_rstate* tcst = nullptr;
+    double* tshift = nullptr;
+    psd_apply_desc* tdesc = nullptr;
+    int* tcnt = nullptr;
+    psd_tr* ttr = nullptr;
+    int treserve(int p) {
+        if (tcst && p <= tcap_p) return 0;
+        trelease();
+        PSD_CHECK(psd_rt_malloc((void**)&tcst, sizeof(psd_rstate) * PSD_TRAIN_MAX));
+        PSD_CHECK(psd_rt_malloc((void**)&tshift, sizeof(double) * (4 * PSD_TRAIN_MAX + 8)));
+        PSD_CHECK(psd_rt_malloc((void**)&tdesc, sizeof(psd_apply_desc) * PSD_TRAIN_MAX));
+        PSD_CHECK(psd_rt_malloc((void**)&tcnt, sizeof(int) * PSD_TRAIN_MAX * (size_t)(p + 8)));
+        PSD_CHECK(psd_rt_malloc((void**)&ttr, sizeof(psd_tr) * PSD_TRAIN_MAX * (size_t)p * PSD_TR_CAP));
+        tcap_p = p;
+        return 0;
+    }
+    void trelease() {
+        if (tcst) psd_rt_free(tcst);
+        if (tshift) psd_rt_free(tshift);
+        if (tdesc) psd_rt_free(tdesc);
+        if (tcnt) psd_rt_free(tcnt);
+        if (ttr) psd_rt_free(ttr);
+        tcst = nullptr; tshift = nullptr; tdesc = nullptr; tcnt = nullptr; ttr = nullptr;
+        tcap_p = 0;
+    }
 #ifndef PSD_HOSTSIM
     hipGraphExec_t hess_exec = nullptr;
     int hess_graph_n = 0, hess_graph_p = 0;
@@ -504,7 +532,28 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
         c->step_lds_set = lds_step;
     }
 #endif
-    PSD_LAUNCH(psd_rq_init, psd_dim3(p), 256, 256 * 8, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog);
+    // multishift trains (experimental; off unless psd_set_train / PSD_TRAIN >= 2): M cursors, each with its own state,
+    // descriptor and lists; cursor 0 is the ordinary state machine
+    const int M = (c->train_m >= 2) ? ((c->train_m > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : c->train_m) : 1;
+    P.cst = nullptr;
+    P.tshift = nullptr;
+    P.lead = c->st;
+    P.tick = 0;
+    if (M > 1) {
+        PSD_CHECK(c->treserve(p));
+        PSD_CHECK(psd_rt_memset(c->tcst, 0, sizeof(psd_rstate) * PSD_TRAIN_MAX, c->stream));
+        PSD_CHECK(psd_rt_memset(c->tdesc, 0, sizeof(psd_apply_desc) * PSD_TRAIN_MAX, c->stream));
+        P.cst = c->tcst;
+        P.tshift = c->tshift;
+        P.desc = c->tdesc;  // slot 0 of the cursor arrays: the fused bulk-update kernel indexes them by cursor
+        P.cnt = c->tcnt;
+        P.tr = c->ttr;
+#ifndef PSD_HOSTSIM
+        PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_rq_step_train),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
+#endif
+    }
+    PSD_LAUNCH(psd_rq_init, psd_dim3(p), 256, 256 * 8, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, M);
     const size_t lds_apply = apply_lds_bytes();
     const int tiles = (n + PSD_APPLY_NT - 1) / PSD_APPLY_NT;
     const int batch = 32;
@@ -530,14 +579,23 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 (void)hipEventRecord(ev0, c->stream);
             }
 #endif
-            PSD_LAUNCH(psd_rq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
+            P.tick = (int)launched;
+            if (M == 1)
+                PSD_LAUNCH(psd_rq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
+            else  // every cursor of the tick in one launch, one workgroup each
+                PSD_LAUNCH(psd_rq_step_train, psd_dim3(M), PSD_STEP_NT, lds_step, c->stream, P, p, p + 8);
 #ifndef PSD_HOSTSIM
             if (sample) {
                 (void)hipEventRecord(ev1, c->stream);
                 pend.emplace_back(ev0, ev1);
             }
 #endif
-            PSD_LAUNCH(psd_rq_apply, psd_dim3(tiles, p, 3), PSD_APPLY_NT, lds_apply, c->stream, P, n, p);
+            if (M == 1) {
+                PSD_LAUNCH(psd_rq_apply, psd_dim3(tiles, p, 3), PSD_APPLY_NT, lds_apply, c->stream, P, n, p);
+            } else {
+                PSD_LAUNCH(psd_rq_apply_train, psd_dim3(tiles, p, 2 * M), PSD_APPLY_NT, lds_apply, c->stream, P, n, p, p + 8, 0);
+                PSD_LAUNCH(psd_rq_apply_train, psd_dim3(tiles, p, M), PSD_APPLY_NT, lds_apply, c->stream, P, n, p, p + 8, 1);
+            }
             ++launched;
         }
 #ifdef PSD_HOSTSIM
@@ -577,6 +635,7 @@ void stats_from_state(psd_stats* s, const psd_rstate& st) {
     s->nwindows = st.nwindows;
     s->nlog = st.nlog;
     for (int q = 0; q < 6; ++q) s->step_cycles[q] = st.cyc[q];
+    s->reserved = st.ntrainsweeps;
 }
 
 // shared tail: run the iteration, fetch eigenvalues / log
@@ -652,9 +711,18 @@ int psd_create(psd_ctx** ctx, int device) {
         }
     }
 #endif
+    if (const char* e = getenv("PSD_TRAIN")) c->train_m = atoi(e);
     *ctx = c;
     return 0;
 }
+
+int psd_set_train(psd_ctx* c, int bulges) {
+    if (!c) return -1;
+    c->train_m = (bulges < 0) ? 0 : ((bulges > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : bulges);
+    return 0;
+}
+
+int psd_get_train(psd_ctx* c) { return c ? c->train_m : -1; }
 
 int psd_destroy(psd_ctx* c) {
     if (!c) return 0;
@@ -663,6 +731,7 @@ int psd_destroy(psd_ctx* c) {
     c->release();
     c->zrelease();
     c->rorelease();
+    c->trelease();
 #ifndef PSD_HOSTSIM
     for (int q = 0; q < 2; ++q) {
         if (c->pev[q]) (void)hipEventDestroy(c->pev[q]);

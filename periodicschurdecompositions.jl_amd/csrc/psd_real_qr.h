@@ -16,6 +16,7 @@
 //     columns of H_{m-1 (cyclic)} and of Z_m.
 #pragma once
 #include "psd_scalar.h"
+#include "psd_hqr.h"
 
 enum {
     PSD_PH_DECIDE = 0,
@@ -25,13 +26,19 @@ enum {
     PSD_PH_DEFLATE = 4,
     PSD_PH_NEXT = 5,
     PSD_PH_FINAL = 6,
-    PSD_PH_DONE = 7
+    PSD_PH_DONE = 7,
+    // multishift trains (experimental, off by default: psd_set_train / PSD_TRAIN): the leader waits for the cursors
+    // behind it (TWAIT); a cursor waits for its start (CWAIT), runs QR windows, and ends in CDONE
+    PSD_PH_TWAIT = 8,
+    PSD_PH_CWAIT = 9,
+    PSD_PH_CDONE = 10
 };
 enum { PSD_TR_R3 = 3, PSD_TR_H2 = 2, PSD_TR_R2 = 4, PSD_TR_G = 5 };
 
 #define PSD_TR_CAP 64     // transform-list capacity per owner and window
 #define PSD_STEP_NT 64    // the chase runs in one wavefront
 #define PSD_APPLY_NT 128  // threads (= tile rows / tile columns) of the bulk-apply kernel
+#define PSD_TRAIN_MAX 8   // bulges (cursors) of a multishift train
 
 struct psd_tr {
     int pos;   // first row/column index (1-based) the transform acts on
@@ -86,6 +93,10 @@ struct psd_rstate {
     // in-kernel cycle accounting (s_memtime): 0 decide, 1 window load, 2 chase, 3 window store, 4 total; 5 = total in
     // 100 MHz wall ticks (s_memrealtime) so that the shader clock can be derived
     long long cyc[6];
+    // multishift train: bulges wanted / in the running train / train number / this state's cursor
+    int train_want, train_n, train_id, cursor;
+    int train_tick0;  // tick (launch index) of the leader's first window of the running train
+    int ntrains, ntrainsweeps;
 };
 
 struct psd_rparams {
@@ -105,6 +116,10 @@ struct psd_rparams {
     double* wr;      // [n] eigenvalues (0-based)
     double* wi;
     int* log;  // [3*maxlog]
+    psd_rstate* cst;   // [PSD_TRAIN_MAX] cursor states of a train (entry 0 unused) or nullptr
+    double* tshift;    // [PSD_TRAIN_MAX][4] shift pairs of the train: rt1r, rt1i, rt2r, rt2i
+    psd_rstate* lead;  // the main state (== st except in a cursor's parameter block)
+    int tick;          // launch index (the driver counts ticks; cursors start at fixed tick offsets)
 };
 
 PSD_HD psd_mat<double> psd_fac(const psd_rparams& P, int n, int j) {
@@ -428,6 +443,107 @@ PSD_D void psd_rq_decide(const psd_rparams& P, psd_rstate& st, double* red, int*
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Multishift trains (experimental, off unless psd_set_train / PSD_TRAIN asks for it).
+// A train is m double-shift sweeps whose shift pairs are the eigenvalues of the trailing 2m x 2m block of the product,
+// fixed before the first sweep starts.  The sweeps run as m cursors two windows apart: cursor 0 is the ordinary state
+// machine (the leader), cursors 1..m-1 are psd_rq_cursor_step launches with their own state, lists and descriptor.
+
+// first column of (P - s1)(P - s2) at the top of the active block (PSD.jl:768-803) for the shift pair `sh`
+PSD_D void psd_rq_startvec(const double h11, const double h12, const double h21, const double h22, const double h32,
+                           const double* sh, double* v) {
+    const double rt1r = sh[0], rt1i = sh[1], rt2r = sh[2], rt2i = sh[3];
+    const double s = fabs(h11 - rt2r) + fabs(rt2i) + fabs(h21);
+    const double h21s = h21 / s;
+    const double v1 = h21s * h12 + (h11 - rt1r) * ((h11 - rt2r) / s) - rt1i * (rt2i / s);
+    const double v2 = h21s * (h11 + h22 - rt1r - rt2r);
+    const double v3 = h21s * h32;
+    const double t = fabs(v1) + fabs(v2) + fabs(v3);
+    v[0] = v1 / t;
+    v[1] = v2 / t;
+    v[2] = v3 / t;
+}
+
+// leading entries of the product band on rows l, l+1, l+2 straight from the factors (the recurrences of
+// psd_rq_decide, PSD.jl:475-495): h11, h12, h21, h22, h32.  Evaluated redundantly by every lane.
+PSD_D void psd_rq_topband(const psd_rparams& P, int n, int p, int l, int i, double& h11, double& h12, double& h21,
+                          double& h22, double& h32) {
+    double d0 = 1.0, e0 = 0.0, d1 = 1.0;
+    for (int j = 2; j <= p; ++j) {
+        const psd_mat<double> Hj = psd_fac(P, n, j);
+        if (l + 1 <= i) e0 = d0 * Hj(l, l + 1) + e0 * Hj(l + 1, l + 1);
+        d0 *= Hj(l, l);
+        if (l + 1 <= i) d1 *= Hj(l + 1, l + 1);
+    }
+    const psd_mat<double> H1 = psd_fac(P, n, 1);
+    h11 = H1(l, l) * d0;
+    h12 = H1(l, l) * e0 + H1(l, l + 1) * d1;
+    h21 = H1(l + 1, l) * d0;
+    h22 = H1(l + 1, l) * e0 + H1(l + 1, l + 1) * d1;
+    h32 = (l + 2 <= i) ? H1(l + 2, l + 1) * d1 : 0.0;
+}
+
+// The 2m shifts of a train: eigenvalues of the trailing K x K block (K = 2m) of H_1 H_2 ... H_p, which is
+// H_1[t0:i, t0-1:i] * (prod_j H_j[t0-1:i, t0-1:i])[:, 2:end] because the other factors are triangular.  One lane.
+// Pairs go to P.tshift; returns false if the small QR iteration fails (no train then).
+PSD_D bool psd_rq_train_shifts(const psd_rparams& P, int n, int p, int i, int m) {
+    const int K = 2 * m, K1 = K + 1, t0 = i - K + 1;
+    double R[(PSD_HQR_MAX + 1) * (PSD_HQR_MAX + 1)], T[PSD_HQR_MAX * PSD_HQR_MAX], tmp[PSD_HQR_MAX + 1];
+    double wr[PSD_HQR_MAX], wi[PSD_HQR_MAX];
+    for (int q = 0; q < K1 * K1; ++q) R[q] = 0.0;
+    for (int q = 0; q < K1; ++q) R[q * K1 + q] = 1.0;
+    for (int j = 2; j <= p; ++j) {  // R <- R * H_j[t0-1:i, t0-1:i]  (both upper triangular)
+        const psd_mat<double> Hj = psd_fac(P, n, j);
+        for (int r = 0; r < K1; ++r) {
+            for (int c = r; c < K1; ++c) {
+                double acc = 0.0;
+                for (int k = r; k <= c; ++k) acc += R[r * K1 + k] * Hj(t0 - 1 + k, t0 - 1 + c);
+                tmp[c] = acc;
+            }
+            for (int c = r; c < K1; ++c) R[r * K1 + c] = tmp[c];
+        }
+    }
+    const psd_mat<double> H1 = psd_fac(P, n, 1);
+    for (int r = 0; r < K; ++r)  // T[r, c] = sum_k H_1[t0 + r, t0 - 1 + k] R[k, c + 1]
+        for (int c = 0; c < K; ++c) {
+            double acc = 0.0;
+            for (int k = r; k <= c + 1; ++k) acc += H1(t0 + r, t0 - 1 + k) * R[k * K1 + (c + 1)];
+            T[r * K + c] = acc;
+        }
+    if (!psd_hqr(T, K, K, wr, wi)) return false;
+    // conjugate pairs first, then the real eigenvalues in ascending order two by two
+    int np = 0;
+    double re[PSD_HQR_MAX];
+    int nre = 0;
+    for (int q = 0; q < K; ++q) {
+        if (!(wr[q] == wr[q]) || !(wi[q] == wi[q])) return false;
+        if (wi[q] > 0.0) {
+            if (np < m) {
+                double* sh = P.tshift + 4 * np;
+                sh[0] = wr[q]; sh[1] = wi[q]; sh[2] = wr[q]; sh[3] = -wi[q];
+                ++np;
+            }
+        } else if (wi[q] == 0.0) {
+            re[nre++] = wr[q];
+        }
+    }
+    for (int a = 1; a < nre; ++a) {  // insertion sort
+        const double x = re[a];
+        int b = a - 1;
+        while (b >= 0 && re[b] > x) {
+            re[b + 1] = re[b];
+            --b;
+        }
+        re[b + 1] = x;
+    }
+    for (int a = 0; a < nre && np < m; a += 2) {
+        double* sh = P.tshift + 4 * np;
+        sh[0] = re[a]; sh[1] = 0.0; sh[2] = (a + 1 < nre) ? re[a + 1] : re[a]; sh[3] = 0.0;
+        ++np;
+    }
+    return np == m;
+}
+
 // PSD.jl:668-803: split test, shifts, first column of the shifted product
 PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st) {
     const int n = st.n, i = st.i, l = st.l;
@@ -483,6 +599,33 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st) {
                 rt1i = rt2i = 0.0;
             }
         }
+        // multishift train: m bulges if the active block leaves room for cursors two windows apart
+        st.train_n = 1;
+        if (st.train_want >= 2 && P.cst != nullptr) {
+            const int nb = st.W - 4, w = i - l + 1;
+            int m = 1 + (w - nb) / (2 * nb);
+            if (m > st.train_want) m = st.train_want;
+            if (m > PSD_TRAIN_MAX) m = PSD_TRAIN_MAX;
+            if (2 * m > PSD_HQR_MAX) m = PSD_HQR_MAX / 2;
+            if (m >= 2 && 2 * m + 2 <= w) {
+                int* okf = (int*)P.tshift + 8 * PSD_TRAIN_MAX;  // (flag word behind the pairs)
+                PSD_SYNC();
+                PSD_ONE { *okf = psd_rq_train_shifts(P, n, st.p, i, m) ? 1 : 0; }
+                PSD_SYNC();
+                if (*okf) {
+                    st.train_n = m;
+                    st.train_tick0 = P.tick;
+                    st.train_id += 1;
+                    st.ntrains += 1;
+                    st.ntrainsweeps += m;
+                    rt1r = P.tshift[0];
+                    rt1i = P.tshift[1];
+                    rt2r = P.tshift[2];
+                    rt2i = P.tshift[3];
+                }
+                PSD_SYNC();
+            }
+        }
     }
     {  // PSD.jl:768-803 with mmax = l (_allow_early_QR[] is false by default)
         const int m = l;
@@ -507,6 +650,22 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st) {
     }
     st.phase = PSD_PH_QR;
     st.kcur = l;
+    if (st.train_n > 1) {  // the cursors behind the leader start from this state
+        PSD_SYNC();
+        PSD_ONE {
+            for (int b = 1; b < st.train_n; ++b) {
+                psd_rstate cs = st;
+                cs.cursor = b;
+                cs.phase = PSD_PH_CWAIT;
+                cs.kcur = 0;
+                cs.nsweeps = cs.nwindows = cs.nlog = 0;
+                cs.maxlog = 0;
+                for (int q = 0; q < 6; ++q) cs.cyc[q] = 0;
+                P.cst[b] = cs;
+            }
+        }
+        PSD_SYNC();
+    }
 }
 
 PSD_D void psd_desc_write(const psd_rparams& P, const psd_rstate& st, const int* lcnt, int plo, int phi, int lc0,
@@ -837,7 +996,7 @@ PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
     st.kcur = ke + 1;
     if (ke >= i - 1) {  // sweep complete (PSD.jl:887)
         st.its += 1;
-        st.phase = PSD_PH_DECIDE;
+        st.phase = (st.cursor > 0) ? PSD_PH_CDONE : ((st.train_n > 1) ? PSD_PH_TWAIT : PSD_PH_DECIDE);
     }
 }
 
@@ -1079,7 +1238,7 @@ PSD_D bool psd_rq_deflate(const psd_rparams& P, psd_rstate& st, double* ldsd, in
 }
 
 // One launch = state transitions until a window's worth of transforms has been emitted.
-PSD_KERNEL_B(PSD_STEP_NT) psd_rq_step(psd_rparams P) {
+PSD_D void psd_rq_step_body(const psd_rparams& P) {
     PSD_LDS_DECL;
     psd_rstate st = *P.st;
     if (st.phase == PSD_PH_DONE) {
@@ -1119,6 +1278,25 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rq_step(psd_rparams P) {
             case PSD_PH_DEFLATE:
                 emitted = psd_rq_deflate(P, st, ldsd, lcnt);
                 break;
+            case PSD_PH_TWAIT: {  // the leader's sweep is done: wait for the cursors of the train, then go on
+                bool all = true;
+                for (int b = 1; b < st.train_n; ++b)
+                    if (P.cst[b].phase != PSD_PH_CDONE || P.cst[b].train_id != st.train_id) all = false;
+                if (all) {
+                    for (int b = 1; b < st.train_n; ++b) {
+                        st.nwindows += P.cst[b].nwindows;
+                        st.nsweeps += 1;
+                        st.its += 1;
+                    }
+                    st.train_n = 1;
+                    st.phase = PSD_PH_DECIDE;
+                    emitted = true;  // (the decision runs in the next launch: the cursors' last bulk updates are
+                                     //  ordered before it by the tick barrier of the driver)
+                } else {
+                    emitted = true;
+                }
+                break;
+            }
             case PSD_PH_NEXT:  // PSD.jl:1057-1060
                 st.maxitleft -= st.its;
                 st.niter += st.its;
@@ -1147,6 +1325,55 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rq_step(psd_rparams P) {
     st.cyc[5] += psd_wallclock() - tw0;
     PSD_SYNC();
     PSD_ONE { *P.st = st; }
+}
+
+// One launch of cursor b >= 1 of a multishift train (P.st = the cursor's state, P.lead = the main state, P.desc / P.cnt /
+// P.tr = the cursor's own descriptor and lists).  Starts two windows behind its predecessor, chases one window per
+// launch, ends in PSD_PH_CDONE.
+PSD_KERNEL_B(PSD_STEP_NT) psd_rq_step(psd_rparams P) { psd_rq_step_body(P); }
+
+PSD_D void psd_rq_cursor_body(const psd_rparams& P, int b) {
+    PSD_LDS_DECL;
+    PSD_ONE { P.desc->active = 0; }
+    psd_rstate st = *P.st;
+    if (st.cursor != b) return;
+    if (st.phase != PSD_PH_CWAIT && st.phase != PSD_PH_QR) return;
+    double* ldsd = (double*)psd_lds;
+    const size_t winb = (size_t)st.p * st.W * (st.W + 1);
+    int* lcnt = (int*)(ldsd + winb + PSD_STEP_NT) + 2 * PSD_STEP_NT;
+    if (st.phase == PSD_PH_CWAIT) {
+        // Cursor b chases its first window exactly 2 b ticks after the leader's: consecutive windows of a sweep overlap
+        // in four positions, so two ticks put a whole finished window (chase and bulk update, both complete at the
+        // tick barrier) between neighbours.  A fixed offset, not a look at the predecessor's progress: the
+        // predecessor's state is being written while this kernel runs.
+        if (P.tick < st.train_tick0 + 2 * b) return;
+        double h11, h12, h21, h22, h32;
+        psd_rq_topband(P, st.n, st.p, st.l, st.i, h11, h12, h21, h22, h32);
+        psd_rq_startvec(h11, h12, h21, h22, h32, P.tshift + 4 * b, st.v);
+        st.kcur = st.l;
+        st.phase = PSD_PH_QR;
+    }
+    psd_rq_qr_window(P, st, ldsd, lcnt);
+    PSD_SYNC();
+    PSD_ONE { *P.st = st; }
+}
+
+// All cursors of a tick in ONE launch: workgroup 0 is the ordinary state machine (the leader), workgroup b >= 1 is cursor
+// b.  P holds the leader's state and slot 0 of the cursor arrays (see psd_rq_apply_train).  No cross-stream events: the
+// chases of a tick run side by side on different compute units, the tick ends with the kernel.
+PSD_KERNEL_B(PSD_STEP_NT) psd_rq_step_train(psd_rparams P, int p, int cstride) {
+    const int b = PSD_BLOCK_X;
+    if (b == 0) {
+        psd_rq_step_body(P);
+        return;
+    }
+    psd_rparams Q = P;
+    Q.lead = P.st;
+    Q.st = P.cst + b;
+    Q.desc = P.desc + b;
+    Q.cnt = P.cnt + (size_t)b * cstride;
+    Q.tr = P.tr + (size_t)b * p * PSD_TR_CAP;
+    psd_rq_cursor_body(Q, b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1201,12 +1428,11 @@ PSD_D int psd_tr_stage(const psd_tr* gtr, int cnt, psd_tr* ltr, int* flags) {
     return !flags[0] ? 1 : (!flags[1] ? -1 : 0);
 }
 
-PSD_KERNEL_B(PSD_APPLY_NT) psd_rq_apply(psd_rparams P, int n, int p) {
+PSD_D void psd_rq_apply_body(const psd_rparams& P, int n, int p, int role) {
     PSD_LDS_DECL;
     const psd_apply_desc d = *P.desc;
     if (!d.active) return;
     const int m = PSD_BLOCK_Y + 1;
-    const int role = PSD_BLOCK_Z;
     const int cnt = P.cnt[m - 1] < PSD_TR_CAP ? P.cnt[m - 1] : PSD_TR_CAP;
     if (cnt <= 0) return;
     const int T = PSD_APPLY_NT;
@@ -1326,9 +1552,27 @@ PSD_KERNEL_B(PSD_APPLY_NT) psd_rq_apply(psd_rparams P, int n, int p) {
     }
 }
 
+PSD_KERNEL_B(PSD_APPLY_NT) psd_rq_apply(psd_rparams P, int n, int p) { psd_rq_apply_body(P, n, p, PSD_BLOCK_Z); }
+
+// Bulk updates of all M cursors of a tick in two launches.  P holds cursor 0's descriptor / counts / lists; cursor b's
+// are b entries (desc), b * cstride (counts) and b * p * PSD_TR_CAP (lists) further.  Updates of different cursors meet
+// only where one cursor's rows cross another's columns, i.e. a rows-role block against a columns-role block of H:
+// pass 0 runs the rows role and the Z role of every cursor (grid.z = 2 M), pass 1 the columns role (grid.z = M).
+PSD_KERNEL_B(PSD_APPLY_NT) psd_rq_apply_train(psd_rparams P, int n, int p, int cstride, int pass) {
+    const int z = PSD_BLOCK_Z;
+    const int b = (pass == 0) ? (z >> 1) : z;
+    const int role = (pass == 0) ? ((z & 1) ? 2 : 0) : 1;
+    psd_rparams Q = P;
+    Q.desc = P.desc + b;
+    Q.cnt = P.cnt + (size_t)b * cstride;
+    Q.tr = P.tr + (size_t)b * p * PSD_TR_CAP;
+    psd_rq_apply_body(Q, n, p, role);
+}
+
 // hnorms[j] = ulp*n*opnorm(H_j, 1), column-1 / sub-Hessenberg clean-up (PSD.jl:379-388,406), and
 // state initialisation.  grid = p blocks.
-PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W, int maxitfac, int maxlog) {
+PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W, int maxitfac, int maxlog,
+                       int train_want) {
     PSD_LDS_DECL;
     double* red = (double*)psd_lds;
     const int j = PSD_BLOCK_X + 1;
@@ -1349,6 +1593,8 @@ PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W,
             st.maxlog = maxlog;
             st.v[0] = st.v[1] = st.v[2] = 0.0;
             for (int q = 0; q < 6; ++q) st.cyc[q] = 0;
+            st.train_want = train_want; st.train_n = 1; st.train_id = 0; st.cursor = 0; st.train_tick0 = 0;
+            st.ntrains = st.ntrainsweeps = 0;
             st.ulp = PSD_DBL_EPS;
             st.smlnum = PSD_DBL_MIN * ((double)n / PSD_DBL_EPS);
             // PSD.jl:366-375 with _AT_pwr16[] = 4: ulpx = ulp^(1 + 4/16)
