@@ -152,21 +152,26 @@ def main():
         ok, err = pt.checkpsd(pt.PSD(Ts, Zs, lam, "R", 1), As, thresh=100 * np.sqrt(n / 32))
 
         nwin = sum(s.nwindows for (_, _, s, _) in results)
+        nlaunch = sum(s.nlaunch_step for (_, _, s, _) in results)
+        ntrain = sum(s.reserved for (_, _, s, _) in results)
         bytes_sw = sum(s.bytes_sweeps for (_, _, s, _) in results)
         ms_iter = sum(s.ms_iter for (_, _, s, _) in results)
         ms_hess = sum(s.ms_hess for (_, _, s, _) in results)
         ms_formq = sum(s.ms_formq for (_, _, s, _) in results)
         ksamples = sum(s.step_kernel_samples for (_, _, s, _) in results)
         kms = (sum(s.step_kernel_ms_avg * s.step_kernel_samples for (_, _, s, _) in results) / ksamples) if ksamples else None
-        bytes_per_launch = bytes_sw / max(nwin, 1)
+        # one launch of the chase kernel = one tick: one window of every bulge (cursor) of the running train
+        bytes_per_launch = bytes_sw / max(nlaunch, 1)
         roof = None
         if kms:
             achieved = bytes_per_launch / (kms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "psd_rq_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roof = {"bound": "hbm", "kernel": "psd_rq_step_train", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, p),
                     "alg_bytes_per_launch": bytes_per_launch, "avg_launch_ms": kms, "launch_samples": ksamples,
-                    "note": "algorithmic bytes of the sweep window one launch chases (2*8*p*w_win*(2n+1)) / HIP-event "
-                            "duration of the chase kernel; the chase is latency-bound on the serial reflector chain"}
+                    "windows_per_launch": nwin / max(nlaunch, 1),
+                    "note": "algorithmic bytes of the sweep windows one launch chases (one window of every bulge of the "
+                            "running multishift train; 2*8*p*w*(2n+1) per sweep) / HIP-event duration of the chase "
+                            "kernel; every bulge is latency-bound on its serial reflector chain"}
         out = {
             "metric": "PSD sweeps/sec (pschur! n=%d p=%d Float64, Hessenberg+Q+iteration, operands in HBM)" % (n, p),
             "value": sweeps_all / elapsed_max,
@@ -183,6 +188,7 @@ def main():
             "config": {"workload": "configs[1]: pschur!(A,:R) N=%d p=%d Float64 wantT wantZ, A_j = I + 0.5*G_j/sqrt(n)" % (n, p),
                        "seed": seed, "parallelism": "replicas x%d" % world, "window": st.window},
             "sweeps_per_step": sweeps / args.steps,
+            "sweeps_in_multishift_trains_per_step": ntrain / args.steps,
             "chase_kernel_cycle_shares": cycle_shares(st),
             "phase_ms_per_step": {"hessenberg": ms_hess / args.steps, "formq": ms_formq / args.steps,
                                   "iteration": ms_iter / args.steps},

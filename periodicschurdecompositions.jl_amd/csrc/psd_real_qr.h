@@ -618,6 +618,7 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st) {
                     st.train_id += 1;
                     st.ntrains += 1;
                     st.ntrainsweeps += m;
+                    for (int b = 1; b < m; ++b) psd_log(P, st, 0, l, i);  // one log entry per bulge of the train
                     rt1r = P.tshift[0];
                     rt1i = P.tshift[1];
                     rt2r = P.tshift[2];
