@@ -486,10 +486,16 @@ PSD_D void psd_rq_topband(const psd_rparams& P, int n, int p, int l, int i, doub
 // The 2m shifts of a train: eigenvalues of the trailing K x K block (K = 2m) of H_1 H_2 ... H_p, which is
 // H_1[t0:i, t0-1:i] * (prod_j H_j[t0-1:i, t0-1:i])[:, 2:end] because the other factors are triangular.  One lane.
 // Pairs go to P.tshift; returns false if the small QR iteration fails (no train then).
-PSD_D bool psd_rq_train_shifts(const psd_rparams& P, int n, int p, int i, int m) {
+// `work`: >= 640 doubles of LDS (the window area is free while the shifts are computed; private arrays of this size
+// would cost ~5 KB of scratch per lane for every launch of the kernel).
+PSD_D bool psd_rq_train_shifts(const psd_rparams& P, int n, int p, int i, int m, double* work) {
     const int K = 2 * m, K1 = K + 1, t0 = i - K + 1;
-    double R[(PSD_HQR_MAX + 1) * (PSD_HQR_MAX + 1)], T[PSD_HQR_MAX * PSD_HQR_MAX], tmp[PSD_HQR_MAX + 1];
-    double wr[PSD_HQR_MAX], wi[PSD_HQR_MAX];
+    double* R = work;                                        // (PSD_HQR_MAX + 1)^2
+    double* T = R + (PSD_HQR_MAX + 1) * (PSD_HQR_MAX + 1);    // PSD_HQR_MAX^2
+    double* tmp = T + PSD_HQR_MAX * PSD_HQR_MAX;              // PSD_HQR_MAX + 1
+    double* wr = tmp + (PSD_HQR_MAX + 1);
+    double* wi = wr + PSD_HQR_MAX;
+    double* re = wi + PSD_HQR_MAX;
     for (int q = 0; q < K1 * K1; ++q) R[q] = 0.0;
     for (int q = 0; q < K1; ++q) R[q * K1 + q] = 1.0;
     for (int j = 2; j <= p; ++j) {  // R <- R * H_j[t0-1:i, t0-1:i]  (both upper triangular)
@@ -513,7 +519,6 @@ PSD_D bool psd_rq_train_shifts(const psd_rparams& P, int n, int p, int i, int m)
     if (!psd_hqr(T, K, K, wr, wi)) return false;
     // conjugate pairs first, then the real eigenvalues in ascending order two by two
     int np = 0;
-    double re[PSD_HQR_MAX];
     int nre = 0;
     for (int q = 0; q < K; ++q) {
         if (!(wr[q] == wr[q]) || !(wi[q] == wi[q])) return false;
@@ -545,7 +550,7 @@ PSD_D bool psd_rq_train_shifts(const psd_rparams& P, int n, int p, int i, int m)
 }
 
 // PSD.jl:668-803: split test, shifts, first column of the shifted product
-PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st) {
+PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work) {
     const int n = st.n, i = st.i, l = st.l;
     if (l >= i - 1) {
         st.phase = PSD_PH_DEFLATE;
@@ -610,7 +615,7 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st) {
             if (m >= 2 && 2 * m + 2 <= w) {
                 int* okf = (int*)P.tshift + 8 * PSD_TRAIN_MAX;  // (flag word behind the pairs)
                 PSD_SYNC();
-                PSD_ONE { *okf = psd_rq_train_shifts(P, n, st.p, i, m) ? 1 : 0; }
+                PSD_ONE { *okf = psd_rq_train_shifts(P, n, st.p, i, m, work) ? 1 : 0; }
                 PSD_SYNC();
                 if (*okf) {
                     st.train_n = m;
@@ -1270,7 +1275,7 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
                 emitted = true;
                 break;
             case PSD_PH_SHIFT:
-                psd_rq_shift(P, st);
+                psd_rq_shift(P, st, ldsd);
                 break;
             case PSD_PH_QR:
                 psd_rq_qr_window(P, st, ldsd, lcnt);

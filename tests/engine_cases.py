@@ -1071,3 +1071,35 @@ def case_ordschur_supplementary_z(eng):
             raise AssertionError("supplementary Z with the right orientation must be rejected")
         except psd_amd.NotImplementedPSD:
             pass
+
+
+# ------------------------------------------------------------------------------------------------
+# Multishift trains of the real pschur! path against the reference's one-shift-one-sweep
+# iteration (psd_set_train(0)): same eigenvalues to the north-star tolerance, the reference's invariants in both modes,
+# both orientations, the wantT / wantZ fast paths, p = 1.
+def case_trains(eng, sizes):
+    m0 = eng.get_train()
+    try:
+        for (n, p, lr) in sizes:
+            As = pt.bench_factors(n, p, seed=300 + n + p)
+            P = pt.product(As, lr == "L")
+            Pn = np.linalg.norm(P, 2)
+            eng.set_train(0)
+            ref = eng.pschur(As, lr)
+            assert ref.stats.reserved == 0
+            for m in (2, 6):
+                eng.set_train(m)
+                ps = eng.pschur(As, lr)
+                assert ps.stats.reserved > 0, (n, p, lr, m, "no train ran")
+                assert ps.stats.nlaunch_step < ref.stats.nlaunch_step
+                ok, err = pt.checkpsd(ps, As, thresh=100 * np.sqrt(max(n / 32, 1)))
+                assert ok, (n, p, lr, m, err)
+                assert pt.match_eigs(ref.values, ps.values) <= 1e-10 * Pn
+                assert pt.match_eigs(np.linalg.eigvals(P), ps.values) <= 1e-10 * Pn
+                # eigenvalues-only and T-without-Z fast paths (PSD.jl:120-124, :675-678)
+                p0 = eng.pschur(As, lr, wantT=False, wantZ=False)
+                assert len(p0.Z) == 0 and pt.match_eigs(ref.values, p0.values) <= 1e-10 * Pn
+                p1 = eng.pschur(As, lr, wantT=True, wantZ=False)
+                assert len(p1.Z) == 0 and pt.match_eigs(ref.values, p1.values) <= 1e-10 * Pn
+    finally:
+        eng.set_train(m0)

@@ -155,3 +155,7 @@ def test_rordschur_edge(gpu_engine):
 
 def test_rphessenberg(gpu_engine):
     ec.case_rphessenberg(gpu_engine)
+
+
+def test_trains(gpu_engine):
+    ec.case_trains(gpu_engine, [(150, 3, "R"), (130, 1, "L"), (120, 5, "L"), (384, 8, "R"), (200, 40, "R")])

@@ -74,3 +74,7 @@ def test_rordschur_edge(sim_engine):
 
 def test_rphessenberg(sim_engine):
     ec.case_rphessenberg(sim_engine)
+
+
+def test_trains(sim_engine):
+    ec.case_trains(sim_engine, [(150, 3, "R"), (130, 1, "L"), (120, 5, "L")])
