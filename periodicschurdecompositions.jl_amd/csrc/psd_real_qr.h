@@ -97,6 +97,7 @@ struct psd_rstate {
     int train_want, train_n, train_id, cursor;
     int train_tick0;  // tick (launch index) of the leader's first window of the running train
     int ntrains, ntrainsweeps;
+    int exc_dec;  // its / 10 at the last exceptional shift of the current block (a train advances its by several)
 };
 
 struct psd_rparams {
@@ -569,13 +570,18 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work) {
     double h33 = 0, h44 = 0, h43h34 = 0;
     double rt1r = 0, rt2r = 0, rt1i = 0, rt2i = 0;
     bool exc = false;
-    if (st.its == 10) {  // PSD.jl:680-689
+    // (its == 10, then its % 10 == 0 in the reference; a train advances its by its number of bulges, so the test is
+    //  "a new decade since the last exceptional shift" — the same thing for unit steps)
+    const int dec = st.its / 10;
+    if (dec > st.exc_dec && dec == 1) {  // PSD.jl:680-689
+        st.exc_dec = dec;
         exc = true;
         const double s = fabs(hsub[l + 1]) + fabs(hsub[l + 2]);
         h44 = dat1 * s + hdiag[l];
         h33 = h44;
         h43h34 = dat2 * s * s;
-    } else if (st.its % 10 == 0) {  // PSD.jl:690-699
+    } else if (dec > st.exc_dec) {  // PSD.jl:690-699
+        st.exc_dec = dec;
         exc = true;
         const double s = fabs(hsub[i]) + fabs(hsub[i - 1]);
         h44 = dat1 * s + hdiag[i];
@@ -1310,6 +1316,7 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
                 st.i = st.l - 1;
                 st.l = 1;
                 st.its = 1;
+                st.exc_dec = 0;
                 st.phase = (st.i >= 1) ? PSD_PH_DECIDE : PSD_PH_FINAL;
                 break;
             case PSD_PH_FINAL: {  // PSD.jl:1066-1073
@@ -1600,7 +1607,7 @@ PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W,
             st.v[0] = st.v[1] = st.v[2] = 0.0;
             for (int q = 0; q < 6; ++q) st.cyc[q] = 0;
             st.train_want = train_want; st.train_n = 1; st.train_id = 0; st.cursor = 0; st.train_tick0 = 0;
-            st.ntrains = st.ntrainsweeps = 0;
+            st.ntrains = st.ntrainsweeps = 0; st.exc_dec = 0;
             st.ulp = PSD_DBL_EPS;
             st.smlnum = PSD_DBL_MIN * ((double)n / PSD_DBL_EPS);
             // PSD.jl:366-375 with _AT_pwr16[] = 4: ulpx = ulp^(1 + 4/16)
