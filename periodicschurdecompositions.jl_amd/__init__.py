@@ -192,6 +192,14 @@ class Engine:
         self.lib.psd_set_train.argtypes = [C.c_void_p, C.c_int]
         self.lib.psd_set_train(self.ctx, int(bulges))
 
+    def set_train_z(self, bulges):
+        self.lib.psd_set_train_z.argtypes = [C.c_void_p, C.c_int]
+        self.lib.psd_set_train_z(self.ctx, int(bulges))
+
+    def get_train_z(self):
+        self.lib.psd_get_train_z.argtypes = [C.c_void_p]
+        return int(self.lib.psd_get_train_z(self.ctx))
+
     def get_train(self):
         self.lib.psd_get_train.argtypes = [C.c_void_p]
         return int(self.lib.psd_get_train(self.ctx))

@@ -126,6 +126,7 @@ struct psd_ctx {
     size_t step_lds_set = 0, zstep_lds_set = 0, rostep_lds_set = 0;
     psd_hess_args* hargs = nullptr;  // device argument block of the graph-replayed Hessenberg reduction
     // multishift trains (experimental): bulges per train (0/1 = off), per-cursor state / descriptor / lists
+    int ztrain_m = 6;  // complex single-shift engine (psd_set_train sets both; psd_set_train_z / PSD_TRAIN_Z this one)
     int train_m = 6;  // default: trains of up to six bulges (psd_set_train / PSD_TRAIN; 0 or 1 = the reference's iteration)
     int tcap_p = 0;
     psd_rstate* tcst = nullptr;
@@ -133,6 +134,34 @@ struct psd_ctx {
     psd_apply_desc* tdesc = nullptr;
     int* tcnt = nullptr;
     psd_tr* ttr = nullptr;
+    // complex engine
+    int ztcap_p = 0;
+    psd_zstate* ztcst = nullptr;
+    psd_zapply_desc* ztdesc = nullptr;
+    int* ztcnt = nullptr;
+    psd_ztr* zttr = nullptr;
+    psd_z* ztshift = nullptr;
+    int ztreserve(int p) {
+        if (ztcst && p <= ztcap_p) return 0;
+        ztrelease();
+        PSD_CHECK(psd_rt_malloc((void**)&ztcst, sizeof(psd_zstate) * PSD_TRAIN_MAX));
+        PSD_CHECK(psd_rt_malloc((void**)&ztdesc, sizeof(psd_zapply_desc) * PSD_TRAIN_MAX));
+        PSD_CHECK(psd_rt_malloc((void**)&ztcnt, sizeof(int) * PSD_TRAIN_MAX * (size_t)(p + 8)));
+        PSD_CHECK(psd_rt_malloc((void**)&zttr, sizeof(psd_ztr) * PSD_TRAIN_MAX * (size_t)p * PSD_ZTR_CAP));
+        PSD_CHECK(psd_rt_malloc((void**)&ztshift, sizeof(psd_z) * (PSD_TRAIN_MAX + 2)));
+        ztcap_p = p;
+        return 0;
+    }
+    void ztrelease() {
+        if (ztcst) psd_rt_free(ztcst);
+        if (ztdesc) psd_rt_free(ztdesc);
+        if (ztcnt) psd_rt_free(ztcnt);
+        if (zttr) psd_rt_free(zttr);
+        if (ztshift) psd_rt_free(ztshift);
+        ztshift = nullptr;
+        ztcst = nullptr; ztdesc = nullptr; ztcnt = nullptr; zttr = nullptr;
+        ztcap_p = 0;
+    }
     int treserve(int p) {
         if (tcst && p <= tcap_p) return 0;
         trelease();
@@ -711,7 +740,8 @@ int psd_create(psd_ctx** ctx, int device) {
         }
     }
 #endif
-    if (const char* e = getenv("PSD_TRAIN")) c->train_m = atoi(e);
+    if (const char* e = getenv("PSD_TRAIN")) c->train_m = c->ztrain_m = atoi(e);
+    if (const char* e = getenv("PSD_TRAIN_Z")) c->ztrain_m = atoi(e);
     *ctx = c;
     return 0;
 }
@@ -719,10 +749,17 @@ int psd_create(psd_ctx** ctx, int device) {
 int psd_set_train(psd_ctx* c, int bulges) {
     if (!c) return -1;
     c->train_m = (bulges < 0) ? 0 : ((bulges > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : bulges);
+    c->ztrain_m = c->train_m;
     return 0;
 }
 
 int psd_get_train(psd_ctx* c) { return c ? c->train_m : -1; }
+int psd_set_train_z(psd_ctx* c, int bulges) {
+    if (!c) return -1;
+    c->ztrain_m = (bulges < 0) ? 0 : ((bulges > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : bulges);
+    return 0;
+}
+int psd_get_train_z(psd_ctx* c) { return c ? c->ztrain_m : -1; }
 
 int psd_destroy(psd_ctx* c) {
     if (!c) return 0;
@@ -732,6 +769,7 @@ int psd_destroy(psd_ctx* c) {
     c->zrelease();
     c->rorelease();
     c->trelease();
+    c->ztrelease();
 #ifndef PSD_HOSTSIM
     for (int q = 0; q < 2; ++q) {
         if (c->pev[q]) (void)hipEventDestroy(c->pev[q]);
@@ -970,7 +1008,26 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
         c->zstep_lds_set = lds_step;
     }
 #endif
-    PSD_LAUNCH(psd_zq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog);
+    // multishift trains (see iterate_dev): cursor 0 = slot 0 of the cursor arrays
+    const int M = (c->ztrain_m >= 2) ? ((c->ztrain_m > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : c->ztrain_m) : 1;
+    P.cst = nullptr;
+    P.tshift = nullptr;
+    P.tick = 0;
+    if (M > 1) {
+        PSD_CHECK(c->ztreserve(p));
+        PSD_CHECK(psd_rt_memset(c->ztcst, 0, sizeof(psd_zstate) * PSD_TRAIN_MAX, c->stream));
+        PSD_CHECK(psd_rt_memset(c->ztdesc, 0, sizeof(psd_zapply_desc) * PSD_TRAIN_MAX, c->stream));
+        P.cst = c->ztcst;
+        P.tshift = c->ztshift;
+        P.desc = c->ztdesc;
+        P.cnt = c->ztcnt;
+        P.tr = c->zttr;
+#ifndef PSD_HOSTSIM
+        PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_zq_step_train),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
+#endif
+    }
+    PSD_LAUNCH(psd_zq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, M);
     const size_t lds_apply = PSD_ZTR_LDS_BYTES + (size_t)32 * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
     const int tiles = (n + PSD_ZAPPLY_NT - 1) / PSD_ZAPPLY_NT;
     const int dtiles = (n + 255) / 256;
@@ -997,14 +1054,23 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
                 (void)hipEventRecord(ev0, c->stream);
             }
 #endif
-            PSD_LAUNCH(psd_zq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
+            P.tick = (int)launched;
+            if (M == 1)
+                PSD_LAUNCH(psd_zq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
+            else
+                PSD_LAUNCH(psd_zq_step_train, psd_dim3(M), PSD_STEP_NT, lds_step, c->stream, P, p, p + 8);
 #ifndef PSD_HOSTSIM
             if (sample) {
                 (void)hipEventRecord(ev1, c->stream);
                 pend.emplace_back(ev0, ev1);
             }
 #endif
-            PSD_LAUNCH(psd_zq_apply, psd_dim3(tiles, p, 3), PSD_ZAPPLY_NT, lds_apply, c->stream, P, n, p);
+            if (M == 1) {
+                PSD_LAUNCH(psd_zq_apply, psd_dim3(tiles, p, 3), PSD_ZAPPLY_NT, lds_apply, c->stream, P, n, p);
+            } else {
+                PSD_LAUNCH(psd_zq_apply_train, psd_dim3(tiles, p, 2 * M), PSD_ZAPPLY_NT, lds_apply, c->stream, P, n, p, p + 8, 0);
+                PSD_LAUNCH(psd_zq_apply_train, psd_dim3(tiles, p, M), PSD_ZAPPLY_NT, lds_apply, c->stream, P, n, p, p + 8, 1);
+            }
             PSD_LAUNCH(psd_zq_defer, psd_dim3(dtiles), 256, 0, c->stream, P, n);
             ++launched;
         }

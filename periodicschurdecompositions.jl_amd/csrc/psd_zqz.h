@@ -13,6 +13,7 @@
 // single-shift sweep with the reference's shift chain (:770-852), final phase normalisation
 // (:860-908).  Case III needs a negative signature (not in this build).
 #pragma once
+#include "psd_zhqr.h"
 #include "psd_complex.h"
 #include "psd_real_qr.h"
 
@@ -22,7 +23,11 @@ enum {
     PSD_ZPH_ZSHIFT = 2,
     PSD_ZPH_CASE2A = 3,
     PSD_ZPH_CASE2B = 4,
-    PSD_ZPH_DONE = 7
+    PSD_ZPH_DONE = 7,
+    // multishift trains (as in psd_real_qr.h): leader waits for its cursors / cursor waits for its start / cursor done
+    PSD_ZPH_TWAIT = 8,
+    PSD_ZPH_CWAIT = 9,
+    PSD_ZPH_CDONE = 10
 };
 #define PSD_ZTR_CAP 32  // rotations per owner and window
 
@@ -54,6 +59,10 @@ struct psd_zstate {
     psd_z s0;
     double smlnum, ulp, safmin;
     long long cyc[6];
+    // multishift train: bulges wanted / in the running train / train number / this state's cursor / tick of the leader's
+    // first window / row whose diagonal entries are this bulge's shift / exceptional-shift bookkeeping / sweeps in trains
+    int train_want, train_n, train_id, cursor, train_tick0, shidx, exc_dec, ntrainsweeps;
+    psd_z shift;  // this bulge's shift (an eigenvalue of the trailing block of the product)
 };
 
 struct psd_zparams {
@@ -68,6 +77,9 @@ struct psd_zparams {
     double* beta;  // [n]
     int* ascale;   // [n]
     int* log;
+    psd_zstate* cst;  // [PSD_TRAIN_MAX] cursor states of a train (entry 0 unused) or nullptr
+    psd_z* tshift;    // [PSD_TRAIN_MAX + 1] shifts of the train, then a flag word
+    int tick;         // launch index
 };
 
 PSD_HD psd_mat<psd_z> psd_zfac(const psd_zparams& P, int n, int j) {
@@ -200,7 +212,85 @@ PSD_D void psd_zq_start_case2(const psd_zparams& P, psd_zstate& st) {
 }
 
 // generalized.jl:302-449,741-806: deflation tests, split, zero-shift decision, shift chain
-PSD_D void psd_zq_check(const psd_zparams& P, psd_zstate& st, double* red, int* redi) {
+// Starting rotation of a single-shift sweep on the active block ifirst.. whose shift is the product of the diagonal
+// entries in row `sh` of the factors (generalized.jl:786-805 with sh = ilast), as a chain of rotations over the factors.
+PSD_D void psd_zq_start_rot(const psd_zparams& P, int n, int p, int ifirst, int sh, double& c, psd_z& s) {
+    const psd_mat<psd_z> H1 = psd_zfac(P, n, 1);
+    psd_z r;
+    psd_zgivens(zmk(1.0, 0.0), zmk(1.0, 0.0), c, s, r);
+    for (int l = p; l >= 2; --l) {
+        const psd_mat<psd_z> Hl = psd_zfac(P, n, l);
+        psd_zgivens(zscal(c, Hl(ifirst, ifirst)), zmul(Hl(sh, sh), zconj(s)), c, s, r);
+    }
+    psd_zgivens(zsub(zscal(c, H1(ifirst, ifirst)), zmul(H1(sh, sh), zconj(s))), zscal(c, H1(ifirst + 1, ifirst)), c, s,
+                r);
+}
+
+// Starting rotation for an explicit shift mu: first column of (P - mu I) on the active block is
+// D (H_1[f,f] - mu / D, H_1[f+1,f]) with D = prod_{l>=2} H_l[f,f]; mu / D by successive divisions (it stays bounded when
+// mu is of the size of the product's entries).  false: not finite (the caller falls back to the reference's shift).
+PSD_D bool psd_zq_start_rot_mu(const psd_zparams& P, int n, int p, int ifirst, psd_z mu, double& c, psd_z& s) {
+    psd_z t = mu;
+    for (int l = p; l >= 2; --l) {
+        const psd_mat<psd_z> Hl = psd_zfac(P, n, l);
+        t = zdiv(t, Hl(ifirst, ifirst));
+    }
+    if (!(zabs1(t) < 1e300)) return false;  // (also false for NaN)
+    const psd_mat<psd_z> H1 = psd_zfac(P, n, 1);
+    psd_z r;
+    psd_zgivens(zsub(H1(ifirst, ifirst), t), H1(ifirst + 1, ifirst), c, s, r);
+    return true;
+}
+
+// The m shifts of a train: eigenvalues of the trailing m x m block of H_1 H_2 ... H_p (see psd_rq_train_shifts).  One lane;
+// `work`: LDS (the window area is free here).  Shifts go to P.tshift ordered by distance from the last diagonal entry
+// of the block (closest first: the leader's).
+PSD_D bool psd_zq_train_shifts(const psd_zparams& P, int n, int p, int ilast, int m, psd_z* work) {
+    const int K = m, K1 = K + 1, t0 = ilast - K + 1;
+    psd_z* R = work;
+    psd_z* T = R + (PSD_ZHQR_MAX + 1) * (PSD_ZHQR_MAX + 1);
+    psd_z* tmp = T + PSD_ZHQR_MAX * PSD_ZHQR_MAX;
+    psd_z* w = tmp + (PSD_ZHQR_MAX + 1);
+    for (int q = 0; q < K1 * K1; ++q) R[q] = zmk(0.0, 0.0);
+    for (int q = 0; q < K1; ++q) R[q * K1 + q] = zmk(1.0, 0.0);
+    for (int j = 2; j <= p; ++j) {
+        const psd_mat<psd_z> Hj = psd_zfac(P, n, j);
+        for (int r = 0; r < K1; ++r) {
+            for (int c = r; c < K1; ++c) {
+                psd_z acc = zmk(0.0, 0.0);
+                for (int k = r; k <= c; ++k) acc = zadd(acc, zmul(R[r * K1 + k], Hj(t0 - 1 + k, t0 - 1 + c)));
+                tmp[c] = acc;
+            }
+            for (int c = r; c < K1; ++c) R[r * K1 + c] = tmp[c];
+        }
+    }
+    const psd_mat<psd_z> H1 = psd_zfac(P, n, 1);
+    for (int r = 0; r < K; ++r)
+        for (int c = 0; c < K; ++c) {
+            psd_z acc = zmk(0.0, 0.0);
+            for (int k = r; k <= c + 1; ++k) acc = zadd(acc, zmul(H1(t0 + r, t0 - 1 + k), R[k * K1 + (c + 1)]));
+            T[r * K + c] = acc;
+        }
+    const psd_z last = T[(K - 1) * K + (K - 1)];
+    if (!psd_zhqr(T, K, K, w)) return false;
+    for (int a = 0; a < K; ++a) {
+        if (!(zabs1(w[a]) < 1e300)) return false;
+    }
+    for (int a = 1; a < K; ++a) {  // insertion sort by distance from the last diagonal entry
+        const psd_z x = w[a];
+        const double dx = zabs1(zsub(x, last));
+        int b = a - 1;
+        while (b >= 0 && zabs1(zsub(w[b], last)) > dx) {
+            w[b + 1] = w[b];
+            --b;
+        }
+        w[b + 1] = x;
+    }
+    for (int a = 0; a < K; ++a) P.tshift[a] = w[a];
+    return true;
+}
+
+PSD_D void psd_zq_check(const psd_zparams& P, psd_zstate& st, double* red, int* redi, psd_z* work) {
     const int n = st.n, p = st.p;
     const int NT = PSD_NTHREADS;
     st.jiter += 1;
@@ -275,6 +365,7 @@ PSD_D void psd_zq_check(const psd_zparams& P, psd_zstate& st, double* red, int* 
             return;
         }
         st.iiter = 0;
+        st.exc_dec = 0;
         if (st.ziter != -1) st.ziter = 0;
         if (!st.wantT) {
             st.ilastm = st.ilast;
@@ -342,18 +433,40 @@ PSD_D void psd_zq_check(const psd_zparams& P, psd_zstate& st, double* red, int* 
     if (!st.wantT) st.ifirstm = st.ifirst;
     double c;
     psd_z s, r;
-    if (st.iiter % 10 == 0) {
+    st.train_n = 1;
+    const int dec = st.iiter / 10;  // (iiter % 10 == 0 in the reference; a train advances iiter by several)
+    if (dec > st.exc_dec) {
+        st.exc_dec = dec;
         // exceptional shift: the reference draws rand(T, 2) (:782); fixed pair for determinism
         psd_zgivens(zmk(0.35, 0.62), zmk(0.81, 0.27), c, s, r);
     } else {
-        const int ifirst = st.ifirst;
-        psd_zgivens(zmk(1.0, 0.0), zmk(1.0, 0.0), c, s, r);
-        for (int l = p; l >= 2; --l) {
-            const psd_mat<psd_z> Hl = psd_zfac(P, n, l);
-            psd_zgivens(zscal(c, Hl(ifirst, ifirst)), zmul(Hl(ilast, ilast), zconj(s)), c, s, r);
+        psd_zq_start_rot(P, n, p, st.ifirst, ilast, c, s);
+        // multishift train: bulge b takes the diagonal entries of row ilast - b of the factors as its shift (the
+        // reference's shift is b = 0, :786-805); cursors two windows apart (see psd_rq_step_train)
+        if (st.train_want >= 2 && P.cst != nullptr) {
+            const int nb = st.W - 3, w = ilast - st.ifirst + 1;
+            int m = 1 + (w - nb) / (2 * nb);
+            if (m > st.train_want) m = st.train_want;
+            if (m > PSD_TRAIN_MAX) m = PSD_TRAIN_MAX;
+            if (m > PSD_ZHQR_MAX) m = PSD_ZHQR_MAX;
+            if (m >= 2 && 2 * m + 2 <= w) {
+                int* okf = (int*)(P.tshift + PSD_TRAIN_MAX);  // (flag word behind the shifts)
+                PSD_SYNC();
+                PSD_ONE { *okf = psd_zq_train_shifts(P, n, p, ilast, m, work) ? 1 : 0; }
+                PSD_SYNC();
+                double cm;
+                psd_z sm;
+                if (*okf && psd_zq_start_rot_mu(P, n, p, st.ifirst, P.tshift[0], cm, sm)) {
+                    st.train_n = m;
+                    st.train_tick0 = P.tick;
+                    st.train_id += 1;
+                    st.ntrainsweeps += m;
+                    c = cm;
+                    s = sm;
+                }
+                PSD_SYNC();
+            }
         }
-        psd_zgivens(zsub(zscal(c, H1(ifirst, ifirst)), zmul(H1(ilast, ilast), zconj(s))),
-                    zscal(c, H1(ifirst + 1, ifirst)), c, s, r);
     }
     st.c0 = c;
     st.s0 = s;
@@ -361,6 +474,25 @@ PSD_D void psd_zq_check(const psd_zparams& P, psd_zstate& st, double* red, int* 
     st.kcur = st.ifirst;
     st.nsweeps += 1;
     psd_zlog(P, st, 0, st.ifirst, ilast);
+    if (st.train_n > 1) {
+        for (int b = 1; b < st.train_n; ++b) psd_zlog(P, st, 0, st.ifirst, ilast);  // one log entry per bulge
+        PSD_SYNC();
+        PSD_ONE {
+            for (int b = 1; b < st.train_n; ++b) {
+                psd_zstate cs = st;
+                cs.cursor = b;
+                cs.phase = PSD_ZPH_CWAIT;
+                cs.shidx = ilast;
+                cs.shift = P.tshift[b];
+                cs.kcur = 0;
+                cs.nsweeps = cs.nwindows = cs.nlog = 0;
+                cs.maxlog = 0;
+                for (int q = 0; q < 6; ++q) cs.cyc[q] = 0;
+                P.cst[b] = cs;
+            }
+        }
+        PSD_SYNC();
+    }
 }
 
 // Hot micro-step of the complex sweep (generalized.jl:823-845, S[l] true), factor l >= 2 at position j:
@@ -489,7 +621,8 @@ PSD_D void psd_zq_sweep_window(const psd_zparams& P, psd_zstate& st, psd_z* ldsz
     psd_zdesc_write(P, st, lcnt, ks, ke + 1, w.be + 1, ilastm, ifirstm, w.bs - 1, 0, 0, 0, 0);
     st.nwindows += 1;
     st.kcur = ke + 1;
-    if (ke >= ilast - 1) st.phase = PSD_ZPH_CHECK;
+    if (ke >= ilast - 1)
+        st.phase = (st.cursor > 0) ? PSD_ZPH_CDONE : ((st.train_n > 1) ? PSD_ZPH_TWAIT : PSD_ZPH_CHECK);
 }
 
 // One window of a downward unshifted pass (positions kcur..): the controlled zero shift
@@ -650,7 +783,7 @@ PSD_D void psd_zq_case2b_window(const psd_zparams& P, psd_zstate& st, psd_z* lds
     if (last) st.phase = PSD_ZPH_CHECK;
 }
 
-PSD_KERNEL_B(PSD_STEP_NT) psd_zq_step(psd_zparams P) {
+PSD_D void psd_zq_step_body(const psd_zparams& P) {
     PSD_LDS_DECL;
     psd_zstate st = *P.st;
     if (st.phase == PSD_ZPH_DONE) {
@@ -671,7 +804,7 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_zq_step(psd_zparams P) {
         ++guard;
         if (st.phase == PSD_ZPH_CHECK) {
             const long long td0 = psd_clock();
-            psd_zq_check(P, st, red, redi);
+            psd_zq_check(P, st, red, redi, ldsz);
             st.cyc[0] += psd_clock() - td0;
         } else if (st.phase == PSD_ZPH_SWEEP) {
             psd_zq_sweep_window(P, st, ldsz, lcnt);
@@ -685,6 +818,21 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_zq_step(psd_zparams P) {
         } else if (st.phase == PSD_ZPH_CASE2B) {
             psd_zq_case2b_window(P, st, ldsz, lcnt);
             emitted = true;
+        } else if (st.phase == PSD_ZPH_TWAIT) {  // the leader's sweep is done: wait for the cursors of the train
+            bool all = true;
+            for (int b = 1; b < st.train_n; ++b)
+                if (P.cst[b].phase != PSD_ZPH_CDONE || P.cst[b].train_id != st.train_id) all = false;
+            if (all) {
+                for (int b = 1; b < st.train_n; ++b) {
+                    st.nwindows += P.cst[b].nwindows;
+                    st.nsweeps += 1;
+                    st.iiter += 1;
+                    st.jiter += 1;
+                }
+                st.train_n = 1;
+                st.phase = PSD_ZPH_CHECK;
+            }
+            emitted = true;  // (the check runs in the next launch, behind the cursors' last bulk updates)
         } else {
             st.phase = PSD_ZPH_DONE;
         }
@@ -693,6 +841,44 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_zq_step(psd_zparams P) {
     st.cyc[5] += psd_wallclock() - tw0;
     PSD_SYNC();
     PSD_ONE { *P.st = st; }
+}
+PSD_KERNEL_B(PSD_STEP_NT) psd_zq_step(psd_zparams P) { psd_zq_step_body(P); }
+
+// cursor b >= 1 of a multishift train (see psd_rq_cursor_body)
+PSD_D void psd_zq_cursor_body(const psd_zparams& P, int b) {
+    PSD_LDS_DECL;
+    PSD_ONE { P.desc->active = 0; P.desc->defer_run = 0; }
+    psd_zstate st = *P.st;
+    if (st.cursor != b) return;
+    if (st.phase != PSD_ZPH_CWAIT && st.phase != PSD_ZPH_SWEEP) return;
+    psd_z* ldsz = (psd_z*)psd_lds;
+    const size_t winb = (size_t)st.p * st.W * (st.W + 1);
+    int* lcnt = (int*)((double*)(ldsz + winb) + PSD_STEP_NT) + 2 * PSD_STEP_NT;
+    if (st.phase == PSD_ZPH_CWAIT) {
+        if (P.tick < st.train_tick0 + 2 * b) return;
+        if (!psd_zq_start_rot_mu(P, st.n, st.p, st.ifirst, st.shift, st.c0, st.s0))
+            psd_zq_start_rot(P, st.n, st.p, st.ifirst, st.shidx, st.c0, st.s0);
+        st.kcur = st.ifirst;
+        st.phase = PSD_ZPH_SWEEP;
+    }
+    psd_zq_sweep_window(P, st, ldsz, lcnt);
+    PSD_SYNC();
+    PSD_ONE { *P.st = st; }
+}
+
+// all cursors of a tick in one launch (see psd_rq_step_train)
+PSD_KERNEL_B(PSD_STEP_NT) psd_zq_step_train(psd_zparams P, int p, int cstride) {
+    const int b = PSD_BLOCK_X;
+    if (b == 0) {
+        psd_zq_step_body(P);
+        return;
+    }
+    psd_zparams Q = P;
+    Q.st = P.cst + b;
+    Q.desc = P.desc + b;
+    Q.cnt = P.cnt + (size_t)b * cstride;
+    Q.tr = P.tr + (size_t)b * p * PSD_ZTR_CAP;
+    psd_zq_cursor_body(Q, b);
 }
 
 // Bulk application of one window's rotation lists.  grid = (tiles, p owners, 3 roles) as in the
@@ -741,12 +927,11 @@ PSD_D int psd_ztr_stage(const psd_ztr* gtr, int cnt, psd_ztr* ltr, int* flags) {
     return !flags[0] ? 1 : (!flags[1] ? -1 : 0);
 }
 
-PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply(psd_zparams P, int n, int p) {
+PSD_D void psd_zq_apply_body(const psd_zparams& P, int n, int p, int role) {
     PSD_LDS_DECL;
     const psd_zapply_desc d = *P.desc;
     if (!d.active) return;
     const int m = PSD_BLOCK_Y + 1;
-    const int role = PSD_BLOCK_Z;
     const int cnt = P.cnt[m - 1] < PSD_ZTR_CAP ? P.cnt[m - 1] : PSD_ZTR_CAP;
     if (cnt <= 0) return;
     const int T = PSD_ZAPPLY_NT;
@@ -872,6 +1057,20 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply(psd_zparams P, int n, int p) {
     }
 }
 
+PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply(psd_zparams P, int n, int p) { psd_zq_apply_body(P, n, p, PSD_BLOCK_Z); }
+
+// bulk updates of all cursors of a tick in two launches (see psd_rq_apply_train)
+PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply_train(psd_zparams P, int n, int p, int cstride, int pass) {
+    const int z = PSD_BLOCK_Z;
+    const int b = (pass == 0) ? (z >> 1) : z;
+    const int role = (pass == 0) ? ((z & 1) ? 2 : 0) : 1;
+    psd_zparams Q = P;
+    Q.desc = P.desc + b;
+    Q.cnt = P.cnt + (size_t)b * cstride;
+    Q.tr = P.tr + (size_t)b * p * PSD_ZTR_CAP;
+    psd_zq_apply_body(Q, n, p, role);
+}
+
 // Deferred right side of H_1 after a zero-shift pass (generalized.jl:436-444):
 // for j = djlo..djhi: rmul!(view(H1, drow0:(j+1), :), G_j').  One thread per row.
 PSD_KERNEL psd_zq_defer(psd_zparams P, int n) {
@@ -920,7 +1119,8 @@ PSD_KERNEL psd_zq_defer(psd_zparams P, int n) {
     }
 }
 
-PSD_KERNEL psd_zq_init(psd_zparams P, int n, int p, int wantT, int wantZ, int W, int maxitfac, int maxlog) {
+PSD_KERNEL psd_zq_init(psd_zparams P, int n, int p, int wantT, int wantZ, int W, int maxitfac, int maxlog,
+                       int train_want) {
     const psd_mat<psd_z> H1 = psd_mat<psd_z>{P.H, n};
     PSD_PAR_FOR(c, n) {
         for (int r = c + 3; r <= n; ++r) H1(r, c + 1) = zmk(0.0, 0.0);  // _gethess!
@@ -942,6 +1142,8 @@ PSD_KERNEL psd_zq_init(psd_zparams P, int n, int p, int wantT, int wantZ, int W,
         st.safmin = PSD_DBL_MIN;
         st.smlnum = PSD_DBL_MIN * ((double)n / PSD_DBL_EPS);
         for (int q = 0; q < 6; ++q) st.cyc[q] = 0;
+        st.train_want = train_want; st.train_n = 1; st.train_id = 0; st.cursor = 0; st.train_tick0 = 0;
+        st.shidx = n; st.exc_dec = 0; st.ntrainsweeps = 0; st.shift = zmk(0.0, 0.0);
         *P.st = st;
         P.desc->active = 0;
         P.desc->defer_run = 0;

@@ -1103,3 +1103,28 @@ def case_trains(eng, sizes):
                 assert len(p1.Z) == 0 and pt.match_eigs(ref.values, p1.values) <= 1e-10 * Pn
     finally:
         eng.set_train(m0)
+
+
+# complex single-shift path: trains (shifts = eigenvalues of the trailing block of the product) against the reference's
+# one-shift iteration
+def case_ztrains(eng, sizes):
+    m0 = eng.get_train_z()
+    try:
+        for (n, p, lr) in sizes:
+            As = pt.bench_factors(n, p, seed=400 + n + p, dtype=np.complex128)
+            P = pt.product(As, lr == "L")
+            Pn = np.linalg.norm(P, 2)
+            eng.set_train_z(0)
+            ref = eng.pschur(As, lr)
+            for m in (2, 6):
+                eng.set_train_z(m)
+                ps = eng.pschur(As, lr)
+                assert ps.stats.nlaunch_step < ref.stats.nlaunch_step, (n, p, lr, m)
+                ok, err = pt.checkpsd(ps, As, thresh=100 * np.sqrt(max(n / 32, 1)))
+                assert ok, (n, p, lr, m, err)
+                assert pt.match_eigs(ref.values, ps.values) <= 1e-10 * Pn
+                assert pt.match_eigs(np.linalg.eigvals(P), ps.values) <= 1e-10 * Pn
+                p0 = eng.pschur(As, lr, wantT=False, wantZ=False)
+                assert pt.match_eigs(ref.values, p0.values) <= 1e-10 * Pn
+    finally:
+        eng.set_train_z(m0)

@@ -110,3 +110,7 @@ def test_ordschur_alignments(gpu_engine):
 
 def test_ordschur_supplementary_z(gpu_engine):
     ec.case_ordschur_supplementary_z(gpu_engine)
+
+
+def test_ztrains(gpu_engine):
+    ec.case_ztrains(gpu_engine, [(150, 3, "R"), (120, 12, "L"), (256, 40, "R")])

@@ -61,3 +61,7 @@ def test_ordschur_alignments(sim_engine):
 
 def test_ordschur_supplementary_z(sim_engine):
     ec.case_ordschur_supplementary_z(sim_engine)
+
+
+def test_ztrains(sim_engine):
+    ec.case_ztrains(sim_engine, [(150, 3, "R"), (120, 12, "L")])
