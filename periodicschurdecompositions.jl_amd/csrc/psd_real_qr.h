@@ -485,69 +485,86 @@ PSD_D void psd_rq_topband(const psd_rparams& P, int n, int p, int l, int i, doub
 }
 
 // The 2m shifts of a train: eigenvalues of the trailing K x K block (K = 2m) of H_1 H_2 ... H_p, which is
-// H_1[t0:i, t0-1:i] * (prod_j H_j[t0-1:i, t0-1:i])[:, 2:end] because the other factors are triangular.  One lane.
-// Pairs go to P.tshift; returns false if the small QR iteration fails (no train then).
-// `work`: >= 640 doubles of LDS (the window area is free while the shifts are computed; private arrays of this size
-// would cost ~5 KB of scratch per lane for every launch of the kernel).
-PSD_D bool psd_rq_train_shifts(const psd_rparams& P, int n, int p, int i, int m, double* work) {
-    const int K = 2 * m, K1 = K + 1, t0 = i - K + 1;
-    double* R = work;                                        // (PSD_HQR_MAX + 1)^2
-    double* T = R + (PSD_HQR_MAX + 1) * (PSD_HQR_MAX + 1);    // PSD_HQR_MAX^2
-    double* tmp = T + PSD_HQR_MAX * PSD_HQR_MAX;              // PSD_HQR_MAX + 1
-    double* wr = tmp + (PSD_HQR_MAX + 1);
+// H_1[t0:i, t0-1:i] * (prod_j H_j[t0-1:i, t0-1:i])[:, 2:end] because the other factors are triangular.
+// Called by every lane: the (K+1) x (K+1) trailing blocks of all factors are staged in LDS by the whole wavefront (read
+// one by one from HBM by a single lane they cost a millisecond per train), the triangular products run one entry per
+// lane, only the small Hessenberg-QR is one lane's work.  `work`: LDS, psd_rq_train_doubles(p, m) doubles (the window
+// area is free while the shifts are computed).  Pairs go to P.tshift; *okf = 1 on success.
+PSD_HD size_t psd_rq_train_doubles(int p, int m) {
+    const size_t K = 2 * (size_t)m, K1 = K + 1;
+    return (size_t)p * K1 * K1 + 2 * K1 * K1 + K * K + 3 * PSD_HQR_MAX + 8;
+}
+PSD_D void psd_rq_train_shifts(const psd_rparams& P, int n, int p, int i, int m, double* work, int* okf) {
+    const int K = 2 * m, K1 = K + 1, t0 = i - K + 1, KK = K1 * K1;
+    double* B = work;                // [p][K1][K1] row-major trailing blocks (rows / columns t0-1 .. i)
+    double* R0 = B + (size_t)p * KK;  // running product, double-buffered
+    double* R1 = R0 + KK;
+    double* T = R1 + KK;             // K x K
+    double* wr = T + K * K;
     double* wi = wr + PSD_HQR_MAX;
     double* re = wi + PSD_HQR_MAX;
-    for (int q = 0; q < K1 * K1; ++q) R[q] = 0.0;
-    for (int q = 0; q < K1; ++q) R[q * K1 + q] = 1.0;
-    for (int j = 2; j <= p; ++j) {  // R <- R * H_j[t0-1:i, t0-1:i]  (both upper triangular)
-        const psd_mat<double> Hj = psd_fac(P, n, j);
-        for (int r = 0; r < K1; ++r) {
-            for (int c = r; c < K1; ++c) {
-                double acc = 0.0;
-                for (int k = r; k <= c; ++k) acc += R[r * K1 + k] * Hj(t0 - 1 + k, t0 - 1 + c);
-                tmp[c] = acc;
-            }
-            for (int c = r; c < K1; ++c) R[r * K1 + c] = tmp[c];
-        }
+    PSD_SYNC();
+    PSD_PAR_FOR(t, p * KK) {
+        const int j = t / KK, q = t - j * KK, r = q / K1, c = q - r * K1;
+        B[t] = psd_fac(P, n, j + 1)(t0 - 1 + r, t0 - 1 + c);
     }
-    const psd_mat<double> H1 = psd_fac(P, n, 1);
-    for (int r = 0; r < K; ++r)  // T[r, c] = sum_k H_1[t0 + r, t0 - 1 + k] R[k, c + 1]
-        for (int c = 0; c < K; ++c) {
+    PSD_PAR_FOR(q, KK) { R0[q] = (q / K1 == q % K1) ? 1.0 : 0.0; }
+    PSD_SYNC();
+    double* cur = R0;
+    double* nxt = R1;
+    for (int j = 2; j <= p; ++j) {  // cur <- cur * B_j (both upper triangular), one entry per lane
+        const double* Bj = B + (size_t)(j - 1) * KK;
+        PSD_PAR_FOR(q, KK) {
+            const int r = q / K1, c = q - r * K1;
             double acc = 0.0;
-            for (int k = r; k <= c + 1; ++k) acc += H1(t0 + r, t0 - 1 + k) * R[k * K1 + (c + 1)];
-            T[r * K + c] = acc;
+            for (int k = r; k <= c; ++k) acc += cur[r * K1 + k] * Bj[k * K1 + c];
+            nxt[q] = acc;
         }
-    if (!psd_hqr(T, K, K, wr, wi)) return false;
-    // conjugate pairs first, then the real eigenvalues in ascending order two by two
-    int np = 0;
-    int nre = 0;
-    for (int q = 0; q < K; ++q) {
-        if (!(wr[q] == wr[q]) || !(wi[q] == wi[q])) return false;
-        if (wi[q] > 0.0) {
-            if (np < m) {
-                double* sh = P.tshift + 4 * np;
-                sh[0] = wr[q]; sh[1] = wi[q]; sh[2] = wr[q]; sh[3] = -wi[q];
-                ++np;
+        PSD_SYNC();
+        double* sw = cur;
+        cur = nxt;
+        nxt = sw;
+    }
+    PSD_PAR_FOR(q, K * K) {  // T[r, c] = sum_k H_1[t0 + r, t0 - 1 + k] R[k, c + 1]
+        const int r = q / K, c = q - r * K;
+        double acc = 0.0;
+        for (int k = r; k <= c + 1; ++k) acc += B[(r + 1) * K1 + k] * cur[k * K1 + (c + 1)];
+        T[q] = acc;
+    }
+    PSD_SYNC();
+    PSD_ONE {
+        bool ok = psd_hqr(T, K, K, wr, wi);
+        int np = 0, nre = 0;
+        // conjugate pairs first, then the real eigenvalues in ascending order two by two
+        for (int q = 0; ok && q < K; ++q) {
+            if (!(wr[q] == wr[q]) || !(wi[q] == wi[q])) ok = false;
+            if (wi[q] > 0.0) {
+                if (np < m) {
+                    double* sh = P.tshift + 4 * np;
+                    sh[0] = wr[q]; sh[1] = wi[q]; sh[2] = wr[q]; sh[3] = -wi[q];
+                    ++np;
+                }
+            } else if (wi[q] == 0.0) {
+                re[nre++] = wr[q];
             }
-        } else if (wi[q] == 0.0) {
-            re[nre++] = wr[q];
         }
-    }
-    for (int a = 1; a < nre; ++a) {  // insertion sort
-        const double x = re[a];
-        int b = a - 1;
-        while (b >= 0 && re[b] > x) {
-            re[b + 1] = re[b];
-            --b;
+        for (int a = 1; a < nre; ++a) {  // insertion sort
+            const double x = re[a];
+            int b = a - 1;
+            while (b >= 0 && re[b] > x) {
+                re[b + 1] = re[b];
+                --b;
+            }
+            re[b + 1] = x;
         }
-        re[b + 1] = x;
+        for (int a = 0; ok && a < nre && np < m; a += 2) {
+            double* sh = P.tshift + 4 * np;
+            sh[0] = re[a]; sh[1] = 0.0; sh[2] = (a + 1 < nre) ? re[a + 1] : re[a]; sh[3] = 0.0;
+            ++np;
+        }
+        *okf = (ok && np == m) ? 1 : 0;
     }
-    for (int a = 0; a < nre && np < m; a += 2) {
-        double* sh = P.tshift + 4 * np;
-        sh[0] = re[a]; sh[1] = 0.0; sh[2] = (a + 1 < nre) ? re[a + 1] : re[a]; sh[3] = 0.0;
-        ++np;
-    }
-    return np == m;
+    PSD_SYNC();
 }
 
 // PSD.jl:668-803: split test, shifts, first column of the shifted product
@@ -618,11 +635,10 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work) {
             if (m > st.train_want) m = st.train_want;
             if (m > PSD_TRAIN_MAX) m = PSD_TRAIN_MAX;
             if (2 * m > PSD_HQR_MAX) m = PSD_HQR_MAX / 2;
+            while (m >= 2 && psd_rq_train_doubles(st.p, m) > (size_t)st.p * st.W * (st.W + 1)) --m;  // LDS of the staging
             if (m >= 2 && 2 * m + 2 <= w) {
                 int* okf = (int*)P.tshift + 8 * PSD_TRAIN_MAX;  // (flag word behind the pairs)
-                PSD_SYNC();
-                PSD_ONE { *okf = psd_rq_train_shifts(P, n, st.p, i, m, work) ? 1 : 0; }
-                PSD_SYNC();
+                psd_rq_train_shifts(P, n, st.p, i, m, work, okf);
                 if (*okf) {
                     st.train_n = m;
                     st.train_tick0 = P.tick;

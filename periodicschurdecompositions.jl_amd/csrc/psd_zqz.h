@@ -242,52 +242,71 @@ PSD_D bool psd_zq_start_rot_mu(const psd_zparams& P, int n, int p, int ifirst, p
     return true;
 }
 
-// The m shifts of a train: eigenvalues of the trailing m x m block of H_1 H_2 ... H_p (see psd_rq_train_shifts).  One lane;
-// `work`: LDS (the window area is free here).  Shifts go to P.tshift ordered by distance from the last diagonal entry
-// of the block (closest first: the leader's).
-PSD_D bool psd_zq_train_shifts(const psd_zparams& P, int n, int p, int ilast, int m, psd_z* work) {
-    const int K = m, K1 = K + 1, t0 = ilast - K + 1;
-    psd_z* R = work;
-    psd_z* T = R + (PSD_ZHQR_MAX + 1) * (PSD_ZHQR_MAX + 1);
-    psd_z* tmp = T + PSD_ZHQR_MAX * PSD_ZHQR_MAX;
-    psd_z* w = tmp + (PSD_ZHQR_MAX + 1);
-    for (int q = 0; q < K1 * K1; ++q) R[q] = zmk(0.0, 0.0);
-    for (int q = 0; q < K1; ++q) R[q * K1 + q] = zmk(1.0, 0.0);
+// The m shifts of a train: eigenvalues of the trailing m x m block of H_1 H_2 ... H_p (see psd_rq_train_shifts: blocks
+// staged in LDS by the whole wavefront, products one entry per lane, the small QR iteration by one lane).  `work`: LDS,
+// psd_zq_train_elems(p, m) complex elements.  Shifts go to P.tshift ordered by distance from the last diagonal entry of
+// the block (closest first: the leader's); *okf = 1 on success.
+PSD_HD size_t psd_zq_train_elems(int p, int m) {
+    const size_t K1 = (size_t)m + 1;
+    return (size_t)p * K1 * K1 + 2 * K1 * K1 + (size_t)m * m + PSD_ZHQR_MAX + 8;
+}
+PSD_D void psd_zq_train_shifts(const psd_zparams& P, int n, int p, int ilast, int m, psd_z* work, int* okf) {
+    const int K = m, K1 = K + 1, t0 = ilast - K + 1, KK = K1 * K1;
+    psd_z* B = work;
+    psd_z* R0 = B + (size_t)p * KK;
+    psd_z* R1 = R0 + KK;
+    psd_z* T = R1 + KK;
+    psd_z* w = T + K * K;
+    PSD_SYNC();
+    PSD_PAR_FOR(t, p * KK) {
+        const int j = t / KK, q = t - j * KK, r = q / K1, c = q - r * K1;
+        B[t] = psd_zfac(P, n, j + 1)(t0 - 1 + r, t0 - 1 + c);
+    }
+    PSD_PAR_FOR(q, KK) { R0[q] = (q / K1 == q % K1) ? zmk(1.0, 0.0) : zmk(0.0, 0.0); }
+    PSD_SYNC();
+    psd_z* cur = R0;
+    psd_z* nxt = R1;
     for (int j = 2; j <= p; ++j) {
-        const psd_mat<psd_z> Hj = psd_zfac(P, n, j);
-        for (int r = 0; r < K1; ++r) {
-            for (int c = r; c < K1; ++c) {
-                psd_z acc = zmk(0.0, 0.0);
-                for (int k = r; k <= c; ++k) acc = zadd(acc, zmul(R[r * K1 + k], Hj(t0 - 1 + k, t0 - 1 + c)));
-                tmp[c] = acc;
-            }
-            for (int c = r; c < K1; ++c) R[r * K1 + c] = tmp[c];
-        }
-    }
-    const psd_mat<psd_z> H1 = psd_zfac(P, n, 1);
-    for (int r = 0; r < K; ++r)
-        for (int c = 0; c < K; ++c) {
+        const psd_z* Bj = B + (size_t)(j - 1) * KK;
+        PSD_PAR_FOR(q, KK) {
+            const int r = q / K1, c = q - r * K1;
             psd_z acc = zmk(0.0, 0.0);
-            for (int k = r; k <= c + 1; ++k) acc = zadd(acc, zmul(H1(t0 + r, t0 - 1 + k), R[k * K1 + (c + 1)]));
-            T[r * K + c] = acc;
+            for (int k = r; k <= c; ++k) acc = zadd(acc, zmul(cur[r * K1 + k], Bj[k * K1 + c]));
+            nxt[q] = acc;
         }
-    const psd_z last = T[(K - 1) * K + (K - 1)];
-    if (!psd_zhqr(T, K, K, w)) return false;
-    for (int a = 0; a < K; ++a) {
-        if (!(zabs1(w[a]) < 1e300)) return false;
+        PSD_SYNC();
+        psd_z* sw = cur;
+        cur = nxt;
+        nxt = sw;
     }
-    for (int a = 1; a < K; ++a) {  // insertion sort by distance from the last diagonal entry
-        const psd_z x = w[a];
-        const double dx = zabs1(zsub(x, last));
-        int b = a - 1;
-        while (b >= 0 && zabs1(zsub(w[b], last)) > dx) {
-            w[b + 1] = w[b];
-            --b;
+    PSD_PAR_FOR(q, K * K) {
+        const int r = q / K, c = q - r * K;
+        psd_z acc = zmk(0.0, 0.0);
+        for (int k = r; k <= c + 1; ++k) acc = zadd(acc, zmul(B[(r + 1) * K1 + k], cur[k * K1 + (c + 1)]));
+        T[q] = acc;
+    }
+    PSD_SYNC();
+    PSD_ONE {
+        const psd_z last = T[(K - 1) * K + (K - 1)];
+        bool ok = psd_zhqr(T, K, K, w);
+        for (int a = 0; ok && a < K; ++a)
+            if (!(zabs1(w[a]) < 1e300)) ok = false;
+        if (ok) {
+            for (int a = 1; a < K; ++a) {  // insertion sort by distance from the last diagonal entry
+                const psd_z x = w[a];
+                const double dx = zabs1(zsub(x, last));
+                int b = a - 1;
+                while (b >= 0 && zabs1(zsub(w[b], last)) > dx) {
+                    w[b + 1] = w[b];
+                    --b;
+                }
+                w[b + 1] = x;
+            }
+            for (int a = 0; a < K; ++a) P.tshift[a] = w[a];
         }
-        w[b + 1] = x;
+        *okf = ok ? 1 : 0;
     }
-    for (int a = 0; a < K; ++a) P.tshift[a] = w[a];
-    return true;
+    PSD_SYNC();
 }
 
 PSD_D void psd_zq_check(const psd_zparams& P, psd_zstate& st, double* red, int* redi, psd_z* work) {
@@ -449,11 +468,10 @@ PSD_D void psd_zq_check(const psd_zparams& P, psd_zstate& st, double* red, int* 
             if (m > st.train_want) m = st.train_want;
             if (m > PSD_TRAIN_MAX) m = PSD_TRAIN_MAX;
             if (m > PSD_ZHQR_MAX) m = PSD_ZHQR_MAX;
+            while (m >= 2 && psd_zq_train_elems(p, m) > (size_t)p * st.W * (st.W + 1)) --m;  // LDS of the staging
             if (m >= 2 && 2 * m + 2 <= w) {
                 int* okf = (int*)(P.tshift + PSD_TRAIN_MAX);  // (flag word behind the shifts)
-                PSD_SYNC();
-                PSD_ONE { *okf = psd_zq_train_shifts(P, n, p, ilast, m, work) ? 1 : 0; }
-                PSD_SYNC();
+                psd_zq_train_shifts(P, n, p, ilast, m, work, okf);
                 double cm;
                 psd_z sm;
                 if (*okf && psd_zq_start_rot_mu(P, n, p, st.ifirst, P.tshift[0], cm, sm)) {
