@@ -187,7 +187,7 @@ class Engine:
         return self.lib.psd_version().decode()
 
     def set_train(self, bulges):
-        """Multishift trains of the real pschur! path (psd_set_train): bulges >= 2 (default 6) or 0 for the reference's
+        """Multishift trains of the real pschur! path (psd_set_train): bulges >= 2 (default 8) or 0 for the reference's
         one-shift-one-sweep iteration."""
         self.lib.psd_set_train.argtypes = [C.c_void_p, C.c_int]
         self.lib.psd_set_train(self.ctx, int(bulges))

@@ -126,8 +126,8 @@ struct psd_ctx {
     size_t step_lds_set = 0, zstep_lds_set = 0, rostep_lds_set = 0;
     psd_hess_args* hargs = nullptr;  // device argument block of the graph-replayed Hessenberg reduction
     // multishift trains (experimental): bulges per train (0/1 = off), per-cursor state / descriptor / lists
-    int ztrain_m = 6;  // complex single-shift engine (psd_set_train sets both; psd_set_train_z / PSD_TRAIN_Z this one)
-    int train_m = 6;  // default: trains of up to six bulges (psd_set_train / PSD_TRAIN; 0 or 1 = the reference's iteration)
+    int ztrain_m = 8;  // complex single-shift engine (psd_set_train sets both; psd_set_train_z / PSD_TRAIN_Z this one)
+    int train_m = 8;  // default: trains of up to eight bulges (psd_set_train / PSD_TRAIN; 0 or 1 = the reference's iteration)
     int tcap_p = 0;
     psd_rstate* tcst = nullptr;
     double* tshift = nullptr;
