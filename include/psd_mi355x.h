@@ -71,10 +71,16 @@ int psd_set_profile(psd_ctx* ctx, int profile);
  * decomposition up to rounding and iteration path; psd_stats.reserved counts the sweeps that ran inside trains. */
 int psd_set_train(psd_ctx* ctx, int bulges);
 int psd_get_train(psd_ctx* ctx);
-/* psd_set_train sets the real and the complex path; these two address the complex single-shift path alone (its bulges
+/* psd_set_train sets every path; these two address the complex single-shift path alone (its bulges
  * take the eigenvalues of the trailing m x m block of the product as shifts) */
 int psd_set_train_z(psd_ctx* ctx, int bulges);
 int psd_get_train_z(psd_ctx* ctx);
+/* the real signed path psd_d_pschur(A, S) (double-shift sweeps of rgeneralized.jl:806-1054): trains with explicit shifts
+ * taken from the trailing 2m x 2m block of prod_{l>=2} H_l^{s_l} * H_1 (default 8; psd_set_train sets this path too,
+ * PSD_TRAIN_G presets it alone).  psd_stats.maxits counts the sweeps that ran inside trains.  -2 (test hook): single
+ * sweeps started from explicit shifts instead of the implicit _qzrots start. */
+int psd_set_train_g(psd_ctx* ctx, int bulges);
+int psd_get_train_g(psd_ctx* ctx);
 const char* psd_version(void);
 
 /* phessenberg!(A)  — PeriodicSchurDecompositions.jl:213-259.

@@ -200,6 +200,15 @@ class Engine:
         self.lib.psd_get_train_z.argtypes = [C.c_void_p]
         return int(self.lib.psd_get_train_z(self.ctx))
 
+    def set_train_g(self, bulges):
+        """Multishift trains of the real signed path (psd_set_train_g; off by default)."""
+        self.lib.psd_set_train_g.argtypes = [C.c_void_p, C.c_int]
+        self.lib.psd_set_train_g(self.ctx, int(bulges))
+
+    def get_train_g(self):
+        self.lib.psd_get_train_g.argtypes = [C.c_void_p]
+        return int(self.lib.psd_get_train_g(self.ctx))
+
     def get_train(self):
         self.lib.psd_get_train.argtypes = [C.c_void_p]
         return int(self.lib.psd_get_train(self.ctx))

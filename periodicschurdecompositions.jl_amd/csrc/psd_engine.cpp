@@ -213,6 +213,31 @@ struct psd_ctx {
     double *gbeta = nullptr, *gxscr = nullptr;
     int *gascale = nullptr, *gcnt = nullptr, *glog = nullptr;
     size_t gstep_lds_set = 0, ghess_lds_set = 0;
+    // multishift trains of the real signed engine (psd_set_train sets all engines; psd_set_train_g / PSD_TRAIN_G this one)
+    int gtrain_m = 8, gtcap_p = 0;
+    psd_gstate* gtcst = nullptr;
+    double* gtshift = nullptr;
+    psd_gapply_desc* gtdesc = nullptr;
+    int* gtcnt = nullptr;
+    psd_gtr* gttr = nullptr;
+    void gtrelease() {
+        void* ptrs[] = {gtcst, gtshift, gtdesc, gtcnt, gttr};
+        for (void* q : ptrs)
+            if (q) psd_rt_free(q);
+        gtcst = nullptr; gtshift = nullptr; gtdesc = nullptr; gtcnt = nullptr; gttr = nullptr;
+        gtcap_p = 0;
+    }
+    int gtreserve(int p) {
+        if (gtcst && p <= gtcap_p) return 0;
+        gtrelease();
+        PSD_CHECK(psd_rt_malloc((void**)&gtcst, sizeof(psd_gstate) * PSD_TRAIN_MAX));
+        PSD_CHECK(psd_rt_malloc((void**)&gtshift, sizeof(double) * (4 * PSD_TRAIN_MAX + 8)));
+        PSD_CHECK(psd_rt_malloc((void**)&gtdesc, sizeof(psd_gapply_desc) * PSD_TRAIN_MAX));
+        PSD_CHECK(psd_rt_malloc((void**)&gtcnt, sizeof(int) * PSD_TRAIN_MAX * (size_t)(p + 8)));
+        PSD_CHECK(psd_rt_malloc((void**)&gttr, sizeof(psd_gtr) * PSD_TRAIN_MAX * (size_t)p * PSD_GTR_CAP));
+        gtcap_p = p;
+        return 0;
+    }
     // complex generalized path (shares zalpha/zbeta/zascale/zlog/zvbuf with the complex path)
     int zgcap_n = 0, zgcap_p = 0;
     psd_zgstate* zgst = nullptr;
@@ -740,8 +765,9 @@ int psd_create(psd_ctx** ctx, int device) {
         }
     }
 #endif
-    if (const char* e = getenv("PSD_TRAIN")) c->train_m = c->ztrain_m = atoi(e);
+    if (const char* e = getenv("PSD_TRAIN")) c->train_m = c->ztrain_m = c->gtrain_m = atoi(e);
     if (const char* e = getenv("PSD_TRAIN_Z")) c->ztrain_m = atoi(e);
+    if (const char* e = getenv("PSD_TRAIN_G")) c->gtrain_m = atoi(e);
     *ctx = c;
     return 0;
 }
@@ -749,7 +775,7 @@ int psd_create(psd_ctx** ctx, int device) {
 int psd_set_train(psd_ctx* c, int bulges) {
     if (!c) return -1;
     c->train_m = (bulges < 0) ? 0 : ((bulges > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : bulges);
-    c->ztrain_m = c->train_m;
+    c->ztrain_m = c->gtrain_m = c->train_m;
     return 0;
 }
 
@@ -760,10 +786,17 @@ int psd_set_train_z(psd_ctx* c, int bulges) {
     return 0;
 }
 int psd_get_train_z(psd_ctx* c) { return c ? c->ztrain_m : -1; }
+int psd_set_train_g(psd_ctx* c, int bulges) {
+    if (!c) return -1;
+    c->gtrain_m = (bulges == -2) ? -2 : ((bulges < 0) ? 0 : ((bulges > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : bulges));
+    return 0;
+}
+int psd_get_train_g(psd_ctx* c) { return c ? c->gtrain_m : -1; }
 
 int psd_destroy(psd_ctx* c) {
     if (!c) return 0;
     c->grelease();
+    c->gtrelease();
     c->zgrelease();
     c->release();
     c->zrelease();
@@ -1883,7 +1916,30 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
         c->ghess_lds_set = lds_hess;
     }
 #endif
-    PSD_LAUNCH(psd_gq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, hessmode);
+    // multishift trains (as iterate_dev): M cursors, cursor 0 is the ordinary state machine
+    const int tw = hessmode ? 0 : c->gtrain_m;
+    const int M = (tw >= 2) ? ((tw > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : tw) : 1;
+    P.cst = nullptr;
+    P.tshift = nullptr;
+    P.tick = 0;
+    if (M > 1 || tw == -2) {
+        PSD_CHECK(c->gtreserve(p));
+        PSD_CHECK(psd_rt_memset(c->gtcst, 0, sizeof(psd_gstate) * PSD_TRAIN_MAX, c->stream));
+        PSD_CHECK(psd_rt_memset(c->gtdesc, 0, sizeof(psd_gapply_desc) * PSD_TRAIN_MAX, c->stream));
+        P.cst = c->gtcst;
+        P.tshift = c->gtshift;
+        if (M > 1) {
+            P.desc = c->gtdesc;
+            P.cnt = c->gtcnt;
+            P.tr = c->gttr;
+#ifndef PSD_HOSTSIM
+            PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_gq_step_train),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
+#endif
+        }
+    }
+    PSD_LAUNCH(psd_gq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, hessmode,
+               (tw == -2) ? -2 : M);
     const size_t lds_apply = PSD_GTR_LDS_BYTES + (size_t)32 * (PSD_GAPPLY_NT + 1) * sizeof(double);
     const int tiles = (n + PSD_GAPPLY_NT - 1) / PSD_GAPPLY_NT;
     const int dtiles = (n + 255) / 256;
@@ -1910,8 +1966,11 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
                 (void)hipEventRecord(ev0, c->stream);
             }
 #endif
+            P.tick = (int)launched;
             if (hess_pipe)
                 PSD_LAUNCH(psd_gq_hess_step, psd_dim3(1), 64 * hess_waves, lds_hess, c->stream, P, hess_links);
+            else if (M > 1)
+                PSD_LAUNCH(psd_gq_step_train, psd_dim3(M), PSD_STEP_NT, lds_step, c->stream, P, p, p + 8);
             else
                 PSD_LAUNCH(psd_gq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
 #ifndef PSD_HOSTSIM
@@ -1920,7 +1979,12 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
                 pend.emplace_back(ev0, ev1);
             }
 #endif
-            PSD_LAUNCH(psd_gq_apply, psd_dim3(tiles, p, 3), PSD_GAPPLY_NT, lds_apply, c->stream, P, n, p);
+            if (M > 1) {
+                PSD_LAUNCH(psd_gq_apply_train, psd_dim3(tiles, p, 2 * M), PSD_GAPPLY_NT, lds_apply, c->stream, P, n, p, p + 8, 0);
+                PSD_LAUNCH(psd_gq_apply_train, psd_dim3(tiles, p, M), PSD_GAPPLY_NT, lds_apply, c->stream, P, n, p, p + 8, 1);
+            } else {
+                PSD_LAUNCH(psd_gq_apply, psd_dim3(tiles, p, 3), PSD_GAPPLY_NT, lds_apply, c->stream, P, n, p);
+            }
             if (!hess_pipe) PSD_LAUNCH(psd_gq_defer, psd_dim3(dtiles), 256, 0, c->stream, P, n);
             ++launched;
         }
@@ -1970,6 +2034,7 @@ int grun_iteration(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8
         stats->nwindows = st.nwindows;
         stats->nlog = st.nlog;
         stats->reserved = st.ncase2 + 1000 * st.ncase3;
+        stats->maxits = st.ntrainsweeps;  // (signed path: sweeps that ran inside multishift trains)
         for (int q = 0; q < 6; ++q) stats->step_cycles[q] = st.cyc[q];
     }
     PSD_CHECK(psd_rt_d2h(alpha, c->galpha, sizeof(psd_z) * n, c->stream));

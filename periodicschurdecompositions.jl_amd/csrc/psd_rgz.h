@@ -21,7 +21,10 @@
 #include "psd_real_qr.h"
 #include "psd_zqz.h"
 
-enum { PSD_GPH_CHECK = 0, PSD_GPH_SWEEP = 1, PSD_GPH_ZSHIFT = 2, PSD_GPH_HESS = 3, PSD_GPH_DONE = 7 };
+enum {
+    PSD_GPH_CHECK = 0, PSD_GPH_SWEEP = 1, PSD_GPH_ZSHIFT = 2, PSD_GPH_HESS = 3, PSD_GPH_DONE = 7,
+    PSD_GPH_TWAIT = 8, PSD_GPH_CWAIT = 9, PSD_GPH_CDONE = 10  // multishift trains, as in psd_real_qr.h
+};
 #define PSD_GTR_CAP 80  // rotations per owner and window
 #define PSD_GAPPLY_NT 128
 
@@ -52,6 +55,10 @@ struct psd_gstate {
     double c1, s1, c2, s2;  // starting rotations of the current sweep
     double smlnum, ulp;
     long long cyc[6];
+    // multishift train (as psd_rstate): bulges wanted (-2: explicit-shift start without a train, test hook) / in the
+    // running train / train number / this state's cursor / tick of the leader's first window / sweeps in trains
+    int train_want, train_n, train_id, cursor, train_tick0, ntrainsweeps;
+    double sh[4];  // this bulge's shift pair: rt1r, rt1i, rt2r, rt2i
 };
 
 struct psd_gparams {
@@ -68,6 +75,9 @@ struct psd_gparams {
     int* ascale;   // [n]
     int* log;
     double* xscr;  // [16 p] scratch of the 2x2 solvers
+    psd_gstate* cst;  // [PSD_TRAIN_MAX] cursor states of a train (entry 0 unused) or nullptr
+    double* tshift;   // [PSD_TRAIN_MAX][4] shift pairs, then a flag word
+    int tick;         // launch index
 };
 
 PSD_HD psd_mat<double> psd_gfac(const psd_gparams& P, int n, int l) {
@@ -1063,7 +1073,7 @@ PSD_D void psd_gq_sweep_window(const psd_gparams& P, psd_gstate& st, double* lds
     psd_gdesc_write(P, st, lcnt, w.bs, w.be, w.be + 1, ilastm, ifirstm, w.bs - 1, 0, 0, 0, 0);
     st.nwindows += 1;
     st.kcur = ke + 1;
-    if (last) st.phase = PSD_GPH_CHECK;
+    if (last) st.phase = (st.cursor > 0) ? PSD_GPH_CDONE : ((st.train_n > 1) ? PSD_GPH_TWAIT : PSD_GPH_CHECK);
 }
 
 // rgeneralized.jl:229-324: one window of the controlled zero shift (positions kcur..)
@@ -1174,6 +1184,142 @@ PSD_D int psd_gq_scan_diag(const psd_gparams& P, const psd_gstate& st, int* redi
 
 // rgeneralized.jl:169-803: deflation tests, split, zero-shift decision, 2x2 blocks, starting rotations.
 // Returns true when a window was emitted (2x2 real deflation).
+// ------------------------------------------------------------------------------------------------
+// Explicit shifts for the signed double-shift sweep (multishift trains).  The sweep's starting
+// rotations act on the columns of H_1, i.e. they are a similarity of P' = T H_1 with T = prod_{l=2..p} H_l^{s_l} (upper
+// triangular; a diagonal block of T is the product of the factors' diagonal blocks, inverted where s_l is false).
+
+// cur <- prod_{l=2..p} (H_l[r0:r0+K-1, r0:r0+K-1])^{s_l}; B: LDS staging [p][K][K], R0/R1: K x K each.  Called by every
+// lane; returns the buffer that holds the product.  A zero diagonal entry of an inverted factor gives non-finite entries
+// (the callers test their results).
+PSD_D double* psd_gq_tprod(const psd_gparams& P, int n, int p, int r0, int K, double* B, double* R0, double* R1) {
+    const int KK = K * K;
+    PSD_SYNC();
+    PSD_PAR_FOR(t, p * KK) {
+        const int j = t / KK, q = t - j * KK, r = q / K, c = q - r * K;
+        B[t] = psd_gfac(P, n, j + 1)(r0 + r, r0 + c);
+    }
+    PSD_PAR_FOR(q, KK) { R0[q] = (q / K == q % K) ? 1.0 : 0.0; }
+    PSD_SYNC();
+    double* cur = R0;
+    double* nxt = R1;
+    for (int j = 2; j <= p; ++j) {
+        const double* Bj = B + (size_t)(j - 1) * KK;
+        if (psd_gsig(P, j)) {
+            PSD_PAR_FOR(q, KK) {
+                const int r = q / K, c = q - r * K;
+                double acc = 0.0;
+                for (int k = r; k <= c; ++k) acc += cur[r * K + k] * Bj[k * K + c];
+                nxt[q] = acc;
+            }
+        } else {  // X B_j = cur, row by row (one lane per row)
+            PSD_PAR_FOR(r, K) {
+                for (int c = 0; c < K; ++c) {
+                    double x = 0.0;
+                    if (c >= r) {
+                        x = cur[r * K + c];
+                        for (int k = r; k < c; ++k) x -= nxt[r * K + k] * Bj[k * K + c];
+                        x /= Bj[c * K + c];
+                    }
+                    nxt[r * K + c] = x;
+                }
+            }
+        }
+        PSD_SYNC();
+        double* sw = cur;
+        cur = nxt;
+        nxt = sw;
+    }
+    return cur;
+}
+
+// starting rotations of a double-shift sweep on the active block ifirst.. for the shift pair sh: first column of
+// (P' - s1)(P' - s2) from the leading 3x3 blocks; false if not finite.  `work`: LDS, >= 9 p + 18 doubles.
+PSD_D bool psd_gq_start_explicit(const psd_gparams& P, int n, int p, int ifirst, const double* sh, double* work, double& c1,
+                                 double& s1, double& c2, double& s2) {
+    double* T3 = psd_gq_tprod(P, n, p, ifirst, 3, work, work + 9 * (size_t)p, work + 9 * (size_t)p + 9);
+    const psd_mat<double> H1 = psd_gfac(P, n, 1);
+    const double h11 = H1(ifirst, ifirst), h21 = H1(ifirst + 1, ifirst), h12 = H1(ifirst, ifirst + 1),
+                 h22 = H1(ifirst + 1, ifirst + 1), h32 = H1(ifirst + 2, ifirst + 1);
+    const double t11 = T3[0], t12 = T3[1], t13 = T3[2], t22 = T3[4], t23 = T3[5], t33 = T3[8];
+    const double a1 = t11 * h11 + t12 * h21, a2 = t22 * h21;             // P' e1
+    const double b1 = h11 * a1 + h12 * a2, b2 = h21 * a1 + h22 * a2, b3 = h32 * a2;  // H_1 (P' e1)
+    const double q1 = t11 * b1 + t12 * b2 + t13 * b3, q2 = t22 * b2 + t23 * b3, q3 = t33 * b3;  // P'^2 e1
+    const double tr = sh[0] + sh[2], det = sh[0] * sh[2] - sh[1] * sh[3];
+    double v1 = q1 - tr * a1 + det, v2 = q2 - tr * a2, v3 = q3;
+    const double sc = fabs(v1) + fabs(v2) + fabs(v3);
+    PSD_SYNC();
+    if (!(sc > 0.0) || !(sc < 1e300)) return false;
+    v1 /= sc;
+    v2 /= sc;
+    v3 /= sc;
+    double r, rr;
+    psd_givens(v2, v3, c2, s2, r);
+    psd_givens(v1, r, c1, s1, rr);
+    return true;
+}
+
+// the 2m shifts of a train: eigenvalues of the trailing K x K block (K = 2m) of P' = T H_1; pairs to P.tshift, *okf = 1 on
+// success.  `work`: LDS, psd_gq_train_doubles(p, m) doubles.
+PSD_HD size_t psd_gq_train_doubles(int p, int m) {
+    const size_t K = 2 * (size_t)m;
+    return (size_t)p * K * K + 3 * K * K + 3 * PSD_HQR_MAX + 8;
+}
+PSD_D void psd_gq_train_shifts(const psd_gparams& P, int n, int p, int ilast, int m, double* work, int* okf) {
+    const int K = 2 * m, KK = K * K, t0 = ilast - K + 1;
+    double* B = work;
+    double* R0 = B + (size_t)p * KK;
+    double* R1 = R0 + KK;
+    double* T = R1 + KK;
+    double* wr = T + KK;
+    double* wi = wr + PSD_HQR_MAX;
+    double* re = wi + PSD_HQR_MAX;
+    const double* Tt = psd_gq_tprod(P, n, p, t0, K, B, R0, R1);
+    PSD_PAR_FOR(q, KK) {  // T = Tt * H_1[t0.., t0..]  (B's first block is H_1's)
+        const int r = q / K, c = q - r * K;
+        double acc = 0.0;
+        const int kmax = (c + 1 < K - 1) ? (c + 1) : (K - 1);
+        for (int k = r; k <= kmax; ++k) acc += Tt[r * K + k] * B[k * K + c];
+        T[q] = acc;
+    }
+    PSD_SYNC();
+    PSD_ONE {
+        bool ok = true;
+        for (int q = 0; q < KK; ++q)
+            if (!(fabs(T[q]) < 1e300)) ok = false;
+        ok = ok && psd_hqr(T, K, K, wr, wi);
+        int np = 0, nre = 0;
+        for (int q = 0; ok && q < K; ++q) {
+            if (!(wr[q] == wr[q]) || !(wi[q] == wi[q])) ok = false;
+            if (wi[q] > 0.0) {
+                if (np < m) {
+                    double* sh = P.tshift + 4 * np;
+                    sh[0] = wr[q]; sh[1] = wi[q]; sh[2] = wr[q]; sh[3] = -wi[q];
+                    ++np;
+                }
+            } else if (wi[q] == 0.0) {
+                re[nre++] = wr[q];
+            }
+        }
+        for (int a = 1; a < nre; ++a) {
+            const double x = re[a];
+            int b = a - 1;
+            while (b >= 0 && re[b] > x) {
+                re[b + 1] = re[b];
+                --b;
+            }
+            re[b + 1] = x;
+        }
+        for (int a = 0; ok && a < nre && np < m; a += 2) {
+            double* sh = P.tshift + 4 * np;
+            sh[0] = re[a]; sh[1] = 0.0; sh[2] = (a + 1 < nre) ? re[a + 1] : re[a]; sh[3] = 0.0;
+            ++np;
+        }
+        *okf = (ok && np == m) ? 1 : 0;
+    }
+    PSD_SYNC();
+}
+
 PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, double* red, int* redi, int* lcnt) {
     const int n = st.n, p = st.p;
     const int NT = PSD_NTHREADS;
@@ -1369,14 +1515,56 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
     }
     PSD_SYNC();
     psd_g_qzrots(P, n, p, ifirst, ilast - ifirst + 1, st.c1, st.s1, st.c2, st.s2);
+    st.train_n = 1;
+    if ((st.train_want >= 2 || st.train_want == -2) && P.tshift != nullptr && ilast - ifirst + 1 >= 4) {
+        const int nb = st.W - 4, w = ilast - ifirst + 1;
+        int m = (st.train_want == -2) ? 1 : (1 + (w - nb) / (2 * nb));
+        if (m > st.train_want && st.train_want >= 2) m = st.train_want;
+        if (m > PSD_TRAIN_MAX) m = PSD_TRAIN_MAX;
+        if (2 * m > PSD_HQR_MAX) m = PSD_HQR_MAX / 2;
+        while (m >= 1 && psd_gq_train_doubles(p, m) > (size_t)p * st.W * (st.W + 1)) --m;
+        if ((m >= 2 || st.train_want == -2) && m >= 1 && 2 * m + 2 <= w) {
+            int* okf = (int*)P.tshift + 8 * PSD_TRAIN_MAX;
+            psd_gq_train_shifts(P, n, p, ilast, m, ldsd, okf);
+            double e1, f1, e2, f2;
+            if (*okf && psd_gq_start_explicit(P, n, p, ifirst, P.tshift, ldsd, e1, f1, e2, f2)) {
+                st.c1 = e1; st.s1 = f1; st.c2 = e2; st.s2 = f2;
+                if (m >= 2) {
+                    st.train_n = m;
+                    st.train_tick0 = P.tick;
+                    st.train_id += 1;
+                    st.ntrainsweeps += m;
+                }
+            }
+            PSD_SYNC();
+        }
+    }
     st.phase = PSD_GPH_SWEEP;
     st.kcur = ifirst;
     st.nsweeps += 1;
     psd_glog(P, st, 0, ifirst, ilast);
+    if (st.train_n > 1) {
+        for (int b = 1; b < st.train_n; ++b) psd_glog(P, st, 0, ifirst, ilast);
+        PSD_SYNC();
+        PSD_ONE {
+            for (int b = 1; b < st.train_n; ++b) {
+                psd_gstate cs = st;
+                cs.cursor = b;
+                cs.phase = PSD_GPH_CWAIT;
+                for (int q = 0; q < 4; ++q) cs.sh[q] = P.tshift[4 * b + q];
+                cs.kcur = 0;
+                cs.nsweeps = cs.nwindows = cs.nlog = 0;
+                cs.maxlog = 0;
+                for (int q = 0; q < 6; ++q) cs.cyc[q] = 0;
+                P.cst[b] = cs;
+            }
+        }
+        PSD_SYNC();
+    }
     return false;
 }
 
-PSD_KERNEL_B(PSD_STEP_NT) psd_gq_step(psd_gparams P) {
+PSD_D void psd_gq_step_body(const psd_gparams& P) {
     PSD_LDS_DECL;
     psd_gstate st = *P.st;
     if (st.phase == PSD_GPH_DONE) {
@@ -1410,6 +1598,19 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_gq_step(psd_gparams P) {
         } else if (st.phase == PSD_GPH_HESS) {
             psd_gq_hess_window(P, st, ldsd, red, lcnt);
             emitted = true;
+        } else if (st.phase == PSD_GPH_TWAIT) {  // the leader's sweep is done: wait for the cursors of the train
+            bool all = true;
+            for (int b = 1; b < st.train_n; ++b)
+                if (P.cst[b].phase != PSD_GPH_CDONE || P.cst[b].train_id != st.train_id) all = false;
+            if (all) {
+                for (int b = 1; b < st.train_n; ++b) {
+                    st.nwindows += P.cst[b].nwindows;
+                    st.nsweeps += 1;
+                }
+                st.train_n = 1;
+                st.phase = PSD_GPH_CHECK;  // (runs in the next launch, behind the cursors' last bulk updates)
+            }
+            emitted = true;
         } else {
             st.phase = PSD_GPH_DONE;
         }
@@ -1418,6 +1619,51 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_gq_step(psd_gparams P) {
     st.cyc[5] += psd_wallclock() - tw0;
     PSD_SYNC();
     PSD_ONE { *P.st = st; }
+}
+
+PSD_KERNEL_B(PSD_STEP_NT) psd_gq_step(psd_gparams P) { psd_gq_step_body(P); }
+
+// cursor b of a multishift train (see psd_rq_cursor_body): starts 2 b ticks behind the leader with its own shift pair
+PSD_D void psd_gq_cursor_body(const psd_gparams& P, int b) {
+    PSD_LDS_DECL;
+    PSD_ONE { P.desc->active = 0; P.desc->defer_run = 0; }
+    psd_gstate st = *P.st;
+    if (st.cursor != b) return;
+    if (st.phase != PSD_GPH_CWAIT && st.phase != PSD_GPH_SWEEP) return;
+    double* ldsd = (double*)psd_lds;
+    const size_t winb = (size_t)st.p * st.W * (st.W + 1);
+    int* lcnt = (int*)(ldsd + winb + PSD_NTHREADS) + 2 * PSD_NTHREADS;
+    if (st.phase == PSD_GPH_CWAIT) {
+        if (P.tick < st.train_tick0 + 2 * b) return;
+        double c1, s1, c2, s2;
+        if (!psd_gq_start_explicit(P, st.n, st.p, st.ifirst, st.sh, ldsd, c1, s1, c2, s2)) {
+            st.phase = PSD_GPH_CDONE;  // (not finite: this bulge is dropped)
+            PSD_SYNC();
+            PSD_ONE { *P.st = st; }
+            return;
+        }
+        st.c1 = c1; st.s1 = s1; st.c2 = c2; st.s2 = s2;
+        st.kcur = st.ifirst;
+        st.phase = PSD_GPH_SWEEP;
+    }
+    psd_gq_sweep_window(P, st, ldsd, lcnt);
+    PSD_SYNC();
+    PSD_ONE { *P.st = st; }
+}
+
+// all cursors of a tick in one launch, one workgroup each (as psd_rq_step_train)
+PSD_KERNEL_B(PSD_STEP_NT) psd_gq_step_train(psd_gparams P, int p, int cstride) {
+    const int b = PSD_BLOCK_X;
+    if (b == 0) {
+        psd_gq_step_body(P);
+        return;
+    }
+    psd_gparams Q = P;
+    Q.st = P.cst + b;
+    Q.desc = P.desc + b;
+    Q.cnt = P.cnt + (size_t)b * cstride;
+    Q.tr = P.tr + (size_t)b * p * PSD_GTR_CAP;
+    psd_gq_cursor_body(Q, b);
 }
 
 // Bulk application of one window's rotation lists, by factor: grid = (tiles, p factors, 3 roles).
@@ -1468,12 +1714,11 @@ PSD_D int psd_gtr_stage(const psd_gtr* gtr, int cnt, psd_gtr* ltr, int* flags) {
     return !flags[0] ? 1 : (!flags[1] ? -1 : 0);
 }
 
-PSD_KERNEL_B(PSD_GAPPLY_NT) psd_gq_apply(psd_gparams P, int n, int p) {
+PSD_D void psd_gq_apply_body(const psd_gparams& P, int n, int p, int role) {
     PSD_LDS_DECL;
     const psd_gapply_desc d = *P.desc;
     if (!d.active) return;
     const int l = PSD_BLOCK_Y + 1;
-    const int role = PSD_BLOCK_Z;
     const int own = (role == 0) ? psd_growner(P, l, p) : (role == 1) ? psd_gcowner(P, l, p) : l;
     const int cnt = P.cnt[own - 1] < PSD_GTR_CAP ? P.cnt[own - 1] : PSD_GTR_CAP;
     if (cnt <= 0) return;
@@ -1595,6 +1840,21 @@ PSD_KERNEL_B(PSD_GAPPLY_NT) psd_gq_apply(psd_gparams P, int n, int p) {
     }
 }
 
+PSD_KERNEL_B(PSD_GAPPLY_NT) psd_gq_apply(psd_gparams P, int n, int p) { psd_gq_apply_body(P, n, p, PSD_BLOCK_Z); }
+
+// bulk updates of all cursors of a tick (as psd_rq_apply_train): pass 0 = rows and Z roles (grid.z = 2 M), pass 1 =
+// columns role (grid.z = M)
+PSD_KERNEL_B(PSD_GAPPLY_NT) psd_gq_apply_train(psd_gparams P, int n, int p, int cstride, int pass) {
+    const int z = PSD_BLOCK_Z;
+    const int b = (pass == 0) ? (z >> 1) : z;
+    const int role = (pass == 0) ? ((z & 1) ? 2 : 0) : 1;
+    psd_gparams Q = P;
+    Q.desc = P.desc + b;
+    Q.cnt = P.cnt + (size_t)b * cstride;
+    Q.tr = P.tr + (size_t)b * p * PSD_GTR_CAP;
+    psd_gq_apply_body(Q, n, p, role);
+}
+
 // Deferred right side of H_1 after a zero-shift pass (rgeneralized.jl:312-320):
 // for j = djlo..djhi: rmul!(view(H1, drow0:(j+1), :), G_j').  One thread per row.
 PSD_KERNEL psd_gq_defer(psd_gparams P, int n) {
@@ -1620,7 +1880,7 @@ PSD_KERNEL psd_gq_defer(psd_gparams P, int n) {
 }
 
 PSD_KERNEL psd_gq_init(psd_gparams P, int n, int p, int wantT, int wantZ, int W, int maxitfac, int maxlog,
-                       int hessmode) {
+                       int hessmode, int train_want) {
     const psd_mat<double> H1 = psd_mat<double>{P.H, n};
     if (!hessmode) PSD_PAR_FOR(c, n) {
         for (int r = c + 3; r <= n; ++r) H1(r, c + 1) = 0.0;  // _gethess!
@@ -1640,6 +1900,9 @@ PSD_KERNEL psd_gq_init(psd_gparams P, int n, int p, int wantT, int wantZ, int W,
         st.nsweeps = st.nzshift = st.nsplit = st.ncase2 = st.ncase3 = st.n2real = st.n2cplx = 0;
         st.nwindows = st.nlog = 0; st.maxlog = maxlog; st.iwarn = 0; st.hj = 0;
         st.c1 = st.c2 = 1.0; st.s1 = st.s2 = 0.0;
+        st.train_want = hessmode ? 0 : train_want; st.train_n = 1; st.train_id = 0; st.cursor = 0; st.train_tick0 = 0;
+        st.ntrainsweeps = 0;
+        for (int q = 0; q < 4; ++q) st.sh[q] = 0.0;
         st.ulp = PSD_DBL_EPS;
         st.smlnum = PSD_DBL_MIN * ((double)n / PSD_DBL_EPS);
         for (int q = 0; q < 6; ++q) st.cyc[q] = 0;

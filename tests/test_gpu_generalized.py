@@ -58,6 +58,11 @@ def test_rg_full_sizes(gpu_engine):
                                        (33, 21, "L", "mix"), (150, 5, "R", "mix"), (128, 8, "L", "mix")])
 
 
+def test_rg_trains(gpu_engine):
+    ec.case_rg_trains(gpu_engine, [(120, 3, "R", "mix"), (150, 6, "L", "mix"), (128, 4, "R", "true"),
+                                   (256, 8, "R", "mix"), (200, 40, "L", "mix")])
+
+
 def test_rg_config4_full(gpu_engine):
     """BASELINE config 4: pschur!(A, S, :R), n = 256, p = 8, Float64, alternating signature, full matrices."""
     n, p = 256, 8

@@ -41,6 +41,10 @@ def test_rg_full_sizes(sim_engine):
     ec.case_rg_full_sizes(sim_engine, [(24, 3, "R", "mix"), (40, 6, "L", "mix"), (30, 4, "R", "true"), (33, 21, "L", "mix")])
 
 
+def test_rg_trains(sim_engine):
+    ec.case_rg_trains(sim_engine, [(120, 3, "R", "mix"), (150, 6, "L", "mix"), (128, 4, "R", "true")])
+
+
 # ---- complex signed path (csrc/psd_zgz.h) ----
 @pytest.mark.parametrize("p", [2, 3, 5])
 def test_zg_hess_ut(sim_engine, p):
