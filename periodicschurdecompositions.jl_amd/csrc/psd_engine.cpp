@@ -2091,15 +2091,15 @@ int sghess_dev(psd_ctx* c, int n, int p, double* dA, double* dQ, const uint8_t* 
                        (double*)nullptr);
             const int nL = (n - i + 3) / 4;   // columns i+1..n of A_l
             const int nR = (n + PSD_HESS_RS - 1) / PSD_HESS_RS;
-            PSD_LAUNCH(psd_hess_apply, psd_dim3(nL + (Ql ? nR : 0)), PSD_HESS_NT, lds_apply, c->stream, Al, Ql, n, i,
-                       i + 1, (const double*)c->vbuf, nL);
+            // one launch: A_l (+ Q_l) and the neighbour A_{l-1} (different matrices, same reflector)
+            const int g1 = nL + (Ql ? nR : 0);
+            const int nLm = (n + 3) / 4;
             if (mrows == 0) {
-                PSD_LAUNCH(psd_hess_apply, psd_dim3(nR), PSD_HESS_NT, lds_apply, c->stream, (double*)nullptr, Am, n, i,
-                           1, (const double*)c->vbuf, 0);
+                PSD_LAUNCH(psd_hess_apply2, psd_dim3(g1 + nR), PSD_HESS_NT, lds_apply, c->stream, Al, Ql, i + 1, nL, g1,
+                           (double*)nullptr, Am, 1, 0, n, i, (const double*)c->vbuf);
             } else {
-                const int nLm = (n + 3) / 4;
-                PSD_LAUNCH(psd_hess_apply, psd_dim3(nLm), PSD_HESS_NT, lds_apply, c->stream, Am, (double*)nullptr, n, i,
-                           1, (const double*)c->vbuf, nLm);
+                PSD_LAUNCH(psd_hess_apply2, psd_dim3(g1 + nLm), PSD_HESS_NT, lds_apply, c->stream, Al, Ql, i + 1, nL, g1, Am,
+                           (double*)nullptr, 1, nLm, n, i, (const double*)c->vbuf);
             }
         }
         PSD_LAUNCH(psd_tril_zero, psd_dim3(n), 256, 0, c->stream, Al, n);

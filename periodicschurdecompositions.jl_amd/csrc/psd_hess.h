@@ -193,6 +193,15 @@ PSD_KERNEL psd_hess_apply(double* AL, double* AR, int n, int r0, int lc0, const 
     psd_hess_apply_body(AL, AR, n, r0, lc0, vbuf, nL, PSD_BLOCK_X);
 }
 
+// two independent panel updates with the same reflector in one launch (stage 1 of the signed reduction: the factor
+// itself + its Q, and the neighbouring factor): blocks [0, g1) run the first operand set, the rest the second
+PSD_KERNEL psd_hess_apply2(double* AL1, double* AR1, int lc1, int nL1, int g1, double* AL2, double* AR2, int lc2, int nL2,
+                           int n, int r0, const double* vbuf) {
+    const int b = PSD_BLOCK_X;
+    if (b < g1) psd_hess_apply_body(AL1, AR1, n, r0, lc1, vbuf, nL1, b);
+    else psd_hess_apply_body(AL2, AR2, n, r0, lc2, vbuf, nL2, b - g1);
+}
+
 // Graph-replay form of one column of the reduction.  The reduction is n-1 columns x p links x 2 launches of small
 // kernels, and issuing them one by one leaves the GPU idle two thirds of the time (host launch rate).  The launch
 // sequence of ONE column is captured into a hipGraph whose kernels take everything that changes from column to
