@@ -75,7 +75,8 @@ int psd_get_train(psd_ctx* ctx);
  * take the eigenvalues of the trailing m x m block of the product as shifts) */
 int psd_set_train_z(psd_ctx* ctx, int bulges);
 int psd_get_train_z(psd_ctx* ctx);
-/* the real signed path psd_d_pschur(A, S) (double-shift sweeps of rgeneralized.jl:806-1054): trains with explicit shifts
+/* the signed paths psd_d_pschur(A, S) / psd_z_pschur(A, S) (double-shift sweeps of rgeneralized.jl:806-1054, single-shift
+ * sweeps of generalized.jl:808-852; the complex one takes the eigenvalues of the trailing m x m block of H_1 T): trains with explicit shifts
  * taken from the trailing 2m x 2m block of prod_{l>=2} H_l^{s_l} * H_1 (default 8; psd_set_train sets this path too,
  * PSD_TRAIN_G presets it alone).  psd_stats.maxits counts the sweeps that ran inside trains.  -2 (test hook): single
  * sweeps started from explicit shifts instead of the implicit _qzrots start. */

@@ -246,6 +246,31 @@ struct psd_ctx {
     unsigned char* zgS = nullptr;
     int* zgcnt = nullptr;
     size_t zgstep_lds_set = 0, zgostep_lds_set = 0, zghess_lds_set = 0;
+    // multishift trains of the complex signed engine (width: gtrain_m, as the real signed engine)
+    int zgtcap_p = 0;
+    psd_zgstate* zgtcst = nullptr;
+    psd_z* zgtshift = nullptr;
+    psd_gapply_desc* zgtdesc = nullptr;
+    int* zgtcnt = nullptr;
+    psd_ztr* zgttr = nullptr;
+    void zgtrelease() {
+        void* ptrs[] = {zgtcst, zgtshift, zgtdesc, zgtcnt, zgttr};
+        for (void* q : ptrs)
+            if (q) psd_rt_free(q);
+        zgtcst = nullptr; zgtshift = nullptr; zgtdesc = nullptr; zgtcnt = nullptr; zgttr = nullptr;
+        zgtcap_p = 0;
+    }
+    int zgtreserve(int p) {
+        if (zgtcst && p <= zgtcap_p) return 0;
+        zgtrelease();
+        PSD_CHECK(psd_rt_malloc((void**)&zgtcst, sizeof(psd_zgstate) * PSD_TRAIN_MAX));
+        PSD_CHECK(psd_rt_malloc((void**)&zgtshift, sizeof(psd_z) * (PSD_TRAIN_MAX + 2)));
+        PSD_CHECK(psd_rt_malloc((void**)&zgtdesc, sizeof(psd_gapply_desc) * PSD_TRAIN_MAX));
+        PSD_CHECK(psd_rt_malloc((void**)&zgtcnt, sizeof(int) * PSD_TRAIN_MAX * (size_t)(p + 8)));
+        PSD_CHECK(psd_rt_malloc((void**)&zgttr, sizeof(psd_ztr) * PSD_TRAIN_MAX * (size_t)p * PSD_GTR_CAP));
+        zgtcap_p = p;
+        return 0;
+    }
 
     void zgrelease() {
         void* ptrs[] = {zgst, zgdesc, zgtr, zgdG, zgS, zgcnt};
@@ -798,6 +823,7 @@ int psd_destroy(psd_ctx* c) {
     c->grelease();
     c->gtrelease();
     c->zgrelease();
+    c->zgtrelease();
     c->release();
     c->zrelease();
     c->rorelease();
@@ -1228,7 +1254,30 @@ int zgiterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
         c->zghess_lds_set = lds_hess;
     }
 #endif
-    PSD_LAUNCH(psd_zgq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, hessmode);
+    // multishift trains (as giterate_dev)
+    const int tw = hessmode ? 0 : c->gtrain_m;
+    const int M = (tw >= 2) ? ((tw > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : tw) : 1;
+    P.cst = nullptr;
+    P.tshift = nullptr;
+    P.tick = 0;
+    if (M > 1 || tw == -2) {
+        PSD_CHECK(c->zgtreserve(p));
+        PSD_CHECK(psd_rt_memset(c->zgtcst, 0, sizeof(psd_zgstate) * PSD_TRAIN_MAX, c->stream));
+        PSD_CHECK(psd_rt_memset(c->zgtdesc, 0, sizeof(psd_gapply_desc) * PSD_TRAIN_MAX, c->stream));
+        P.cst = c->zgtcst;
+        P.tshift = c->zgtshift;
+        if (M > 1) {
+            P.desc = c->zgtdesc;
+            P.cnt = c->zgtcnt;
+            P.tr = c->zgttr;
+#ifndef PSD_HOSTSIM
+            PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_zgq_step_train),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
+#endif
+        }
+    }
+    PSD_LAUNCH(psd_zgq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, hessmode,
+               (tw == -2) ? -2 : M);
     const size_t lds_apply = sizeof(psd_ztr) * PSD_GTR_CAP + (size_t)32 * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
     const int tiles = (n + PSD_ZAPPLY_NT - 1) / PSD_ZAPPLY_NT;
     const int dtiles = (n + 255) / 256;
@@ -1246,11 +1295,19 @@ int zgiterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
 #endif
     for (;;) {
         for (int b = 0; b < batch; ++b) {
+            P.tick = (int)launched;
             if (hess_pipe)
                 PSD_LAUNCH(psd_zgq_hess_step, psd_dim3(1), 64 * hess_waves, lds_hess, c->stream, P, hess_links);
+            else if (M > 1)
+                PSD_LAUNCH(psd_zgq_step_train, psd_dim3(M), PSD_STEP_NT, lds_step, c->stream, P, p, p + 8);
             else
                 PSD_LAUNCH(psd_zgq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
-            PSD_LAUNCH(psd_zgq_apply, psd_dim3(tiles, p, 3), PSD_ZAPPLY_NT, lds_apply, c->stream, P, n, p);
+            if (M > 1) {
+                PSD_LAUNCH(psd_zgq_apply_train, psd_dim3(tiles, p, 2 * M), PSD_ZAPPLY_NT, lds_apply, c->stream, P, n, p, p + 8, 0);
+                PSD_LAUNCH(psd_zgq_apply_train, psd_dim3(tiles, p, M), PSD_ZAPPLY_NT, lds_apply, c->stream, P, n, p, p + 8, 1);
+            } else {
+                PSD_LAUNCH(psd_zgq_apply, psd_dim3(tiles, p, 3), PSD_ZAPPLY_NT, lds_apply, c->stream, P, n, p);
+            }
             if (!hess_pipe) PSD_LAUNCH(psd_zgq_defer, psd_dim3(dtiles), 256, 0, c->stream, P, n);
             ++launched;
         }
@@ -1294,6 +1351,7 @@ int zgrun_iteration(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_
         stats->ndefl1 = st.nsplit;
         stats->ndefl2 = st.ncase2;
         stats->reserved = st.ncase2 + 1000 * st.ncase3;
+        stats->maxits = st.ntrainsweeps;  // (signed path: sweeps that ran inside multishift trains)
         stats->nwindows = st.nwindows;
         stats->nlog = st.nlog;
     }

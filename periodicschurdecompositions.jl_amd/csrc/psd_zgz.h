@@ -13,6 +13,7 @@
 // sweep with the signed shift chain (:770-852), phase normalisation with signature (:860-908).
 #pragma once
 #include "psd_rgz.h"
+#include "psd_zhqr.h"
 
 struct psd_zgstate {
     int n, p, wantT, wantZ, W;
@@ -24,6 +25,9 @@ struct psd_zgstate {
     psd_z s0;
     double smlnum, ulp, safmin;
     long long cyc[6];
+    // multishift train (as psd_gstate); -2: explicit-shift start without a train (test hook)
+    int train_want, train_n, train_id, cursor, train_tick0, ntrainsweeps;
+    psd_z sh;  // this bulge's shift
 };
 
 struct psd_zgparams {
@@ -39,6 +43,9 @@ struct psd_zgparams {
     double* beta;  // [n]
     int* ascale;   // [n]
     int* log;
+    psd_zgstate* cst;  // [PSD_TRAIN_MAX] cursor states of a train (entry 0 unused) or nullptr
+    psd_z* tshift;     // [PSD_TRAIN_MAX] shifts, then a flag word
+    int tick;          // launch index
 };
 
 PSD_HD psd_mat<psd_z> psd_zgfac(const psd_zgparams& P, int n, int l) {
@@ -373,7 +380,7 @@ PSD_D void psd_zgq_sweep_window(const psd_zgparams& P, psd_zgstate& st, psd_z* l
     psd_zgdesc_write(P, st, lcnt, w.bs, w.be, w.be + 1, ilastm, ifirstm, w.bs - 1, 0, 0, 0, 0);
     st.nwindows += 1;
     st.kcur = ke + 1;
-    if (ke >= ilast - 1) st.phase = PSD_GPH_CHECK;
+    if (ke >= ilast - 1) st.phase = (st.cursor > 0) ? PSD_GPH_CDONE : ((st.train_n > 1) ? PSD_GPH_TWAIT : PSD_GPH_CHECK);
 }
 
 // generalized.jl:356-448: one window of the controlled zero shift
@@ -647,7 +654,109 @@ PSD_D int psd_zgq_scan_diag(const psd_zgparams& P, const psd_zgstate& st, int* r
 }
 
 // generalized.jl:302-449,741-806
-PSD_D void psd_zgq_check(const psd_zgparams& P, psd_zgstate& st, int* redi) {
+// ------------------------------------------------------------------------------------------------
+// Explicit shifts for multishift trains of the signed single-shift sweep (see psd_rgz.h): the sweep is a similarity of
+// H_1 T in Z_1 space, T = prod_{l=2..p} H_l^{s_l} (upper triangular).
+// start rotation for the shift mu: first column of H_1 T - mu I, i.e. (H_1[f,f] - mu / T[f,f], H_1[f+1,f]); mu / T[f,f] by
+// successive divisions / multiplications.  false: not finite.
+PSD_D bool psd_zgq_start_rot_mu(const psd_zgparams& P, int n, int p, int ifirst, psd_z mu, double& c, psd_z& s) {
+    psd_z t = mu;
+    for (int l = p; l >= 2; --l) {
+        const psd_z d = psd_zgfac(P, n, l)(ifirst, ifirst);
+        if (psd_zgsig(P, l)) t = zdiv(t, d);
+        else t = zmul(t, d);
+    }
+    if (!(zabs1(t) < 1e300)) return false;  // (also false for NaN)
+    const psd_mat<psd_z> H1 = psd_zgfac(P, n, 1);
+    psd_z r;
+    psd_zgivens(zsub(H1(ifirst, ifirst), t), H1(ifirst + 1, ifirst), c, s, r);
+    return true;
+}
+
+// the m shifts of a train: eigenvalues of the trailing m x m block of H_1 T (exact: the blocks carry one extra leading
+// row / column for the subdiagonal term); inverted factors by back-substitution, one row per lane.  `work`: LDS,
+// psd_zgq_train_elems(p, m) complex elements; shifts to P.tshift, closest to the last diagonal entry first.
+PSD_HD size_t psd_zgq_train_elems(int p, int m) {
+    const size_t K1 = (size_t)m + 1;
+    return (size_t)p * K1 * K1 + 2 * K1 * K1 + (size_t)m * m + PSD_ZHQR_MAX + 8;
+}
+PSD_D void psd_zgq_train_shifts(const psd_zgparams& P, int n, int p, int ilast, int m, psd_z* work, int* okf) {
+    const int K = m, K1 = K + 1, t0 = ilast - K + 1, KK = K1 * K1;
+    psd_z* B = work;
+    psd_z* R0 = B + (size_t)p * KK;
+    psd_z* R1 = R0 + KK;
+    psd_z* T = R1 + KK;
+    psd_z* w = T + K * K;
+    PSD_SYNC();
+    PSD_PAR_FOR(t, p * KK) {
+        const int j = t / KK, q = t - j * KK, r = q / K1, c = q - r * K1;
+        B[t] = psd_zgfac(P, n, j + 1)(t0 - 1 + r, t0 - 1 + c);
+    }
+    PSD_PAR_FOR(q, KK) { R0[q] = (q / K1 == q % K1) ? zmk(1.0, 0.0) : zmk(0.0, 0.0); }
+    PSD_SYNC();
+    psd_z* cur = R0;
+    psd_z* nxt = R1;
+    for (int j = 2; j <= p; ++j) {
+        const psd_z* Bj = B + (size_t)(j - 1) * KK;
+        if (psd_zgsig(P, j)) {
+            PSD_PAR_FOR(q, KK) {
+                const int r = q / K1, c = q - r * K1;
+                psd_z acc = zmk(0.0, 0.0);
+                for (int k = r; k <= c; ++k) acc = zadd(acc, zmul(cur[r * K1 + k], Bj[k * K1 + c]));
+                nxt[q] = acc;
+            }
+        } else {  // X B_j = cur, row by row
+            PSD_PAR_FOR(r, K1) {
+                for (int c = 0; c < K1; ++c) {
+                    psd_z x = zmk(0.0, 0.0);
+                    if (c >= r) {
+                        x = cur[r * K1 + c];
+                        for (int k = r; k < c; ++k) x = zsub(x, zmul(nxt[r * K1 + k], Bj[k * K1 + c]));
+                        x = zdiv(x, Bj[c * K1 + c]);
+                    }
+                    nxt[r * K1 + c] = x;
+                }
+            }
+        }
+        PSD_SYNC();
+        psd_z* sw = cur;
+        cur = nxt;
+        nxt = sw;
+    }
+    PSD_PAR_FOR(q, K * K) {
+        const int r = q / K, c = q - r * K;
+        psd_z acc = zmk(0.0, 0.0);
+        for (int k = r; k <= c + 1; ++k) acc = zadd(acc, zmul(B[(r + 1) * K1 + k], cur[k * K1 + (c + 1)]));
+        T[q] = acc;
+    }
+    PSD_SYNC();
+    PSD_ONE {
+        bool ok = true;
+        for (int q = 0; q < K * K; ++q)
+            if (!(zabs1(T[q]) < 1e300)) ok = false;
+        const psd_z last = T[(K - 1) * K + (K - 1)];
+        ok = ok && psd_zhqr(T, K, K, w);
+        for (int a = 0; ok && a < K; ++a)
+            if (!(zabs1(w[a]) < 1e300)) ok = false;
+        if (ok) {
+            for (int a = 1; a < K; ++a) {
+                const psd_z x = w[a];
+                const double dx = zabs1(zsub(x, last));
+                int b = a - 1;
+                while (b >= 0 && zabs1(zsub(w[b], last)) > dx) {
+                    w[b + 1] = w[b];
+                    --b;
+                }
+                w[b + 1] = x;
+            }
+            for (int a = 0; a < K; ++a) P.tshift[a] = w[a];
+        }
+        *okf = ok ? 1 : 0;
+    }
+    PSD_SYNC();
+}
+
+PSD_D void psd_zgq_check(const psd_zgparams& P, psd_zgstate& st, int* redi, psd_z* work) {
     const int n = st.n, p = st.p;
     const int NT = PSD_NTHREADS;
     st.jiter += 1;
@@ -765,15 +874,59 @@ PSD_D void psd_zgq_check(const psd_zgparams& P, psd_zgstate& st, int* redi) {
         psd_zgivens(zsub(zscal(c, H1(ifirst, ifirst)), zmul(H1(ilast, ilast), zconj(s))),
                     zscal(c, H1(ifirst + 1, ifirst)), c, s, r);
     }
+    st.train_n = 1;
+    if ((st.train_want >= 2 || st.train_want == -2) && P.tshift != nullptr && st.iiter % 10 != 0) {
+        const int nb = st.W - 3, w = ilast - st.ifirst + 1;
+        int m = (st.train_want == -2) ? 1 : (1 + (w - nb) / (2 * nb));
+        if (m > st.train_want && st.train_want >= 2) m = st.train_want;
+        if (m > PSD_TRAIN_MAX) m = PSD_TRAIN_MAX;
+        if (m > PSD_ZHQR_MAX) m = PSD_ZHQR_MAX;
+        while (m >= 1 && psd_zgq_train_elems(p, m) > (size_t)p * st.W * (st.W + 1)) --m;
+        if ((m >= 2 || st.train_want == -2) && m >= 1 && m + 2 <= w) {
+            int* okf = (int*)(P.tshift + PSD_TRAIN_MAX);
+            psd_zgq_train_shifts(P, n, p, ilast, m, work, okf);
+            double cm;
+            psd_z sm;
+            if (*okf && psd_zgq_start_rot_mu(P, n, p, st.ifirst, P.tshift[0], cm, sm)) {
+                c = cm;
+                s = sm;
+                if (m >= 2) {
+                    st.train_n = m;
+                    st.train_tick0 = P.tick;
+                    st.train_id += 1;
+                    st.ntrainsweeps += m;
+                }
+            }
+            PSD_SYNC();
+        }
+    }
     st.c0 = c;
     st.s0 = s;
     st.phase = PSD_GPH_SWEEP;
     st.kcur = st.ifirst;
     st.nsweeps += 1;
     psd_zglog(P, st, 0, st.ifirst, ilast);
+    if (st.train_n > 1) {
+        for (int b = 1; b < st.train_n; ++b) psd_zglog(P, st, 0, st.ifirst, ilast);
+        PSD_SYNC();
+        PSD_ONE {
+            for (int b = 1; b < st.train_n; ++b) {
+                psd_zgstate cs = st;
+                cs.cursor = b;
+                cs.phase = PSD_GPH_CWAIT;
+                cs.sh = P.tshift[b];
+                cs.kcur = 0;
+                cs.nsweeps = cs.nwindows = cs.nlog = 0;
+                cs.maxlog = 0;
+                for (int q = 0; q < 6; ++q) cs.cyc[q] = 0;
+                P.cst[b] = cs;
+            }
+        }
+        PSD_SYNC();
+    }
 }
 
-PSD_KERNEL_B(PSD_STEP_NT) psd_zgq_step(psd_zgparams P) {
+PSD_D void psd_zgq_step_body(const psd_zgparams& P) {
     PSD_LDS_DECL;
     psd_zgstate st = *P.st;
     if (st.phase == PSD_GPH_DONE) {
@@ -794,7 +947,7 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_zgq_step(psd_zgparams P) {
         ++guard;
         if (st.phase == PSD_GPH_CHECK) {
             const int nc = st.ncase2 + st.ncase3;
-            psd_zgq_check(P, st, redi);
+            psd_zgq_check(P, st, redi, ldsz);
             if (st.ncase2 + st.ncase3 != nc) break;
         } else if (st.phase == PSD_GPH_SWEEP) {
             psd_zgq_sweep_window(P, st, ldsz, lcnt);
@@ -804,6 +957,19 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_zgq_step(psd_zgparams P) {
             emitted = true;
         } else if (st.phase == PSD_GPH_HESS) {
             psd_zgq_hess_window(P, st, ldsz, side, lcnt);
+            emitted = true;
+        } else if (st.phase == PSD_GPH_TWAIT) {  // the leader's sweep is done: wait for the cursors of the train
+            bool all = true;
+            for (int b = 1; b < st.train_n; ++b)
+                if (P.cst[b].phase != PSD_GPH_CDONE || P.cst[b].train_id != st.train_id) all = false;
+            if (all) {
+                for (int b = 1; b < st.train_n; ++b) {
+                    st.nwindows += P.cst[b].nwindows;
+                    st.nsweeps += 1;
+                }
+                st.train_n = 1;
+                st.phase = PSD_GPH_CHECK;  // (runs in the next launch, behind the cursors' last bulk updates)
+            }
             emitted = true;
         } else {
             st.phase = PSD_GPH_DONE;
@@ -815,13 +981,59 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_zgq_step(psd_zgparams P) {
     PSD_ONE { *P.st = st; }
 }
 
+PSD_KERNEL_B(PSD_STEP_NT) psd_zgq_step(psd_zgparams P) { psd_zgq_step_body(P); }
+
+// cursor b of a multishift train (see psd_gq_cursor_body)
+PSD_D void psd_zgq_cursor_body(const psd_zgparams& P, int b) {
+    PSD_LDS_DECL;
+    PSD_ONE { P.desc->active = 0; P.desc->defer_run = 0; }
+    psd_zgstate st = *P.st;
+    if (st.cursor != b) return;
+    if (st.phase != PSD_GPH_CWAIT && st.phase != PSD_GPH_SWEEP) return;
+    const int NT = PSD_NTHREADS;
+    psd_z* ldsz = (psd_z*)psd_lds;
+    const size_t winb = (size_t)st.p * st.W * (st.W + 1);
+    int* lcnt = (int*)((double*)(ldsz + winb) + NT) + 2 * NT;
+    if (st.phase == PSD_GPH_CWAIT) {
+        if (P.tick < st.train_tick0 + 2 * b) return;
+        double c;
+        psd_z s;
+        if (!psd_zgq_start_rot_mu(P, st.n, st.p, st.ifirst, st.sh, c, s)) {
+            st.phase = PSD_GPH_CDONE;  // (not finite: this bulge is dropped)
+            PSD_SYNC();
+            PSD_ONE { *P.st = st; }
+            return;
+        }
+        st.c0 = c;
+        st.s0 = s;
+        st.kcur = st.ifirst;
+        st.phase = PSD_GPH_SWEEP;
+    }
+    psd_zgq_sweep_window(P, st, ldsz, lcnt);
+    PSD_SYNC();
+    PSD_ONE { *P.st = st; }
+}
+
+PSD_KERNEL_B(PSD_STEP_NT) psd_zgq_step_train(psd_zgparams P, int p, int cstride) {
+    const int b = PSD_BLOCK_X;
+    if (b == 0) {
+        psd_zgq_step_body(P);
+        return;
+    }
+    psd_zgparams Q = P;
+    Q.st = P.cst + b;
+    Q.desc = P.desc + b;
+    Q.cnt = P.cnt + (size_t)b * cstride;
+    Q.tr = P.tr + (size_t)b * p * PSD_GTR_CAP;
+    psd_zgq_cursor_body(Q, b);
+}
+
 // Bulk application of one window's rotation lists, by factor: grid = (tiles, p factors, 3 roles); tiles 64 wide
-PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zgq_apply(psd_zgparams P, int n, int p) {
+PSD_D void psd_zgq_apply_body(const psd_zgparams& P, int n, int p, int role) {
     PSD_LDS_DECL;
     const psd_gapply_desc d = *P.desc;
     if (!d.active) return;
     const int l = PSD_BLOCK_Y + 1;
-    const int role = PSD_BLOCK_Z;
     const int own = (role == 0) ? psd_zgrowner(P, l, p) : (role == 1) ? psd_zgcowner(P, l, p) : l;
     const int cnt = P.cnt[own - 1] < PSD_GTR_CAP ? P.cnt[own - 1] : PSD_GTR_CAP;
     if (cnt <= 0) return;
@@ -900,6 +1112,20 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zgq_apply(psd_zgparams P, int n, int p) {
     }
 }
 
+PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zgq_apply(psd_zgparams P, int n, int p) { psd_zgq_apply_body(P, n, p, PSD_BLOCK_Z); }
+
+// bulk updates of all cursors of a tick: pass 0 = rows and Z roles (grid.z = 2 M), pass 1 = columns role (grid.z = M)
+PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zgq_apply_train(psd_zgparams P, int n, int p, int cstride, int pass) {
+    const int z = PSD_BLOCK_Z;
+    const int b = (pass == 0) ? (z >> 1) : z;
+    const int role = (pass == 0) ? ((z & 1) ? 2 : 0) : 1;
+    psd_zgparams Q = P;
+    Q.desc = P.desc + b;
+    Q.cnt = P.cnt + (size_t)b * cstride;
+    Q.tr = P.tr + (size_t)b * p * PSD_GTR_CAP;
+    psd_zgq_apply_body(Q, n, p, role);
+}
+
 // Deferred right side of H_1 after a zero-shift pass (generalized.jl:436-444)
 PSD_KERNEL psd_zgq_defer(psd_zgparams P, int n) {
     const psd_gapply_desc d = *P.desc;
@@ -925,7 +1151,7 @@ PSD_KERNEL psd_zgq_defer(psd_zgparams P, int n) {
 }
 
 PSD_KERNEL psd_zgq_init(psd_zgparams P, int n, int p, int wantT, int wantZ, int W, int maxitfac, int maxlog,
-                        int hessmode) {
+                        int hessmode, int train_want) {
     const psd_mat<psd_z> H1 = psd_mat<psd_z>{P.H, n};
     if (!hessmode) PSD_PAR_FOR(c, n) {
         for (int r = c + 3; r <= n; ++r) H1(r, c + 1) = zmk(0.0, 0.0);  // _gethess!
@@ -941,6 +1167,8 @@ PSD_KERNEL psd_zgq_init(psd_zgparams P, int n, int p, int wantT, int wantZ, int 
         st.nsweeps = st.nzshift = st.nsplit = st.ncase2 = st.ncase3 = st.nwindows = st.nlog = 0;
         st.maxlog = maxlog;
         st.c0 = 1.0; st.s0 = zmk(0.0, 0.0);
+        st.train_want = hessmode ? 0 : train_want; st.train_n = 1; st.train_id = 0; st.cursor = 0; st.train_tick0 = 0;
+        st.ntrainsweeps = 0; st.sh = zmk(0.0, 0.0);
         st.ulp = PSD_DBL_EPS;
         st.safmin = PSD_DBL_MIN;
         st.smlnum = PSD_DBL_MIN * ((double)n / PSD_DBL_EPS);

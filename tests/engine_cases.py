@@ -718,6 +718,32 @@ def case_rg_trains(eng, sizes):
         eng.set_train_g(m0)
 
 
+# complex signed path: multishift trains (width shared with the real signed path, psd_set_train_g)
+def case_zg_trains(eng, sizes):
+    m0 = eng.get_train_g()
+    try:
+        for (n, p, lr) in sizes:
+            S = [bool((q * 7 + n) % 3) for q in range(p)]
+            S[p - 1 if lr == "L" else 0] = True
+            A = pt.bench_factors(n, p, seed=600 + n + p, dtype=np.complex128)
+            eng.set_train_g(0)
+            ref = eng.pschur_([a.copy(order="F") for a in A], lr, S=S)
+            assert ref.stats.maxits == 0
+            fin = np.isfinite(ref.values)
+            scale = max(1.0, abs(ref.values[fin]).max())
+            for m in (-2, 2, 6):  # -2: explicit-shift start without a train
+                eng.set_train_g(m)
+                ps = eng.pschur_([a.copy(order="F") for a in A], lr, S=S)
+                if m >= 2:
+                    assert ps.stats.maxits > 0, (n, p, lr, m, "no train ran")
+                pt.gpschur_check(A, S, ps, tol=100 * max(1.0, n / 32))
+                assert pt.match_eigs(ref.values[fin], ps.values[np.isfinite(ps.values)]) < 1e-8 * scale, (n, p, lr, m)
+                p0 = eng.pschur_([a.copy(order="F") for a in A], lr, S=S, wantT=False, wantZ=False)
+                assert pt.match_eigs(ref.values[fin], p0.values[np.isfinite(p0.values)]) < 1e-8 * scale, (n, p, lr, m)
+    finally:
+        eng.set_train_g(m0)
+
+
 # ---- complex generalized (signed) path: generalized.jl with S containing false; test/generalized.jl complex parts ----
 def _zg_run(eng, A, S, tol=100, **kw):
     ps = eng.zpschur_hess_(A[0].copy(order="F"), [a.copy(order="F") for a in A[1:]], S, **kw)

@@ -126,3 +126,7 @@ def test_gpschur_pairs(gpu_engine):
 
 def test_hess_pipeline_vs_serial(gpu_engine):
     ec.case_hess_pipeline_vs_serial(gpu_engine)
+
+
+def test_zg_trains(gpu_engine):
+    ec.case_zg_trains(gpu_engine, [(100, 3, "R"), (120, 6, "L"), (256, 8, "R"), (200, 40, "L")])

@@ -94,3 +94,7 @@ def test_gpschur_pairs(sim_engine):
 
 def test_hess_pipeline_vs_serial(sim_engine):
     ec.case_hess_pipeline_vs_serial(sim_engine)
+
+
+def test_zg_trains(sim_engine):
+    ec.case_zg_trains(sim_engine, [(100, 3, "R"), (120, 6, "L")])
