@@ -1388,15 +1388,15 @@ int zsghess_dev(psd_ctx* c, int n, int p, psd_z* dA, psd_z* dQ, const uint8_t* S
             PSD_LAUNCH(psd_zhess_refl, psd_dim3(1), PSD_HESS_NT, lds_refl, c->stream, Al, n, i, i, c->zvbuf, (psd_z*)nullptr);
             const int nL = (n - i + 3) / 4;
             const int nR = (n + PSD_HESS_RS - 1) / PSD_HESS_RS;
-            PSD_LAUNCH(psd_zhess_apply, psd_dim3(nL + (Ql ? nR : 0)), PSD_HESS_NT, lds_apply, c->stream, Al, Ql, n, i,
-                       i + 1, (const psd_z*)c->zvbuf, nL);
+            // one launch: A_l (+ Q_l) and the neighbour A_{l-1} (see sghess_dev)
+            const int g1 = nL + (Ql ? nR : 0);
+            const int nLm = (n + 3) / 4;
             if (mrows == 0) {
-                PSD_LAUNCH(psd_zhess_apply, psd_dim3(nR), PSD_HESS_NT, lds_apply, c->stream, (psd_z*)nullptr, Am, n, i, 1,
-                           (const psd_z*)c->zvbuf, 0);
+                PSD_LAUNCH(psd_zhess_apply2, psd_dim3(g1 + nR), PSD_HESS_NT, lds_apply, c->stream, Al, Ql, i + 1, nL, g1,
+                           (psd_z*)nullptr, Am, 1, 0, n, i, (const psd_z*)c->zvbuf);
             } else {
-                const int nLm = (n + 3) / 4;
-                PSD_LAUNCH(psd_zhess_apply, psd_dim3(nLm), PSD_HESS_NT, lds_apply, c->stream, Am, (psd_z*)nullptr, n, i, 1,
-                           (const psd_z*)c->zvbuf, nLm);
+                PSD_LAUNCH(psd_zhess_apply2, psd_dim3(g1 + nLm), PSD_HESS_NT, lds_apply, c->stream, Al, Ql, i + 1, nL, g1, Am,
+                           (psd_z*)nullptr, 1, nLm, n, i, (const psd_z*)c->zvbuf);
             }
         }
         PSD_LAUNCH(psd_ztril_zero, psd_dim3(n), 256, 0, c->stream, Al, n);

@@ -85,7 +85,7 @@ PSD_KERNEL psd_zhess_refl(psd_z* A, int n, int r0, int c, psd_z* vbuf, psd_z* ta
 }
 
 // blocks [0,nL): AL[r0:n, lc0:n] <- H' AL ; blocks [nL,..): AR[:, r0:n] <- AR H
-PSD_KERNEL psd_zhess_apply(psd_z* AL, psd_z* AR, int n, int r0, int lc0, const psd_z* vbuf, int nL) {
+PSD_D void psd_zhess_apply_body(psd_z* AL, psd_z* AR, int n, int r0, int lc0, const psd_z* vbuf, int nL, int b) {
     PSD_LDS_DECL;
     const int NT = PSD_NTHREADS;  // 256
     const int m = n - r0 + 1;
@@ -93,7 +93,6 @@ PSD_KERNEL psd_zhess_apply(psd_z* AL, psd_z* AR, int n, int r0, int lc0, const p
     if (ziszero(tau)) return;
     psd_z* red = (psd_z*)psd_lds;  // NT
     psd_z* vs = red + NT;          // m
-    const int b = PSD_BLOCK_X;
     if (b < nL) {
         if (!AL) return;
         const psd_mat<psd_z> M = psd_mat<psd_z>{AL, n};
@@ -157,6 +156,17 @@ PSD_KERNEL psd_zhess_apply(psd_z* AL, psd_z* AR, int n, int r0, int lc0, const p
             }
         }
     }
+}
+
+PSD_KERNEL psd_zhess_apply(psd_z* AL, psd_z* AR, int n, int r0, int lc0, const psd_z* vbuf, int nL) {
+    psd_zhess_apply_body(AL, AR, n, r0, lc0, vbuf, nL, PSD_BLOCK_X);
+}
+// two independent panel updates with the same reflector in one launch (see psd_hess_apply2)
+PSD_KERNEL psd_zhess_apply2(psd_z* AL1, psd_z* AR1, int lc1, int nL1, int g1, psd_z* AL2, psd_z* AR2, int lc2, int nL2, int n,
+                            int r0, const psd_z* vbuf) {
+    const int b = PSD_BLOCK_X;
+    if (b < g1) psd_zhess_apply_body(AL1, AR1, n, r0, lc1, vbuf, nL1, b);
+    else psd_zhess_apply_body(AL2, AR2, n, r0, lc2, vbuf, nL2, b - g1);
 }
 
 PSD_KERNEL psd_zset_identity(psd_z* Q, int n) {
