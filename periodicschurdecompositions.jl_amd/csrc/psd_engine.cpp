@@ -632,7 +632,9 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
 #endif
     }
-    PSD_LAUNCH(psd_rq_init, psd_dim3(p), 256, 256 * 8, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, M);
+    int train_oc = 104;
+    if (const char* e = getenv("PSD_TRAIN_OC")) train_oc = atoi(e);  // (tuning hook)
+    PSD_LAUNCH(psd_rq_init, psd_dim3(p), 256, 256 * 8, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, M, train_oc);
     const size_t lds_apply = apply_lds_bytes();
     const int tiles = (n + PSD_APPLY_NT - 1) / PSD_APPLY_NT;
     const int batch = 32;
@@ -640,7 +642,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     memset(&hst, 0, sizeof(hst));
     long long launched = 0;
     // every window advances the chase by >= 1 position; generous cap against a runaway loop
-    const long long cap = (long long)maxitfac * n * ((long long)n / (W - 4) + 4) + 4LL * n + 1024;
+    const long long cap = (long long)maxitfac * n * ((long long)n / 8 + 4) + 4LL * n + 1024;  // (trains run windows down to 8 positions)
     double sample_ms = 0.0;
     int samples = 0;
 #ifndef PSD_HOSTSIM
@@ -1086,7 +1088,9 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
 #endif
     }
-    PSD_LAUNCH(psd_zq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, M);
+    int train_oc = 100;
+    if (const char* e = getenv("PSD_TRAIN_OC")) train_oc = atoi(e);  // (tuning hook)
+    PSD_LAUNCH(psd_zq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, M, train_oc);
     const size_t lds_apply = PSD_ZTR_LDS_BYTES + (size_t)32 * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
     const int tiles = (n + PSD_ZAPPLY_NT - 1) / PSD_ZAPPLY_NT;
     const int dtiles = (n + 255) / 256;
@@ -1094,7 +1098,7 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
     psd_zstate hst;
     memset(&hst, 0, sizeof(hst));
     long long launched = 0;
-    const int nbmin = (W - 3 > 0) ? (W - 3) : 1;
+    const int nbmin = (W - 3 > 0) ? ((W - 3 < 8) ? (W - 3) : 8) : 1;  // (trains run windows down to 8 positions)
     const long long cap = (long long)maxitfac * n * ((long long)n / nbmin + 4) + 4LL * n + 1024;
     double sample_ms = 0.0;
     int samples = 0;
@@ -1276,8 +1280,10 @@ int zgiterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
 #endif
         }
     }
+    int train_oc = 50;
+    if (const char* e = getenv("PSD_TRAIN_OC")) train_oc = atoi(e);  // (tuning hook)
     PSD_LAUNCH(psd_zgq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, hessmode,
-               (tw == -2) ? -2 : M);
+               (tw == -2) ? -2 : M, train_oc);
     const size_t lds_apply = sizeof(psd_ztr) * PSD_GTR_CAP + (size_t)32 * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
     const int tiles = (n + PSD_ZAPPLY_NT - 1) / PSD_ZAPPLY_NT;
     const int dtiles = (n + 255) / 256;
@@ -1285,7 +1291,7 @@ int zgiterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
     psd_zgstate hst;
     memset(&hst, 0, sizeof(hst));
     long long launched = 0;
-    const int nbmin = (W - 3 > 0) ? (W - 3) : 1;
+    const int nbmin = (W - 3 > 0) ? ((W - 3 < 8) ? (W - 3) : 8) : 1;  // (trains run windows down to 8 positions)
     const long long cap = (long long)maxitfac * n * ((long long)n / nbmin + 8) + 8LL * n + 1024 + (hessmode ? (long long)n * n : 0);
 #ifndef PSD_HOSTSIM
     double sample_ms = 0.0;
@@ -1996,8 +2002,10 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
 #endif
         }
     }
+    int train_oc = 50;  // (a position of a signed factor costs about 1 us, a tick's overhead about 50 us)
+    if (const char* e = getenv("PSD_TRAIN_OC")) train_oc = atoi(e);  // (tuning hook)
     PSD_LAUNCH(psd_gq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, hessmode,
-               (tw == -2) ? -2 : M);
+               (tw == -2) ? -2 : M, train_oc);
     const size_t lds_apply = PSD_GTR_LDS_BYTES + (size_t)32 * (PSD_GAPPLY_NT + 1) * sizeof(double);
     const int tiles = (n + PSD_GAPPLY_NT - 1) / PSD_GAPPLY_NT;
     const int dtiles = (n + 255) / 256;
@@ -2005,7 +2013,7 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
     psd_gstate hst;
     memset(&hst, 0, sizeof(hst));
     long long launched = 0;
-    const int nbmin = (W - 5 > 0) ? (W - 5) : 1;
+    const int nbmin = (W - 5 > 0) ? ((W - 5 < 8) ? (W - 5) : 8) : 1;  // (trains run windows down to 8 positions)
     const long long cap = (long long)maxitfac * n * ((long long)n / nbmin + 8) + 8LL * n + 1024 + (hessmode ? (long long)n * n : 0);
     double sample_ms = 0.0;
     int samples = 0;

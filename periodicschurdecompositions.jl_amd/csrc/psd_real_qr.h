@@ -80,7 +80,9 @@ struct psd_apply_desc {
 };
 
 struct psd_rstate {
-    int n, p, wantT, wantZ, W;
+    int n, p, wantT, wantZ, W;  // W: window width of the running sweep (<= Wmax, the width the LDS is laid out for)
+    int Wmax;
+    int train_oc;  // o / c of the window-width rule in psd_rq_shift
     int phase, info;
     int i, l, its, maxitleft;
     int i1, i2;
@@ -630,16 +632,34 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work) {
         // multishift train: m bulges if the active block leaves room for cursors two windows apart
         st.train_n = 1;
         if (st.train_want >= 2 && P.cst != nullptr) {
-            const int nb = st.W - 4, w = i - l + 1;
-            int m = 1 + (w - nb) / (2 * nb);
-            if (m > st.train_want) m = st.train_want;
-            if (m > PSD_TRAIN_MAX) m = PSD_TRAIN_MAX;
-            if (2 * m > PSD_HQR_MAX) m = PSD_HQR_MAX / 2;
-            while (m >= 2 && psd_rq_train_doubles(st.p, m) > (size_t)st.p * st.W * (st.W + 1)) --m;  // LDS of the staging
+            // Window width of this train: nb positions per window cost a tick of about nb p c + o (c: one position of one
+            // factor, o: launches, window transfer and bulk updates of a tick; o / c = train_oc, about 104), a train of m
+            // cursors two windows apart takes w / nb + 2 (m - 1) ticks, and m is limited by the room, m <= 1 + (w - nb) /
+            // (2 nb).  The width with the least modelled time per sweep is taken (narrow windows: more, cheaper ticks and
+            // more cursors).
+            const int w = i - l + 1;
+            int mt = st.train_want;
+            if (mt > PSD_TRAIN_MAX) mt = PSD_TRAIN_MAX;
+            if (2 * mt > PSD_HQR_MAX) mt = PSD_HQR_MAX / 2;
+            int nb = st.Wmax - 4, m = 1;
+            double best = 1e300;
+            for (int nbc = (st.Wmax - 4 < 8) ? ((st.Wmax > 5) ? st.Wmax - 4 : 1) : 8; nbc <= st.Wmax - 4; ++nbc) {
+                int mc = 1 + (w - nbc) / (2 * nbc);
+                if (mc > mt) mc = mt;
+                if (mc < 2) break;
+                const double cost = (double)((w + nbc - 1) / nbc + 2 * (mc - 1)) * (double)(nbc * st.p + st.train_oc) / mc;
+                if (cost < best) {
+                    best = cost;
+                    nb = nbc;
+                    m = mc;
+                }
+            }
+            while (m >= 2 && psd_rq_train_doubles(st.p, m) > (size_t)st.p * st.Wmax * (st.Wmax + 1)) --m;  // LDS of the staging
             if (m >= 2 && 2 * m + 2 <= w) {
                 int* okf = (int*)P.tshift + 8 * PSD_TRAIN_MAX;  // (flag word behind the pairs)
                 psd_rq_train_shifts(P, n, st.p, i, m, work, okf);
                 if (*okf) {
+                    st.W = nb + 4;
                     st.train_n = m;
                     st.train_tick0 = P.tick;
                     st.train_id += 1;
@@ -1275,7 +1295,7 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
     }
     const int NT = PSD_NTHREADS;
     double* ldsd = (double*)psd_lds;
-    const size_t winb = (size_t)st.p * st.W * (st.W + 1);
+    const size_t winb = (size_t)st.p * st.Wmax * (st.Wmax + 1);
     double* red = ldsd + winb;
     int* redi = (int*)(red + NT);
     int* lcnt = redi + 2 * NT;
@@ -1317,6 +1337,7 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
                         st.its += 1;
                     }
                     st.train_n = 1;
+                    st.W = st.Wmax;
                     st.phase = PSD_PH_DECIDE;
                     emitted = true;  // (the decision runs in the next launch: the cursors' last bulk updates are
                                      //  ordered before it by the tick barrier of the driver)
@@ -1368,7 +1389,7 @@ PSD_D void psd_rq_cursor_body(const psd_rparams& P, int b) {
     if (st.cursor != b) return;
     if (st.phase != PSD_PH_CWAIT && st.phase != PSD_PH_QR) return;
     double* ldsd = (double*)psd_lds;
-    const size_t winb = (size_t)st.p * st.W * (st.W + 1);
+    const size_t winb = (size_t)st.p * st.Wmax * (st.Wmax + 1);
     int* lcnt = (int*)(ldsd + winb + PSD_STEP_NT) + 2 * PSD_STEP_NT;
     if (st.phase == PSD_PH_CWAIT) {
         // Cursor b chases its first window exactly 2 b ticks after the leader's: consecutive windows of a sweep overlap
@@ -1601,7 +1622,7 @@ PSD_KERNEL_B(PSD_APPLY_NT) psd_rq_apply_train(psd_rparams P, int n, int p, int c
 // hnorms[j] = ulp*n*opnorm(H_j, 1), column-1 / sub-Hessenberg clean-up (PSD.jl:379-388,406), and
 // state initialisation.  grid = p blocks.
 PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W, int maxitfac, int maxlog,
-                       int train_want) {
+                       int train_want, int train_oc) {
     PSD_LDS_DECL;
     double* red = (double*)psd_lds;
     const int j = PSD_BLOCK_X + 1;
@@ -1614,7 +1635,7 @@ PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W,
         }
         PSD_ONE {
             psd_rstate st;
-            st.n = n; st.p = p; st.wantT = wantT; st.wantZ = wantZ; st.W = W;
+            st.n = n; st.p = p; st.wantT = wantT; st.wantZ = wantZ; st.W = st.Wmax = W; st.train_oc = train_oc;
             st.phase = PSD_PH_DECIDE; st.info = 0;
             st.i = n; st.l = 1; st.its = 1; st.maxitleft = maxitfac * n;
             st.i1 = 1; st.i2 = n; st.kcur = 0; st.maxits = 0; st.niter = 0;

@@ -58,6 +58,7 @@ struct psd_gstate {
     // multishift train (as psd_rstate): bulges wanted (-2: explicit-shift start without a train, test hook) / in the
     // running train / train number / this state's cursor / tick of the leader's first window / sweeps in trains
     int train_want, train_n, train_id, cursor, train_tick0, ntrainsweeps;
+    int Wmax, train_oc;  // LDS layout width (W is the running sweep's, <= Wmax); o / c of the width rule (psd_rq_shift)
     double sh[4];  // this bulge's shift pair: rt1r, rt1i, rt2r, rt2i
 };
 
@@ -1517,12 +1518,25 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
     psd_g_qzrots(P, n, p, ifirst, ilast - ifirst + 1, st.c1, st.s1, st.c2, st.s2);
     st.train_n = 1;
     if ((st.train_want >= 2 || st.train_want == -2) && P.tshift != nullptr && ilast - ifirst + 1 >= 4) {
-        const int nb = st.W - 4, w = ilast - ifirst + 1;
-        int m = (st.train_want == -2) ? 1 : (1 + (w - nb) / (2 * nb));
-        if (m > st.train_want && st.train_want >= 2) m = st.train_want;
-        if (m > PSD_TRAIN_MAX) m = PSD_TRAIN_MAX;
-        if (2 * m > PSD_HQR_MAX) m = PSD_HQR_MAX / 2;
-        while (m >= 1 && psd_gq_train_doubles(p, m) > (size_t)p * st.W * (st.W + 1)) --m;
+        // window width of the train by the cost model of psd_rq_shift
+        const int w = ilast - ifirst + 1;
+        int mt = (st.train_want == -2) ? 1 : st.train_want;
+        if (mt > PSD_TRAIN_MAX) mt = PSD_TRAIN_MAX;
+        if (2 * mt > PSD_HQR_MAX) mt = PSD_HQR_MAX / 2;
+        int nb = st.Wmax - 4, m = 1;
+        double best = 1e300;
+        for (int nbc = (st.Wmax - 4 < 8) ? ((st.Wmax > 5) ? st.Wmax - 4 : 1) : 8; nbc <= st.Wmax - 4 && mt >= 2; ++nbc) {
+            int mc = 1 + (w - nbc) / (2 * nbc);
+            if (mc > mt) mc = mt;
+            if (mc < 2) break;
+            const double cost = (double)((w + nbc - 1) / nbc + 2 * (mc - 1)) * (double)(nbc * p + st.train_oc) / mc;
+            if (cost < best) {
+                best = cost;
+                nb = nbc;
+                m = mc;
+            }
+        }
+        while (m >= 1 && psd_gq_train_doubles(p, m) > (size_t)p * st.Wmax * (st.Wmax + 1)) --m;
         if ((m >= 2 || st.train_want == -2) && m >= 1 && 2 * m + 2 <= w) {
             int* okf = (int*)P.tshift + 8 * PSD_TRAIN_MAX;
             psd_gq_train_shifts(P, n, p, ilast, m, ldsd, okf);
@@ -1530,6 +1544,7 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
             if (*okf && psd_gq_start_explicit(P, n, p, ifirst, P.tshift, ldsd, e1, f1, e2, f2)) {
                 st.c1 = e1; st.s1 = f1; st.c2 = e2; st.s2 = f2;
                 if (m >= 2) {
+                    st.W = nb + 4;
                     st.train_n = m;
                     st.train_tick0 = P.tick;
                     st.train_id += 1;
@@ -1573,7 +1588,7 @@ PSD_D void psd_gq_step_body(const psd_gparams& P) {
     }
     const int NT = PSD_NTHREADS;
     double* ldsd = (double*)psd_lds;
-    const size_t winb = (size_t)st.p * st.W * (st.W + 1);
+    const size_t winb = (size_t)st.p * st.Wmax * (st.Wmax + 1);
     double* red = ldsd + winb;
     int* redi = (int*)(red + NT);
     int* lcnt = redi + 2 * NT;
@@ -1608,6 +1623,7 @@ PSD_D void psd_gq_step_body(const psd_gparams& P) {
                     st.nsweeps += 1;
                 }
                 st.train_n = 1;
+                st.W = st.Wmax;
                 st.phase = PSD_GPH_CHECK;  // (runs in the next launch, behind the cursors' last bulk updates)
             }
             emitted = true;
@@ -1631,7 +1647,7 @@ PSD_D void psd_gq_cursor_body(const psd_gparams& P, int b) {
     if (st.cursor != b) return;
     if (st.phase != PSD_GPH_CWAIT && st.phase != PSD_GPH_SWEEP) return;
     double* ldsd = (double*)psd_lds;
-    const size_t winb = (size_t)st.p * st.W * (st.W + 1);
+    const size_t winb = (size_t)st.p * st.Wmax * (st.Wmax + 1);
     int* lcnt = (int*)(ldsd + winb + PSD_NTHREADS) + 2 * PSD_NTHREADS;
     if (st.phase == PSD_GPH_CWAIT) {
         if (P.tick < st.train_tick0 + 2 * b) return;
@@ -1880,7 +1896,7 @@ PSD_KERNEL psd_gq_defer(psd_gparams P, int n) {
 }
 
 PSD_KERNEL psd_gq_init(psd_gparams P, int n, int p, int wantT, int wantZ, int W, int maxitfac, int maxlog,
-                       int hessmode, int train_want) {
+                       int hessmode, int train_want, int train_oc) {
     const psd_mat<double> H1 = psd_mat<double>{P.H, n};
     if (!hessmode) PSD_PAR_FOR(c, n) {
         for (int r = c + 3; r <= n; ++r) H1(r, c + 1) = 0.0;  // _gethess!
@@ -1891,7 +1907,7 @@ PSD_KERNEL psd_gq_init(psd_gparams P, int n, int p, int wantT, int wantZ, int W,
     }
     PSD_ONE {
         psd_gstate st;
-        st.n = n; st.p = p; st.wantT = wantT; st.wantZ = wantZ; st.W = W;
+        st.n = n; st.p = p; st.wantT = wantT; st.wantZ = wantZ; st.W = st.Wmax = W; st.train_oc = train_oc;
         st.phase = PSD_GPH_CHECK; st.info = 0;
         st.ilast = n; st.ifirst = 1; st.ifirstm = 1; st.ilastm = n;
         st.ziter = (p >= 20) ? -1 : 0;  // :107: p >= log2(floatmin)/log2(eps) = 19.65

@@ -27,6 +27,7 @@ struct psd_zgstate {
     long long cyc[6];
     // multishift train (as psd_gstate); -2: explicit-shift start without a train (test hook)
     int train_want, train_n, train_id, cursor, train_tick0, ntrainsweeps;
+    int Wmax, train_oc;  // LDS layout width (W is the running sweep's, <= Wmax); o / c of the width rule (psd_rq_shift)
     psd_z sh;  // this bulge's shift
 };
 
@@ -876,12 +877,25 @@ PSD_D void psd_zgq_check(const psd_zgparams& P, psd_zgstate& st, int* redi, psd_
     }
     st.train_n = 1;
     if ((st.train_want >= 2 || st.train_want == -2) && P.tshift != nullptr && st.iiter % 10 != 0) {
-        const int nb = st.W - 3, w = ilast - st.ifirst + 1;
-        int m = (st.train_want == -2) ? 1 : (1 + (w - nb) / (2 * nb));
-        if (m > st.train_want && st.train_want >= 2) m = st.train_want;
-        if (m > PSD_TRAIN_MAX) m = PSD_TRAIN_MAX;
-        if (m > PSD_ZHQR_MAX) m = PSD_ZHQR_MAX;
-        while (m >= 1 && psd_zgq_train_elems(p, m) > (size_t)p * st.W * (st.W + 1)) --m;
+        // window width of the train by the cost model of psd_rq_shift
+        const int w = ilast - st.ifirst + 1;
+        int mt = (st.train_want == -2) ? 1 : st.train_want;
+        if (mt > PSD_TRAIN_MAX) mt = PSD_TRAIN_MAX;
+        if (mt > PSD_ZHQR_MAX) mt = PSD_ZHQR_MAX;
+        int nb = st.Wmax - 3, m = 1;
+        double best = 1e300;
+        for (int nbc = (st.Wmax - 3 < 8) ? ((st.Wmax > 4) ? st.Wmax - 3 : 1) : 8; nbc <= st.Wmax - 3 && mt >= 2; ++nbc) {
+            int mc = 1 + (w - nbc) / (2 * nbc);
+            if (mc > mt) mc = mt;
+            if (mc < 2) break;
+            const double cost = (double)((w + nbc - 1) / nbc + 2 * (mc - 1)) * (double)(nbc * p + st.train_oc) / mc;
+            if (cost < best) {
+                best = cost;
+                nb = nbc;
+                m = mc;
+            }
+        }
+        while (m >= 1 && psd_zgq_train_elems(p, m) > (size_t)p * st.Wmax * (st.Wmax + 1)) --m;
         if ((m >= 2 || st.train_want == -2) && m >= 1 && m + 2 <= w) {
             int* okf = (int*)(P.tshift + PSD_TRAIN_MAX);
             psd_zgq_train_shifts(P, n, p, ilast, m, work, okf);
@@ -891,6 +905,7 @@ PSD_D void psd_zgq_check(const psd_zgparams& P, psd_zgstate& st, int* redi, psd_
                 c = cm;
                 s = sm;
                 if (m >= 2) {
+                    st.W = nb + 3;
                     st.train_n = m;
                     st.train_tick0 = P.tick;
                     st.train_id += 1;
@@ -935,7 +950,7 @@ PSD_D void psd_zgq_step_body(const psd_zgparams& P) {
     }
     const int NT = PSD_NTHREADS;
     psd_z* ldsz = (psd_z*)psd_lds;
-    const size_t winb = (size_t)st.p * st.W * (st.W + 1);
+    const size_t winb = (size_t)st.p * st.Wmax * (st.Wmax + 1);
     psd_z* side = ldsz + winb;  // NT/2 complex = NT doubles
     int* redi = (int*)((double*)side + NT);
     int* lcnt = redi + 2 * NT;
@@ -968,6 +983,7 @@ PSD_D void psd_zgq_step_body(const psd_zgparams& P) {
                     st.nsweeps += 1;
                 }
                 st.train_n = 1;
+                st.W = st.Wmax;
                 st.phase = PSD_GPH_CHECK;  // (runs in the next launch, behind the cursors' last bulk updates)
             }
             emitted = true;
@@ -992,7 +1008,7 @@ PSD_D void psd_zgq_cursor_body(const psd_zgparams& P, int b) {
     if (st.phase != PSD_GPH_CWAIT && st.phase != PSD_GPH_SWEEP) return;
     const int NT = PSD_NTHREADS;
     psd_z* ldsz = (psd_z*)psd_lds;
-    const size_t winb = (size_t)st.p * st.W * (st.W + 1);
+    const size_t winb = (size_t)st.p * st.Wmax * (st.Wmax + 1);
     int* lcnt = (int*)((double*)(ldsz + winb) + NT) + 2 * NT;
     if (st.phase == PSD_GPH_CWAIT) {
         if (P.tick < st.train_tick0 + 2 * b) return;
@@ -1151,14 +1167,14 @@ PSD_KERNEL psd_zgq_defer(psd_zgparams P, int n) {
 }
 
 PSD_KERNEL psd_zgq_init(psd_zgparams P, int n, int p, int wantT, int wantZ, int W, int maxitfac, int maxlog,
-                        int hessmode, int train_want) {
+                        int hessmode, int train_want, int train_oc) {
     const psd_mat<psd_z> H1 = psd_mat<psd_z>{P.H, n};
     if (!hessmode) PSD_PAR_FOR(c, n) {
         for (int r = c + 3; r <= n; ++r) H1(r, c + 1) = zmk(0.0, 0.0);  // _gethess!
     }
     PSD_ONE {
         psd_zgstate st;
-        st.n = n; st.p = p; st.wantT = wantT; st.wantZ = wantZ; st.W = W;
+        st.n = n; st.p = p; st.wantT = wantT; st.wantZ = wantZ; st.W = st.Wmax = W; st.train_oc = train_oc;
         st.phase = PSD_GPH_CHECK; st.info = 0;
         st.ilast = n; st.ifirst = 1; st.ifirstm = 1; st.ilastm = n; st.iiter = 1;
         st.ziter = (p >= 20) ? -1 : 0;

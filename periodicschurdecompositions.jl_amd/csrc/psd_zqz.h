@@ -50,6 +50,7 @@ struct psd_zapply_desc {
 
 struct psd_zstate {
     int n, p, wantT, wantZ, W;
+    int Wmax, train_oc;  // LDS layout width (W is the running sweep's, <= Wmax); o / c of the width rule (psd_rq_shift)
     int phase, info;
     int ilast, ifirst, ifirstm, ilastm, iiter, ziter, jiter, maxit;
     int jlo, kcur, zflag;
@@ -463,18 +464,32 @@ PSD_D void psd_zq_check(const psd_zparams& P, psd_zstate& st, double* red, int* 
         // multishift train: bulge b takes the diagonal entries of row ilast - b of the factors as its shift (the
         // reference's shift is b = 0, :786-805); cursors two windows apart (see psd_rq_step_train)
         if (st.train_want >= 2 && P.cst != nullptr) {
-            const int nb = st.W - 3, w = ilast - st.ifirst + 1;
-            int m = 1 + (w - nb) / (2 * nb);
-            if (m > st.train_want) m = st.train_want;
-            if (m > PSD_TRAIN_MAX) m = PSD_TRAIN_MAX;
-            if (m > PSD_ZHQR_MAX) m = PSD_ZHQR_MAX;
-            while (m >= 2 && psd_zq_train_elems(p, m) > (size_t)p * st.W * (st.W + 1)) --m;  // LDS of the staging
+            // window width of the train by the cost model of psd_rq_shift
+            const int w = ilast - st.ifirst + 1;
+            int mt = st.train_want;
+            if (mt > PSD_TRAIN_MAX) mt = PSD_TRAIN_MAX;
+            if (mt > PSD_ZHQR_MAX) mt = PSD_ZHQR_MAX;
+            int nb = st.Wmax - 3, m = 1;
+            double best = 1e300;
+            for (int nbc = (st.Wmax - 3 < 8) ? ((st.Wmax > 4) ? st.Wmax - 3 : 1) : 8; nbc <= st.Wmax - 3; ++nbc) {
+                int mc = 1 + (w - nbc) / (2 * nbc);
+                if (mc > mt) mc = mt;
+                if (mc < 2) break;
+                const double cost = (double)((w + nbc - 1) / nbc + 2 * (mc - 1)) * (double)(nbc * p + st.train_oc) / mc;
+                if (cost < best) {
+                    best = cost;
+                    nb = nbc;
+                    m = mc;
+                }
+            }
+            while (m >= 2 && psd_zq_train_elems(p, m) > (size_t)p * st.Wmax * (st.Wmax + 1)) --m;  // LDS of the staging
             if (m >= 2 && 2 * m + 2 <= w) {
                 int* okf = (int*)(P.tshift + PSD_TRAIN_MAX);  // (flag word behind the shifts)
                 psd_zq_train_shifts(P, n, p, ilast, m, work, okf);
                 double cm;
                 psd_z sm;
                 if (*okf && psd_zq_start_rot_mu(P, n, p, st.ifirst, P.tshift[0], cm, sm)) {
+                    st.W = nb + 3;
                     st.train_n = m;
                     st.train_tick0 = P.tick;
                     st.train_id += 1;
@@ -810,7 +825,7 @@ PSD_D void psd_zq_step_body(const psd_zparams& P) {
     }
     const int NT = PSD_NTHREADS;
     psd_z* ldsz = (psd_z*)psd_lds;
-    const size_t winb = (size_t)st.p * st.W * (st.W + 1);
+    const size_t winb = (size_t)st.p * st.Wmax * (st.Wmax + 1);
     double* red = (double*)(ldsz + winb);
     int* redi = (int*)(red + NT);
     int* lcnt = redi + 2 * NT;
@@ -848,6 +863,7 @@ PSD_D void psd_zq_step_body(const psd_zparams& P) {
                     st.jiter += 1;
                 }
                 st.train_n = 1;
+                st.W = st.Wmax;
                 st.phase = PSD_ZPH_CHECK;
             }
             emitted = true;  // (the check runs in the next launch, behind the cursors' last bulk updates)
@@ -870,7 +886,7 @@ PSD_D void psd_zq_cursor_body(const psd_zparams& P, int b) {
     if (st.cursor != b) return;
     if (st.phase != PSD_ZPH_CWAIT && st.phase != PSD_ZPH_SWEEP) return;
     psd_z* ldsz = (psd_z*)psd_lds;
-    const size_t winb = (size_t)st.p * st.W * (st.W + 1);
+    const size_t winb = (size_t)st.p * st.Wmax * (st.Wmax + 1);
     int* lcnt = (int*)((double*)(ldsz + winb) + PSD_STEP_NT) + 2 * PSD_STEP_NT;
     if (st.phase == PSD_ZPH_CWAIT) {
         if (P.tick < st.train_tick0 + 2 * b) return;
@@ -1138,14 +1154,14 @@ PSD_KERNEL psd_zq_defer(psd_zparams P, int n) {
 }
 
 PSD_KERNEL psd_zq_init(psd_zparams P, int n, int p, int wantT, int wantZ, int W, int maxitfac, int maxlog,
-                       int train_want) {
+                       int train_want, int train_oc) {
     const psd_mat<psd_z> H1 = psd_mat<psd_z>{P.H, n};
     PSD_PAR_FOR(c, n) {
         for (int r = c + 3; r <= n; ++r) H1(r, c + 1) = zmk(0.0, 0.0);  // _gethess!
     }
     PSD_ONE {
         psd_zstate st;
-        st.n = n; st.p = p; st.wantT = wantT; st.wantZ = wantZ; st.W = W;
+        st.n = n; st.p = p; st.wantT = wantT; st.wantZ = wantZ; st.W = st.Wmax = W; st.train_oc = train_oc;
         st.phase = PSD_ZPH_CHECK; st.info = 0;
         st.ilast = n; st.ifirst = -1; st.ifirstm = 1; st.ilastm = n; st.iiter = 1;
         // generalized.jl:199: p >= log2(floatmin)/log2(eps) = 19.65
