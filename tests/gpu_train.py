@@ -1,5 +1,5 @@
 """Experimental multishift trains (psd_set_train) against the default iteration at cfg2 on one GPU: wall time, ticks,
-sweeps, invariants.  usage: gpu_train.py [n] [p] [bulges ...]   (GPU_MAX_HW_QUEUES is raised before HIP starts: every
+sweeps, invariants.  usage: gpu_train.py [n] [p] [bulges ...]   (PSD_ELTYPE=c128: ComplexF64; GPU_MAX_HW_QUEUES is raised before HIP starts: every
 cursor needs its own hardware queue to run beside the others)"""
 import json
 import os
@@ -20,13 +20,14 @@ import psdtest as pt  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 p = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 ms = [int(x) for x in sys.argv[3:]] or [1, 2, 4, 6]
-As = pt.bench_factors(n, p, seed=1236)
+DT = np.complex128 if os.environ.get("PSD_ELTYPE") == "c128" else np.float64
+As = pt.bench_factors(n, p, seed=1236, dtype=DT)
 P = pt.product(As)
 lam = np.linalg.eigvals(P)
 eng = psd_amd.Engine()
 for m in ms:
     eng.set_train(m)
-    eng.pschur(pt.bench_factors(64, p, seed=1), "R")  # warm-up
+    eng.pschur(pt.bench_factors(64, p, seed=1, dtype=DT), "R")  # warm-up
     t0 = time.time()
     ps = eng.pschur(As, "R")
     wall = time.time() - t0
