@@ -4,7 +4,7 @@
 #pragma once
 #include "psd_complex.h"
 
-#define PSD_ZHQR_MAX 8
+#define PSD_ZHQR_MAX 16
 
 // principal square root of a complex number
 PSD_HD psd_z psd_zsqrt(psd_z a) {
