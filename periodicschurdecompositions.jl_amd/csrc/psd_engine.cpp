@@ -127,7 +127,7 @@ struct psd_ctx {
     psd_hess_args* hargs = nullptr;  // device argument block of the graph-replayed Hessenberg reduction
     // multishift trains (experimental): bulges per train (0/1 = off), per-cursor state / descriptor / lists
     int ztrain_m = 16;  // complex single-shift engine (psd_set_train sets both; psd_set_train_z / PSD_TRAIN_Z this one)
-    int train_m = 8;  // default: trains of up to eight bulges (psd_set_train / PSD_TRAIN; 0 or 1 = the reference's iteration)
+    int train_m = 16;  // default: trains of up to sixteen bulges (psd_set_train / PSD_TRAIN; 0 or 1 = the reference's iteration)
     int tcap_p = 0;
     psd_rstate* tcst = nullptr;
     double* tshift = nullptr;
@@ -613,8 +613,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
 #endif
     // multishift trains (experimental; off unless psd_set_train / PSD_TRAIN >= 2): M cursors, each with its own state,
     // descriptor and lists; cursor 0 is the ordinary state machine
-    const int Mcap = (PSD_HQR_MAX / 2 < PSD_TRAIN_MAX) ? PSD_HQR_MAX / 2 : PSD_TRAIN_MAX;  // (2 m shifts from one small QR)
-    const int M = (c->train_m >= 2) ? ((c->train_m > Mcap) ? Mcap : c->train_m) : 1;
+    const int M = (c->train_m >= 2) ? ((c->train_m > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : c->train_m) : 1;
     P.cst = nullptr;
     P.tshift = nullptr;
     P.lead = c->st;
@@ -1983,8 +1982,7 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
 #endif
     // multishift trains (as iterate_dev): M cursors, cursor 0 is the ordinary state machine
     const int tw = hessmode ? 0 : c->gtrain_m;
-    const int Mcap = (PSD_HQR_MAX / 2 < PSD_TRAIN_MAX) ? PSD_HQR_MAX / 2 : PSD_TRAIN_MAX;
-    const int M = (tw >= 2) ? ((tw > Mcap) ? Mcap : tw) : 1;
+    const int M = (tw >= 2) ? ((tw > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : tw) : 1;
     P.cst = nullptr;
     P.tshift = nullptr;
     P.tick = 0;

@@ -38,7 +38,7 @@ enum { PSD_TR_R3 = 3, PSD_TR_H2 = 2, PSD_TR_R2 = 4, PSD_TR_G = 5 };
 #define PSD_TR_CAP 64     // transform-list capacity per owner and window
 #define PSD_STEP_NT 64    // the chase runs in one wavefront
 #define PSD_APPLY_NT 128  // threads (= tile rows / tile columns) of the bulk-apply kernel
-#define PSD_TRAIN_MAX 16  // bulges (cursors) of a multishift train (the real engines stop at PSD_HQR_MAX / 2 = 8)
+#define PSD_TRAIN_MAX 16  // bulges (cursors) of a multishift train
 
 struct psd_tr {
     int pos;   // first row/column index (1-based) the transform acts on
@@ -640,7 +640,6 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work) {
             const int w = i - l + 1;
             int mt = st.train_want;
             if (mt > PSD_TRAIN_MAX) mt = PSD_TRAIN_MAX;
-            if (2 * mt > PSD_HQR_MAX) mt = PSD_HQR_MAX / 2;
             int nb = st.Wmax - 4, m = 1;
             double best = 1e300;
             for (int nbc = (st.Wmax - 4 < 8) ? ((st.Wmax > 5) ? st.Wmax - 4 : 1) : 8; nbc <= st.Wmax - 4; ++nbc) {
@@ -654,10 +653,21 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work) {
                     m = mc;
                 }
             }
-            while (m >= 2 && psd_rq_train_doubles(st.p, m) > (size_t)st.p * st.Wmax * (st.Wmax + 1)) --m;  // LDS of the staging
+            // the shift pairs come from one lane's Hessenberg-QR of a block of order <= PSD_HQR_MAX: a longer train
+            // runs through them twice
+            int ms = (2 * m > PSD_HQR_MAX) ? PSD_HQR_MAX / 2 : m;
+            while (ms >= 2 && psd_rq_train_doubles(st.p, ms) > (size_t)st.p * st.Wmax * (st.Wmax + 1)) --ms;  // LDS of the staging
+            if (ms < m && ms < PSD_HQR_MAX / 2) m = ms;
             if (m >= 2 && 2 * m + 2 <= w) {
                 int* okf = (int*)P.tshift + 8 * PSD_TRAIN_MAX;  // (flag word behind the pairs)
-                psd_rq_train_shifts(P, n, st.p, i, m, work, okf);
+                psd_rq_train_shifts(P, n, st.p, i, ms, work, okf);
+                if (*okf && m > ms) {
+                    PSD_ONE {
+                        for (int b = ms; b < m; ++b)
+                            for (int q = 0; q < 4; ++q) P.tshift[4 * b + q] = P.tshift[4 * (b - ms) + q];
+                    }
+                    PSD_SYNC();
+                }
                 if (*okf) {
                     st.W = nb + 4;
                     st.train_n = m;

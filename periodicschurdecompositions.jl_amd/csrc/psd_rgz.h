@@ -1522,7 +1522,6 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
         const int w = ilast - ifirst + 1;
         int mt = (st.train_want == -2) ? 1 : st.train_want;
         if (mt > PSD_TRAIN_MAX) mt = PSD_TRAIN_MAX;
-        if (2 * mt > PSD_HQR_MAX) mt = PSD_HQR_MAX / 2;
         int nb = st.Wmax - 4, m = 1;
         double best = 1e300;
         for (int nbc = (st.Wmax - 4 < 8) ? ((st.Wmax > 5) ? st.Wmax - 4 : 1) : 8; nbc <= st.Wmax - 4 && mt >= 2; ++nbc) {
@@ -1536,10 +1535,20 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
                 m = mc;
             }
         }
-        while (m >= 1 && psd_gq_train_doubles(p, m) > (size_t)p * st.Wmax * (st.Wmax + 1)) --m;
+        // (a train longer than PSD_HQR_MAX / 2 runs through its shift pairs twice, as in psd_rq_shift)
+        int ms = (2 * m > PSD_HQR_MAX) ? PSD_HQR_MAX / 2 : m;
+        while (ms >= 1 && psd_gq_train_doubles(p, ms) > (size_t)p * st.Wmax * (st.Wmax + 1)) --ms;
+        if (ms < m && ms < PSD_HQR_MAX / 2) m = ms;
         if ((m >= 2 || st.train_want == -2) && m >= 1 && 2 * m + 2 <= w) {
             int* okf = (int*)P.tshift + 8 * PSD_TRAIN_MAX;
-            psd_gq_train_shifts(P, n, p, ilast, m, ldsd, okf);
+            psd_gq_train_shifts(P, n, p, ilast, ms, ldsd, okf);
+            if (*okf && m > ms) {
+                PSD_ONE {
+                    for (int b = ms; b < m; ++b)
+                        for (int q = 0; q < 4; ++q) P.tshift[4 * b + q] = P.tshift[4 * (b - ms) + q];
+                }
+                PSD_SYNC();
+            }
             double e1, f1, e2, f2;
             if (*okf && psd_gq_start_explicit(P, n, p, ifirst, P.tshift, ldsd, e1, f1, e2, f2)) {
                 st.c1 = e1; st.s1 = f1; st.c2 = e2; st.s2 = f2;
