@@ -64,7 +64,7 @@ int psd_create(psd_ctx** ctx, int device);
 int psd_destroy(psd_ctx* ctx);
 /* profile != 0: sample the chase kernel's duration with HIP events (every 4th launch) */
 int psd_set_profile(psd_ctx* ctx, int profile);
-/* Multishift trains in the real and the complex periodic QR / QZ iteration.  bulges >= 2 (default and maximum 16; PSD_TRAIN in the
+/* Multishift trains in the real and the complex periodic QR / QZ iteration.  bulges >= 2 (default and maximum 32, 16 in the complex engines; PSD_TRAIN in the
  * environment presets it): a sweep of a large active block becomes a train of up to `bulges` double-shift sweeps whose
  * shifts are the eigenvalues of the trailing 2m x 2m block of the product (m <= 8; a longer train runs through the pairs
  * twice), chased as cursors two windows apart by one workgroup each, in windows whose width a cost model picks per train.  0 or 1: the reference's one-shift-one-sweep iteration (PSD.jl:729-763), sweep for sweep.  Same
@@ -77,7 +77,7 @@ int psd_set_train_z(psd_ctx* ctx, int bulges);
 int psd_get_train_z(psd_ctx* ctx);
 /* the signed paths psd_d_pschur(A, S) / psd_z_pschur(A, S) (double-shift sweeps of rgeneralized.jl:806-1054, single-shift
  * sweeps of generalized.jl:808-852; the complex one takes the eigenvalues of the trailing m x m block of H_1 T): trains with explicit shifts
- * taken from the trailing 2m x 2m block of prod_{l>=2} H_l^{s_l} * H_1 (default 16; psd_set_train sets this path too,
+ * taken from the trailing 2m x 2m block of prod_{l>=2} H_l^{s_l} * H_1 (default 32, the complex one stops at 16; psd_set_train sets this path too,
  * PSD_TRAIN_G presets it alone).  psd_stats.maxits counts the sweeps that ran inside trains.  -2 (test hook): single
  * sweeps started from explicit shifts instead of the implicit _qzrots start. */
 int psd_set_train_g(psd_ctx* ctx, int bulges);

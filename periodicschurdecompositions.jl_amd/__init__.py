@@ -187,7 +187,7 @@ class Engine:
         return self.lib.psd_version().decode()
 
     def set_train(self, bulges):
-        """Multishift trains of the real pschur! path (psd_set_train): bulges >= 2 (default 16) or 0 for the reference's
+        """Multishift trains of the real pschur! path (psd_set_train): bulges >= 2 (default 32) or 0 for the reference's
         one-shift-one-sweep iteration."""
         self.lib.psd_set_train.argtypes = [C.c_void_p, C.c_int]
         self.lib.psd_set_train(self.ctx, int(bulges))
@@ -201,7 +201,7 @@ class Engine:
         return int(self.lib.psd_get_train_z(self.ctx))
 
     def set_train_g(self, bulges):
-        """Multishift trains of the signed paths, real and complex (psd_set_train_g; default 16; 0 = the reference's iteration)."""
+        """Multishift trains of the signed paths, real and complex (psd_set_train_g; default 32; 0 = the reference's iteration)."""
         self.lib.psd_set_train_g.argtypes = [C.c_void_p, C.c_int]
         self.lib.psd_set_train_g(self.ctx, int(bulges))
 

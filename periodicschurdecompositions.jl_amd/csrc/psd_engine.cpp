@@ -126,8 +126,8 @@ struct psd_ctx {
     size_t step_lds_set = 0, zstep_lds_set = 0, rostep_lds_set = 0;
     psd_hess_args* hargs = nullptr;  // device argument block of the graph-replayed Hessenberg reduction
     // multishift trains (experimental): bulges per train (0/1 = off), per-cursor state / descriptor / lists
-    int ztrain_m = 16;  // complex single-shift engine (psd_set_train sets both; psd_set_train_z / PSD_TRAIN_Z this one)
-    int train_m = 16;  // default: trains of up to sixteen bulges (psd_set_train / PSD_TRAIN; 0 or 1 = the reference's iteration)
+    int ztrain_m = 32;  // complex single-shift engine (its trains stop at PSD_ZHQR_MAX = 16 bulges) (psd_set_train sets both; psd_set_train_z / PSD_TRAIN_Z this one)
+    int train_m = 32;  // default: trains of up to 32 bulges (psd_set_train / PSD_TRAIN; 0 or 1 = the reference's iteration)
     int tcap_p = 0;
     psd_rstate* tcst = nullptr;
     double* tshift = nullptr;
@@ -214,7 +214,7 @@ struct psd_ctx {
     int *gascale = nullptr, *gcnt = nullptr, *glog = nullptr;
     size_t gstep_lds_set = 0, ghess_lds_set = 0;
     // multishift trains of the real signed engine (psd_set_train sets all engines; psd_set_train_g / PSD_TRAIN_G this one)
-    int gtrain_m = 16, gtcap_p = 0;
+    int gtrain_m = 32, gtcap_p = 0;
     psd_gstate* gtcst = nullptr;
     double* gtshift = nullptr;
     psd_gapply_desc* gtdesc = nullptr;
@@ -1070,7 +1070,8 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
     }
 #endif
     // multishift trains (see iterate_dev): cursor 0 = slot 0 of the cursor arrays
-    const int M = (c->ztrain_m >= 2) ? ((c->ztrain_m > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : c->ztrain_m) : 1;
+    const int Mcap = (PSD_ZHQR_MAX < PSD_TRAIN_MAX) ? PSD_ZHQR_MAX : PSD_TRAIN_MAX;  // (one shift per bulge from one small QR)
+    const int M = (c->ztrain_m >= 2) ? ((c->ztrain_m > Mcap) ? Mcap : c->ztrain_m) : 1;
     P.cst = nullptr;
     P.tshift = nullptr;
     P.tick = 0;
@@ -1260,7 +1261,8 @@ int zgiterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
 #endif
     // multishift trains (as giterate_dev)
     const int tw = hessmode ? 0 : c->gtrain_m;
-    const int M = (tw >= 2) ? ((tw > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : tw) : 1;
+    const int Mcap = (PSD_ZHQR_MAX < PSD_TRAIN_MAX) ? PSD_ZHQR_MAX : PSD_TRAIN_MAX;
+    const int M = (tw >= 2) ? ((tw > Mcap) ? Mcap : tw) : 1;
     P.cst = nullptr;
     P.tshift = nullptr;
     P.tick = 0;

@@ -38,7 +38,7 @@ enum { PSD_TR_R3 = 3, PSD_TR_H2 = 2, PSD_TR_R2 = 4, PSD_TR_G = 5 };
 #define PSD_TR_CAP 64     // transform-list capacity per owner and window
 #define PSD_STEP_NT 64    // the chase runs in one wavefront
 #define PSD_APPLY_NT 128  // threads (= tile rows / tile columns) of the bulk-apply kernel
-#define PSD_TRAIN_MAX 16  // bulges (cursors) of a multishift train
+#define PSD_TRAIN_MAX 32  // bulges (cursors) of a multishift train
 
 struct psd_tr {
     int pos;   // first row/column index (1-based) the transform acts on
