@@ -126,7 +126,7 @@ struct psd_ctx {
     size_t step_lds_set = 0, zstep_lds_set = 0, rostep_lds_set = 0;
     psd_hess_args* hargs = nullptr;  // device argument block of the graph-replayed Hessenberg reduction
     // multishift trains (experimental): bulges per train (0/1 = off), per-cursor state / descriptor / lists
-    int ztrain_m = 32;  // complex single-shift engine (its trains stop at PSD_ZHQR_MAX = 16 bulges) (psd_set_train sets both; psd_set_train_z / PSD_TRAIN_Z this one)
+    int ztrain_m = 32;  // complex single-shift engine (shifts from a block of order <= PSD_ZHQR_MAX, reused by longer trains) (psd_set_train sets both; psd_set_train_z / PSD_TRAIN_Z this one)
     int train_m = 32;  // default: trains of up to 32 bulges (psd_set_train / PSD_TRAIN; 0 or 1 = the reference's iteration)
     int tcap_p = 0;
     psd_rstate* tcst = nullptr;
@@ -1070,8 +1070,7 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
     }
 #endif
     // multishift trains (see iterate_dev): cursor 0 = slot 0 of the cursor arrays
-    const int Mcap = (PSD_ZHQR_MAX < PSD_TRAIN_MAX) ? PSD_ZHQR_MAX : PSD_TRAIN_MAX;  // (one shift per bulge from one small QR)
-    const int M = (c->ztrain_m >= 2) ? ((c->ztrain_m > Mcap) ? Mcap : c->ztrain_m) : 1;
+    const int M = (c->ztrain_m >= 2) ? ((c->ztrain_m > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : c->ztrain_m) : 1;
     P.cst = nullptr;
     P.tshift = nullptr;
     P.tick = 0;

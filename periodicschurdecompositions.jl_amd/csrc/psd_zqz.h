@@ -468,7 +468,6 @@ PSD_D void psd_zq_check(const psd_zparams& P, psd_zstate& st, double* red, int* 
             const int w = ilast - st.ifirst + 1;
             int mt = st.train_want;
             if (mt > PSD_TRAIN_MAX) mt = PSD_TRAIN_MAX;
-            if (mt > PSD_ZHQR_MAX) mt = PSD_ZHQR_MAX;
             int nb = st.Wmax - 3, m = 1;
             double best = 1e300;
             for (int nbc = (st.Wmax - 3 < 8) ? ((st.Wmax > 4) ? st.Wmax - 3 : 1) : 8; nbc <= st.Wmax - 3; ++nbc) {
@@ -482,10 +481,19 @@ PSD_D void psd_zq_check(const psd_zparams& P, psd_zstate& st, double* red, int* 
                     m = mc;
                 }
             }
-            while (m >= 2 && psd_zq_train_elems(p, m) > (size_t)p * st.Wmax * (st.Wmax + 1)) --m;  // LDS of the staging
+            // (a train longer than the block the small QR and its LDS staging take runs through the shifts again)
+            int ms = (m > PSD_ZHQR_MAX) ? PSD_ZHQR_MAX : m;
+            while (ms >= 2 && psd_zq_train_elems(p, ms) > (size_t)p * st.Wmax * (st.Wmax + 1)) --ms;  // LDS of the staging
+            if (ms < 2) m = 1;
             if (m >= 2 && 2 * m + 2 <= w) {
                 int* okf = (int*)(P.tshift + PSD_TRAIN_MAX);  // (flag word behind the shifts)
-                psd_zq_train_shifts(P, n, p, ilast, m, work, okf);
+                psd_zq_train_shifts(P, n, p, ilast, ms, work, okf);
+                if (*okf && m > ms) {
+                    PSD_ONE {
+                        for (int b = ms; b < m; ++b) P.tshift[b] = P.tshift[b - ms];
+                    }
+                    PSD_SYNC();
+                }
                 double cm;
                 psd_z sm;
                 if (*okf && psd_zq_start_rot_mu(P, n, p, st.ifirst, P.tshift[0], cm, sm)) {
