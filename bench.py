@@ -3,9 +3,13 @@
 
 A *step* is one pass of the hot path over one synthetic problem: a complete `pschur!(A, :R; wantZ, wantT)`
 (periodic Hessenberg-triangular reduction, Q formation, periodic QR iteration to full deflation) on operands that
-are already resident in HBM when the timed region starts (`psd_d_pschur_dev`).  N=1 workload: BASELINE.json
-configs[1], n=512, p=16, Float64.  N>1: one process per GPU, each solves an independent replica of the same
-workload ("replicas only", DESIGN.md "Multi-GPU"); value = all sweeps of all ranks / max-over-ranks time.
+are already resident in HBM when the timed region starts (`psd_d_pschur_dev`).  N=1 workload: the size
+BASELINE.json quotes its target on, n=1024, p=64, Float64 (0.5 GiB of factors + 0.5 GiB of Schur vectors, past the
+256 MiB Infinity Cache); `--n 512 --p 16` gives BASELINE configs[1] as a secondary line.  N>1: see DESIGN.md
+"Multi-GPU"; value = all sweeps of all ranks / max-over-ranks time.
+
+The accuracy gate (device checkpsd + eigenvalues against LAPACK on the explicit product) runs outside the timed
+region; a failed gate makes the exit status non-zero.
 
 Prints ONE JSON line on rank 0.
 """
@@ -43,19 +47,79 @@ def aggregate(dist, seconds, units, device):
     return float(t.item()), int(round(u.item()))
 
 
-def cpu_baseline(n, p, seed):
-    """The oracle (C++ restatement of the reference algorithm, one thread) on the same workload, rank 0 only."""
+def cpu_baseline(n, p, seed, eng, gpu_positions, budget_cols=None, budget_sweeps=None):
+    """CPU baseline on a BOUNDED sample of the same workload: the oracle (C++ restatement of the reference algorithm,
+    g++ -O3, test infrastructure) runs (a) the first K columns of the periodic Hessenberg reduction (K * p reflector
+    links on the full-size factors) and (b) S full-width double-shift sweeps of the periodic QR iteration (wantT,
+    wantZ) on the Hessenberg-triangular form of the same input, once on one thread and — the Hessenberg sample, whose
+    large rank-one updates are what a threaded BLAS would thread in the reference (householder.jl:215,252) — once on
+    all host cores (OpenMP).  The 3-row updates of a sweep stay serial, as in the reference.  Rank 0, N = 1 only."""
+    import ctypes as C
+
+    import numpy as np
     import psdtest as pt
 
+    lib = pt.oracle_lib()
+    lib.psdo_d_phessenberg_cols.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
+    lib.psdo_set_sweep_cap.argtypes = [C.c_longlong]
+    lib.psdo_set_threads.argtypes = [C.c_int]
+    big = n >= 768
+    K = budget_cols or (6 if big else max(8, n // 16))
+    S = budget_sweeps or (4 if big else 12)
     As = pt.bench_factors(n, p, seed)
+    ncores = os.cpu_count()
+
+    def hess_sample(threads):
+        lib.psdo_set_threads(threads)
+        A = pt.pack(As)
+        tau = np.zeros((p, n))
+        t0 = time.time()
+        lib.psdo_d_phessenberg_cols(n, p, pt._dp(A), pt._dp(tau), K)
+        dt = time.time() - t0
+        lib.psdo_set_threads(1)
+        return dt
+
+    t_h1 = hess_sample(1)
+    t_hN = hess_sample(ncores)
+    # algorithmic bytes of columns 1..K against the whole reduction: sum_i [(n-i+1)(n-i) + n(n-i+1)] elements per factor
+    col_el = lambda i: (n - i + 1) * (n - i) + n * (n - i + 1)
+    frac = sum(col_el(i) for i in range(1, K + 1)) / sum(col_el(i) for i in range(1, n))
+    # (b) sweeps on the Hessenberg-triangular form (the engine's own reduction of the same input supplies it)
+    W = [a.copy(order="F") for a in As]
+    Hs, _, _ = eng.phessenberg_(W)
+    H = pt.pack(Hs)
+    Z = pt.pack([np.eye(n) for _ in range(p)])
+    wr, wi = np.zeros(n), np.zeros(n)
+    niter, nlog = C.c_int64(0), C.c_int64(0)
+    log = np.zeros(3 * (S + 64), dtype=np.int32)
+    lib.psdo_set_sweep_cap(S)
     t0 = time.time()
-    po = pt.oracle_pschur(As, "R")
-    dt = time.time() - t0
-    nsw = int((po.sweeplog[:, 0] == 0).sum())
-    return {"value": nsw / dt, "unit": "sweeps/s", "cores": 1, "kind": "port",
-            "sample": f"1 full pschur!(A,:R) n={n} p={p} Float64 wantZ wantT ({nsw} sweeps, {dt:.1f} s), "
-                      f"C++ restatement of the reference algorithm, g++ -O3, 1 thread of {os.cpu_count()} host cores",
-            "seconds": dt, "phase_ms": [float(x) for x in po.phase_ms]}
+    rc = lib.psdo_d_pschur_hess(n, p, pt._dp(H), pt._dp(Z), 1, 1, 30, pt._dp(wr), pt._dp(wi), C.byref(niter),
+                                log.ctypes.data_as(C.POINTER(C.c_int32)), S + 64, C.byref(nlog))
+    t_s = time.time() - t0
+    lib.psdo_set_sweep_cap(-1)
+    lg = log[: 3 * min(nlog.value, S + 64)].reshape(-1, 3)
+    sw = lg[lg[:, 0] == 0]
+    pos = int((sw[:, 2] - sw[:, 1] + 1).sum()) if len(sw) else 0
+    nsw = len(sw)
+    pos_per_s = pos / t_s if t_s > 0 else 0.0
+    est_hess = t_h1 / frac
+    est_iter = gpu_positions / pos_per_s if pos_per_s else None
+    return {"value": nsw / t_s, "unit": "sweeps/s", "cores": 1, "kind": "port",
+            "sample": f"oracle (C++ restatement of the reference algorithm, g++ -O3 -fopenmp): {nsw} double-shift sweeps "
+                      f"of width {int(sw[0, 2] - sw[0, 1] + 1) if nsw else 0} of pschur!(H1,Hs) n={n} p={p} Float64 wantT "
+                      f"wantZ in {t_s:.1f} s (stopped by a sweep cap, rc={rc}), and the first {K} of {n - 1} columns of "
+                      f"phessenberg! ({K * p} links, {100 * frac:.2f} % of the reduction's algorithmic bytes) in "
+                      f"{t_h1:.1f} s on 1 thread / {t_hN:.1f} s on {ncores} threads; host has {ncores} cores",
+            "sweep_positions_per_s": pos_per_s,
+            "hessenberg_sample_s": {"threads_1": t_h1, f"threads_{ncores}": t_hN, "columns": K},
+            "allcore": {"cores": ncores, "hessenberg_speedup": t_h1 / t_hN if t_hN > 0 else None,
+                        "note": "sweeps are 3-row updates and stay serial, as in the reference"},
+            "estimated_time_to_solution_s": {"hessenberg_1thread": est_hess, "hessenberg_allcore": t_hN / frac,
+                                             "iteration_at_gpu_position_count": est_iter,
+                                             "note": "extrapolated from the sample by algorithmic bytes / chase "
+                                                     "positions; the iteration estimate charges the CPU with the "
+                                                     "GPU's position count (multishift trains take more sweeps)"}}
 
 
 def cycle_shares(st):
@@ -71,24 +135,27 @@ def cycle_shares(st):
 
 
 def pmc_traffic(n, p):
-    """HBM bytes per chase launch (step + apply kernels) from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE, separate runs, gfx950 correction of the guide applied; profiles/r01/pmc_traffic_cfg2.json says how).
-    Counters cannot be collected from inside this process, so the figure is the one measured for this configuration
-    with tools/psd_profile; None for any other configuration."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic_cfg2.json")
-    if (n, p) != (512, 16) or not os.path.exists(path):
-        return None
-    with open(path) as fh:
-        return json.load(fh)["traffic_bytes_per_step_launch"]
+    """HBM bytes per chase launch (step + apply kernels) from the committed PMC passes at THIS size (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE, separate runs of this command, gfx950 correction of the guide applied;
+    profiles/r02/pmc_traffic_<n>x<p>.json records the command, the sweep / tick counts of the counted run and the raw
+    counters).  Counters cannot be collected from inside this process; None if no pass exists for the size."""
+    root = os.path.dirname(os.path.abspath(__file__))
+    for rnd in ("r02",):
+        path = os.path.join(root, "profiles", rnd, f"pmc_traffic_{n}x{p}.json")
+        if os.path.exists(path):
+            with open(path) as fh:
+                d = json.load(fh)
+            return d.get("traffic_bytes_per_step_launch"), {k: d.get(k) for k in ("source", "sweeps", "ticks", "command")}
+    return None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=512)
-    ap.add_argument("--p", type=int, default=16)
+    ap.add_argument("--n", type=int, default=1024)
+    ap.add_argument("--p", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -137,19 +204,24 @@ def main():
     elapsed = time.perf_counter() - t0
     eng.set_profile(False)
 
+    exit_code = 0
     sweeps = sum(st.nsweeps for (_, _, st, _) in results)
     elapsed_max, sweeps_all = aggregate(dist if world > 1 else None, elapsed, sweeps, device)
 
     if rank == 0:
         st = results[-1][2]
         lam = results[-1][0]
-        # accuracy gate on the last timed step (outside the timed region)
+        # accuracy gate on the last timed step (outside the timed region): eigenvalues against LAPACK on the explicit
+        # product, and the reference's checkpsd (diagnostics.jl:190-263) evaluated on the device
         P = pt.product(As)
         lam_ref = np.linalg.eigvals(P)
         lam_err = pt.match_eigs(lam_ref, lam) / np.linalg.norm(P, 2)
-        Ts = pt.unpack(bufs[-1].cpu().numpy())
-        Zs = pt.unpack(zbufs[-1].cpu().numpy())
-        ok, err = pt.checkpsd(pt.PSD(Ts, Zs, lam, "R", 1), As, thresh=100 * np.sqrt(n / 32))
+        dA0 = host.to(device)
+        thresh = 100 * np.sqrt(n / 32)
+        ok, err, orth, tri = eng.checkpsd_dev(bufs[-1].data_ptr(), zbufs[-1].data_ptr(), dA0.data_ptr(), n, p, "R", 1,
+                                              thresh=thresh)
+        del dA0
+        gate_ok = bool(ok) and lam_err <= 1e-10
 
         nwin = sum(s.nwindows for (_, _, s, _) in results)
         nlaunch = sum(s.nlaunch_step for (_, _, s, _) in results)
@@ -166,7 +238,7 @@ def main():
         if kms:
             achieved = bytes_per_launch / (kms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "psd_rq_step_train", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, p),
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, p)[0], "traffic_source": pmc_traffic(n, p)[1],
                     "alg_bytes_per_launch": bytes_per_launch, "avg_launch_ms": kms, "launch_samples": ksamples,
                     "windows_per_launch": nwin / max(nlaunch, 1),
                     "note": "algorithmic bytes of the sweep windows one launch chases (one window of every bulge of the "
@@ -185,7 +257,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: pschur!(A,:R) N=%d p=%d Float64 wantT wantZ, A_j = I + 0.5*G_j/sqrt(n)" % (n, p),
+            "config": {"workload": "%spschur!(A,:R) N=%d p=%d Float64 wantT wantZ, A_j = I + 0.5*G_j/sqrt(n)"
+                                   % ("north_star target size: " if (n, p) == (1024, 64) else
+                                      ("configs[1]: " if (n, p) == (512, 16) else ""), n, p),
                        "seed": seed, "parallelism": "replicas x%d" % world, "window": st.window},
             "sweeps_per_step": sweeps / args.steps,
             "sweeps_in_multishift_trains_per_step": ntrain / args.steps,
@@ -195,15 +269,25 @@ def main():
             "algorithmic_GBps": {"sweeps": bytes_sw / (ms_iter * 1e-3) / 1e9 if ms_iter else None,
                                  "hessenberg": st.bytes_hess / (st.ms_hess * 1e-3) / 1e9 if st.ms_hess else None,
                                  "whole_call": (bytes_sw / args.steps + st.bytes_hess + st.bytes_formq) * args.steps / elapsed / 1e9},
-            "accuracy": {"eig_rel_err_vs_numpy_prod": lam_err, "checkpsd_ok": bool(ok), "checkpsd_max_err_eps": float(err.max())},
+            "time_to_solution_s": elapsed_max / args.steps,
+            "accuracy": {"gate_ok": gate_ok, "eig_rel_err_vs_numpy_prod": lam_err, "eig_tol": 1e-10, "checkpsd_ok": bool(ok),
+                         "checkpsd_max_err_eps": float(err.max()), "checkpsd_thresh_eps": thresh,
+                         "orth_max_over_eps_n": float(orth.max() / (pt.EPS * n)), "evaluated": "device (psd_d_checkpsd_dev)"},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, p, seed)
+            positions = sum(int((lg[lg[:, 0] == 0][:, 2] - lg[lg[:, 0] == 0][:, 1] + 1).sum()) for (_, _, _, lg) in results)
+            out["sweep_positions_per_step"] = positions / args.steps
+            out["cpu_baseline"] = cpu_baseline(n, p, seed, eng, positions / args.steps)
         print(json.dumps(out))
+        if not gate_ok:
+            sys.stderr.write("bench.py: ACCURACY GATE FAILED\n")
+            exit_code = 1
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        raise SystemExit(exit_code)
 
 
 if __name__ == "__main__":

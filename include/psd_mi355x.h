@@ -62,7 +62,7 @@ typedef struct psd_stats {
 /* context: device selection, stream, workspace cache. One call at a time per context. */
 int psd_create(psd_ctx** ctx, int device);
 int psd_destroy(psd_ctx* ctx);
-/* profile != 0: sample the chase kernel's duration with HIP events (every 4th launch) */
+/* profile != 0: sample the chase kernel's duration with HIP events (every 16th launch) */
 int psd_set_profile(psd_ctx* ctx, int profile);
 /* Multishift trains in the real and the complex periodic QR / QZ iteration.  bulges >= 2 (default and maximum 32, 16 in the complex signed engine; PSD_TRAIN in the
  * environment presets it): a sweep of a large active block becomes a train of up to `bulges` double-shift sweeps whose
@@ -204,6 +204,24 @@ int psd_d_rphessenberg(psd_ctx* ctx, int m, int n, int p, double* Ap, double* co
                        int* info);
 int psd_z_rphessenberg(psd_ctx* ctx, int m, int n, int p, double* Ap, double* const* A, double* const* Q, int nq, int nqc,
                        int* info);
+
+/* checkpsd(P, As; thresh, strict) — diagnostics.jl:190-263 — as a device-side verifier (matrix cores: three n x n x n
+ * FP64 products per factor).  T, Z, A: p pointers each, USER order of the decomposition (T[schurindex-1] is the
+ * quasi-triangular factor), S the user-order signature (NULL = all true), wi (real variant, may be NULL) the imaginary
+ * parts of P.values (non-zero subdiagonals below real eigenvalues are only a warning in the reference, :223-230).
+ * err[p]: ||Z_a T_l Z_b' - A_l||_F / eps / opnorm(A_l, 1) with (a, b) by the signature and orientation (:247-252);
+ * orth[p] / tri[p] (may be NULL): ||Z_l Z_l' - I||_F and ||tril(T_l, -1 or -2)||_F; *ok: the reference's Bool
+ * (tri <= (strict ? 0 : 10 eps n), orth <= 10 eps n, err <= thresh).  psd_z_*: ComplexF64 interleaved.
+ * psd_d_checkpsd_dev: operands already in HBM as [p][n][n] blocks in user order. */
+int psd_d_checkpsd(psd_ctx* ctx, int n, int p, double* const* T, double* const* Z, double* const* A, const uint8_t* S,
+                   char orient, int schurindex, const double* wi, double thresh, int strict, double* err, double* orth,
+                   double* tri, int* ok, int* info);
+int psd_z_checkpsd(psd_ctx* ctx, int n, int p, double* const* T, double* const* Z, double* const* A, const uint8_t* S,
+                   char orient, int schurindex, double thresh, int strict, double* err, double* orth, double* tri, int* ok,
+                   int* info);
+int psd_d_checkpsd_dev(psd_ctx* ctx, int n, int p, const double* dT, const double* dZ, const double* dA,
+                       const uint8_t* S, char orient, int schurindex, double thresh, int strict, double* err,
+                       double* orth, double* tri, int* ok, int* info);
 
 #ifdef __cplusplus
 }

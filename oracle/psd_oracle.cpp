@@ -11,8 +11,20 @@
 #include "psd_oracle_rhessx.hpp"
 
 #include <chrono>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 using namespace psdo;
+
+#ifdef _OPENMP
+// the restatement is serial unless bench.py's all-core baseline asks for threads (psdo_set_threads)
+namespace {
+struct OneThreadByDefault {
+    OneThreadByDefault() { omp_set_num_threads(1); }
+} one_thread_by_default;
+}  // namespace
+#endif
 
 extern "C" {
 double psdo_dbg_maxdust(int reset) { double v = dbg_maxdust; if (reset) dbg_maxdust = 0; return v; }
@@ -27,6 +39,37 @@ int psdo_d_phessenberg(int n, int p, double* A, double* tau) {
     for (int j = 1; j <= p; ++j)
         for (int i = 1; i <= n; ++i) tau[(size_t)(j - 1) * n + (i - 1)] = t[j][i];
     return 0;
+}
+
+// bounded sample: only the first ncols columns of the reduction (bench.py cpu_baseline)
+int psdo_d_phessenberg_cols(int n, int p, double* A, double* tau, int ncols) {
+    std::vector<MatD> Av(p + 1);
+    for (int j = 1; j <= p; ++j) Av[j] = MatD{A + (size_t)(j - 1) * n * n, n};
+    std::vector<std::vector<double>> t;
+    phessenberg(n, p, Av, t, ncols);
+    for (int j = 1; j <= p; ++j)
+        for (int i = 1; i <= n; ++i) tau[(size_t)(j - 1) * n + (i - 1)] = t[j][i];
+    return 0;
+}
+// cap < 0: no cap.  With a cap, psdo_d_pschur_hess returns -77 after that many QR sweeps (H, Z left mid-iteration).
+void psdo_set_sweep_cap(long long cap) {
+    g_sweep_cap = cap;
+    g_sweeps_done = 0;
+}
+// threads of the Householder applications (1 = the serial restatement; the reference itself is serial apart from BLAS)
+void psdo_set_threads(int nthreads) {
+#ifdef _OPENMP
+    omp_set_num_threads(nthreads < 1 ? 1 : nthreads);
+#else
+    (void)nthreads;
+#endif
+}
+int psdo_get_max_threads() {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
 }
 
 // Explicit Q factors of a phessenberg! result (what PSD.jl:136-143 builds).  Q is [p][n][n].

@@ -37,6 +37,13 @@ struct MatD {
 
 // ---------------------------------------------------------------------------------------------
 // householder.jl:5-24  _norm2 (real): scaled sum of squares
+#ifndef PSDO_OMP_MIN_WORK
+#define PSDO_OMP_MIN_WORK (1LL << 17)  // elements of a panel below which a Householder application stays on one thread
+#endif
+// bounded samples for the CPU baseline of bench.py: stop pschur_hess after this many QR sweeps (< 0: no cap)
+static long long g_sweep_cap = -1;
+static long long g_sweeps_done = 0;
+
 inline double norm2(const double* x, int n, int inc) {
     if (n < 1) return 0.0;
     if (n == 1) return std::fabs(x[0]);
@@ -92,6 +99,9 @@ inline double xreflector(double* x, int n, int inc) {
 // v has m-1 entries with stride vinc.
 inline void lmul_Hadj(const double* v, int vinc, double tau, const MatD& A, int r0, int c0, int m,
                       int ncols) {
+    // columns are independent: the all-core CPU baseline (bench.py cpu_baseline.allcore) threads them, the way a
+    // threaded BLAS would thread the reference's gemv / ger! (householder.jl:215,252); one thread by default
+#pragma omp parallel for schedule(static) if ((long long)m * ncols >= PSDO_OMP_MIN_WORK)
     for (int j = 0; j < ncols; ++j) {
         double va = A(r0, c0 + j);
         for (int r = 1; r < m; ++r) va += v[(size_t)(r - 1) * vinc] * A(r0 + r, c0 + j);
@@ -110,11 +120,41 @@ inline void lmul_H(const double* v, int vinc, double tau, const MatD& A, int r0,
 // householder.jl:207-220  rmul!(A, H): A is nrows x m starting at (r0,c0)
 inline void rmul_H(const MatD& A, int r0, int c0, int nrows, int m, const double* v, int vinc,
                    double tau) {
-    for (int r = 0; r < nrows; ++r) {
-        double x = A(r0 + r, c0);
-        for (int c = 1; c < m; ++c) x += A(r0 + r, c0 + c) * v[(size_t)(c - 1) * vinc];
-        A(r0 + r, c0) -= tau * x;
-        for (int c = 1; c < m; ++c) A(r0 + r, c0 + c) -= tau * x * v[(size_t)(c - 1) * vinc];
+    // x = a1 + A1 v column by column (the reference's gemv, householder.jl:215), then the rank-one update column by
+    // column (ger!, :218,252).  Per row the floating-point operations and their order are those of the row-by-row
+    // form x = A[r,1] + sum_c A[r,c] v[c]; A[r,c] -= (tau x) v[c], so results are bit-identical to it; the column
+    // order only makes the pass over a large matrix stream through memory.  Row chunks are independent (threaded for
+    // the all-core baseline, see lmul_Hadj).
+    if (nrows <= 4) {
+        for (int r = 0; r < nrows; ++r) {
+            double x = A(r0 + r, c0);
+            for (int c = 1; c < m; ++c) x += A(r0 + r, c0 + c) * v[(size_t)(c - 1) * vinc];
+            A(r0 + r, c0) -= tau * x;
+            for (int c = 1; c < m; ++c) A(r0 + r, c0 + c) -= tau * x * v[(size_t)(c - 1) * vinc];
+        }
+        return;
+    }
+    const int CH = 512;  // rows per chunk: x stays in L1
+#pragma omp parallel for schedule(static) if ((long long)m * nrows >= PSDO_OMP_MIN_WORK)
+    for (int rb = 0; rb < nrows; rb += CH) {
+        const int nr = (nrows - rb < CH) ? (nrows - rb) : CH;
+        double x[CH];
+        double* a1 = &A(r0 + rb, c0);
+        for (int r = 0; r < nr; ++r) x[r] = a1[r];
+        for (int c = 1; c < m; ++c) {
+            const double vc = v[(size_t)(c - 1) * vinc];
+            const double* ac = &A(r0 + rb, c0 + c);
+            for (int r = 0; r < nr; ++r) x[r] += ac[r] * vc;
+        }
+        for (int r = 0; r < nr; ++r) {
+            a1[r] -= tau * x[r];
+            x[r] = tau * x[r];
+        }
+        for (int c = 1; c < m; ++c) {
+            const double vc = v[(size_t)(c - 1) * vinc];
+            double* ac = &A(r0 + rb, c0 + c);
+            for (int r = 0; r < nr; ++r) ac[r] -= x[r] * vc;
+        }
     }
 }
 
@@ -298,9 +338,10 @@ inline double opnorm1(const MatD& M, int r0, int r1, int c0, int c1) {
 // ---------------------------------------------------------------------------------------------
 // PSD.jl:213-259  phessenberg!: A[j] (j = 1..p, 1-based) overwritten LAPACK-style (H above, reflectors
 // below), tau[j] of length n (tau[1][n] unused, tau[j>=2][n] = 0).
-inline void phessenberg(int n, int p, std::vector<MatD>& A, std::vector<std::vector<double>>& tau) {
+inline void phessenberg(int n, int p, std::vector<MatD>& A, std::vector<std::vector<double>>& tau, int ncols = -1) {
     tau.assign(p + 1, std::vector<double>(n + 1, 0.0));
-    for (int i = 1; i <= n - 1; ++i) {
+    const int ilast = (ncols >= 0 && ncols < n - 1) ? ncols : (n - 1);  // (ncols: bounded sample of the first columns)
+    for (int i = 1; i <= ilast; ++i) {
         const int i1 = i + 1;
         for (int j = p; j >= 2; --j) {
             double* xi = &A[j](i, i);
@@ -519,6 +560,8 @@ inline int pschur_hess(int n, int p, std::vector<MatD>& H, std::vector<MatD>& Z,
                 i1 = l;
                 i2 = i;
             }
+            if (g_sweep_cap >= 0 && g_sweeps_done >= g_sweep_cap) return -77;  // bounded sample (bench.py)
+            ++g_sweeps_done;
             if (log) log->add(0, l, i);
             bool exc_shift = false;
             if (its == 10) {  // PSD.jl:680-689

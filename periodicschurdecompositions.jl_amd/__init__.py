@@ -178,6 +178,13 @@ class Engine:
         lib.psd_d_gordschur.argtypes = lib.psd_z_gordschur.argtypes
         lib.psd_d_ordschur.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, dpp, C.c_char, C.c_int, C.POINTER(C.c_uint8),
                                        C.c_int, dp, dp, C.POINTER(Stats), ip]
+        u8p = C.POINTER(C.c_uint8)
+        lib.psd_d_checkpsd.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, dpp, dpp, u8p, C.c_char, C.c_int, dp,
+                                       C.c_double, C.c_int, dp, dp, dp, ip, ip]
+        lib.psd_z_checkpsd.argtypes = [C.c_void_p, C.c_int, C.c_int, dpp, dpp, dpp, u8p, C.c_char, C.c_int,
+                                       C.c_double, C.c_int, dp, dp, dp, ip, ip]
+        lib.psd_d_checkpsd_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, u8p,
+                                           C.c_char, C.c_int, C.c_double, C.c_int, dp, dp, dp, ip, ip]
         self.ctx = C.c_void_p()
         rc = lib.psd_create(C.byref(self.ctx), device)
         if rc != 0:
@@ -677,6 +684,56 @@ class Engine:
         P.values = wr + 1j * wi
         P.stats = st
         return P
+
+    def checkpsd(self, P, As, thresh=100, strict=True, S=None, details=False):
+        """checkpsd(P, As; thresh, strict) — src/diagnostics.jl:190-263 — evaluated on the device (matrix cores).
+        Returns (ok, err) like the reference; with details=True also the orthogonality and triangularity norms."""
+        p = len(As)
+        if P.period != p:
+            raise DimensionMismatch("length of Hs vector must match period of P")  # diagnostics.jl:194-196
+        n = P.Ts[0].shape[0]
+        for a in As:
+            if a.ndim != 2 or a.shape[0] != n or a.shape[1] != n:
+                raise DimensionMismatch("size of Hs matrices must match P")  # diagnostics.jl:197-202
+        if S is None and isinstance(P, GeneralizedPeriodicSchur):
+            S = P.S
+        cplx = self._is_complex(P.Ts) or self._is_complex(As) or self._is_complex(P.Z)
+        dt = np.complex128 if cplx else np.float64
+        Tw = [np.asfortranarray(t, dtype=dt) for t in P.Ts]
+        Zw = [np.asfortranarray(z, dtype=dt) for z in P.Z]
+        Aw = [np.asfortranarray(a, dtype=dt) for a in As]
+        sig = (C.c_uint8 * p)(*[1 if x else 0 for x in S]) if S is not None else None
+        err, orth, tri = np.zeros(p), np.zeros(p), np.zeros(p)
+        ok, info = C.c_int(0), C.c_int(0)
+        dp = C.POINTER(C.c_double)
+        if cplx:
+            self.lib.psd_z_checkpsd(self.ctx, n, p, self._ptrs(Tw), self._ptrs(Zw), self._ptrs(Aw), sig,
+                                    P.orientation.encode(), P.schurindex, float(thresh), int(strict),
+                                    err.ctypes.data_as(dp), orth.ctypes.data_as(dp), tri.ctypes.data_as(dp),
+                                    C.byref(ok), C.byref(info))
+        else:
+            wi = np.ascontiguousarray(np.asarray(P.values).imag, dtype=np.float64)
+            self.lib.psd_d_checkpsd(self.ctx, n, p, self._ptrs(Tw), self._ptrs(Zw), self._ptrs(Aw), sig,
+                                    P.orientation.encode(), P.schurindex, wi.ctypes.data_as(dp), float(thresh),
+                                    int(strict), err.ctypes.data_as(dp), orth.ctypes.data_as(dp),
+                                    tri.ctypes.data_as(dp), C.byref(ok), C.byref(info))
+        self._raise(info.value)
+        if details:
+            return bool(ok.value), err, orth, tri
+        return bool(ok.value), err
+
+    def checkpsd_dev(self, dT_ptr, dZ_ptr, dA_ptr, n, p, lr="R", schurindex=1, thresh=100, strict=True, S=None):
+        """checkpsd on operands already resident in HBM ([p][n][n] Float64 blocks in user order)."""
+        sig = (C.c_uint8 * p)(*[1 if x else 0 for x in S]) if S is not None else None
+        err, orth, tri = np.zeros(p), np.zeros(p), np.zeros(p)
+        ok, info = C.c_int(0), C.c_int(0)
+        dp = C.POINTER(C.c_double)
+        self.lib.psd_d_checkpsd_dev(self.ctx, n, p, C.c_void_p(dT_ptr), C.c_void_p(dZ_ptr), C.c_void_p(dA_ptr), sig,
+                                    char_lr(lr).encode(), schurindex, float(thresh), int(strict),
+                                    err.ctypes.data_as(dp), orth.ctypes.data_as(dp), tri.ctypes.data_as(dp),
+                                    C.byref(ok), C.byref(info))
+        self._raise(info.value)
+        return bool(ok.value), err, orth, tri
 
     def pschur_dev(self, dA_ptr, n, p, lr="R", dZ_ptr=None, wantT=True, maxitfac=30):
         """Device-resident pschur!: dA_ptr / dZ_ptr are device addresses of [p][n][n] column-major blocks."""

@@ -1,0 +1,136 @@
+// Host side of the device verifier (psd_check.h): checkpsd(P, As; thresh, strict), src/diagnostics.jl:190-263.
+// Included at the end of psd_engine.cpp (one translation unit).
+
+namespace {
+
+// T, Z, A: [p][n][n] device blocks in USER order (ES doubles per element).  err[p] (host) receives the normalized
+// factorization errors, orth[p] / tri[p] (host, optional) the orthogonality and triangularity norms.
+template <bool CPLX>
+int checkpsd_dev(psd_ctx* c, int n, int p, const double* dT, const double* dZ, const double* dA, const uint8_t* S,
+                 char orient, int schurindex, const double* dwi, double thresh, int strict, double* err, double* orth,
+                 double* tri, int* ok) {
+    constexpr int E = CPLX ? 2 : 1;
+    const size_t nn = (size_t)n * n * E;
+    double *dW = nullptr, *dacc = nullptr;
+    PSD_CHECK(psd_rt_malloc((void**)&dW, nn * sizeof(double)));
+    PSD_CHECK(psd_rt_malloc((void**)&dacc, sizeof(double) * 5 * (size_t)p));
+    PSD_CHECK(psd_rt_memset(dacc, 0, sizeof(double) * 5 * (size_t)p, c->stream));
+    const bool left = orient == 'L';
+    const int tiles = (n + PSD_CK_TM - 1) / PSD_CK_TM;
+    (void)tiles;
+    for (int l = 0; l < p; ++l) {
+        const int l1 = (l + 1) % p;
+        const double* Tl = dT + (size_t)l * nn;
+        const double* Al = dA + (size_t)l * nn;
+        const int sub = (!CPLX && l == schurindex - 1) ? 1 : 0;  // diagnostics.jl:223-233
+        if (CPLX)
+            PSD_LAUNCH(psd_ck_small_z, psd_dim3(1), 256, 256 * 8, c->stream, Tl, Al, n, sub, dwi, dacc + 5 * l + 2);
+        else
+            PSD_LAUNCH(psd_ck_small_d, psd_dim3(1), 256, 256 * 8, c->stream, Tl, Al, n, sub, dwi, dacc + 5 * l + 2);
+        const bool sl = S ? (S[l] != 0) : true;
+        const int a = (sl != left) ? l : l1, b = (sl != left) ? l1 : l;  // diagnostics.jl:247-251
+        psd_ck_args g[3];
+        g[0].A = dZ + (size_t)l * nn; g[0].B = dZ + (size_t)l * nn; g[0].C = nullptr; g[0].D = nullptr;
+        g[0].acc = dacc + 5 * l + 0; g[0].n = n; g[0].mode = 2; g[0].bconjt = 1;
+        g[1].A = Tl; g[1].B = dZ + (size_t)b * nn; g[1].C = dW; g[1].D = nullptr;
+        g[1].acc = nullptr; g[1].n = n; g[1].mode = 0; g[1].bconjt = 1;
+        g[2].A = dZ + (size_t)a * nn; g[2].B = dW; g[2].C = nullptr; g[2].D = Al;
+        g[2].acc = dacc + 5 * l + 1; g[2].n = n; g[2].mode = 1; g[2].bconjt = 0;
+        for (int q = 0; q < 3; ++q) {
+#ifdef PSD_HOSTSIM
+            psd_ck_gemm_sim<CPLX>(g[q]);
+#else
+            hipLaunchKernelGGL(psd_ck_gemm<CPLX>, dim3(tiles, tiles), dim3(256), 0, c->stream, g[q]);
+#endif
+        }
+    }
+    std::vector<double> acc(5 * (size_t)p);
+    PSD_CHECK(psd_rt_d2h(acc.data(), dacc, sizeof(double) * 5 * (size_t)p, c->stream));
+    PSD_CHECK(psd_rt_sync(c->stream));
+    PSD_CHECK(psd_rt_last_error());
+    psd_rt_free(dW);
+    psd_rt_free(dacc);
+    const double eps = PSD_DBL_EPS;
+    bool good = true;
+    for (int l = 0; l < p; ++l) {
+        const double o = sqrt(acc[5 * l + 0]), r = sqrt(acc[5 * l + 1]), t = sqrt(acc[5 * l + 2]);
+        const double anorm = acc[5 * l + 3];
+        const double cmp = strict ? 0.0 : 10.0 * eps * n;
+        if (t > cmp) good = false;
+        if (o > 10.0 * eps * n) good = false;
+        const double e = r / eps / anorm;
+        if (!(e <= thresh)) good = false;
+        err[l] = e;
+        if (orth) orth[l] = o;
+        if (tri) tri[l] = t;
+    }
+    if (ok) *ok = good ? 1 : 0;
+    return 0;
+}
+
+template <bool CPLX>
+int checkpsd_host(psd_ctx* c, int n, int p, double* const* T, double* const* Z, double* const* A, const uint8_t* S,
+                  char orient, int schurindex, const double* wi, double thresh, int strict, double* err, double* orth,
+                  double* tri, int* ok, int* info) {
+    int dummy;
+    if (!info) info = &dummy;
+    if (!c) return *info = -1;
+    if ((*info = check_dims(n, p)) != 0) return *info;
+    if (!T || !Z || !A) return *info = -4;
+    if (orient != 'R' && orient != 'L') return *info = -8;
+    if (schurindex < 1 || schurindex > p) return *info = -9;
+    if (!err) return *info = -13;
+    constexpr int E = CPLX ? 2 : 1;
+    const size_t nn = (size_t)n * n * E;
+    double *dT = nullptr, *dZ = nullptr, *dA = nullptr, *dwi = nullptr;
+    PSD_CHECK(psd_rt_malloc((void**)&dT, nn * p * sizeof(double)));
+    PSD_CHECK(psd_rt_malloc((void**)&dZ, nn * p * sizeof(double)));
+    PSD_CHECK(psd_rt_malloc((void**)&dA, nn * p * sizeof(double)));
+    for (int l = 0; l < p; ++l) {
+        PSD_CHECK(psd_rt_h2d(dT + l * nn, T[l], nn * 8, c->stream));
+        PSD_CHECK(psd_rt_h2d(dZ + l * nn, Z[l], nn * 8, c->stream));
+        PSD_CHECK(psd_rt_h2d(dA + l * nn, A[l], nn * 8, c->stream));
+    }
+    if (wi && !CPLX) {
+        PSD_CHECK(psd_rt_malloc((void**)&dwi, sizeof(double) * (size_t)n));
+        PSD_CHECK(psd_rt_h2d(dwi, wi, sizeof(double) * (size_t)n, c->stream));
+    }
+    const int rc = checkpsd_dev<CPLX>(c, n, p, dT, dZ, dA, S, orient, schurindex, dwi, thresh, strict, err, orth, tri, ok);
+    psd_rt_free(dT);
+    psd_rt_free(dZ);
+    psd_rt_free(dA);
+    if (dwi) psd_rt_free(dwi);
+    return *info = rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int psd_d_checkpsd(psd_ctx* c, int n, int p, double* const* T, double* const* Z, double* const* A, const uint8_t* S,
+                   char orient, int schurindex, const double* wi, double thresh, int strict, double* err, double* orth,
+                   double* tri, int* ok, int* info) {
+    return checkpsd_host<false>(c, n, p, T, Z, A, S, orient, schurindex, wi, thresh, strict, err, orth, tri, ok, info);
+}
+
+int psd_z_checkpsd(psd_ctx* c, int n, int p, double* const* T, double* const* Z, double* const* A, const uint8_t* S,
+                   char orient, int schurindex, double thresh, int strict, double* err, double* orth, double* tri, int* ok,
+                   int* info) {
+    return checkpsd_host<true>(c, n, p, T, Z, A, S, orient, schurindex, nullptr, thresh, strict, err, orth, tri, ok, info);
+}
+
+int psd_d_checkpsd_dev(psd_ctx* c, int n, int p, const double* dT, const double* dZ, const double* dA, const uint8_t* S,
+                       char orient, int schurindex, double thresh, int strict, double* err, double* orth, double* tri,
+                       int* ok, int* info) {
+    int dummy;
+    if (!info) info = &dummy;
+    if (!c) return *info = -1;
+    if ((*info = check_dims(n, p)) != 0) return *info;
+    if (!dT || !dZ || !dA) return *info = -4;
+    if (orient != 'R' && orient != 'L') return *info = -8;
+    if (schurindex < 1 || schurindex > p) return *info = -9;
+    if (!err) return *info = -12;
+    return *info = checkpsd_dev<false>(c, n, p, dT, dZ, dA, S, orient, schurindex, nullptr, thresh, strict, err, orth, tri, ok);
+}
+
+}  // extern "C"

@@ -12,6 +12,7 @@
 #include "psd_zgord.h"
 #include "psd_grord.h"
 #include "psd_rhessx.h"
+#include "psd_check.h"
 
 #include "../../include/psd_mi355x.h"
 
@@ -2597,3 +2598,5 @@ int psd_z_rphessenberg(psd_ctx* c, int m, int n, int p, double* Ap, double* cons
     return rphessenberg_host<psd_rh_cplx, 16>(c, m, n, p, Ap, A, Q, nq, nqc, info);
 }
 }  // extern "C"
+
+#include "psd_check_host.inl"

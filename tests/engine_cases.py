@@ -1184,3 +1184,64 @@ def case_ztrains(eng, sizes):
                 assert pt.match_eigs(ref.values, p0.values) <= 1e-10 * Pn
     finally:
         eng.set_train_z(m0)
+
+
+# ---- device-side checkpsd (src/diagnostics.jl:190-263, csrc/psd_check.h) -----------------------------------------
+def _checkpsd_numpy_details(ps, As, S=None):
+    """orthogonality / triangularity norms the way pt.checkpsd (the numpy restatement of the reference) forms them."""
+    real = not np.iscomplexobj(ps.Ts[0])
+    n = As[0].shape[0]
+    orth = np.array([np.linalg.norm(z @ z.conj().T - np.eye(n)) for z in ps.Z])
+    tri = np.array([np.linalg.norm(np.tril(t, -2 if (real and l == ps.schurindex - 1) else -1))
+                    for l, t in enumerate(ps.Ts)])
+    return orth, tri
+
+
+def case_checkpsd(eng, sizes):
+    """The device verifier against the numpy restatement of the reference's checkpsd on decompositions produced by the
+    engine (real + complex, both orientations, signed), and on deliberately damaged ones (it has to say no)."""
+    for (n, p, lr, kind) in sizes:
+        cplx = kind.startswith("z")
+        S = None
+        if kind.endswith("g"):  # signed
+            S = [True] + [bool(q % 2 == 0) for q in range(1, p)]
+        A = pt.bench_factors(n, p, seed=900 + n + p, dtype=np.complex128 if cplx else np.float64)
+        if S is None:
+            ps = eng.pschur(A, lr)
+        else:
+            ps = eng.pschur_([a.copy(order="F") for a in A], lr, S=S)
+        thresh = 100 * np.sqrt(max(n / 32, 1))
+        ok_ref, err_ref = pt.checkpsd(ps, A, thresh=thresh, S=S)
+        ok, err, orth, tri = eng.checkpsd(ps, A, thresh=thresh, S=S, details=True)
+        orth_ref, tri_ref = _checkpsd_numpy_details(ps, A, S)
+        assert ok == ok_ref and ok, (n, p, lr, kind, err, err_ref)
+        # the residual is a difference at rounding level: two summation orders agree to a few eps-units, not to digits
+        assert np.all(np.abs(err - err_ref) <= 0.25 * err_ref + 2.0), (err, err_ref)
+        assert np.all(np.abs(orth - orth_ref) <= 0.5 * orth_ref + 4 * pt.EPS * np.sqrt(n)), (orth, orth_ref)
+        assert np.all(tri == tri_ref)
+        # damage: a non-zero below the diagonal, a perturbed Z, a perturbed T
+        j = p // 2
+        keep = ps.Ts[j][n - 1, 0]
+        ps.Ts[j][n - 1, 0] = 1e-3
+        ok1, _, _, tri1 = eng.checkpsd(ps, A, thresh=thresh, S=S, details=True)
+        assert not ok1 and abs(tri1[j] - 1e-3) < 1e-12
+        ok1s, _ = eng.checkpsd(ps, A, thresh=1e9, strict=False, S=S)
+        assert not ok1s  # 1e-3 is far above 10 eps n as well
+        ps.Ts[j][n - 1, 0] = keep
+        Zk = ps.Z[0].copy()
+        ps.Z[0] = np.asfortranarray(ps.Z[0] * (1 + 1e-9))
+        ok2, err2, orth2, _ = eng.checkpsd(ps, A, thresh=thresh, S=S, details=True)
+        ok2_ref, err2_ref = pt.checkpsd(ps, A, thresh=thresh, S=S)
+        assert not ok2 and not ok2_ref and orth2[0] > 10 * pt.EPS * n
+        assert np.allclose(err2, err2_ref, rtol=1e-3, atol=2.0)
+        ps.Z[0] = Zk
+        keep = ps.Ts[0][0, n - 1]
+        ps.Ts[0][0, n - 1] += 1e-6
+        ok3, err3 = eng.checkpsd(ps, A, thresh=thresh, S=S)
+        ok3_ref, err3_ref = pt.checkpsd(ps, A, thresh=thresh, S=S)
+        assert not ok3 and not ok3_ref
+        assert np.allclose(err3, err3_ref, rtol=1e-3, atol=2.0)
+        ps.Ts[0][0, n - 1] = keep
+    # argument errors (diagnostics.jl:194-202)
+    with pytest.raises(Exception):
+        eng.checkpsd(ps, A[:-1] if p > 1 else A + A)

@@ -49,8 +49,9 @@ def test_zwindow_widths(gpu_engine):
 
 
 def test_config3_shape_reduced(gpu_engine):
-    """BASELINE config 3 is n=1024, p=64 ComplexF64 (2 GiB; minutes on one GPU).  Same code path, same window width
-    (p = 64 -> W = 12), reduced order: eigenvalues vs numpy's eigvals of the explicit product + invariants."""
+    """The code path and window width (p = 64 -> W = 12) of BASELINE configs[2] at a reduced order n = 128 (the full
+    n = 1024 case is tests/test_gpu_baseline_configs.py::test_config3_full_size): eigenvalues vs numpy's eigvals of the
+    explicit product + invariants."""
     n, p = 128, 64
     As = pt.bench_factors(n, p, seed=1234 + 3, dtype=np.complex128)
     ps = gpu_engine.pschur(As, "R")

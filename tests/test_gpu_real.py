@@ -159,3 +159,10 @@ def test_rphessenberg(gpu_engine):
 
 def test_trains(gpu_engine):
     ec.case_trains(gpu_engine, [(150, 3, "R"), (130, 1, "L"), (120, 5, "L"), (384, 8, "R"), (200, 40, "R")])
+
+
+def test_checkpsd(gpu_engine):
+    """device checkpsd (matrix cores) against the numpy restatement of diagnostics.jl:190-263; sizes off the 64-tile
+    grid and off the K-step of 16 on purpose"""
+    ec.case_checkpsd(gpu_engine, [(12, 3, "R", "d"), (70, 4, "L", "d"), (129, 2, "R", "z"), (64, 3, "L", "z"),
+                                  (100, 4, "R", "dg"), (200, 5, "R", "d")])

@@ -78,3 +78,8 @@ def test_rphessenberg(sim_engine):
 
 def test_trains(sim_engine):
     ec.case_trains(sim_engine, [(150, 3, "R"), (130, 1, "L"), (120, 5, "L")])
+
+
+def test_checkpsd(sim_engine):
+    ec.case_checkpsd(sim_engine, [(12, 3, "R", "d"), (17, 4, "L", "d"), (10, 2, "R", "z"), (14, 3, "L", "z"),
+                                  (12, 4, "R", "dg")])
