@@ -2,6 +2,7 @@
 // Built by hipcc (-x hip, gfx950).  tests/hostsim builds the same file with g++ -DPSD_HOSTSIM as a
 // serial simulation for the CPU-only test tier; the package never loads that build.
 #include "psd_hess.h"
+#include "psd_hess2.h"
 #include "psd_real_qr.h"
 #include "psd_zhess.h"
 #include "psd_zqz.h"
@@ -186,6 +187,10 @@ struct psd_ctx {
 #ifndef PSD_HOSTSIM
     hipGraphExec_t hess_exec = nullptr;
     int hess_graph_n = 0, hess_graph_p = 0;
+    // look-ahead reduction (psd_hess2.h)
+    double* h2ring = nullptr;
+    int h2ring_n = 0;
+    int hess_lookahead = 1;  // PSD_HESS_LOOKAHEAD=0: the two-launch form of psd_hess.h
 #endif
     psd_rostate* rost = nullptr;
     psd_tq* rotq = nullptr;
@@ -333,6 +338,9 @@ struct psd_ctx {
         if (hess_exec) (void)hipGraphExecDestroy(hess_exec);
         hess_exec = nullptr;
         hess_graph_n = hess_graph_p = 0;
+        if (h2ring) psd_rt_free(h2ring);
+        h2ring = nullptr;
+        h2ring_n = 0;
 #endif
         void* ptrs[] = {dH, dZ, tau, vbuf, hdiag, hsub, hsup, Pd, Pe, Pf, hnorms, wr, wi, st, desc, tr, cnt, log};
         for (void* q : ptrs)
@@ -518,12 +526,58 @@ void fill_bytes(psd_stats* s, int n, int p, int wantT, int wantZ, const std::vec
     s->bytes_sweeps = b;
 }
 
+#ifndef PSD_HOSTSIM
+// look-ahead form (psd_hess2.h): one launch per chain link, the panel updates ride one launch behind the chain
+template <int NK, int CR>
+int hessenberg2_launches(psd_ctx* c, int n, int p, const psd_hess2_args& ha) {
+    const int nC = (n + CR - 1) / CR + 1, nT = (n + PSD_H2_ROWS - 1) / PSD_H2_ROWS, nB = (n + 3) / 4;
+    const size_t lds = ((size_t)n + 8 + 2 * PSD_H2_NT + 64) * sizeof(double);
+    int gridx = nC + nT + nB;
+    if (const char* e = getenv("PSD_H2_EXPERIMENT")) {  // timing experiments only (results are wrong)
+        const int x = atoi(e);
+        if (x == 1) gridx = nC;
+        if (x == 2) gridx = 1;
+        if (x == 3) gridx = nC + nT;
+    }
+    auto link = [&](int i, int j) {
+        hipLaunchKernelGGL((psd_hess2_link<NK, CR>), dim3(gridx), dim3(PSD_H2_NT), lds, c->stream, ha, n, i, j, nC, nT);
+    };
+    link(0, 1);  // the position before link (1, p): stages column 1 of A_p
+    for (int i = 1; i <= n - 1; ++i)
+        for (int j = p; j >= 1; --j) link(i, j);
+    link(n, p);      // drain: the panel updates of the last two links
+    link(n, p - 1);
+    return 0;
+}
+int hessenberg2_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
+    if (!c->h2ring || c->h2ring_n < n) {
+        if (c->h2ring) psd_rt_free(c->h2ring);
+        c->h2ring = nullptr;
+        PSD_CHECK(psd_rt_malloc((void**)&c->h2ring, 4 * psd_h2_slot_doubles(n) * sizeof(double)));
+        c->h2ring_n = n;
+    }
+    PSD_CHECK(psd_rt_memset(c->h2ring, 0, 4 * psd_h2_slot_doubles(c->h2ring_n) * sizeof(double), c->stream));
+    psd_hess2_args ha;
+    ha.H = dH;
+    ha.tau = dtau;
+    ha.ring = c->h2ring;
+    ha.p = p;
+    if (n <= 256) return hessenberg2_launches<4, 8>(c, n, p, ha);
+    if (n <= 512) return hessenberg2_launches<8, 8>(c, n, p, ha);
+    if (n <= 1024) return hessenberg2_launches<16, 4>(c, n, p, ha);
+    return hessenberg2_launches<32, 8>(c, n, p, ha);
+}
+#endif
+
 // PSD.jl:213-259 on device: dH [p][n][n] internal order, overwritten LAPACK-style; tau [p][n]
 int hessenberg_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
     PSD_CHECK(psd_rt_memset(dtau, 0, sizeof(double) * (size_t)n * p, c->stream));
     const size_t lds_refl = PSD_HESS_NT * 8;
     const size_t lds_apply = (PSD_HESS_NT + (size_t)n + 8) * 8;
     if (n < 2) return 0;
+#ifndef PSD_HOSTSIM
+    if (p >= 3 && n <= 2048 && c->hess_lookahead) return hessenberg2_dev(c, n, p, dH, dtau);
+#endif
     if (!c->hargs) PSD_CHECK(psd_rt_malloc((void**)&c->hargs, sizeof(psd_hess_args)));
     psd_hess_args ha;
     ha.H = dH;
@@ -792,6 +846,9 @@ int psd_create(psd_ctx** ctx, int device) {
             return PSD_INFO_RUNTIME + 5;
         }
     }
+#endif
+#ifndef PSD_HOSTSIM
+    if (const char* e = getenv("PSD_HESS_LOOKAHEAD")) c->hess_lookahead = atoi(e);
 #endif
     if (const char* e = getenv("PSD_TRAIN")) c->train_m = c->ztrain_m = c->gtrain_m = atoi(e);
     if (const char* e = getenv("PSD_TRAIN_Z")) c->ztrain_m = atoi(e);

@@ -1,0 +1,431 @@
+// Periodic Hessenberg-triangular reduction, look-ahead form (real, p >= 3): ONE launch per chain link.
+//
+// Replaces the loop body of phessenberg!(A) — /root/reference/src/PeriodicSchurDecompositions.jl:229-247 — with the
+// reflector algebra of /root/reference/src/householder.jl:66-108 (_xreflector!) and :207-237 (rmul!(A,H), lmul!(H',A)).
+//
+// The reduction is a serial chain of (n-1) p reflector generations: link q = (column i, factor j) needs column i of A_j
+// AFTER the right update by the previous link's reflector — and only that column.  So the chain and the bandwidth work
+// are separated (psd_hess.h runs two dependent launches per link and makes the chain wait for the whole panel update):
+//
+//   chain#q   (blocks [0, nC), 8-row strips of M_{q+1}, the next link's matrix): forms v_q from the unscaled column
+//             and the partial norms the previous launch left in the ring, w = M_{q+1}[rows, r0_q:n] v_q (a GEMV: the
+//             block is only READ), and from it the next link's column  M_{q+1}[rows, r0_q] - tau_q w  plus its partial
+//             norms.  Block 0 also stores v_q LAPACK-style into A_j and publishes (v_q, tau_q) for the bulk.
+//   bulk B(q-1)  (the remaining blocks): the deferred update of the matrix of link q-1,
+//             M_{q-1} <- H(v_{q-1})' (M_{q-1} H(v_{q-2})), fused into ONE pass over the matrix: every element is read
+//             once and written once for both reflectors (bottom rows: per column  a - tau w v_c,  then the left
+//             reflector, column in registers; rows above the reflector: fused GEMV + rank-one update per 8-row strip).
+//
+// Dependencies: B(q-1) needs v_{q-1} (made by the previous launch) and w of link q-2; chain#q reads M_{q+1} = M_{q+1-p},
+// last written by B(q+1-p) in launch q+2-p <= q-1 for p >= 3 (p <= 2 keeps the two-launch form of psd_hess.h).  All
+// per-link data lives in a 4-slot ring indexed by q & 3, so a launch never writes a slot another part of it reads.
+// HBM traffic per link: 8 m^2 (GEMV) + 16 n m (fused update) against the 16 (n m + m^2) of the two separate
+// panel updates the algorithmic-bytes figure counts.
+#pragma once
+#include "psd_scalar.h"
+
+#ifndef PSD_HOSTSIM
+#define PSD_H2_NT 256
+#define PSD_H2_ROWS 8
+
+struct psd_hess2_args {
+    double* H;     // [p][n][n]
+    double* tau;   // [p][n]
+    double* ring;  // 4 slots of psd_h2_slot_doubles(n)
+    int p;         // period
+};
+// slot layout: v[n+8] | w[n+8] | col[n+8] | hdr[8] (tau, beta) | part[2 * (n/4 + 2)]
+PSD_HD size_t psd_h2_slot_doubles(int n) { return 3 * (size_t)(n + 8) + 8 + 2 * (size_t)(n / 4 + 2); }
+struct psd_h2_slot {
+    double *v, *w, *col, *hdr, *part;
+};
+PSD_D psd_h2_slot psd_h2_get(double* ring, int n, int q) {
+    double* b = ring + (size_t)(q & 3) * psd_h2_slot_doubles(n);
+    psd_h2_slot s;
+    s.v = b;
+    s.w = b + (n + 8);
+    s.col = b + 2 * (size_t)(n + 8);
+    s.hdr = b + 3 * (size_t)(n + 8);
+    s.part = s.hdr + 8;
+    return s;
+}
+struct psd_h2_link {
+    int valid, i, j, r0;  // 1-based column, factor, first row of the reflector
+};
+// link (i, j) shifted by d in {-2, -1, 0, +1} chain positions (the order is j = p..1 inside a column, then i + 1);
+// (i, j) itself may lie one or two positions outside the chain (staging launch, drain launches)
+PSD_D psd_h2_link psd_h2_linkat(int i, int j, int d, int n, int p) {
+    int jj = j - d, ii = i;
+    if (jj < 1) {
+        jj += p;
+        ii += 1;
+    } else if (jj > p) {
+        jj -= p;
+        ii -= 1;
+    }
+    psd_h2_link L;
+    L.valid = (ii >= 1 && ii <= n - 1) ? 1 : 0;
+    L.i = ii;
+    L.j = jj;
+    L.r0 = (jj == 1) ? (ii + 1) : ii;
+    return L;
+}
+
+typedef double psd_h2_v2 __attribute__((ext_vector_type(2), aligned(8)));
+
+// two consecutive rows (r, r+1) of column c (0-based); the second is masked at the bottom edge
+PSD_D void psd_h2_ld2(const double* M, int n, int r, int c, bool ok0, bool ok1, double& x0, double& x1) {
+    x0 = x1 = 0.0;
+    if (ok0 && ok1) {
+        const psd_h2_v2 t = *(const psd_h2_v2*)(M + (size_t)c * n + r);
+        x0 = t.x;
+        x1 = t.y;
+    } else if (ok0) {
+        x0 = M[(size_t)c * n + r];
+    } else if (ok1) {
+        x1 = M[(size_t)c * n + r + 1];
+    }
+}
+PSD_D void psd_h2_st2(double* M, int n, int r, int c, bool ok0, bool ok1, double x0, double x1) {
+    if (ok0 && ok1) {
+        psd_h2_v2 t;
+        t.x = x0;
+        t.y = x1;
+        *(psd_h2_v2*)(M + (size_t)c * n + r) = t;
+    } else if (ok0) {
+        M[(size_t)c * n + r] = x0;
+    } else if (ok1) {
+        M[(size_t)c * n + r + 1] = x1;
+    }
+}
+
+PSD_D double psd_h2_wave_sum(double x) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) x += __shfl_xor(x, s, 64);
+    return x;
+}
+PSD_D double psd_h2_wave_max(double x) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) x = fmax(x, __shfl_xor(x, s, 64));
+    return x;
+}
+
+// (tau, beta, mult) of the reflector of x = (alpha; tail) from the tail's scaled norm (householder.jl:77-105, dlarfg);
+// tau = 0: H = I (householder.jl:74-76)
+PSD_D void psd_h2_larfg(double alpha, double xnorm, double& tau, double& beta, double& mult) {
+    if (xnorm == 0.0) {
+        tau = 0.0;
+        beta = alpha;
+        mult = 0.0;
+        return;
+    }
+    const double sfmin = 2.0 * PSD_DBL_MIN / PSD_DBL_EPS;
+    {  // dlapy2 (the library hypot costs several hundred cycles on the chain)
+        const double aa = fabs(alpha), ww = fmax(aa, xnorm), zz = fmin(aa, xnorm) / ww;
+        beta = -copysign(ww * sqrt(1.0 + zz * zz), alpha);
+    }
+    if (fabs(beta) >= sfmin) {
+        tau = (beta - alpha) / beta;
+        mult = 1.0 / (alpha - beta);
+        return;
+    }
+    int kount = 0;
+    double acc = 1.0;
+    if (fabs(beta) < sfmin) {
+        const double rsfmin = 1.0 / sfmin;
+        bool smallb = true;
+        while (smallb) {
+            kount += 1;
+            acc *= rsfmin;
+            beta *= rsfmin;
+            alpha *= rsfmin;
+            smallb = (fabs(beta) < sfmin) && (kount < 20);
+        }
+        xnorm *= acc;
+        beta = -copysign(hypot(alpha, xnorm), alpha);
+    }
+    tau = (beta - alpha) / beta;
+    mult = acc * (1.0 / (alpha - beta));
+    for (int q = 0; q < kount; ++q) beta *= sfmin;
+}
+
+// One launch = chain#q + bulk B(q-1).  The link index q is a launch argument (no dependent load in front of the data
+// loads; the launches are issued one by one: at 5-15 us each the host keeps up).  NK: ceil(n / 64) rounded up
+// (register panel depth); CR: rows per chain strip (8, or 4 for large n: twice the workgroups on the GEMV).
+// grid = nC + nT + nB blocks with nC = ceil(n / CR), nT = ceil(n / 8), nB = ceil(n / 4);
+// LDS: (n + 8 + 2 * PSD_H2_NT + 64) doubles.
+template <int NK, int CR>
+__global__ void __launch_bounds__(PSD_H2_NT, (NK > 16 ? 2 : 4)) psd_hess2_link(const psd_hess2_args Gv, int n, int qi, int qj, int nC, int nT) {
+    extern __shared__ __attribute__((aligned(16))) char psd_lds[];
+    double* vs = (double*)psd_lds;       // n + 8: the reflector (v[0] = 1) the strip kernels multiply with
+    double* red = vs + (n + 8);          // 2 * NT + 64
+    const psd_hess2_args* G = &Gv;
+    const int p = G->p;
+    // chain position relative to the ends: q = -1 (staging), 0 .. Q-1 (links), Q, Q+1 (drain), given as (column, factor)
+    const psd_h2_link L = psd_h2_linkat(qi, qj, 0, n, p);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    if (b < nC) {
+        // ------------------------------------------------------------------ chain#q
+        const psd_h2_link Ln = psd_h2_linkat(qi, qj, 1, n, p);
+        if (!L.valid && !Ln.valid) return;  // drain launches have no chain part
+        if (!L.valid && qi > 1) return;
+        const int q = L.valid ? 0 : -1;  // (q = -1: the very first column is only staged)
+        const int slot = qi * p - qj;    // ring position: any number that advances by one per link
+        const psd_h2_slot S = psd_h2_get(G->ring, n, slot), Sn = psd_h2_get(G->ring, n, slot + 1);
+        const int r0 = L.r0 - 1;  // 0-based first row of v_q
+        const int m = (q >= 0) ? (n - r0) : 0;
+        constexpr int RP = CR / 2;                  // row pairs of a strip = lanes per column
+        constexpr int CL = PSD_H2_NT / RP;          // column lanes
+        constexpr int NKS = (64 * NK + CL - 1) / CL;  // column steps of a strip
+        const int ntileC = (n + CR - 1) / CR;
+        // Everything this block reads from memory is requested up front, so that the strip of the next matrix (HBM) is
+        // in flight while the reflector is being formed: (half of) the strip itself, this thread's entries of the
+        // unscaled column, its partial norm.
+        const double* M = Ln.valid ? (G->H + (size_t)(Ln.j - 1) * n * n) : G->H;
+        const int r0n = Ln.r0 - 1;
+        const int cfirst = (q >= 0) ? r0 : (Ln.i - 1);  // column that becomes the next reflector's
+        const int t = r0n / CR + (b - 1);  // block 0 forms and publishes v_q only
+        const bool strip = Ln.valid && b > 0 && t < ntileC;
+        const int rp = tid % RP, cl = tid / RP;
+        const int r = CR * t + 2 * rp;
+        const bool ok0 = strip && r < n && r >= r0n, ok1 = strip && r + 1 < n && r + 1 >= r0n;
+        constexpr int NK1 = (NKS + 1) / 2;  // steps requested before the reflector is formed
+        double a0[NKS], a1[NKS];
+        const int rfin = CR * t + tid;  // the row thread tid < CR finishes
+        const bool fin = strip && tid < CR && rfin < n && rfin >= r0n;
+        constexpr int NV = (64 * NK + PSD_H2_NT - 1) / PSD_H2_NT;  // entries of v per thread
+        double xcol[NV];
+        double tau = 0.0, beta = 0.0, mult = 0.0;
+        double am = 0.0, sq = 0.0, alpha = 0.0;
+        // (vector memory operations return in issue order: the small ring reads go first, so that forming the reflector
+        //  does not wait for the strip)
+        if (q >= 0) {
+            const int np_ = ntileC - r0 / CR;
+            if (tid < np_) {
+                am = S.part[2 * tid];
+                sq = S.part[2 * tid + 1];
+            }
+            alpha = S.col[r0];
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int k = tid + PSD_H2_NT * u;
+                xcol[u] = (k < m) ? S.col[r0 + k] : 0.0;
+            }
+        }
+        const double mfirst = fin ? M[(size_t)cfirst * n + rfin] : 0.0;
+        if (q >= 0) {
+#pragma unroll
+            for (int k = 0; k < NKS; ++k) {
+                const int cc = cl + CL * k;
+                a0[k] = a1[k] = 0.0;
+                if (cc < m) psd_h2_ld2(M, n, r, r0 + cc, ok0, ok1, a0[k], a1[k]);
+            }
+        }
+        if (q >= 0) {
+            // norm of the tail from the partials of the launch that staged the column: (amax, ssq) pairs combine as
+            // amax = max, ssq = sum ssq_k (amax_k / amax)^2 (dlassq); one pair per thread, one LDS exchange
+            const double amw = psd_h2_wave_max(am);
+            double ssw = 0.0;
+            if (amw > 0.0) {
+                const double f = am / amw;
+                ssw = sq * (f * f);
+            }
+            ssw = psd_h2_wave_sum(ssw);
+            if (lane == 0) {
+                red[2 * wave] = amw;
+                red[2 * wave + 1] = ssw;
+            }
+            __syncthreads();
+            const double amax = fmax(fmax(red[0], red[2]), fmax(red[4], red[6]));
+            double tot = 0.0;
+            if (amax > 0.0) {
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) {
+                    const double f = red[2 * wv] / amax;
+                    tot += red[2 * wv + 1] * (f * f);
+                }
+            }
+            const double xnorm = (m > 1) ? amax * sqrt(tot) : 0.0;
+            psd_h2_larfg(alpha, xnorm, tau, beta, mult);
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int k = tid + PSD_H2_NT * u;
+                if (k < m) vs[k] = (k == 0) ? 1.0 : xcol[u] * mult;
+            }
+            __syncthreads();
+            if (b == 0) {  // publish v_q, store it LAPACK-style (PSD.jl:232-236,241-244)
+                double* Mq = G->H + (size_t)(L.j - 1) * n * n;
+                const int c = L.i - 1;
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int k = tid + PSD_H2_NT * u;
+                    if (k < m) {
+                        S.v[k] = vs[k];
+                        Mq[(size_t)c * n + r0 + k] = (tau != 0.0) ? ((k == 0) ? beta : vs[k]) : xcol[u];
+                    }
+                }
+                if (tid == 0) {
+                    S.hdr[0] = tau;
+                    S.hdr[1] = beta;
+                    G->tau[(size_t)(L.j - 1) * n + (L.i - 1)] = tau;
+                }
+            }
+        }
+        if (!strip) return;
+        // GEMV on the next link's matrix: rows >= r0n, columns r0.. (q = -1: plain staging of column 1 of A_p)
+        double acc0 = 0.0, acc1 = 0.0;
+        if (q >= 0 && tau != 0.0) {
+#pragma unroll
+            for (int k = 0; k < NKS; ++k) {
+                const int cc = cl + CL * k;
+                if (cc < m) {
+                    const double vv = vs[cc];
+                    acc0 += a0[k] * vv;
+                    acc1 += a1[k] * vv;
+                }
+            }
+        }
+        // reduce over the column lanes of a row pair: inside a wave (lanes with equal lane % RP), then the 4 waves
+#pragma unroll
+        for (int sft = RP; sft < 64; sft <<= 1) {
+            acc0 += __shfl_xor(acc0, sft, 64);
+            acc1 += __shfl_xor(acc1, sft, 64);
+        }
+        if (lane < RP) {
+            red[(wave * RP + lane) * 2] = acc0;
+            red[(wave * RP + lane) * 2 + 1] = acc1;
+        }
+        __syncthreads();
+        double amt = 0.0, y = 0.0;
+        if (fin) {
+            const double w = red[tid] + red[CR + tid] + red[2 * CR + tid] + red[3 * CR + tid];
+            y = mfirst - tau * w;
+            Sn.col[rfin] = y;
+            S.w[rfin] = w;
+            if (rfin > r0n) amt = fabs(y);
+            else y = 0.0;  // the reflector's first entry is not part of the tail
+        }
+        if (wave == 0) {
+            // partial scaled sum of squares of this strip's tail entries (lanes 0..CR-1 carry them)
+            const double amax = psd_h2_wave_max(amt);
+            double sq = 0.0;
+            if (amax > 0.0 && amt > 0.0) {
+                const double z = y / amax;
+                sq = z * z;
+            }
+            sq = psd_h2_wave_sum(sq);
+            if (lane == 0) {
+                Sn.part[2 * (b - 1)] = amax;
+                Sn.part[2 * (b - 1) + 1] = sq;
+            }
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- bulk B(q-1) on M_{q-1}
+    const psd_h2_link Lb = psd_h2_linkat(qi, qj, -1, n, p), La = psd_h2_linkat(qi, qj, -2, n, p);
+    if (!Lb.valid && !La.valid) return;
+    const int slotb = qi * p - qj - 1;
+    // matrix of link qb (after the last link: the matrix the last reflector acts on from the right, A_p)
+    const int jb = Lb.valid ? Lb.j : p;
+    double* M = G->H + (size_t)(jb - 1) * n * n;
+    const psd_h2_slot SR = psd_h2_get(G->ring, n, slotb - 1), SL = psd_h2_get(G->ring, n, slotb);
+    const double tauR = La.valid ? SR.hdr[0] : 0.0;
+    const double tauL = Lb.valid ? SL.hdr[0] : 0.0;
+    const int rR = La.valid ? (La.r0 - 1) : 0;      // right reflector acts on columns rR..n-1
+    const int mR = n - rR;
+    const int R0 = Lb.valid ? (Lb.r0 - 1) : n;      // left reflector acts on rows R0..n-1
+    if (b < nC + nT) {
+        // rows above the left reflector: fused GEMV + rank-one update, 8-row strips (right reflector only)
+        if (tauR == 0.0) return;
+        const int t = b - nC;
+        if (PSD_H2_ROWS * t >= R0) return;
+        const int rp = tid & 3, cl = tid >> 2;
+        const int r = PSD_H2_ROWS * t + 2 * rp;
+        const bool ok0 = r < R0, ok1 = r + 1 < R0;
+        double a0[NK], a1[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {  // the panel is requested before the reflector is staged
+            const int cc = cl + 64 * k;
+            a0[k] = a1[k] = 0.0;
+            if (cc < mR) psd_h2_ld2(M, n, r, rR + cc, ok0, ok1, a0[k], a1[k]);
+        }
+        for (int k = tid; k < mR; k += PSD_H2_NT) vs[k] = SR.v[k];
+        __syncthreads();
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int cc = cl + 64 * k;
+            if (cc < mR) {
+                const double vv = vs[cc];
+                acc0 += a0[k] * vv;
+                acc1 += a1[k] * vv;
+            }
+        }
+#pragma unroll
+        for (int s = 4; s < 64; s <<= 1) {
+            acc0 += __shfl_xor(acc0, s, 64);
+            acc1 += __shfl_xor(acc1, s, 64);
+        }
+        if (lane < 4) {
+            red[(wave * 4 + lane) * 2] = acc0;
+            red[(wave * 4 + lane) * 2 + 1] = acc1;
+        }
+        __syncthreads();
+        const int k0 = rp * 2;
+        const double w0 = tauR * (red[k0] + red[8 + k0] + red[16 + k0] + red[24 + k0]);
+        const double w1 = tauR * (red[k0 + 1] + red[8 + k0 + 1] + red[16 + k0 + 1] + red[24 + k0 + 1]);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int cc = cl + 64 * k;
+            if (cc < mR) {
+                const double vv = vs[cc];
+                psd_h2_st2(M, n, r, rR + cc, ok0, ok1, a0[k] - w0 * vv, a1[k] - w1 * vv);
+            }
+        }
+        return;
+    }
+    // rows R0..n-1: one wavefront per column, the column in registers: a <- a - tauR w v_c, then the left reflector
+    if (!Lb.valid) return;
+    if (tauR == 0.0 && tauL == 0.0) return;
+    const int c = Lb.i + 4 * (b - nC - nT) + wave;  // 0-based column: the columns right of the reflector's (Lb.i - 1)
+    if (c >= n) return;
+    const int mL = n - R0;
+    constexpr int NKC = (NK + 1) / 2;  // row pairs per lane: 128 rows per step
+    double a0[NKC], a1[NKC];
+    const double vc = (tauR != 0.0 && c >= rR) ? tauR * SR.v[c - rR] : 0.0;
+    double z = 0.0;
+#pragma unroll
+    for (int k = 0; k < NKC; ++k) {
+        const int rr = 2 * lane + 128 * k;  // offset inside the reflector
+        a0[k] = a1[k] = 0.0;
+        if (rr < mL) {
+            const bool ok1 = rr + 1 < mL;
+            psd_h2_ld2(M, n, R0 + rr, c, true, ok1, a0[k], a1[k]);
+            if (vc != 0.0) {
+                a0[k] -= vc * SR.w[R0 + rr];
+                if (ok1) a1[k] -= vc * SR.w[R0 + rr + 1];
+            }
+            if (tauL != 0.0) {
+                z += a0[k] * SL.v[rr];
+                if (ok1) z += a1[k] * SL.v[rr + 1];
+            }
+        }
+    }
+    z = tauL * psd_h2_wave_sum(z);
+#pragma unroll
+    for (int k = 0; k < NKC; ++k) {
+        const int rr = 2 * lane + 128 * k;
+        if (rr < mL) {
+            const bool ok1 = rr + 1 < mL;
+            double x0 = a0[k], x1 = a1[k];
+            if (tauL != 0.0) {
+                x0 -= z * SL.v[rr];
+                if (ok1) x1 -= z * SL.v[rr + 1];
+            }
+            psd_h2_st2(M, n, R0 + rr, c, true, ok1, x0, x1);
+        }
+    }
+}
+
+#endif

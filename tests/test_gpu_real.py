@@ -166,3 +166,19 @@ def test_checkpsd(gpu_engine):
     grid and off the K-step of 16 on purpose"""
     ec.case_checkpsd(gpu_engine, [(12, 3, "R", "d"), (70, 4, "L", "d"), (129, 2, "R", "z"), (64, 3, "L", "z"),
                                   (100, 4, "R", "dg"), (200, 5, "R", "d")])
+
+
+@pytest.mark.parametrize("n,p", [(2, 3), (3, 4), (7, 3), (9, 5), (33, 3), (64, 7), (130, 4), (257, 5), (300, 16), (520, 3)])
+def test_phessenberg_lookahead_vs_oracle(gpu_engine, n, p):
+    """The look-ahead reduction (csrc/psd_hess2.h: one launch per chain link, panel updates one launch behind) against
+    the oracle's packed Householder storage and tau (PSD.jl:213-259): odd orders, orders off the 8-row strips and off
+    the 64-column steps, the shortest period it serves (p = 3)."""
+    A = pt.bench_factors(n, p, seed=70 + n + p)
+    W = [a.copy(order="F") for a in A]
+    Hs, tau, _ = gpu_engine.phessenberg_(W)
+    Ho, Qo, packed, tauo = pt.oracle_phessenberg(A)
+    for j in range(p):
+        assert np.linalg.norm(W[j] - packed[j]) < 1e-11 * max(np.linalg.norm(packed[j]), 1.0), (j,)
+        assert np.allclose(tau[j], tauo[j], rtol=0, atol=1e-11)
+        Ax = Qo[j] @ Hs[j] @ Qo[(j + 1) % p].T
+        assert np.linalg.norm(A[j] - Ax) < 1e-10 * max(np.linalg.norm(A[j]), 1.0)
