@@ -192,6 +192,8 @@ struct psd_ctx {
     int h2ring_n = 0;
     int hess_lookahead = 1;  // PSD_HESS_LOOKAHEAD=0: the two-launch form of psd_hess.h
 #endif
+    int apply_worklist = 1;   // PSD_APPLY_WL=0: the grid-per-cursor bulk-apply kernels
+    int apply_wl_grid = 2048; // workgroups of the work-list bulk apply (PSD_APPLY_WL_GRID)
     psd_rostate* rost = nullptr;
     psd_tq* rotq = nullptr;
     unsigned char* rosel = nullptr;
@@ -726,7 +728,12 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 pend.emplace_back(ev0, ev1);
             }
 #endif
-            if (M == 1) {
+            if (c->apply_worklist) {
+                // work-list form: one grid of single-wave workgroups loops over the items of the tick
+                const int wl_grid = c->apply_wl_grid;
+                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, P, n, p, p + 8, 0, M);
+                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, P, n, p, p + 8, 1, M);
+            } else if (M == 1) {
                 PSD_LAUNCH(psd_rq_apply, psd_dim3(tiles, p, 3), PSD_APPLY_NT, lds_apply, c->stream, P, n, p);
             } else {
                 PSD_LAUNCH(psd_rq_apply_train, psd_dim3(tiles, p, 2 * M), PSD_APPLY_NT, lds_apply, c->stream, P, n, p, p + 8, 0);
@@ -849,6 +856,11 @@ int psd_create(psd_ctx** ctx, int device) {
 #endif
 #ifndef PSD_HOSTSIM
     if (const char* e = getenv("PSD_HESS_LOOKAHEAD")) c->hess_lookahead = atoi(e);
+#endif
+    if (const char* e = getenv("PSD_APPLY_WL")) c->apply_worklist = atoi(e);
+    if (const char* e = getenv("PSD_APPLY_WL_GRID")) c->apply_wl_grid = atoi(e) > 0 ? atoi(e) : 2048;
+#ifdef PSD_HOSTSIM
+    c->apply_wl_grid = 3;  // (serial simulation: a few workgroups exercise the item loop)
 #endif
     if (const char* e = getenv("PSD_TRAIN")) c->train_m = c->ztrain_m = c->gtrain_m = atoi(e);
     if (const char* e = getenv("PSD_TRAIN_Z")) c->ztrain_m = atoi(e);

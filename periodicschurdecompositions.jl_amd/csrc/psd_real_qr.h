@@ -1629,6 +1629,232 @@ PSD_KERNEL_B(PSD_APPLY_NT) psd_rq_apply_train(psd_rparams P, int n, int p, int c
     psd_rq_apply_body(Q, n, p, role);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Bulk application, work-list form: ONE grid of single-wave workgroups loops over the (cursor, owner, role, tile)
+// items of a tick, so that no workgroup is launched only to find its cursor idle (the grid-per-cursor form above starts
+// tiles x p x 2M workgroups per launch, almost all of which read a descriptor and leave: at n = 1024, p = 64 that is
+// 32 768 workgroups and most of the launch's 70-100 us).  An item = 64 lines (rows role: columns of H_m; column roles:
+// rows of H_{m-1} / Z_m) x the window span S <= 32 (17 KiB of LDS + the list: eight workgroups per compute unit, so
+// that one item's loads overlap another's arithmetic): the tile goes HBM -> LDS, every lane streams
+// its line through a three-element register window (the lists of a sweep visit their positions monotonically, so an
+// element is read from LDS once and written once), and the tile goes back.  Lists that are not monotone (2x2 deflation
+// passes) are applied record by record in LDS.  pass 0: rows and Z roles of every cursor; pass 1: column roles (one
+// cursor's rows cross another's columns, as in psd_rq_apply_train).
+#define PSD_WL_NT 64
+#define PSD_WL_LINES 64
+#define PSD_WL_LD 33
+PSD_HD size_t psd_wl_lds_bytes() {
+    return PSD_TR_LDS_BYTES + (size_t)PSD_WL_LINES * PSD_WL_LD * sizeof(double) + (size_t)(3 * PSD_TRAIN_MAX + 4) * sizeof(int);
+}
+
+// the three-element window of one line moving up (UP) or down through positions; L: the line in LDS (S elements)
+template <bool UP>
+PSD_D void psd_wl_stream(double* L, int S, const psd_tr* ltr, int cnt, int plo) {
+    if (UP) {
+        int base = 0, nx = 3;
+        double a1 = L[0], a2 = (1 < S) ? L[1] : 0.0, a3 = (2 < S) ? L[2] : 0.0;
+        for (int e = 0; e < cnt; ++e) {
+            const psd_tr tr = ltr[e];
+            const int rp = tr.pos - plo;
+            while (base < rp) {
+                L[base] = a1;
+                a1 = a2;
+                a2 = a3;
+                a3 = (nx < S) ? L[nx] : 0.0;
+                ++nx;
+                ++base;
+            }
+            psd_tr_apply(tr, a1, a2, a3);
+        }
+        L[base] = a1;
+        if (base + 1 < S) L[base + 1] = a2;
+        if (base + 2 < S) L[base + 2] = a3;
+    } else {
+        int base = ltr[0].pos - plo;  // window = elements base .. base + 2, starting at the first (highest) record
+        double a1 = L[base], a2 = (base + 1 < S) ? L[base + 1] : 0.0, a3 = (base + 2 < S) ? L[base + 2] : 0.0;
+        for (int e = 0; e < cnt; ++e) {
+            const psd_tr tr = ltr[e];
+            const int rp = tr.pos - plo;
+            while (base > rp) {
+                if (base + 2 < S) L[base + 2] = a3;
+                a3 = a2;
+                a2 = a1;
+                --base;
+                a1 = L[base];
+            }
+            psd_tr_apply(tr, a1, a2, a3);
+        }
+        L[base] = a1;
+        if (base + 1 < S) L[base + 1] = a2;
+        if (base + 2 < S) L[base + 2] = a3;
+    }
+}
+
+PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride, int pass, int M) {
+    PSD_LDS_DECL;
+    psd_tr* ltr = (psd_tr*)psd_lds;
+    int* flags = (int*)(psd_lds + sizeof(psd_tr) * PSD_TR_LDS_RECS);
+    double* tile = (double*)(psd_lds + PSD_TR_LDS_BYTES);
+    int* ioff = (int*)(tile + (size_t)PSD_WL_LINES * PSD_WL_LD);  // [M + 1] item offsets, [M] tiles A, [M] tiles B
+    int* tA = ioff + PSD_TRAIN_MAX + 2;
+    int* tB = tA + PSD_TRAIN_MAX;
+    const int TL = PSD_WL_LINES, LD = PSD_WL_LD;
+    // item table: cursor b contributes p * (tiles of role A + tiles of role B) items (pass 0: A = rows, B = Z;
+    // pass 1: A = columns, B = none)
+    PSD_PAR_FOR(b, M) {
+        const psd_apply_desc d = P.desc[b];
+        int a = 0, z = 0;
+        if (d.active) {
+            if (pass == 0) {
+                a = (d.lc1 >= d.lc0) ? ((d.lc1 - d.lc0 + 1 + TL - 1) / TL) : 0;
+                z = (d.zr1 >= d.zr0) ? ((d.zr1 - d.zr0 + 1 + TL - 1) / TL) : 0;
+            } else {
+                a = (d.rr1 >= d.rr0) ? ((d.rr1 - d.rr0 + 1 + TL - 1) / TL) : 0;
+            }
+        }
+        tA[b] = a;
+        tB[b] = z;
+    }
+    PSD_SYNC();
+    PSD_ONE {
+        int acc = 0;
+        for (int b = 0; b < M; ++b) {
+            ioff[b] = acc;
+            acc += p * (tA[b] + tB[b]);
+        }
+        ioff[M] = acc;
+    }
+    PSD_SYNC();
+    const int total = ioff[M];
+    for (int item = PSD_BLOCK_X; item < total; item += PSD_GRID_X) {
+        int b = 0;
+        while (b + 1 < M && ioff[b + 1] <= item) ++b;
+        const int per = tA[b] + tB[b];
+        const int q = item - ioff[b];
+        const int m = q / per + 1, tt = q - (m - 1) * per;
+        const int role = (pass == 0) ? ((tt < tA[b]) ? 0 : 2) : 1;
+        const int tix = (role == 2) ? (tt - tA[b]) : tt;
+        const psd_apply_desc d = P.desc[b];
+        int cnt = P.cnt[(size_t)b * cstride + (m - 1)];
+        if (cnt > PSD_TR_CAP) cnt = PSD_TR_CAP;
+        if (cnt <= 0) continue;
+        const psd_tr* gtr = P.tr + ((size_t)b * p + (m - 1)) * PSD_TR_CAP;
+        const int S = d.phi - d.plo + 1;
+        PSD_SYNC();  // (the previous item's tile and list are no longer in use)
+        const int order = psd_tr_stage(gtr, cnt, ltr, flags);
+        int lo, hi;
+        double* base;
+        int jm;
+        if (role == 0) {
+            lo = d.lc0; hi = d.lc1; base = P.H; jm = m;
+        } else if (role == 1) {
+            lo = d.rr0; hi = d.rr1; base = P.H; jm = (m == 1) ? p : (m - 1);
+        } else {
+            lo = d.zr0; hi = d.zr1; base = P.Z; jm = m;
+        }
+        const int l0 = lo + tix * TL;  // first line (1-based column for the rows role, row for the column roles)
+        const int nl = (hi - l0 + 1 < TL) ? (hi - l0 + 1) : TL;
+        const psd_mat<double> Mx = psd_mat<double>{base + (size_t)(jm - 1) * n * n, n};
+        if (role == 0) {
+            // rows panel: line = column l0 + c, elements = rows plo .. phi (contiguous): a lane moves two rows of a column,
+            // 16 lanes a column, four columns per step
+            PSD_PAR_FOR(t, PSD_WL_NT) {
+                const int rr = 2 * (t & 15), cq = t >> 4;
+                if (rr < S) {
+                    const bool pair = rr + 1 < S;
+                    for (int k = 0; k < TL / 4; k += 8) {
+                        psd_pair v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int c = 4 * (k + u) + cq;
+                            v[u].a = v[u].b = 0.0;
+                            if (c < nl) {
+                                const double* src = &Mx(d.plo + rr, l0 + c);
+                                if (pair) v[u] = psd_pair_load(src);
+                                else v[u].a = src[0];
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int c = 4 * (k + u) + cq;
+                            tile[c * LD + rr] = v[u].a;
+                            if (pair) tile[c * LD + rr + 1] = v[u].b;
+                        }
+                    }
+                }
+            }
+        } else {
+            // columns panel: line = row l0 + t, elements = columns plo .. phi (a wavefront reads 512 contiguous bytes
+            // per column); all loads of the line are in flight together
+            PSD_PAR_FOR(t, PSD_WL_NT) {
+                if (t < nl) {
+                    double v[32];
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) v[u] = (u < S) ? Mx(l0 + t, d.plo + u) : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 32; ++u)
+                        if (u < S) tile[t * LD + u] = v[u];
+                }
+            }
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(t, PSD_WL_NT) {
+            {
+                const int line = t;
+                if (line >= nl) continue;
+                double* L = tile + line * LD;
+                if (order > 0) {
+                    psd_wl_stream<true>(L, S, ltr, cnt, d.plo);
+                } else if (order < 0) {
+                    psd_wl_stream<false>(L, S, ltr, cnt, d.plo);
+                } else {
+                    for (int e = 0; e < cnt; ++e) {
+                        const psd_tr tr = ltr[e];
+                        const int r = tr.pos - d.plo;
+                        const int len = psd_tr_len(tr);
+                        double a1 = L[r], a2 = L[r + 1], a3 = (len == 3) ? L[r + 2] : 0.0;
+                        psd_tr_apply(tr, a1, a2, a3);
+                        L[r] = a1;
+                        L[r + 1] = a2;
+                        if (len == 3) L[r + 2] = a3;
+                    }
+                }
+            }
+        }
+        PSD_SYNC();
+        if (role == 0) {
+            PSD_PAR_FOR(t, PSD_WL_NT) {
+                const int rr = 2 * (t & 15), cq = t >> 4;
+                if (rr < S) {
+                    const bool pair = rr + 1 < S;
+                    for (int k = 0; k < TL / 4; ++k) {
+                        const int c = 4 * k + cq;
+                        if (c < nl) {
+                            double* dst = &Mx(d.plo + rr, l0 + c);
+                            if (pair) {
+                                psd_pair x;
+                                x.a = tile[c * LD + rr];
+                                x.b = tile[c * LD + rr + 1];
+                                psd_pair_store(dst, x);
+                            } else {
+                                dst[0] = tile[c * LD + rr];
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            PSD_PAR_FOR(t, PSD_WL_NT) {
+                if (t < nl) {
+#pragma unroll
+                    for (int u = 0; u < 32; ++u)
+                        if (u < S) Mx(l0 + t, d.plo + u) = tile[t * LD + u];
+                }
+            }
+        }
+    }
+}
+
 // hnorms[j] = ulp*n*opnorm(H_j, 1), column-1 / sub-Hessenberg clean-up (PSD.jl:379-388,406), and
 // state initialisation.  grid = p blocks.
 PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W, int maxitfac, int maxlog,
