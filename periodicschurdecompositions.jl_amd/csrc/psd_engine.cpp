@@ -164,14 +164,21 @@ struct psd_ctx {
         ztcst = nullptr; ztdesc = nullptr; ztcnt = nullptr; zttr = nullptr;
         ztcap_p = 0;
     }
+    // (sized for the PSD_SLOTS slots of the multi-block scheduler; the single-range train mode uses the first
+    //  PSD_TRAIN_MAX entries)
+    psd_rglobal* tgl = nullptr;
+    int* tslotw = nullptr;  // role[PSD_SLOTS] | epoch[PSD_SLOTS] | cdone[PSD_SLOTS]
+    int mblock = 1;         // PSD_MB=0: one active range at a time, as the reference
     int treserve(int p) {
         if (tcst && p <= tcap_p) return 0;
         trelease();
-        PSD_CHECK(psd_rt_malloc((void**)&tcst, sizeof(psd_rstate) * PSD_TRAIN_MAX));
-        PSD_CHECK(psd_rt_malloc((void**)&tshift, sizeof(double) * (4 * PSD_TRAIN_MAX + 8)));
-        PSD_CHECK(psd_rt_malloc((void**)&tdesc, sizeof(psd_apply_desc) * PSD_TRAIN_MAX));
-        PSD_CHECK(psd_rt_malloc((void**)&tcnt, sizeof(int) * PSD_TRAIN_MAX * (size_t)(p + 8)));
-        PSD_CHECK(psd_rt_malloc((void**)&ttr, sizeof(psd_tr) * PSD_TRAIN_MAX * (size_t)p * PSD_TR_CAP));
+        PSD_CHECK(psd_rt_malloc((void**)&tcst, sizeof(psd_rstate) * PSD_SLOTS));
+        PSD_CHECK(psd_rt_malloc((void**)&tshift, sizeof(double) * PSD_TSHIFT_STRIDE * PSD_SLOTS));
+        PSD_CHECK(psd_rt_malloc((void**)&tdesc, sizeof(psd_apply_desc) * PSD_SLOTS));
+        PSD_CHECK(psd_rt_malloc((void**)&tcnt, sizeof(int) * PSD_SLOTS * (size_t)(p + 8)));
+        PSD_CHECK(psd_rt_malloc((void**)&ttr, sizeof(psd_tr) * PSD_SLOTS * (size_t)p * PSD_TR_CAP));
+        PSD_CHECK(psd_rt_malloc((void**)&tgl, sizeof(psd_rglobal)));
+        PSD_CHECK(psd_rt_malloc((void**)&tslotw, sizeof(int) * 3 * PSD_SLOTS));
         tcap_p = p;
         return 0;
     }
@@ -181,7 +188,10 @@ struct psd_ctx {
         if (tdesc) psd_rt_free(tdesc);
         if (tcnt) psd_rt_free(tcnt);
         if (ttr) psd_rt_free(ttr);
+        if (tgl) psd_rt_free(tgl);
+        if (tslotw) psd_rt_free(tslotw);
         tcst = nullptr; tshift = nullptr; tdesc = nullptr; tcnt = nullptr; ttr = nullptr;
+        tgl = nullptr; tslotw = nullptr;
         tcap_p = 0;
     }
 #ifndef PSD_HOSTSIM
@@ -675,28 +685,46 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     P.tshift = nullptr;
     P.lead = c->st;
     P.tick = 0;
+    P.gl = nullptr;
+    P.role = P.epoch = P.cdone = nullptr;
+    // multi-block scheduler (default with trains on; PSD_MB=0: one active range at a time): PSD_SLOTS workgroup slots,
+    // leaders of independent active ranges and the cursors of their trains
+    const bool mb = (M > 1) && c->mblock;
+    const int NSL = mb ? PSD_SLOTS : M;
     if (M > 1) {
         PSD_CHECK(c->treserve(p));
-        PSD_CHECK(psd_rt_memset(c->tcst, 0, sizeof(psd_rstate) * PSD_TRAIN_MAX, c->stream));
-        PSD_CHECK(psd_rt_memset(c->tdesc, 0, sizeof(psd_apply_desc) * PSD_TRAIN_MAX, c->stream));
+        PSD_CHECK(psd_rt_memset(c->tcst, 0, sizeof(psd_rstate) * PSD_SLOTS, c->stream));
+        PSD_CHECK(psd_rt_memset(c->tdesc, 0, sizeof(psd_apply_desc) * PSD_SLOTS, c->stream));
         P.cst = c->tcst;
         P.tshift = c->tshift;
         P.desc = c->tdesc;  // slot 0 of the cursor arrays: the fused bulk-update kernel indexes them by cursor
         P.cnt = c->tcnt;
         P.tr = c->ttr;
+        if (mb) {
+            P.st = c->tcst;
+            P.lead = c->tcst;
+            P.gl = c->tgl;
+            P.role = c->tslotw;
+            P.epoch = c->tslotw + PSD_SLOTS;
+            P.cdone = c->tslotw + 2 * PSD_SLOTS;
+        }
 #ifndef PSD_HOSTSIM
         PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_rq_step_train),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
+        PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_rq_step_mb),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
 #endif
     }
     int train_oc = 104;
     if (const char* e = getenv("PSD_TRAIN_OC")) train_oc = atoi(e);  // (tuning hook)
-    PSD_LAUNCH(psd_rq_init, psd_dim3(p), 256, 256 * 8, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, M, train_oc);
+    PSD_LAUNCH(psd_rq_init, psd_dim3(p), 256, 256 * 8, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, M, train_oc, mb ? 1 : 0);
     const size_t lds_apply = apply_lds_bytes();
     const int tiles = (n + PSD_APPLY_NT - 1) / PSD_APPLY_NT;
     const int batch = 32;
     psd_rstate hst;
     memset(&hst, 0, sizeof(hst));
+    psd_rglobal hgl;
+    memset(&hgl, 0, sizeof(hgl));
     long long launched = 0;
     // every window advances the chase by >= 1 position; generous cap against a runaway loop
     const long long cap = (long long)maxitfac * n * ((long long)n / 8 + 4) + 4LL * n + 1024;  // (trains run windows down to 8 positions)
@@ -720,6 +748,8 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
             P.tick = (int)launched;
             if (M == 1)
                 PSD_LAUNCH(psd_rq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
+            else if (mb)  // every slot of the scheduler in one launch
+                PSD_LAUNCH(psd_rq_step_mb, psd_dim3(PSD_SLOTS), PSD_STEP_NT, lds_step, c->stream, P, p, p + 8);
             else  // every cursor of the tick in one launch, one workgroup each
                 PSD_LAUNCH(psd_rq_step_train, psd_dim3(M), PSD_STEP_NT, lds_step, c->stream, P, p, p + 8);
 #ifndef PSD_HOSTSIM
@@ -731,8 +761,8 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
             if (c->apply_worklist) {
                 // work-list form: one grid of single-wave workgroups loops over the items of the tick
                 const int wl_grid = c->apply_wl_grid;
-                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, P, n, p, p + 8, 0, M);
-                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, P, n, p, p + 8, 1, M);
+                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, P, n, p, p + 8, 0, NSL);
+                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, P, n, p, p + 8, 1, NSL);
             } else if (M == 1) {
                 PSD_LAUNCH(psd_rq_apply, psd_dim3(tiles, p, 3), PSD_APPLY_NT, lds_apply, c->stream, P, n, p);
             } else {
@@ -740,6 +770,52 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 PSD_LAUNCH(psd_rq_apply_train, psd_dim3(tiles, p, M), PSD_APPLY_NT, lds_apply, c->stream, P, n, p, p + 8, 1);
             }
             ++launched;
+        }
+        if (mb) {
+#ifdef PSD_HOSTSIM
+            PSD_CHECK(psd_rt_d2h(&hgl, c->tgl, sizeof(hgl), c->stream));
+            PSD_CHECK(psd_rt_sync(c->stream));
+#else
+            PSD_CHECK(poller.poll(&hgl, c->tgl, sizeof(hgl), pend));
+#endif
+            if (hgl.done) {
+                hst.phase = PSD_PH_DONE;
+                hst.info = hgl.info;
+                hst.niter = hgl.niter;
+                hst.maxits = hgl.maxits;
+                hst.nsweeps = hgl.nsweeps;
+                hst.nrqpass = hgl.nrqpass;
+                hst.ndefl1 = hgl.ndefl1;
+                hst.ndefl2 = hgl.ndefl2;
+                hst.nwindows = hgl.nwindows;
+                hst.nlog = hgl.nlog;
+                hst.ntrains = hgl.ntrains;
+                hst.ntrainsweeps = hgl.ntrainsweeps;
+                for (int q = 0; q < 6; ++q) hst.cyc[q] = hgl.cyc[q];
+                break;
+            }
+            if (launched > cap || (getenv("PSD_DBG_CAP") && launched > atoll(getenv("PSD_DBG_CAP")))) {
+#ifdef PSD_HOSTSIM
+                fprintf(stderr, "mb runaway: launched %lld nactive %d nspawn %d nslotmax %d nsweeps %d\n", launched, hgl.nactive,
+                        hgl.nspawn, hgl.nslotmax, hgl.nsweeps);
+                for (int q = 0; q < PSD_SLOTS; ++q) {
+                    const psd_rstate& x = c->tcst[q];
+                    if (c->tslotw[q] != PSD_ROLE_FREE)
+                        fprintf(stderr, " slot %d role %d epoch %d phase %d cursor %d parent %d lo %d l %d i %d its %d train_n %d key %d kcur %d tick0 %d\n",
+                                q, c->tslotw[q], c->tslotw[PSD_SLOTS + q], x.phase, x.cursor, x.parent, x.lo, x.l, x.i, x.its,
+                                x.train_n, x.train_key, x.kcur, x.train_tick0);
+                    if (c->tslotw[q] == PSD_ROLE_LEADER && x.phase == PSD_PH_TWAIT)
+                        for (int b = 1; b < x.train_n; ++b)
+                            fprintf(stderr, "   cursor %d slot %d cdone %d (slot state: cursor %d parent %d key %d phase %d kcur %d i %d l %d tick0 %d)\n", b, x.cslots[b],
+                                    c->tslotw[2 * PSD_SLOTS + x.cslots[b]], c->tcst[x.cslots[b]].cursor, c->tcst[x.cslots[b]].parent,
+                                    c->tcst[x.cslots[b]].train_key, c->tcst[x.cslots[b]].phase, c->tcst[x.cslots[b]].kcur,
+                                    c->tcst[x.cslots[b]].i, c->tcst[x.cslots[b]].l, c->tcst[x.cslots[b]].train_tick0);
+                }
+#endif
+                *st_out = hst;
+                return PSD_INFO_RUNTIME + 0xfffe;
+            }
+            continue;
         }
 #ifdef PSD_HOSTSIM
         PSD_CHECK(psd_rt_d2h(&hst, c->st, sizeof(hst), c->stream));
@@ -857,6 +933,7 @@ int psd_create(psd_ctx** ctx, int device) {
 #ifndef PSD_HOSTSIM
     if (const char* e = getenv("PSD_HESS_LOOKAHEAD")) c->hess_lookahead = atoi(e);
 #endif
+    if (const char* e = getenv("PSD_MB")) c->mblock = atoi(e);
     if (const char* e = getenv("PSD_APPLY_WL")) c->apply_worklist = atoi(e);
     if (const char* e = getenv("PSD_APPLY_WL_GRID")) c->apply_wl_grid = atoi(e) > 0 ? atoi(e) : 2048;
 #ifdef PSD_HOSTSIM

@@ -62,6 +62,15 @@ static inline void psd_sqrt_pair_fast(double s, double& g, double& rg) {
 }
 static inline long long psd_clock() { return 0; }
 static inline long long psd_wallclock() { return 0; }
+// cross-workgroup words (agent-scope atomics on the GPU; the simulation runs the workgroups one after the other)
+static inline int psd_atomic_add(int* q, int v) { const int o = *q; *q = o + v; return o; }
+static inline long long psd_atomic_add_ll(long long* q, long long v) { const long long o = *q; *q = o + v; return o; }
+static inline int psd_atomic_cas(int* q, int expect, int v) { const int o = *q; if (o == expect) *q = v; return o; }
+static inline int psd_atomic_load(const int* q) { return *q; }
+static inline void psd_atomic_store(int* q, int v) { *q = v; }
+static inline int psd_atomic_max(int* q, int v) { const int o = *q; if (v > o) *q = v; return o; }
+static inline void psd_release_fence() {}
+static inline void psd_acquire_fence() {}
 typedef int psd_stream_t;
 #define PSD_LAUNCH(kern, grid_, nthreads_, ldsbytes_, stream_, ...)                  \
     do {                                                                              \
@@ -178,6 +187,36 @@ __device__ __forceinline__ void psd_sqrt_pair_fast(double s, double& g, double& 
     gg = __builtin_fma(d, h, gg);
     g = gg;
     rg = h + h;
+}
+// Cross-workgroup words of one launch (slot roles, done flags, global counters): agent-scope atomics.  Data handed
+// from one workgroup to another INSIDE a launch goes behind a release fence on the producer and an acquire fence on
+// the consumer (MI355X: per-XCD L2s are not coherent, a CU's L1 is never refreshed by other CUs' stores).
+__device__ __forceinline__ int psd_atomic_add(int* q, int v) {
+    return __hip_atomic_fetch_add(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ long long psd_atomic_add_ll(long long* q, long long v) {
+    return __hip_atomic_fetch_add(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int psd_atomic_cas(int* q, int expect, int v) {
+    __hip_atomic_compare_exchange_strong(q, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return expect;
+}
+__device__ __forceinline__ int psd_atomic_load(const int* q) {
+    return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void psd_atomic_store(int* q, int v) {
+    __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int psd_atomic_max(int* q, int v) {
+    return __hip_atomic_fetch_max(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void psd_release_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void psd_acquire_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 __device__ __forceinline__ long long psd_clock() { return (long long)__builtin_amdgcn_s_memtime(); }
 __device__ __forceinline__ long long psd_wallclock() { return (long long)__builtin_amdgcn_s_memrealtime(); }

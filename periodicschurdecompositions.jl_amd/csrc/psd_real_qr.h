@@ -39,6 +39,9 @@ enum { PSD_TR_R3 = 3, PSD_TR_H2 = 2, PSD_TR_R2 = 4, PSD_TR_G = 5 };
 #define PSD_STEP_NT 64    // the chase runs in one wavefront
 #define PSD_APPLY_NT 128  // threads (= tile rows / tile columns) of the bulk-apply kernel
 #define PSD_TRAIN_MAX 32  // bulges (cursors) of a multishift train
+#define PSD_SLOTS 64      // workgroup slots of the multi-block scheduler (leaders of independent active blocks + cursors)
+enum { PSD_ROLE_FREE = 0, PSD_ROLE_CLAIMED = 1, PSD_ROLE_LEADER = 2, PSD_ROLE_CURSOR = 3 };
+#define PSD_EPOCH_NEVER 0x7fffffff
 
 struct psd_tr {
     int pos;   // first row/column index (1-based) the transform acts on
@@ -100,6 +103,23 @@ struct psd_rstate {
     int train_tick0;  // tick (launch index) of the leader's first window of the running train
     int ntrains, ntrainsweeps;
     int exc_dec;  // its / 10 at the last exceptional shift of the current block (a train advances its by several)
+    // multi-block scheduler: this state's slot, the leader a cursor belongs to, the lower end of
+    // the range this leader owns (the reference works bottom-up through ONE range 1..n, PSD.jl:1057-1060; here the part
+    // above a negligible subdiagonal is handed to another workgroup as soon as it is found), the running train's key
+    int mb, slot, parent, lo, train_key;
+    int cslots[PSD_TRAIN_MAX];  // slots of the running train's cursors (entry 0 unused)
+};
+
+// global words of the multi-block scheduler
+struct psd_rglobal {
+    int done, info, abort;
+    int nactive;    // leaders alive
+    int nlog;       // entries of the shared sweep log
+    int train_seq;  // train keys
+    int itbudget;   // the reference's maxitleft (PSD.jl:471,1057): ONE budget of maxitfac * n sweeps for all ranges
+    int nsweeps, nrqpass, ndefl1, ndefl2, nwindows, ntrains, ntrainsweeps, maxits, nspawn, nslotmax;
+    long long niter;
+    long long cyc[6];
 };
 
 struct psd_rparams {
@@ -123,7 +143,15 @@ struct psd_rparams {
     double* tshift;    // [PSD_TRAIN_MAX][4] shift pairs of the train: rt1r, rt1i, rt2r, rt2i
     psd_rstate* lead;  // the main state (== st except in a cursor's parameter block)
     int tick;          // launch index (the driver counts ticks; cursors start at fixed tick offsets)
+    // multi-block scheduler (nullptr / 0 otherwise): slot s has state cst[s], descriptor desc[s], lists tr + s p CAP,
+    // shift pairs tshift + s PSD_TSHIFT_STRIDE
+    psd_rglobal* gl;
+    int* role;   // [PSD_SLOTS] PSD_ROLE_*
+    int* epoch;  // [PSD_SLOTS] tick at which a claimed slot's state was written (PSD_EPOCH_NEVER while free)
+    int* cdone;  // [PSD_SLOTS] per LEADER slot: cursors of its running train that have finished (a cursor's own slot
+                 // may be reused by another train before the leader looks)
 };
+#define PSD_TSHIFT_STRIDE (4 * PSD_TRAIN_MAX + 8)
 
 PSD_HD psd_mat<double> psd_fac(const psd_rparams& P, int n, int j) {
     return psd_mat<double>{P.H + (size_t)(j - 1) * n * n, n};
@@ -305,13 +333,109 @@ PSD_D void psd_record(const psd_rparams& P, int* lcnt, int m, const psd_tr& tr) 
 
 PSD_D void psd_log(const psd_rparams& P, psd_rstate& st, int kind, int l, int i) {
     PSD_ONE {
-        if (st.nlog < st.maxlog) {
-            P.log[3 * st.nlog + 0] = kind;
-            P.log[3 * st.nlog + 1] = l;
-            P.log[3 * st.nlog + 2] = i;
+        // (multi-block mode: several leaders share the log, entries land in the order the leaders reach them)
+        const int at = P.gl ? psd_atomic_add(&P.gl->nlog, 1) : st.nlog;
+        if (at < st.maxlog) {
+            P.log[3 * at + 0] = kind;
+            P.log[3 * at + 1] = l;
+            P.log[3 * at + 2] = i;
         }
     }
     st.nlog += 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multi-block scheduler.  PSD_SLOTS workgroup slots; a slot is FREE, CLAIMED (its state is being
+// written, or was written in this launch), a LEADER (the state machine of one active range lo..i) or a CURSOR of some
+// leader's train.  A slot's workgroup is the only one that reads its state, and it starts doing so in the launch AFTER
+// the one that wrote it (epoch < tick), so state never crosses workgroups inside a launch; what does are the role
+// words (agent-scope CAS), the per-leader counters of finished cursors and the counters of psd_rglobal.
+PSD_D int psd_mb_claim(const psd_rparams& P, int self) {  // (one lane)
+    for (int s = 0; s < PSD_SLOTS; ++s) {
+        if (s == self) continue;
+        if (psd_atomic_load(P.role + s) != PSD_ROLE_FREE) continue;
+        if (psd_atomic_cas(P.role + s, PSD_ROLE_FREE, PSD_ROLE_CLAIMED) == PSD_ROLE_FREE) {
+            psd_atomic_max(&P.gl->nslotmax, s + 1);
+            return s;
+        }
+    }
+    return -1;
+}
+// hands a slot back: everything this workgroup stored must be out before another workgroup may reuse the slot
+PSD_D void psd_mb_release_slot(const psd_rparams& P, int s) {  // (one lane)
+    psd_release_fence();
+    psd_atomic_store(P.epoch + s, PSD_EPOCH_NEVER);
+    psd_atomic_store(P.role + s, PSD_ROLE_FREE);
+}
+// A negligible subdiagonal at l > lo splits the range: rows/columns lo..l-1 become an active range of their own with
+// its own leader (if a slot is free; otherwise they wait their turn as in the reference, PSD.jl:1057-1060).
+// bc: LDS broadcast cell.
+PSD_D void psd_mb_spawn(const psd_rparams& P, psd_rstate& st, int* bc) {
+    PSD_SYNC();
+    PSD_ONE {
+        const int s = psd_mb_claim(P, st.slot);
+        if (s >= 0) {
+            psd_rstate cs = st;
+            cs.slot = s;
+            cs.parent = -1;
+            cs.cursor = 0;
+            cs.i = st.l - 1;
+            cs.l = st.lo;
+            cs.its = 1;
+            cs.maxitleft = psd_atomic_load(&P.gl->itbudget);
+            cs.exc_dec = 0;
+            cs.kcur = 0;
+            cs.phase = PSD_PH_DECIDE;
+            cs.train_n = 1;
+            cs.W = st.Wmax;
+            cs.niter = 0;
+            cs.maxits = 0;
+            cs.nsweeps = cs.nrqpass = cs.ndefl1 = cs.ndefl2 = cs.nwindows = cs.nlog = 0;
+            cs.ntrains = cs.ntrainsweeps = 0;
+            for (int q = 0; q < 6; ++q) cs.cyc[q] = 0;
+            P.cst[s] = cs;
+            psd_atomic_add(&P.gl->nactive, 1);
+            psd_atomic_add(&P.gl->nspawn, 1);
+            psd_atomic_store(P.epoch + s, P.tick);
+        }
+        bc[0] = s;
+    }
+    PSD_SYNC();
+    if (bc[0] >= 0) st.lo = st.l;
+    PSD_SYNC();
+}
+// a leader whose range is exhausted: totals to psd_rglobal, the last one alive finishes the decomposition
+// (PSD.jl:1066-1073) and raises `done`
+PSD_D void psd_mb_finish_leader(const psd_rparams& P, psd_rstate& st, int* bc) {
+    PSD_SYNC();
+    PSD_ONE {
+        psd_rglobal* g = P.gl;
+        psd_atomic_add(&g->nsweeps, st.nsweeps);
+        psd_atomic_add(&g->nrqpass, st.nrqpass);
+        psd_atomic_add(&g->ndefl1, st.ndefl1);
+        psd_atomic_add(&g->ndefl2, st.ndefl2);
+        psd_atomic_add(&g->nwindows, st.nwindows);
+        psd_atomic_add(&g->ntrains, st.ntrains);
+        psd_atomic_add(&g->ntrainsweeps, st.ntrainsweeps);
+        psd_atomic_max(&g->maxits, st.maxits);
+        psd_atomic_add_ll(&g->niter, st.niter);
+        for (int q = 0; q < 6; ++q) psd_atomic_add_ll(&g->cyc[q], st.cyc[q]);
+        psd_release_fence();  // (eigenvalues of this range are read by whoever finishes last)
+        bc[0] = psd_atomic_add(&g->nactive, -1) - 1;
+    }
+    PSD_SYNC();
+    const int left = bc[0];
+    PSD_SYNC();
+    if (left == 0) {
+        psd_acquire_fence();
+        const psd_mat<double> H1 = psd_fac(P, st.n, 1);
+        PSD_PAR_FOR(q, st.n - 1) {
+            if (P.wi[q] == 0.0) H1(q + 2, q + 1) = 0.0;
+        }
+        PSD_SYNC();
+        PSD_ONE { psd_atomic_store(&P.gl->done, 1); }
+    }
+    st.phase = PSD_PH_DONE;  // (psd_rq_step_body hands the slot back after its last store)
 }
 
 // opnorm(view(H1, lo:hi, lo:hi), 1) — PSD.jl:537,596 fallback when a diagonal pair is exactly zero
@@ -344,6 +468,13 @@ PSD_D void psd_rq_decide(const psd_rparams& P, psd_rstate& st, double* red, int*
     if (!(st.its < st.maxitleft)) {  // PSD.jl:471,891-893
         st.info = i;
         st.phase = PSD_PH_DONE;
+        if (st.mb) {
+            PSD_ONE {
+                psd_atomic_store(&P.gl->info, i);
+                psd_atomic_store(&P.gl->abort, 1);
+                psd_atomic_store(&P.gl->done, 1);
+            }
+        }
         return;
     }
     const psd_mat<double> H1 = psd_fac(P, n, 1);
@@ -373,10 +504,10 @@ PSD_D void psd_rq_decide(const psd_rparams& P, psd_rstate& st, double* red, int*
         } else if (r > lo) {
             P.hsub[r] = H1(r, r - 1) * P.Pd[r - 1];
             P.hdiag[r] = H1(r, r - 1) * P.Pe[r - 1] + H1(r, r) * P.Pd[r];
-            P.hsup[n - i + r] = H1(r, r - 1) * P.Pf[r - 1] + H1(r, r) * P.Pe[r] + H1(r, r + 1) * P.Pd[r + 1];
+            P.hsup[r] = H1(r, r - 1) * P.Pf[r - 1] + H1(r, r) * P.Pe[r] + H1(r, r + 1) * P.Pd[r + 1];
         } else {
             P.hdiag[r] = H1(r, r) * P.Pd[r];
-            P.hsup[n - i + r] = H1(r, r) * P.Pe[r] + H1(r, r + 1) * P.Pd[r + 1];
+            P.hsup[r] = H1(r, r) * P.Pe[r] + H1(r, r + 1) * P.Pd[r + 1];
         }
     }
     PSD_SYNC();
@@ -387,7 +518,7 @@ PSD_D void psd_rq_decide(const psd_rparams& P, psd_rstate& st, double* red, int*
         PSD_PAR_FOR(t, NT) {
             int best = 0, need = 0;
             for (int k = i - t; k >= lo + 1; k -= NT) {
-                const double hh21 = P.hsub[k], hh22 = P.hdiag[k], hh11 = P.hdiag[k - 1], hh12 = P.hsup[n - i + k - 1];
+                const double hh21 = P.hsub[k], hh22 = P.hdiag[k], hh11 = P.hdiag[k - 1], hh12 = P.hsup[k - 1];
                 double tst1 = fabs(hh11) + fabs(hh22);
                 if (tst1 == 0) {
                     if (h1norm < 0) {
@@ -570,8 +701,11 @@ PSD_D void psd_rq_train_shifts(const psd_rparams& P, int n, int p, int i, int m,
 }
 
 // PSD.jl:668-803: split test, shifts, first column of the shifted product
-PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work) {
+PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int* bc) {
     const int n = st.n, i = st.i, l = st.l;
+    // (after the RQ clean-up at l, which still touches position l - 1; a block that deflates at once is not worth a
+    //  hand-over: the range above it simply stays with this leader, as in the reference)
+    if (st.mb && st.l > st.lo && st.l < i - 1) psd_mb_spawn(P, st, bc);
     if (l >= i - 1) {
         st.phase = PSD_PH_DEFLATE;
         return;
@@ -609,7 +743,7 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work) {
     } else {  // PSD.jl:729-762 (dlahqr shifts; _slicot_shifts[] is false by default)
         h44 = hdiag[i];
         h33 = hdiag[i - 1];
-        double h43 = hsub[i], h34 = hsup[n - 1];
+        double h43 = hsub[i], h34 = hsup[i - 1];
         const double s = fabs(h33) + fabs(h34) + fabs(h43) + fabs(h44);
         if (s != 0) {
             h33 /= s; h44 /= s; h34 /= s; h43 /= s;
@@ -668,7 +802,29 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work) {
                     }
                     PSD_SYNC();
                 }
-                if (*okf) {
+                int mgot = m;
+                if (*okf && st.mb) {  // the cursors need slots: as many as are free
+                    PSD_SYNC();
+                    PSD_ONE {
+                        int got = 1;
+                        for (int b = 1; b < m; ++b) {
+                            const int sl = psd_mb_claim(P, st.slot);
+                            if (sl < 0) break;
+                            bc[2 + b] = sl;
+                            ++got;
+                        }
+                        bc[0] = got;
+                        bc[1] = psd_atomic_add(&P.gl->train_seq, 1) + 1;
+                        psd_atomic_store(P.cdone + st.slot, 0);  // (no cursor of an earlier train of this leader is left)
+                    }
+                    PSD_SYNC();
+                    mgot = bc[0];
+                    st.train_key = bc[1];
+                    for (int b = 1; b < mgot; ++b) st.cslots[b] = bc[2 + b];
+                    PSD_SYNC();
+                }
+                if (*okf && mgot >= 2) {
+                    m = mgot;
                     st.W = nb + 4;
                     st.train_n = m;
                     st.train_tick0 = P.tick;
@@ -687,7 +843,7 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work) {
     }
     {  // PSD.jl:768-803 with mmax = l (_allow_early_QR[] is false by default)
         const int m = l;
-        const double h11 = hdiag[m], h12 = hsup[n - i + m], h21 = hsub[m + 1], h22 = hdiag[m + 1];
+        const double h11 = hdiag[m], h12 = hsup[m], h21 = hsub[m + 1], h22 = hdiag[m + 1];
         double v1, v2, v3;
         if (exc) {
             const double h44s = h44 - h11, h33s = h33 - h11;
@@ -719,7 +875,14 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work) {
                 cs.nsweeps = cs.nwindows = cs.nlog = 0;
                 cs.maxlog = 0;
                 for (int q = 0; q < 6; ++q) cs.cyc[q] = 0;
-                P.cst[b] = cs;
+                if (st.mb) {  // (the slot's workgroup picks the state up in the next launch: epoch < tick)
+                    cs.parent = st.slot;
+                    cs.slot = st.cslots[b];
+                    P.cst[cs.slot] = cs;
+                    psd_atomic_store(P.epoch + cs.slot, P.tick);
+                } else {
+                    P.cst[b] = cs;
+                }
             }
         }
         PSD_SYNC();
@@ -1170,7 +1333,7 @@ PSD_D bool psd_rq_deflate(const psd_rparams& P, psd_rstate& st, double* ldsd, in
         hh12 = w.at(1, i - 1, i - 1) * hp12 + w.at(1, i - 1, i) * hp22;
     } else {  // PSD.jl:921-926
         hh11 = P.hdiag[i - 1];
-        hh12 = P.hsup[n - 1];
+        hh12 = P.hsup[i - 1];
         hh21 = P.hsub[i];
         hh22 = P.hdiag[i];
     }
@@ -1327,7 +1490,7 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
                 emitted = true;
                 break;
             case PSD_PH_SHIFT:
-                psd_rq_shift(P, st, ldsd);
+                psd_rq_shift(P, st, ldsd, redi);
                 break;
             case PSD_PH_QR:
                 psd_rq_qr_window(P, st, ldsd, lcnt);
@@ -1338,11 +1501,15 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
                 break;
             case PSD_PH_TWAIT: {  // the leader's sweep is done: wait for the cursors of the train, then go on
                 bool all = true;
-                for (int b = 1; b < st.train_n; ++b)
-                    if (P.cst[b].phase != PSD_PH_CDONE || P.cst[b].train_id != st.train_id) all = false;
+                if (st.mb) {  // a cursor adds one to its leader's counter after its last window
+                    all = psd_atomic_load(P.cdone + st.slot) == st.train_n - 1;
+                } else {
+                    for (int b = 1; b < st.train_n; ++b)
+                        if (P.cst[b].phase != PSD_PH_CDONE || P.cst[b].train_id != st.train_id) all = false;
+                }
                 if (all) {
                     for (int b = 1; b < st.train_n; ++b) {
-                        st.nwindows += P.cst[b].nwindows;
+                        if (!st.mb) st.nwindows += P.cst[b].nwindows;  // (multi-block: a cursor adds its own to psd_rglobal)
                         st.nsweeps += 1;
                         st.its += 1;
                     }
@@ -1357,16 +1524,27 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
                 break;
             }
             case PSD_PH_NEXT:  // PSD.jl:1057-1060
+                if (st.mb) {  // the budget is shared by all ranges
+                    PSD_SYNC();
+                    PSD_ONE { redi[0] = psd_atomic_add(&P.gl->itbudget, -st.its); }
+                    PSD_SYNC();
+                    st.maxitleft = redi[0];  // (value before the subtraction: the line below takes `its` off)
+                    PSD_SYNC();
+                }
                 st.maxitleft -= st.its;
                 st.niter += st.its;
                 if (st.its > st.maxits) st.maxits = st.its;
                 st.i = st.l - 1;
-                st.l = 1;
+                st.l = st.mb ? st.lo : 1;
                 st.its = 1;
                 st.exc_dec = 0;
-                st.phase = (st.i >= 1) ? PSD_PH_DECIDE : PSD_PH_FINAL;
+                st.phase = (st.i >= st.l) ? PSD_PH_DECIDE : PSD_PH_FINAL;
                 break;
             case PSD_PH_FINAL: {  // PSD.jl:1066-1073
+                if (st.mb) {
+                    psd_mb_finish_leader(P, st, redi);
+                    break;
+                }
                 const psd_mat<double> H1 = psd_fac(P, st.n, 1);
                 PSD_SYNC();
                 PSD_PAR_FOR(q, st.n - 1) {
@@ -1384,7 +1562,10 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
     st.cyc[4] += psd_clock() - tk0;
     st.cyc[5] += psd_wallclock() - tw0;
     PSD_SYNC();
-    PSD_ONE { *P.st = st; }
+    PSD_ONE {
+        *P.st = st;
+        if (st.mb && st.phase == PSD_PH_DONE && st.info == 0) psd_mb_release_slot(P, st.slot);
+    }
 }
 
 // One launch of cursor b >= 1 of a multishift train (P.st = the cursor's state, P.lead = the main state, P.desc / P.cnt /
@@ -1416,6 +1597,14 @@ PSD_D void psd_rq_cursor_body(const psd_rparams& P, int b) {
     psd_rq_qr_window(P, st, ldsd, lcnt);
     PSD_SYNC();
     PSD_ONE { *P.st = st; }
+    if (st.mb && st.phase == PSD_PH_CDONE) {  // last window of this bulge: report, hand the slot back
+        PSD_ONE {
+            psd_atomic_add(&P.gl->nwindows, st.nwindows);
+            for (int q = 1; q < 4; ++q) psd_atomic_add_ll(&P.gl->cyc[q], st.cyc[q]);
+            psd_mb_release_slot(P, st.slot);
+            psd_atomic_add(P.cdone + st.parent, 1);
+        }
+    }
 }
 
 // All cursors of a tick in ONE launch: workgroup 0 is the ordinary state machine (the leader), workgroup b >= 1 is cursor
@@ -1434,6 +1623,34 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rq_step_train(psd_rparams P, int p, int cstride) {
     Q.cnt = P.cnt + (size_t)b * cstride;
     Q.tr = P.tr + (size_t)b * p * PSD_TR_CAP;
     psd_rq_cursor_body(Q, b);
+}
+
+// Multi-block tick: workgroup s runs slot s (see psd_mb_claim).  P holds slot 0 of every per-slot array.
+PSD_KERNEL_B(PSD_STEP_NT) psd_rq_step_mb(psd_rparams P, int p, int cstride) {
+    const int s = PSD_BLOCK_X;
+    psd_rparams Q = P;
+    Q.st = P.cst + s;
+    Q.desc = P.desc + s;
+    Q.cnt = P.cnt + (size_t)s * cstride;
+    Q.tr = P.tr + (size_t)s * p * PSD_TR_CAP;
+    PSD_ONE { Q.desc->active = 0; }
+    if (psd_atomic_load(&P.gl->done) || psd_atomic_load(&P.gl->abort)) return;
+    int role = psd_atomic_load(P.role + s);
+    if (role == PSD_ROLE_CLAIMED && psd_atomic_load(P.epoch + s) < P.tick) {
+        // written in an earlier launch: the slot goes live (only this workgroup ever changes a claimed slot's role)
+        role = (P.cst[s].cursor > 0) ? PSD_ROLE_CURSOR : PSD_ROLE_LEADER;
+        PSD_ONE { psd_atomic_store(P.role + s, role); }
+    }
+    if (role == PSD_ROLE_LEADER) {
+        Q.lead = Q.st;
+        Q.tshift = P.tshift + (size_t)s * PSD_TSHIFT_STRIDE;
+        psd_rq_step_body(Q);
+    } else if (role == PSD_ROLE_CURSOR) {
+        const int parent = P.cst[s].parent;
+        Q.lead = P.cst + parent;
+        Q.tshift = P.tshift + (size_t)parent * PSD_TSHIFT_STRIDE;
+        psd_rq_cursor_body(Q, P.cst[s].cursor);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1644,7 +1861,7 @@ PSD_KERNEL_B(PSD_APPLY_NT) psd_rq_apply_train(psd_rparams P, int n, int p, int c
 #define PSD_WL_LINES 64
 #define PSD_WL_LD 33
 PSD_HD size_t psd_wl_lds_bytes() {
-    return PSD_TR_LDS_BYTES + (size_t)PSD_WL_LINES * PSD_WL_LD * sizeof(double) + (size_t)(3 * PSD_TRAIN_MAX + 4) * sizeof(int);
+    return PSD_TR_LDS_BYTES + (size_t)PSD_WL_LINES * PSD_WL_LD * sizeof(double) + (size_t)(3 * PSD_SLOTS + 4) * sizeof(int);
 }
 
 // the three-element window of one line moving up (UP) or down through positions; L: the line in LDS (S elements)
@@ -1696,8 +1913,8 @@ PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride
     int* flags = (int*)(psd_lds + sizeof(psd_tr) * PSD_TR_LDS_RECS);
     double* tile = (double*)(psd_lds + PSD_TR_LDS_BYTES);
     int* ioff = (int*)(tile + (size_t)PSD_WL_LINES * PSD_WL_LD);  // [M + 1] item offsets, [M] tiles A, [M] tiles B
-    int* tA = ioff + PSD_TRAIN_MAX + 2;
-    int* tB = tA + PSD_TRAIN_MAX;
+    int* tA = ioff + PSD_SLOTS + 2;
+    int* tB = tA + PSD_SLOTS;
     const int TL = PSD_WL_LINES, LD = PSD_WL_LD;
     // item table: cursor b contributes p * (tiles of role A + tiles of role B) items (pass 0: A = rows, B = Z;
     // pass 1: A = columns, B = none)
@@ -1858,7 +2075,7 @@ PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride
 // hnorms[j] = ulp*n*opnorm(H_j, 1), column-1 / sub-Hessenberg clean-up (PSD.jl:379-388,406), and
 // state initialisation.  grid = p blocks.
 PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W, int maxitfac, int maxlog,
-                       int train_want, int train_oc) {
+                       int train_want, int train_oc, int mb) {
     PSD_LDS_DECL;
     double* red = (double*)psd_lds;
     const int j = PSD_BLOCK_X + 1;
@@ -1889,8 +2106,28 @@ PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W,
             s = sqrt(s);          // iu = 4 -> selected
             ulpx *= s;
             st.ulpx = ulpx;
+            st.mb = mb;
+            st.slot = 0;
+            st.parent = -1;
+            st.lo = 1;
+            st.train_key = 0;
+            for (int q = 0; q < PSD_TRAIN_MAX; ++q) st.cslots[q] = 0;
             *P.st = st;
             P.desc->active = 0;
+            if (mb) {  // slot 0 leads the whole range; every other slot is free
+                psd_rglobal g;
+                memset(&g, 0, sizeof(g));
+                g.nactive = 1;
+                g.nslotmax = 1;
+                g.itbudget = maxitfac * n;
+                *P.gl = g;
+                for (int q = 0; q < PSD_SLOTS; ++q) {
+                    P.role[q] = (q == 0) ? PSD_ROLE_LEADER : PSD_ROLE_FREE;
+                    P.epoch[q] = PSD_EPOCH_NEVER;
+                    P.cdone[q] = 0;
+                    P.desc[q].active = 0;
+                }
+            }
         }
     } else {
         PSD_PAR_FOR(r, n - 1) { Hj(r + 2, 1) = 0.0; }
