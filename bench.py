@@ -67,7 +67,9 @@ def cpu_baseline(n, p, seed, eng, gpu_positions, budget_cols=None, budget_sweeps
     K = budget_cols or (6 if big else max(8, n // 16))
     S = budget_sweeps or (4 if big else 12)
     As = pt.bench_factors(n, p, seed)
-    ncores = os.cpu_count()
+    # threads the process may actually use (the GPU box gives one GPU's share of the host's cores to a job)
+    ncores = min(len(os.sched_getaffinity(0)), 64) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    ncores = int(os.environ.get('PSD_BENCH_THREADS', ncores))
 
     def hess_sample(threads):
         lib.psdo_set_threads(threads)
@@ -110,7 +112,7 @@ def cpu_baseline(n, p, seed, eng, gpu_positions, budget_cols=None, budget_sweeps
                       f"of width {int(sw[0, 2] - sw[0, 1] + 1) if nsw else 0} of pschur!(H1,Hs) n={n} p={p} Float64 wantT "
                       f"wantZ in {t_s:.1f} s (stopped by a sweep cap, rc={rc}), and the first {K} of {n - 1} columns of "
                       f"phessenberg! ({K * p} links, {100 * frac:.2f} % of the reduction's algorithmic bytes) in "
-                      f"{t_h1:.1f} s on 1 thread / {t_hN:.1f} s on {ncores} threads; host has {ncores} cores",
+                      f"{t_h1:.1f} s on 1 thread / {t_hN:.1f} s on {ncores} threads; the job may use {ncores} of the host's {os.cpu_count()} cores",
             "sweep_positions_per_s": pos_per_s,
             "hessenberg_sample_s": {"threads_1": t_h1, f"threads_{ncores}": t_hN, "columns": K},
             "allcore": {"cores": ncores, "hessenberg_speedup": t_h1 / t_hN if t_hN > 0 else None,
@@ -126,9 +128,10 @@ def cycle_shares(st):
     """In-kernel s_memtime accounting of the chase kernel (psd_stats.step_cycles): share of decide / window load /
     chase / window store in the kernel's own time, and the shader clock derived from s_memrealtime."""
     c = list(st.step_cycles)
-    if not c[4]:
+    if not c[4] or not (c[0] + c[1] + c[2] + c[3]):
         return None
-    out = {"decide": c[0] / c[4], "window_load": c[1] / c[4], "chase": c[2] / c[4], "window_store": c[3] / c[4]}
+    tot = c[0] + c[1] + c[2] + c[3]  # (all workgroups of a tick: leaders and cursors)
+    out = {"decide": c[0] / tot, "window_load": c[1] / tot, "chase": c[2] / tot, "window_store": c[3] / tot}
     if c[5]:
         out["shader_clock_GHz"] = c[4] / (c[5] * 10e-9) / 1e9  # s_memrealtime ticks at 100 MHz
     return out
@@ -221,7 +224,7 @@ def main():
         ok, err, orth, tri = eng.checkpsd_dev(bufs[-1].data_ptr(), zbufs[-1].data_ptr(), dA0.data_ptr(), n, p, "R", 1,
                                               thresh=thresh)
         del dA0
-        gate_ok = bool(ok) and lam_err <= 1e-10
+        gate_ok = bool(bool(ok) and float(lam_err) <= 1e-10)
 
         nwin = sum(s.nwindows for (_, _, s, _) in results)
         nlaunch = sum(s.nlaunch_step for (_, _, s, _) in results)
@@ -237,13 +240,14 @@ def main():
         roof = None
         if kms:
             achieved = bytes_per_launch / (kms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "psd_rq_step_train", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roof = {"bound": "hbm", "kernel": "psd_rq_step_mb", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, p)[0], "traffic_source": pmc_traffic(n, p)[1],
                     "alg_bytes_per_launch": bytes_per_launch, "avg_launch_ms": kms, "launch_samples": ksamples,
                     "windows_per_launch": nwin / max(nlaunch, 1),
-                    "note": "algorithmic bytes of the sweep windows one launch chases (one window of every bulge of the "
-                            "running multishift train; 2*8*p*w*(2n+1) per sweep) / HIP-event duration of the chase "
-                            "kernel; every bulge is latency-bound on its serial reflector chain"}
+                    "note": "algorithmic bytes of the sweep windows one launch chases (one window of every bulge in flight: "
+                            "the cursors of the multishift trains of all active ranges; 2*8*p*w*(2n+1) per sweep) / "
+                            "HIP-event duration of the chase kernel; every bulge is latency-bound on its serial "
+                            "reflector chain"}
         out = {
             "metric": "PSD sweeps/sec (pschur! n=%d p=%d Float64, Hessenberg+Q+iteration, operands in HBM)" % (n, p),
             "value": sweeps_all / elapsed_max,
@@ -260,7 +264,7 @@ def main():
             "config": {"workload": "%spschur!(A,:R) N=%d p=%d Float64 wantT wantZ, A_j = I + 0.5*G_j/sqrt(n)"
                                    % ("north_star target size: " if (n, p) == (1024, 64) else
                                       ("configs[1]: " if (n, p) == (512, 16) else ""), n, p),
-                       "seed": seed, "parallelism": "replicas x%d" % world, "window": st.window},
+                       "seed": seed, "parallelism": ("1 GPU" if world == 1 else "replicas x%d" % world), "window": st.window},
             "sweeps_per_step": sweeps / args.steps,
             "sweeps_in_multishift_trains_per_step": ntrain / args.steps,
             "chase_kernel_cycle_shares": cycle_shares(st),
@@ -270,7 +274,7 @@ def main():
                                  "hessenberg": st.bytes_hess / (st.ms_hess * 1e-3) / 1e9 if st.ms_hess else None,
                                  "whole_call": (bytes_sw / args.steps + st.bytes_hess + st.bytes_formq) * args.steps / elapsed / 1e9},
             "time_to_solution_s": elapsed_max / args.steps,
-            "accuracy": {"gate_ok": gate_ok, "eig_rel_err_vs_numpy_prod": lam_err, "eig_tol": 1e-10, "checkpsd_ok": bool(ok),
+            "accuracy": {"gate_ok": gate_ok, "eig_rel_err_vs_numpy_prod": float(lam_err), "eig_tol": 1e-10, "checkpsd_ok": bool(ok),
                          "checkpsd_max_err_eps": float(err.max()), "checkpsd_thresh_eps": thresh,
                          "orth_max_over_eps_n": float(orth.max() / (pt.EPS * n)), "evaluated": "device (psd_d_checkpsd_dev)"},
             "roofline": roof,

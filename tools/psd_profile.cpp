@@ -1,10 +1,13 @@
 // Standalone driver for profiler runs (rocprofv3 --pmc crashes under the python/torch harness on this image).
 // Usage: psd_profile [n] [p] [repeat]  — solves pschur!(A,:R) on A_j = I + 0.5 G_j/sqrt(n) through the C ABI.
+// Linked DIRECTLY against libpsd_mi355x.so (round 1 dlopen()ed it after the profiler had initialised the GPU; the
+// unfiltered --pmc run of that build died with a SIGSEGV on a profiler thread, gpurun_out/pmc_fetch.log).  With
+// PSD_PROFILE_MAPS=<file> the process writes /proc/self/maps there once the library and the HIP runtime are up, so
+// that the frames of a crash can be attributed to a library.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
-#include <dlfcn.h>
 #include <vector>
 
 #include "../include/psd_mi355x.h"
@@ -22,14 +25,21 @@ static double gauss(uint64_t& s) {
 
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 512, p = argc > 2 ? atoi(argv[2]) : 16, rep = argc > 3 ? atoi(argv[3]) : 1;
-    const char* path = getenv("LIBPSD_MI355X");
-    void* h = dlopen(path ? path : "periodicschurdecompositions.jl_amd/libpsd_mi355x.so", RTLD_NOW);
-    if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
-    auto create = (int (*)(psd_ctx**, int))dlsym(h, "psd_create");
-    auto destroy = (int (*)(psd_ctx*))dlsym(h, "psd_destroy");
-    auto pschur = (decltype(&psd_d_pschur))dlsym(h, "psd_d_pschur");
+    auto create = &psd_create;
+    auto destroy = &psd_destroy;
+    auto pschur = &psd_d_pschur;
     psd_ctx* ctx = nullptr;
     if (create(&ctx, 0) != 0) { fprintf(stderr, "psd_create failed\n"); return 3; }
+    if (const char* mp = getenv("PSD_PROFILE_MAPS")) {
+        FILE* in = fopen("/proc/self/maps", "r");
+        FILE* out = fopen(mp, "w");
+        if (in && out) {
+            char line[1024];
+            while (fgets(line, sizeof(line), in)) fputs(line, out);
+        }
+        if (in) fclose(in);
+        if (out) fclose(out);
+    }
     const size_t nn = (size_t)n * n;
     std::vector<std::vector<double>> A0(p, std::vector<double>(nn)), A(p), Z(p, std::vector<double>(nn));
     uint64_t s = 1236;
