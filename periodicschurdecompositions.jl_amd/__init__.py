@@ -185,6 +185,8 @@ class Engine:
                                        C.c_double, C.c_int, dp, dp, dp, ip, ip]
         lib.psd_d_checkpsd_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, u8p,
                                            C.c_char, C.c_int, C.c_double, C.c_int, dp, dp, dp, ip, ip]
+        lib.psd_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.psd_shard_owned.argtypes = [C.c_void_p, C.c_int, C.c_char, u8p]
         self.ctx = C.c_void_p()
         rc = lib.psd_create(C.byref(self.ctx), device)
         if rc != 0:
@@ -219,6 +221,22 @@ class Engine:
     def get_train(self):
         self.lib.psd_get_train.argtypes = [C.c_void_p]
         return int(self.lib.psd_get_train(self.ctx))
+
+    def set_shard(self, rank, world):
+        """Period sharding (include/psd_mi355x.h, psd_set_shard): this engine keeps the Schur vectors Z_j of its
+        contiguous slice of the period; the chains and the factors are computed identically on every rank."""
+        rc = self.lib.psd_set_shard(self.ctx, int(rank), int(world))
+        if rc != 0:
+            raise ValueError(f"psd_set_shard({rank}, {world}): argument {-rc} invalid")
+        self.shard = (int(rank), int(world))
+
+    def owned_slots(self, p, lr="R"):
+        """Boolean mask over the user slots of Z that this (sharded) engine holds after a call with orientation lr."""
+        owned = (C.c_uint8 * p)()
+        rc = self.lib.psd_shard_owned(self.ctx, p, char_lr(lr).encode(), owned)
+        if rc != 0:
+            raise ValueError(f"psd_shard_owned: argument {-rc} invalid")
+        return np.array([bool(x) for x in owned])
 
     def set_profile(self, on):
         self.lib.psd_set_profile(self.ctx, int(on))

@@ -127,7 +127,7 @@ struct psd_ctx {
     int logcap = 0;
     size_t step_lds_set = 0, zstep_lds_set = 0, rostep_lds_set = 0;
     psd_hess_args* hargs = nullptr;  // device argument block of the graph-replayed Hessenberg reduction
-    // multishift trains (experimental): bulges per train (0/1 = off), per-cursor state / descriptor / lists
+    // multishift trains: bulges per train (0/1 = off), per-cursor state / descriptor / lists
     int ztrain_m = 32;  // complex single-shift engine (shifts from a block of order <= PSD_ZHQR_MAX, reused by longer trains) (psd_set_train sets both; psd_set_train_z / PSD_TRAIN_Z this one)
     int train_m = 32;  // default: trains of up to 32 bulges (psd_set_train / PSD_TRAIN; 0 or 1 = the reference's iteration)
     int tcap_p = 0;
@@ -146,7 +146,7 @@ struct psd_ctx {
     int ztreserve(int p) {
         if (ztcst && p <= ztcap_p) return 0;
         ztrelease();
-        PSD_CHECK(psd_rt_malloc((void**)&ztcst, sizeof(psd_zstate) * PSD_TRAIN_MAX));
+        PSD_CHECK(psd_rt_malloc((void**)&ztcst, sizeof(psd_zstate) * PSD_TRAIN_MAX + sizeof(int) * (PSD_TRAIN_MAX + 8)));
         PSD_CHECK(psd_rt_malloc((void**)&ztdesc, sizeof(psd_zapply_desc) * PSD_TRAIN_MAX));
         PSD_CHECK(psd_rt_malloc((void**)&ztcnt, sizeof(int) * PSD_TRAIN_MAX * (size_t)(p + 8)));
         PSD_CHECK(psd_rt_malloc((void**)&zttr, sizeof(psd_ztr) * PSD_TRAIN_MAX * (size_t)p * PSD_ZTR_CAP));
@@ -202,6 +202,13 @@ struct psd_ctx {
     int h2ring_n = 0;
     int hess_lookahead = 1;  // PSD_HESS_LOOKAHEAD=0: the two-launch form of psd_hess.h
 #endif
+    // period sharding (psd_set_shard): this context holds the Schur vectors Z_j of a contiguous slice of the period
+    int shard_rank = 0, shard_world = 1;
+    void slice(int p, int& lo, int& hi) const {  // [lo, hi), 0-based internal factor index
+        const int base = p / shard_world, rem = p % shard_world;
+        lo = shard_rank * base + (shard_rank < rem ? shard_rank : rem);
+        hi = lo + base + (shard_rank < rem ? 1 : 0);
+    }
     int apply_worklist = 1;   // PSD_APPLY_WL=0: the grid-per-cursor bulk-apply kernels
     int apply_wl_grid = 2048; // workgroups of the work-list bulk apply (PSD_APPLY_WL_GRID)
     psd_rostate* rost = nullptr;
@@ -248,7 +255,7 @@ struct psd_ctx {
     int gtreserve(int p) {
         if (gtcst && p <= gtcap_p) return 0;
         gtrelease();
-        PSD_CHECK(psd_rt_malloc((void**)&gtcst, sizeof(psd_gstate) * PSD_TRAIN_MAX));
+        PSD_CHECK(psd_rt_malloc((void**)&gtcst, sizeof(psd_gstate) * PSD_TRAIN_MAX + sizeof(int) * (PSD_TRAIN_MAX + 8)));
         PSD_CHECK(psd_rt_malloc((void**)&gtshift, sizeof(double) * (4 * PSD_TRAIN_MAX + 8)));
         PSD_CHECK(psd_rt_malloc((void**)&gtdesc, sizeof(psd_gapply_desc) * PSD_TRAIN_MAX));
         PSD_CHECK(psd_rt_malloc((void**)&gtcnt, sizeof(int) * PSD_TRAIN_MAX * (size_t)(p + 8)));
@@ -281,7 +288,7 @@ struct psd_ctx {
     int zgtreserve(int p) {
         if (zgtcst && p <= zgtcap_p) return 0;
         zgtrelease();
-        PSD_CHECK(psd_rt_malloc((void**)&zgtcst, sizeof(psd_zgstate) * PSD_TRAIN_MAX));
+        PSD_CHECK(psd_rt_malloc((void**)&zgtcst, sizeof(psd_zgstate) * PSD_TRAIN_MAX + sizeof(int) * (PSD_TRAIN_MAX + 8)));
         PSD_CHECK(psd_rt_malloc((void**)&zgtshift, sizeof(psd_z) * (PSD_TRAIN_MAX + 2)));
         PSD_CHECK(psd_rt_malloc((void**)&zgtdesc, sizeof(psd_gapply_desc) * PSD_TRAIN_MAX));
         PSD_CHECK(psd_rt_malloc((void**)&zgtcnt, sizeof(int) * PSD_TRAIN_MAX * (size_t)(p + 8)));
@@ -639,11 +646,15 @@ int hessenberg_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
 }
 
 int formq_dev(psd_ctx* c, int n, int p, const double* dH, const double* dtau, double* dQ) {
-    PSD_LAUNCH(psd_set_identity, psd_dim3(n, p), 64, 0, c->stream, dQ, n);
+    // a period-sharded context forms only the Q_j of its slice (psd_set_shard)
+    int jlo = 0, jhi = p;
+    c->slice(p, jlo, jhi);
+    if (jhi <= jlo) return 0;
+    PSD_LAUNCH(psd_set_identity, psd_dim3(n, jhi - jlo), 64, 0, c->stream, dQ + (size_t)jlo * n * n, n);
     const size_t lds = PSD_HESS_NT * 8;
     for (int i = n - 1; i >= 1; --i) {
         const int tiles = (n - i + 1 + 3) / 4;
-        PSD_LAUNCH(psd_formq_step, psd_dim3(tiles, p), PSD_HESS_NT, lds, c->stream, dH, dtau, dQ, n, i);
+        PSD_LAUNCH(psd_formq_step, psd_dim3(tiles, jhi - jlo), PSD_HESS_NT, lds, c->stream, dH, dtau, dQ, n, i, jlo);
     }
     return 0;
 }
@@ -678,7 +689,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
         c->step_lds_set = lds_step;
     }
 #endif
-    // multishift trains (experimental; off unless psd_set_train / PSD_TRAIN >= 2): M cursors, each with its own state,
+    // multishift trains (default: up to 32 bulges; psd_set_train / PSD_TRAIN): M cursors, each with its own state,
     // descriptor and lists; cursor 0 is the ordinary state machine
     const int M = (c->train_m >= 2) ? ((c->train_m > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : c->train_m) : 1;
     P.cst = nullptr;
@@ -686,6 +697,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     P.lead = c->st;
     P.tick = 0;
     P.gl = nullptr;
+    P.cep = nullptr;
     P.role = P.epoch = P.cdone = nullptr;
     // multi-block scheduler (default with trains on; PSD_MB=0: one active range at a time): PSD_SLOTS workgroup slots,
     // leaders of independent active ranges and the cursors of their trains
@@ -696,6 +708,8 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
         PSD_CHECK(psd_rt_memset(c->tcst, 0, sizeof(psd_rstate) * PSD_SLOTS, c->stream));
         PSD_CHECK(psd_rt_memset(c->tdesc, 0, sizeof(psd_apply_desc) * PSD_SLOTS, c->stream));
         P.cst = c->tcst;
+        P.cep = c->tslotw;  // (single-range train mode; the multi-block scheduler uses the same words as role/epoch/cdone)
+        PSD_CHECK(psd_rt_memset(c->tslotw, 0, sizeof(int) * 3 * PSD_SLOTS, c->stream));
         P.tshift = c->tshift;
         P.desc = c->tdesc;  // slot 0 of the cursor arrays: the fused bulk-update kernel indexes them by cursor
         P.cnt = c->tcnt;
@@ -721,6 +735,9 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     const size_t lds_apply = apply_lds_bytes();
     const int tiles = (n + PSD_APPLY_NT - 1) / PSD_APPLY_NT;
     const int batch = 32;
+    int zlo0 = 0, zhi0 = p;
+    c->slice(p, zlo0, zhi0);
+    const int zlo1 = zlo0 + 1, zhi1 = zhi0;  // owners (1-based, inclusive) whose Z_m this context updates
     psd_rstate hst;
     memset(&hst, 0, sizeof(hst));
     psd_rglobal hgl;
@@ -758,11 +775,13 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 pend.emplace_back(ev0, ev1);
             }
 #endif
-            if (c->apply_worklist) {
+            if (c->apply_worklist || c->shard_world > 1) {
                 // work-list form: one grid of single-wave workgroups loops over the items of the tick
                 const int wl_grid = c->apply_wl_grid;
-                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, P, n, p, p + 8, 0, NSL);
-                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, P, n, p, p + 8, 1, NSL);
+                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, P, n, p, p + 8, 0, NSL,
+                           zlo1, zhi1);
+                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, P, n, p, p + 8, 1, NSL,
+                           zlo1, zhi1);
             } else if (M == 1) {
                 PSD_LAUNCH(psd_rq_apply, psd_dim3(tiles, p, 3), PSD_APPLY_NT, lds_apply, c->stream, P, n, p);
             } else {
@@ -889,7 +908,7 @@ int run_iteration(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, i
         const int64_t m = nl < maxlog_user ? nl : maxlog_user;
         for (int64_t q = 0; q < 3 * m; ++q) sweeplog[q] = hlog[q];
     }
-    *info = (st.info != 0) ? (PSD_INFO_NOCONV + st.info) : 0;
+    *info = (st.info == PSD_LIST_OVERFLOW) ? (PSD_INFO_RUNTIME + 77) : ((st.info != 0) ? (PSD_INFO_NOCONV + st.info) : 0);
     return *info;
 }
 
@@ -986,6 +1005,31 @@ int psd_destroy(psd_ctx* c) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
 #endif
     delete c;
+    return 0;
+}
+
+int psd_set_shard(psd_ctx* c, int rank, int world) {
+    if (!c) return -1;
+    if (world < 1) return -3;
+    if (rank < 0 || rank >= world) return -2;
+    c->shard_rank = rank;
+    c->shard_world = world;
+    return 0;
+}
+
+int psd_shard_owned(psd_ctx* c, int p, char orient, uint8_t* owned) {
+    if (!c) return -1;
+    if (p < 1) return -2;
+    if (orient != 'R' && orient != 'L') return -3;
+    if (!owned) return -4;
+    int lo = 0, hi = p;
+    c->slice(p, lo, hi);
+    for (int s = 0; s < p; ++s) owned[s] = 0;
+    for (int j = lo; j < hi; ++j) {
+        // internal factor j (0-based) -> user slot of Z_j: 'R' identity; 'L': Z_1 stays, Z_2..Z_p reverse (PSD.jl:1078-1092)
+        const int slot = (orient == 'R' || j == 0) ? j : (p - j);
+        owned[slot] = 1;
+    }
     return 0;
 }
 
@@ -1219,13 +1263,15 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
     // multishift trains (see iterate_dev): cursor 0 = slot 0 of the cursor arrays
     const int M = (c->ztrain_m >= 2) ? ((c->ztrain_m > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : c->ztrain_m) : 1;
     P.cst = nullptr;
+    P.cep = nullptr;
     P.tshift = nullptr;
     P.tick = 0;
     if (M > 1) {
         PSD_CHECK(c->ztreserve(p));
-        PSD_CHECK(psd_rt_memset(c->ztcst, 0, sizeof(psd_zstate) * PSD_TRAIN_MAX, c->stream));
+        PSD_CHECK(psd_rt_memset(c->ztcst, 0, sizeof(psd_zstate) * PSD_TRAIN_MAX + sizeof(int) * (PSD_TRAIN_MAX + 8), c->stream));
         PSD_CHECK(psd_rt_memset(c->ztdesc, 0, sizeof(psd_zapply_desc) * PSD_TRAIN_MAX, c->stream));
         P.cst = c->ztcst;
+        P.cep = (int*)(c->ztcst + PSD_TRAIN_MAX);
         P.tshift = c->ztshift;
         P.desc = c->ztdesc;
         P.cnt = c->ztcnt;
@@ -1356,7 +1402,7 @@ int zrun_iteration(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, in
         const int64_t m = nl < maxlog_user ? nl : maxlog_user;
         for (int64_t q = 0; q < 3 * m; ++q) sweeplog[q] = hlog[q];
     }
-    *info = (st.info != 0) ? (PSD_INFO_NOCONV + st.info) : 0;
+    *info = (st.info == PSD_LIST_OVERFLOW) ? (PSD_INFO_RUNTIME + 77) : ((st.info != 0) ? (PSD_INFO_NOCONV + st.info) : 0);
     return *info;
 }
 
@@ -1410,13 +1456,15 @@ int zgiterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
     const int Mcap = (PSD_ZHQR_MAX < PSD_TRAIN_MAX) ? PSD_ZHQR_MAX : PSD_TRAIN_MAX;
     const int M = (tw >= 2) ? ((tw > Mcap) ? Mcap : tw) : 1;
     P.cst = nullptr;
+    P.cep = nullptr;
     P.tshift = nullptr;
     P.tick = 0;
     if (M > 1 || tw == -2) {
         PSD_CHECK(c->zgtreserve(p));
-        PSD_CHECK(psd_rt_memset(c->zgtcst, 0, sizeof(psd_zgstate) * PSD_TRAIN_MAX, c->stream));
+        PSD_CHECK(psd_rt_memset(c->zgtcst, 0, sizeof(psd_zgstate) * PSD_TRAIN_MAX + sizeof(int) * (PSD_TRAIN_MAX + 8), c->stream));
         PSD_CHECK(psd_rt_memset(c->zgtdesc, 0, sizeof(psd_gapply_desc) * PSD_TRAIN_MAX, c->stream));
         P.cst = c->zgtcst;
+        P.cep = (int*)(c->zgtcst + PSD_TRAIN_MAX);
         P.tshift = c->zgtshift;
         if (M > 1) {
             P.desc = c->zgtdesc;
@@ -1515,7 +1563,7 @@ int zgrun_iteration(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_
     PSD_CHECK(psd_rt_d2h(hsc.data(), c->zascale, sizeof(int) * n, c->stream));
     PSD_CHECK(psd_rt_sync(c->stream));
     for (int q = 0; q < n; ++q) ascale[q] = hsc[q];
-    return *info = (st.info != 0) ? (PSD_INFO_NOCONV + st.info) : 0;
+    return *info = (st.info == PSD_LIST_OVERFLOW) ? (PSD_INFO_RUNTIME + 77) : ((st.info != 0) ? (PSD_INFO_NOCONV + st.info) : 0);
 }
 
 // _phessenberg!(A, S; wantQ) for ComplexF64 on device — generalized.jl:988-1082
@@ -2132,13 +2180,15 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
     const int tw = hessmode ? 0 : c->gtrain_m;
     const int M = (tw >= 2) ? ((tw > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : tw) : 1;
     P.cst = nullptr;
+    P.cep = nullptr;
     P.tshift = nullptr;
     P.tick = 0;
     if (M > 1 || tw == -2) {
         PSD_CHECK(c->gtreserve(p));
-        PSD_CHECK(psd_rt_memset(c->gtcst, 0, sizeof(psd_gstate) * PSD_TRAIN_MAX, c->stream));
+        PSD_CHECK(psd_rt_memset(c->gtcst, 0, sizeof(psd_gstate) * PSD_TRAIN_MAX + sizeof(int) * (PSD_TRAIN_MAX + 8), c->stream));
         PSD_CHECK(psd_rt_memset(c->gtdesc, 0, sizeof(psd_gapply_desc) * PSD_TRAIN_MAX, c->stream));
         P.cst = c->gtcst;
+        P.cep = (int*)(c->gtcst + PSD_TRAIN_MAX);
         P.tshift = c->gtshift;
         if (M > 1) {
             P.desc = c->gtdesc;
@@ -2275,7 +2325,7 @@ int grun_iteration(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8
         const int64_t m = nl < maxlog_user ? nl : maxlog_user;
         for (int64_t q = 0; q < 3 * m; ++q) sweeplog[q] = hlog[q];
     }
-    *info = (st.info != 0) ? (PSD_INFO_NOCONV + st.info) : 0;
+    *info = (st.info == PSD_LIST_OVERFLOW) ? (PSD_INFO_RUNTIME + 77) : ((st.info != 0) ? (PSD_INFO_NOCONV + st.info) : 0);
     return *info;
 }
 

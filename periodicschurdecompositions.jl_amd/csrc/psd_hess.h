@@ -251,11 +251,12 @@ PSD_KERNEL psd_set_identity(double* Q, int n) {
 
 // One step (reflector index i) of the backward accumulation Q_j = H_{j,1} ... H_{j,n-1}, all
 // factors at once (what Matrix(H.Q) / Matrix(QR.Q) produce, PSD.jl:136-143).  grid = (tiles, p).
-PSD_KERNEL psd_formq_step(const double* Hp, const double* tau, double* Q, int n, int i) {
+// (j0: first factor of the slice this launch forms, 0-based: a period-sharded context forms the Q_j it owns)
+PSD_KERNEL psd_formq_step(const double* Hp, const double* tau, double* Q, int n, int i, int j0) {
     PSD_LDS_DECL;
     double* red = (double*)psd_lds;
     const int NT = PSD_NTHREADS;
-    const int j = PSD_BLOCK_Y + 1;
+    const int j = j0 + PSD_BLOCK_Y + 1;
     const int r0 = i + ((j == 1) ? 1 : 0);
     const int m = n - r0 + 1;
     if (m < 2) return;

@@ -249,3 +249,40 @@ struct psd_mat {
     int ld;
     PSD_HD T& operator()(int r, int c) const { return a[(size_t)(c - 1) * ld + (r - 1)]; }
 };
+
+// State that one workgroup publishes for ANOTHER workgroup to pick up in a later launch (cursor states of a multishift
+// train): a sequence lock on an epoch word.  The writer raises PSD_EPOCH_NEVER, writes, then stores the tick; a reader
+// takes the block only if the epoch is older than its own launch and unchanged after the copy, so it can never act on a
+// block that is being written in the launch it runs in (the workgroups of a launch are not ordered against each other).
+#ifndef PSD_EPOCH_NEVER
+#define PSD_EPOCH_NEVER 0x7fffffff
+#endif
+PSD_D void psd_pub_begin(int* ep) {
+    psd_atomic_store(ep, PSD_EPOCH_NEVER);
+    psd_release_fence();
+}
+PSD_D void psd_pub_end(int* ep, int tick) {
+    psd_release_fence();
+    psd_atomic_store(ep, tick);
+}
+template <class S>
+PSD_D bool psd_pub_read(const int* ep, int tick, const S* src, S& dst) {
+    const int e1 = psd_atomic_load(ep);
+    if (e1 >= tick) return false;
+    psd_acquire_fence();
+    dst = *src;
+    psd_acquire_fence();
+    return psd_atomic_load(ep) == e1;
+}
+
+// A window emitted more transforms for one owner than its list holds (PSD_*TR_CAP): the lists would be applied
+// truncated.  The window kernels never do that by construction (<= 2 records per chase position and owner, windows of
+// <= 28 positions), but a change of a width or a capacity must fail loudly, not return wrong factors with info = 0:
+// the state machine stops with this code, the host maps it to PSD_INFO_RUNTIME + 77.
+#define PSD_LIST_OVERFLOW (-7777)
+PSD_D bool psd_list_overflow(const int* lcnt, int p, int cap) {  // (every lane, after the barrier that published lcnt)
+    bool over = false;
+    for (int m = 0; m < p; ++m)
+        if (lcnt[m] > cap) over = true;
+    return over;
+}

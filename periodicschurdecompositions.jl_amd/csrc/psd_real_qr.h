@@ -27,7 +27,7 @@ enum {
     PSD_PH_NEXT = 5,
     PSD_PH_FINAL = 6,
     PSD_PH_DONE = 7,
-    // multishift trains (experimental, off by default: psd_set_train / PSD_TRAIN): the leader waits for the cursors
+    // multishift trains (on by default: up to 32 bulges, psd_set_train / PSD_TRAIN): the leader waits for the cursors
     // behind it (TWAIT); a cursor waits for its start (CWAIT), runs QR windows, and ends in CDONE
     PSD_PH_TWAIT = 8,
     PSD_PH_CWAIT = 9,
@@ -146,6 +146,8 @@ struct psd_rparams {
     // multi-block scheduler (nullptr / 0 otherwise): slot s has state cst[s], descriptor desc[s], lists tr + s p CAP,
     // shift pairs tshift + s PSD_TSHIFT_STRIDE
     psd_rglobal* gl;
+    int* cep;    // single-range train mode: [PSD_TRAIN_MAX] epoch words of the cursor states (psd_pub_*), then the count
+                 // of finished cursors
     int* role;   // [PSD_SLOTS] PSD_ROLE_*
     int* epoch;  // [PSD_SLOTS] tick at which a claimed slot's state was written (PSD_EPOCH_NEVER while free)
     int* cdone;  // [PSD_SLOTS] per LEADER slot: cursors of its running train that have finished (a cursor's own slot
@@ -578,7 +580,7 @@ PSD_D void psd_rq_decide(const psd_rparams& P, psd_rstate& st, double* red, int*
 }
 
 // ------------------------------------------------------------------------------------------------
-// Multishift trains (experimental, off unless psd_set_train / PSD_TRAIN asks for it).
+// Multishift trains (the default iteration strategy on large active blocks, psd_set_train / PSD_TRAIN).
 // A train is m double-shift sweeps whose shift pairs are the eigenvalues of the trailing 2m x 2m block of the product,
 // fixed before the first sweep starts.  The sweeps run as m cursors two windows apart: cursor 0 is the ordinary state
 // machine (the leader), cursors 1..m-1 are psd_rq_cursor_step launches with their own state, lists and descriptor.
@@ -867,6 +869,7 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
     if (st.train_n > 1) {  // the cursors behind the leader start from this state
         PSD_SYNC();
         PSD_ONE {
+            if (!st.mb) psd_atomic_store(P.cep + PSD_TRAIN_MAX, 0);  // finished cursors of this train
             for (int b = 1; b < st.train_n; ++b) {
                 psd_rstate cs = st;
                 cs.cursor = b;
@@ -881,7 +884,9 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
                     P.cst[cs.slot] = cs;
                     psd_atomic_store(P.epoch + cs.slot, P.tick);
                 } else {
+                    psd_pub_begin(P.cep + b);
                     P.cst[b] = cs;
+                    psd_pub_end(P.cep + b, P.tick);
                 }
             }
         }
@@ -889,13 +894,25 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
     }
 }
 
-PSD_D void psd_desc_write(const psd_rparams& P, const psd_rstate& st, const int* lcnt, int plo, int phi, int lc0,
+PSD_D void psd_desc_write(const psd_rparams& P, psd_rstate& st, const int* lcnt, int plo, int phi, int lc0,
                           int lc1, int rr0, int rr1) {
     PSD_SYNC();
+    const bool over = psd_list_overflow(lcnt, st.p, PSD_TR_CAP);
+    if (over) {  // never apply truncated lists
+        st.info = PSD_LIST_OVERFLOW;
+        st.phase = PSD_PH_DONE;
+        if (st.mb) {
+            PSD_ONE {
+                psd_atomic_store(&P.gl->info, PSD_LIST_OVERFLOW);
+                psd_atomic_store(&P.gl->abort, 1);
+                psd_atomic_store(&P.gl->done, 1);
+            }
+        }
+    }
     PSD_PAR_FOR(m, st.p) { P.cnt[m] = lcnt[m]; }
     PSD_ONE {
         psd_apply_desc d;
-        d.active = 1;
+        d.active = over ? 0 : 1;
         d.plo = plo;
         d.phi = phi;
         d.lc0 = lc0;
@@ -1503,9 +1520,9 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
                 bool all = true;
                 if (st.mb) {  // a cursor adds one to its leader's counter after its last window
                     all = psd_atomic_load(P.cdone + st.slot) == st.train_n - 1;
-                } else {
-                    for (int b = 1; b < st.train_n; ++b)
-                        if (P.cst[b].phase != PSD_PH_CDONE || P.cst[b].train_id != st.train_id) all = false;
+                } else {  // a cursor counts itself in after its last store; its slot's state is then complete
+                    all = psd_atomic_load(P.cep + PSD_TRAIN_MAX) == st.train_n - 1;
+                    if (all) psd_acquire_fence();
                 }
                 if (all) {
                     for (int b = 1; b < st.train_n; ++b) {
@@ -1561,6 +1578,7 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
     }
     st.cyc[4] += psd_clock() - tk0;
     st.cyc[5] += psd_wallclock() - tw0;
+    if (st.info == PSD_LIST_OVERFLOW) st.phase = PSD_PH_DONE;  // (a window that overran a list ends the call)
     PSD_SYNC();
     PSD_ONE {
         *P.st = st;
@@ -1576,7 +1594,12 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rq_step(psd_rparams P) { psd_rq_step_body(P); }
 PSD_D void psd_rq_cursor_body(const psd_rparams& P, int b) {
     PSD_LDS_DECL;
     PSD_ONE { P.desc->active = 0; }
-    psd_rstate st = *P.st;
+    psd_rstate st;
+    if (P.gl) {
+        st = *P.st;  // (multi-block: a slot's state is only ever read by its own workgroup, see psd_rq_step_mb)
+    } else if (!psd_pub_read(P.cep + b, P.tick, P.st, st)) {
+        return;  // (published in an earlier launch, not being rewritten)
+    }
     if (st.cursor != b) return;
     if (st.phase != PSD_PH_CWAIT && st.phase != PSD_PH_QR) return;
     double* ldsd = (double*)psd_lds;
@@ -1597,6 +1620,12 @@ PSD_D void psd_rq_cursor_body(const psd_rparams& P, int b) {
     psd_rq_qr_window(P, st, ldsd, lcnt);
     PSD_SYNC();
     PSD_ONE { *P.st = st; }
+    if (!st.mb && st.phase == PSD_PH_CDONE) {  // last window: count this cursor in (its state and lists are out first)
+        PSD_ONE {
+            psd_release_fence();
+            psd_atomic_add(P.cep + PSD_TRAIN_MAX, 1);
+        }
+    }
     if (st.mb && st.phase == PSD_PH_CDONE) {  // last window of this bulge: report, hand the slot back
         PSD_ONE {
             psd_atomic_add(&P.gl->nwindows, st.nwindows);
@@ -1907,7 +1936,9 @@ PSD_D void psd_wl_stream(double* L, int S, const psd_tr* ltr, int cnt, int plo) 
     }
 }
 
-PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride, int pass, int M) {
+// zlo..zhi: the owners m (1-based) whose Z_m this context holds (period-sharded contexts: the Z role of the others is
+// some other rank's work; 1..p otherwise)
+PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride, int pass, int M, int zlo, int zhi) {
     PSD_LDS_DECL;
     psd_tr* ltr = (psd_tr*)psd_lds;
     int* flags = (int*)(psd_lds + sizeof(psd_tr) * PSD_TR_LDS_RECS);
@@ -1951,6 +1982,7 @@ PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride
         const int m = q / per + 1, tt = q - (m - 1) * per;
         const int role = (pass == 0) ? ((tt < tA[b]) ? 0 : 2) : 1;
         const int tix = (role == 2) ? (tt - tA[b]) : tt;
+        if (role == 2 && (m < zlo || m > zhi)) continue;
         const psd_apply_desc d = P.desc[b];
         int cnt = P.cnt[(size_t)b * cstride + (m - 1)];
         if (cnt > PSD_TR_CAP) cnt = PSD_TR_CAP;

@@ -77,6 +77,7 @@ struct psd_gparams {
     int* log;
     double* xscr;  // [16 p] scratch of the 2x2 solvers
     psd_gstate* cst;  // [PSD_TRAIN_MAX] cursor states of a train (entry 0 unused) or nullptr
+    int* cep;  // [PSD_TRAIN_MAX] epoch words of the cursor states (psd_pub_*), then the count of finished cursors
     double* tshift;   // [PSD_TRAIN_MAX][4] shift pairs, then a flag word
     int tick;         // launch index
 };
@@ -124,14 +125,19 @@ PSD_D void psd_glog(const psd_gparams& P, psd_gstate& st, int kind, int lo, int 
     st.nlog += 1;
 }
 
-PSD_D void psd_gdesc_write(const psd_gparams& P, const psd_gstate& st, const int* lcnt, int plo, int phi, int lc0,
+PSD_D void psd_gdesc_write(const psd_gparams& P, psd_gstate& st, const int* lcnt, int plo, int phi, int lc0,
                            int lc1, int rr0, int rr1, int defer_h1, int defer_run, int djlo, int djhi, int h1mode = 0,
                            int h1c0 = 0) {
     PSD_SYNC();
+    const bool over = psd_list_overflow(lcnt, st.p, PSD_GTR_CAP);
+    if (over) {  // never apply truncated lists
+        st.info = PSD_LIST_OVERFLOW;
+        st.phase = PSD_GPH_DONE;
+    }
     PSD_PAR_FOR(m, st.p) { P.cnt[m] = lcnt[m]; }
     PSD_ONE {
         psd_gapply_desc d;
-        d.active = 1;
+        d.active = over ? 0 : 1;
         d.plo = plo;
         d.phi = phi;
         d.lc0 = lc0;
@@ -985,6 +991,7 @@ PSD_KERNEL_B(64 * PSD_GHESS_MAXWAVES) psd_gq_hess_step(psd_gparams P, int L) {
     }
     st.cyc[4] += psd_clock() - tk0;
     st.cyc[5] += psd_wallclock() - tw0;
+    if (st.info == PSD_LIST_OVERFLOW) st.phase = PSD_GPH_DONE;  // (a window that overran a list ends the call)
     PSD_SYNC();
     PSD_ONE { *P.st = st; }
 }
@@ -1571,6 +1578,7 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
         for (int b = 1; b < st.train_n; ++b) psd_glog(P, st, 0, ifirst, ilast);
         PSD_SYNC();
         PSD_ONE {
+            psd_atomic_store(P.cep + PSD_TRAIN_MAX, 0);  // finished cursors of this train
             for (int b = 1; b < st.train_n; ++b) {
                 psd_gstate cs = st;
                 cs.cursor = b;
@@ -1580,7 +1588,9 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
                 cs.nsweeps = cs.nwindows = cs.nlog = 0;
                 cs.maxlog = 0;
                 for (int q = 0; q < 6; ++q) cs.cyc[q] = 0;
+                psd_pub_begin(P.cep + b);
                 P.cst[b] = cs;
+                psd_pub_end(P.cep + b, P.tick);
             }
         }
         PSD_SYNC();
@@ -1624,8 +1634,9 @@ PSD_D void psd_gq_step_body(const psd_gparams& P) {
             emitted = true;
         } else if (st.phase == PSD_GPH_TWAIT) {  // the leader's sweep is done: wait for the cursors of the train
             bool all = true;
-            for (int b = 1; b < st.train_n; ++b)
-                if (P.cst[b].phase != PSD_GPH_CDONE || P.cst[b].train_id != st.train_id) all = false;
+            // (a cursor counts itself in after its last store; its slot's state is then complete)
+            all = psd_atomic_load(P.cep + PSD_TRAIN_MAX) == st.train_n - 1;
+            if (all) psd_acquire_fence();
             if (all) {
                 for (int b = 1; b < st.train_n; ++b) {
                     st.nwindows += P.cst[b].nwindows;
@@ -1642,6 +1653,7 @@ PSD_D void psd_gq_step_body(const psd_gparams& P) {
     }
     st.cyc[4] += psd_clock() - tk0;
     st.cyc[5] += psd_wallclock() - tw0;
+    if (st.info == PSD_LIST_OVERFLOW) st.phase = PSD_GPH_DONE;  // (a window that overran a list ends the call)
     PSD_SYNC();
     PSD_ONE { *P.st = st; }
 }
@@ -1652,7 +1664,8 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_gq_step(psd_gparams P) { psd_gq_step_body(P); }
 PSD_D void psd_gq_cursor_body(const psd_gparams& P, int b) {
     PSD_LDS_DECL;
     PSD_ONE { P.desc->active = 0; P.desc->defer_run = 0; }
-    psd_gstate st = *P.st;
+    psd_gstate st;
+    if (!psd_pub_read(P.cep + b, P.tick, P.st, st)) return;  // (published in an earlier launch, not being rewritten)
     if (st.cursor != b) return;
     if (st.phase != PSD_GPH_CWAIT && st.phase != PSD_GPH_SWEEP) return;
     double* ldsd = (double*)psd_lds;
@@ -1664,7 +1677,11 @@ PSD_D void psd_gq_cursor_body(const psd_gparams& P, int b) {
         if (!psd_gq_start_explicit(P, st.n, st.p, st.ifirst, st.sh, ldsd, c1, s1, c2, s2)) {
             st.phase = PSD_GPH_CDONE;  // (not finite: this bulge is dropped)
             PSD_SYNC();
-            PSD_ONE { *P.st = st; }
+            PSD_ONE {
+                *P.st = st;
+                psd_release_fence();
+                psd_atomic_add(P.cep + PSD_TRAIN_MAX, 1);
+            }
             return;
         }
         st.c1 = c1; st.s1 = s1; st.c2 = c2; st.s2 = s2;
@@ -1673,7 +1690,13 @@ PSD_D void psd_gq_cursor_body(const psd_gparams& P, int b) {
     }
     psd_gq_sweep_window(P, st, ldsd, lcnt);
     PSD_SYNC();
-    PSD_ONE { *P.st = st; }
+    PSD_ONE {
+        *P.st = st;
+        if (st.phase == PSD_GPH_CDONE) {  // last window: count this cursor in (its state and lists are out first)
+            psd_release_fence();
+            psd_atomic_add(P.cep + PSD_TRAIN_MAX, 1);
+        }
+    }
 }
 
 // all cursors of a tick in one launch, one workgroup each (as psd_rq_step_train)

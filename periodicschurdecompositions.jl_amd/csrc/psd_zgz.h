@@ -45,6 +45,7 @@ struct psd_zgparams {
     int* ascale;   // [n]
     int* log;
     psd_zgstate* cst;  // [PSD_TRAIN_MAX] cursor states of a train (entry 0 unused) or nullptr
+    int* cep;  // [PSD_TRAIN_MAX] epoch words of the cursor states (psd_pub_*), then the count of finished cursors
     psd_z* tshift;     // [PSD_TRAIN_MAX] shifts, then a flag word
     int tick;          // launch index
 };
@@ -70,14 +71,19 @@ PSD_D void psd_zglog(const psd_zgparams& P, psd_zgstate& st, int kind, int lo, i
     }
     st.nlog += 1;
 }
-PSD_D void psd_zgdesc_write(const psd_zgparams& P, const psd_zgstate& st, const int* lcnt, int plo, int phi, int lc0,
+PSD_D void psd_zgdesc_write(const psd_zgparams& P, psd_zgstate& st, const int* lcnt, int plo, int phi, int lc0,
                             int lc1, int rr0, int rr1, int defer_h1, int defer_run, int djlo, int djhi, int h1mode = 0,
                             int h1c0 = 0) {
     PSD_SYNC();
+    const bool over = psd_list_overflow(lcnt, st.p, PSD_GTR_CAP);
+    if (over) {  // never apply truncated lists
+        st.info = PSD_LIST_OVERFLOW;
+        st.phase = PSD_GPH_DONE;
+    }
     PSD_PAR_FOR(m, st.p) { P.cnt[m] = lcnt[m]; }
     PSD_ONE {
         psd_gapply_desc d;
-        d.active = 1;
+        d.active = over ? 0 : 1;
         d.plo = plo;
         d.phi = phi;
         d.lc0 = lc0;
@@ -925,6 +931,7 @@ PSD_D void psd_zgq_check(const psd_zgparams& P, psd_zgstate& st, int* redi, psd_
         for (int b = 1; b < st.train_n; ++b) psd_zglog(P, st, 0, st.ifirst, ilast);
         PSD_SYNC();
         PSD_ONE {
+            psd_atomic_store(P.cep + PSD_TRAIN_MAX, 0);  // finished cursors of this train
             for (int b = 1; b < st.train_n; ++b) {
                 psd_zgstate cs = st;
                 cs.cursor = b;
@@ -934,7 +941,9 @@ PSD_D void psd_zgq_check(const psd_zgparams& P, psd_zgstate& st, int* redi, psd_
                 cs.nsweeps = cs.nwindows = cs.nlog = 0;
                 cs.maxlog = 0;
                 for (int q = 0; q < 6; ++q) cs.cyc[q] = 0;
+                psd_pub_begin(P.cep + b);
                 P.cst[b] = cs;
+                psd_pub_end(P.cep + b, P.tick);
             }
         }
         PSD_SYNC();
@@ -975,8 +984,9 @@ PSD_D void psd_zgq_step_body(const psd_zgparams& P) {
             emitted = true;
         } else if (st.phase == PSD_GPH_TWAIT) {  // the leader's sweep is done: wait for the cursors of the train
             bool all = true;
-            for (int b = 1; b < st.train_n; ++b)
-                if (P.cst[b].phase != PSD_GPH_CDONE || P.cst[b].train_id != st.train_id) all = false;
+            // (a cursor counts itself in after its last store; its slot's state is then complete)
+            all = psd_atomic_load(P.cep + PSD_TRAIN_MAX) == st.train_n - 1;
+            if (all) psd_acquire_fence();
             if (all) {
                 for (int b = 1; b < st.train_n; ++b) {
                     st.nwindows += P.cst[b].nwindows;
@@ -993,6 +1003,7 @@ PSD_D void psd_zgq_step_body(const psd_zgparams& P) {
     }
     st.cyc[4] += psd_clock() - tk0;
     st.cyc[5] += psd_wallclock() - tw0;
+    if (st.info == PSD_LIST_OVERFLOW) st.phase = PSD_GPH_DONE;  // (a window that overran a list ends the call)
     PSD_SYNC();
     PSD_ONE { *P.st = st; }
 }
@@ -1003,7 +1014,8 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_zgq_step(psd_zgparams P) { psd_zgq_step_body(P); }
 PSD_D void psd_zgq_cursor_body(const psd_zgparams& P, int b) {
     PSD_LDS_DECL;
     PSD_ONE { P.desc->active = 0; P.desc->defer_run = 0; }
-    psd_zgstate st = *P.st;
+    psd_zgstate st;
+    if (!psd_pub_read(P.cep + b, P.tick, P.st, st)) return;  // (published in an earlier launch, not being rewritten)
     if (st.cursor != b) return;
     if (st.phase != PSD_GPH_CWAIT && st.phase != PSD_GPH_SWEEP) return;
     const int NT = PSD_NTHREADS;
@@ -1017,7 +1029,11 @@ PSD_D void psd_zgq_cursor_body(const psd_zgparams& P, int b) {
         if (!psd_zgq_start_rot_mu(P, st.n, st.p, st.ifirst, st.sh, c, s)) {
             st.phase = PSD_GPH_CDONE;  // (not finite: this bulge is dropped)
             PSD_SYNC();
-            PSD_ONE { *P.st = st; }
+            PSD_ONE {
+                *P.st = st;
+                psd_release_fence();
+                psd_atomic_add(P.cep + PSD_TRAIN_MAX, 1);
+            }
             return;
         }
         st.c0 = c;
@@ -1027,7 +1043,13 @@ PSD_D void psd_zgq_cursor_body(const psd_zgparams& P, int b) {
     }
     psd_zgq_sweep_window(P, st, ldsz, lcnt);
     PSD_SYNC();
-    PSD_ONE { *P.st = st; }
+    PSD_ONE {
+        *P.st = st;
+        if (st.phase == PSD_GPH_CDONE) {  // last window: count this cursor in (its state and lists are out first)
+            psd_release_fence();
+            psd_atomic_add(P.cep + PSD_TRAIN_MAX, 1);
+        }
+    }
 }
 
 PSD_KERNEL_B(PSD_STEP_NT) psd_zgq_step_train(psd_zgparams P, int p, int cstride) {

@@ -79,6 +79,7 @@ struct psd_zparams {
     int* ascale;   // [n]
     int* log;
     psd_zstate* cst;  // [PSD_TRAIN_MAX] cursor states of a train (entry 0 unused) or nullptr
+    int* cep;  // [PSD_TRAIN_MAX] epoch words of the cursor states (psd_pub_*), then the count of finished cursors
     psd_z* tshift;    // [PSD_TRAIN_MAX + 1] shifts of the train, then a flag word
     int tick;         // launch index
 };
@@ -122,13 +123,18 @@ PSD_D void psd_zlog(const psd_zparams& P, psd_zstate& st, int kind, int lo, int 
     st.nlog += 1;
 }
 
-PSD_D void psd_zdesc_write(const psd_zparams& P, const psd_zstate& st, const int* lcnt, int plo, int phi, int lc0,
+PSD_D void psd_zdesc_write(const psd_zparams& P, psd_zstate& st, const int* lcnt, int plo, int phi, int lc0,
                            int lc1, int rr0, int rr1, int defer_h1, int defer_run, int djlo, int djhi) {
     PSD_SYNC();
+    const bool over = psd_list_overflow(lcnt, st.p, PSD_ZTR_CAP);
+    if (over) {  // never apply truncated lists
+        st.info = PSD_LIST_OVERFLOW;
+        st.phase = PSD_ZPH_DONE;
+    }
     PSD_PAR_FOR(m, st.p) { P.cnt[m] = lcnt[m]; }
     PSD_ONE {
         psd_zapply_desc d;
-        d.active = 1;
+        d.active = over ? 0 : 1;
         d.plo = plo;
         d.phi = phi;
         d.lc0 = lc0;
@@ -519,6 +525,7 @@ PSD_D void psd_zq_check(const psd_zparams& P, psd_zstate& st, double* red, int* 
         for (int b = 1; b < st.train_n; ++b) psd_zlog(P, st, 0, st.ifirst, ilast);  // one log entry per bulge
         PSD_SYNC();
         PSD_ONE {
+            psd_atomic_store(P.cep + PSD_TRAIN_MAX, 0);  // finished cursors of this train
             for (int b = 1; b < st.train_n; ++b) {
                 psd_zstate cs = st;
                 cs.cursor = b;
@@ -529,7 +536,9 @@ PSD_D void psd_zq_check(const psd_zparams& P, psd_zstate& st, double* red, int* 
                 cs.nsweeps = cs.nwindows = cs.nlog = 0;
                 cs.maxlog = 0;
                 for (int q = 0; q < 6; ++q) cs.cyc[q] = 0;
+                psd_pub_begin(P.cep + b);
                 P.cst[b] = cs;
+                psd_pub_end(P.cep + b, P.tick);
             }
         }
         PSD_SYNC();
@@ -861,8 +870,9 @@ PSD_D void psd_zq_step_body(const psd_zparams& P) {
             emitted = true;
         } else if (st.phase == PSD_ZPH_TWAIT) {  // the leader's sweep is done: wait for the cursors of the train
             bool all = true;
-            for (int b = 1; b < st.train_n; ++b)
-                if (P.cst[b].phase != PSD_ZPH_CDONE || P.cst[b].train_id != st.train_id) all = false;
+            // (a cursor counts itself in after its last store; its slot's state is then complete)
+            all = psd_atomic_load(P.cep + PSD_TRAIN_MAX) == st.train_n - 1;
+            if (all) psd_acquire_fence();
             if (all) {
                 for (int b = 1; b < st.train_n; ++b) {
                     st.nwindows += P.cst[b].nwindows;
@@ -881,6 +891,7 @@ PSD_D void psd_zq_step_body(const psd_zparams& P) {
     }
     st.cyc[4] += psd_clock() - tk0;
     st.cyc[5] += psd_wallclock() - tw0;
+    if (st.info == PSD_LIST_OVERFLOW) st.phase = PSD_ZPH_DONE;  // (a window that overran a list ends the call)
     PSD_SYNC();
     PSD_ONE { *P.st = st; }
 }
@@ -890,7 +901,8 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_zq_step(psd_zparams P) { psd_zq_step_body(P); }
 PSD_D void psd_zq_cursor_body(const psd_zparams& P, int b) {
     PSD_LDS_DECL;
     PSD_ONE { P.desc->active = 0; P.desc->defer_run = 0; }
-    psd_zstate st = *P.st;
+    psd_zstate st;
+    if (!psd_pub_read(P.cep + b, P.tick, P.st, st)) return;  // (published in an earlier launch, not being rewritten)
     if (st.cursor != b) return;
     if (st.phase != PSD_ZPH_CWAIT && st.phase != PSD_ZPH_SWEEP) return;
     psd_z* ldsz = (psd_z*)psd_lds;
@@ -905,7 +917,13 @@ PSD_D void psd_zq_cursor_body(const psd_zparams& P, int b) {
     }
     psd_zq_sweep_window(P, st, ldsz, lcnt);
     PSD_SYNC();
-    PSD_ONE { *P.st = st; }
+    PSD_ONE {
+        *P.st = st;
+        if (st.phase == PSD_ZPH_CDONE) {  // last window: count this cursor in (its state and lists are out first)
+            psd_release_fence();
+            psd_atomic_add(P.cep + PSD_TRAIN_MAX, 1);
+        }
+    }
 }
 
 // all cursors of a tick in one launch (see psd_rq_step_train)

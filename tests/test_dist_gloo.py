@@ -30,3 +30,78 @@ def test_bench_aggregation_gloo_world2(tmp_path):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["t"] == 2.0 and res["units"] == 30 and res["slice"] == [0, 8]
+
+
+_SHARD_WORKER = r'''
+import sys, os, json
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch.distributed as dist
+import psd_amd, psdtest as pt
+import importlib.util  # (the package directory name contains a dot: load the module by path, as psd_amd.py does)
+spec = importlib.util.spec_from_file_location("psd_sharded", os.path.join(ROOT, "periodicschurdecompositions.jl_amd", "sharded.py"))
+sharded = importlib.util.module_from_spec(spec); spec.loader.exec_module(sharded)
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+# TEST-ONLY serial simulation of the device code (tests/hostsim): one engine per rank, as one process per GPU would have
+eng = psd_amd.Engine(libpath=os.path.join(ROOT, "tests", "hostsim", "_build", "libpsd_hostsim.so"))
+out = {}
+for (n, p, lr) in CASES:
+    A = pt.bench_factors(n, p, seed=77 + n + p)
+    ref = eng.pschur(A, lr)                               # one rank holding everything
+    part = sharded.pschur_sharded(eng, A, lr, dist=dist, gather=False)
+    owned = part.owned
+    assert owned == list(eng_owned(eng, p, lr, rank, world)), (owned,)
+    # the chains and the factors are replicated: bit-identical to the unsharded run on every rank
+    assert all(np.array_equal(a, b) for a, b in zip(ref.Ts, part.Ts))
+    assert np.array_equal(ref.values, part.values)
+    # owned Schur vectors are the unsharded ones, bit for bit; the others were not computed here
+    for j in range(p):
+        if owned[j]:
+            assert np.array_equal(ref.Z[j], part.Z[j]), j
+    full = sharded.pschur_sharded(eng, A, lr, dist=dist, gather=True)
+    assert all(np.array_equal(a, b) for a, b in zip(ref.Z, full.Z))
+    ok, err = pt.checkpsd(full, A, thresh=100 * np.sqrt(max(n / 32, 1)))
+    assert ok, err
+    P = pt.product(A, left=(lr == "L"))
+    assert pt.match_eigs(np.linalg.eigvals(P), full.values) <= 1e-10 * np.linalg.norm(P, 2)
+    out[f"{n}x{p}{lr}"] = {"owned": int(sum(owned)), "resid": float(err.max())}
+if rank == 0:
+    print(json.dumps(out))
+dist.destroy_process_group()
+'''
+
+
+def _run_sharded(tmp_path, world, cases, port):
+    script = tmp_path / "shard_worker.py"
+    head = (f"ROOT = {ROOT!r}\nCASES = {cases!r}\n"
+            "def eng_owned(eng, p, lr, rank, world):\n"
+            "    eng.set_shard(rank, world)\n"
+            "    o = eng.owned_slots(p, lr)\n"
+            "    eng.set_shard(0, 1)\n"
+            "    return [bool(x) for x in o]\n")
+    script.write_text(head + _SHARD_WORKER)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hostsim")])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    import json
+
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_period_sharded_pschur_gloo_world2(tmp_path):
+    """The period-sharded engine (psd_set_shard: Z_j of a contiguous slice of the period per rank, chains replicated,
+    one all-gather of the slices at the end) on two ranks: same decomposition as one rank, bit for bit, both
+    orientations, a period the ranks split evenly and one they do not."""
+    res = _run_sharded(tmp_path, 2, [(24, 4, "R"), (30, 5, "L"), (40, 3, "R")], 29541)
+    assert res["24x4R"]["owned"] == 2 and res["30x5L"]["owned"] == 3 and res["40x3R"]["owned"] == 2
+
+
+def test_period_sharded_pschur_gloo_world3(tmp_path):
+    res = _run_sharded(tmp_path, 3, [(20, 7, "R"), (18, 2, "L")], 29543)
+    assert res["20x7R"]["owned"] == 3 and res["18x2L"]["owned"] == 1
