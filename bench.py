@@ -40,6 +40,8 @@ def aggregate(dist, seconds, units, device):
 
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return seconds, units
+    if dist.get_backend() == "gloo":
+        device = None
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     u = torch.tensor([float(units)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -157,9 +159,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1024)
-    ap.add_argument("--p", type=int, default=64)
+    ap.add_argument("--n", "--order", dest="n", type=int, default=1024)
+    ap.add_argument("--p", "--period", dest="p", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded",
+                    help="N > 1: 'sharded' = ONE problem, Schur vectors split by period over the ranks (strong scaling); "
+                         "'replicas' = one independent problem per rank (weak scaling)")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
 
@@ -175,14 +180,29 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    backend = os.environ.get("PSD_BENCH_BACKEND", "nccl")  # ("gloo": rehearsal of the N > 1 path on a one-GPU box)
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     n, p = args.n, args.p
     seed = 1234 + 2  # BASELINE config index 2
     eng = psd_amd.Engine(device=local_rank)
+    sharded = world > 1 and args.mode == "sharded"
+    if sharded:
+        import importlib.util
+
+        spec = importlib.util.spec_from_file_location(
+            "psd_sharded", os.path.join(ROOT, "periodicschurdecompositions.jl_amd", "sharded.py"))
+        shmod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(shmod)
+        eng.set_shard(rank, world)
     As = pt.bench_factors(n, p, seed)
     host = torch.from_numpy(pt.pack(As))
     total = args.steps + args.warmup
@@ -191,7 +211,10 @@ def main():
     torch.cuda.synchronize()
 
     def run(k):
-        return eng.pschur_dev(bufs[k].data_ptr(), n, p, "R", dZ_ptr=zbufs[k].data_ptr())
+        r = eng.pschur_dev(bufs[k].data_ptr(), n, p, "R", dZ_ptr=zbufs[k].data_ptr())
+        if sharded:  # the one collective of the sharded mode: every rank ends up with every Z_j (RCCL all-gather)
+            shmod.allgather_z_device(dist, zbufs[k].view(p, n, n), p, world, rank)
+        return r
 
     for k in range(args.warmup):
         run(k)
@@ -210,6 +233,8 @@ def main():
     exit_code = 0
     sweeps = sum(st.nsweeps for (_, _, st, _) in results)
     elapsed_max, sweeps_all = aggregate(dist if world > 1 else None, elapsed, sweeps, device)
+    if sharded:
+        sweeps_all = sweeps  # ONE problem: every rank ran the same (replicated) chain, its sweeps count once
 
     if rank == 0:
         st = results[-1][2]
@@ -257,14 +282,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed_max / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "%spschur!(A,:R) N=%d p=%d Float64 wantT wantZ, A_j = I + 0.5*G_j/sqrt(n)"
                                    % ("north_star target size: " if (n, p) == (1024, 64) else
                                       ("configs[1]: " if (n, p) == (512, 16) else ""), n, p),
-                       "seed": seed, "parallelism": ("1 GPU" if world == 1 else "replicas x%d" % world), "window": st.window},
+                       "seed": seed, "parallelism": ("1 GPU" if world == 1 else
+                                       ("period-sharded x%d (Z_j by slices of the period, chains replicated, one "
+                                        "all-gather of Z)" % world if sharded else "replicas x%d" % world)), "window": st.window},
             "sweeps_per_step": sweeps / args.steps,
             "sweeps_in_multishift_trains_per_step": ntrain / args.steps,
             "chase_kernel_cycle_shares": cycle_shares(st),

@@ -63,6 +63,19 @@ def allgather_z_device(dist, dZ, p, world, rank):
     passed to pschur_dev; on return all p blocks are valid everywhere.  Equal slices go through one
     all_gather_into_tensor (a single RCCL ring all-gather of p n^2 8 / G bytes per rank); ragged ones per block."""
     lo, hi = period_slice(p, world, rank)
+    if dist.get_backend() == "gloo":  # (rehearsal on one GPU / on CPUs: gloo gathers host tensors)
+        import torch
+
+        per = max(period_slice(p, world, r)[1] - period_slice(p, world, r)[0] for r in range(world))
+        send = torch.zeros((per,) + tuple(dZ.shape[1:]), dtype=dZ.dtype)
+        send[: hi - lo] = dZ[lo:hi].cpu()
+        recv = [torch.zeros_like(send) for _ in range(world)]
+        dist.all_gather(recv, send)
+        for r in range(world):
+            l, h = period_slice(p, world, r)
+            if r != rank and h > l:
+                dZ[l:h] = recv[r][: h - l].to(dZ.device)
+        return
     if p % world == 0:
         dist.all_gather_into_tensor(dZ.view(-1), dZ[lo:hi].reshape(-1).clone())
         return
