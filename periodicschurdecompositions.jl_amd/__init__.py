@@ -703,6 +703,83 @@ class Engine:
         P.stats = st
         return P
 
+    def eigvecs(self, ps0, select, shifted=True):
+        """LinearAlgebra.eigvecs(ps::PeriodicSchur, select; shifted) — src/vectors.jl:25-138: selected right
+        eigenvectors of the product (and of its circular shifts).  A loop of `ordschur!` calls (on the device) that
+        brings one selected eigenvalue (or conjugate pair) after the other to the top, where its vector is read off
+        the leading Schur vectors; for a pair the 2x2 cyclic problem is solved (babd.jl, here a dense 2p x 2p solve).
+        `select` is completed to conjugate pairs for a real decomposition (vectors.jl:42-62); `ps0` is not modified.
+        Returns a list of p (shifted) or one complex n x nvec matrices, normalised so that A_l v_l = mu v_{l+1},
+        mu^p = lambda_k (left orientation)."""
+        import copy
+
+        if len(ps0.Z) == 0 or ps0.Z[0].shape[0] == 0:
+            raise ValueError("eigvecs requires Schur vectors in the PSD")  # vectors.jl:30-32
+        n, m = ps0.Z[0].shape
+        select = [bool(x) for x in select]
+        if len(select) != m:
+            raise ValueError("length of `select` must correspond to rank of Schur (sub-)space")  # vectors.jl:34-36
+        real = not np.iscomplexobj(ps0.Ts[0])
+        dt = np.float64 if real else np.complex128
+        ps = PeriodicSchur([np.array(t, dtype=dt, order="F") for t in ps0.Ts],
+                           [np.array(z, dtype=dt, order="F") for z in ps0.Z], np.array(ps0.values, dtype=complex),
+                           ps0.orientation, ps0.schurindex)
+        p = ps.period
+        left = ps.orientation == "L"
+        if not all(select):
+            if real:  # vectors.jl:42-62
+                j = 0
+                while j < m:
+                    if ps.values[j].imag != 0 and j + 1 < m:
+                        if select[j] or select[j + 1]:
+                            select[j] = select[j + 1] = True
+                        j += 2
+                    else:
+                        j += 1
+            self.ordschur_(ps, select)
+        nvec = sum(select)
+        sel = [k < nvec for k in range(m)]
+        nmat = p if shifted else 1
+        Vs = [np.zeros((n, nvec), dtype=np.complex128, order="F") for _ in range(nmat)]
+        k = 0
+        while k < nvec:
+            lam = complex(ps.values[0])
+            mu = lam ** (1.0 / p)
+            if real and lam.imag != 0:
+                # the 2x2 cyclic problem (vectors.jl:73-112): | D1 0 .. Lp ; L1 D2 .. ; .. Lp-1 Dp | x = e1 with the
+                # first row replaced by the normalisation x_1[1] + x_1[2] = 1
+                M = np.zeros((2 * p, 2 * p), dtype=np.complex128)
+                for l in range(p):
+                    M[2 * l:2 * l + 2, 2 * l:2 * l + 2] += -mu * np.eye(2)
+                for l in range(1, p + 1):
+                    lx = l if left else (p + 1 - l)
+                    blk = ps.Ts[l - 1][0:2, 0:2]
+                    r = lx % p  # block column lx (1-based) couples into block row lx + 1 (cyclically)
+                    M[2 * r:2 * r + 2, 2 * (lx - 1):2 * (lx - 1) + 2] += blk
+                y = np.zeros(2 * p, dtype=np.complex128)
+                M[0, :] = 0.0
+                M[0, 0:2] = 1.0
+                y[0] = 1.0
+                x = np.linalg.solve(M, y)
+                t = 1.0 / np.linalg.norm(x[0:2])
+                for l in range(1, nmat + 1):
+                    i0 = (l - 1) * 2 if left else (0 if l == 1 else (p + 1 - l) * 2)
+                    Vs[l - 1][:, k] = t * (ps.Z[l - 1][:, 0:2] @ x[i0:i0 + 2])
+                    Vs[l - 1][:, k + 1] = np.conj(Vs[l - 1][:, k])
+                nl = 2
+            else:  # A_1 x_1 = T_1[1,1] Z_2[:,1] = mu x_2, ... (vectors.jl:113-129)
+                fac = 1.0 + 0.0j
+                for l in range(1, nmat + 1):
+                    Vs[l - 1][:, k] = fac * ps.Z[l - 1][:, 0]
+                    fac *= ps.Ts[l - 1][0, 0] / mu
+                nl = 1
+            for q in range(nl):
+                sel[q] = False
+            self.ordschur_(ps, sel)  # vectors.jl:133
+            k += nl
+            sel = sel[nl:] + sel[:nl]  # circshift!(sel, -nl)
+        return Vs
+
     def checkpsd(self, P, As, thresh=100, strict=True, S=None, details=False):
         """checkpsd(P, As; thresh, strict) — src/diagnostics.jl:190-263 — evaluated on the device (matrix cores).
         Returns (ok, err) like the reference; with details=True also the orthogonality and triangularity norms."""

@@ -1245,3 +1245,85 @@ def case_checkpsd(eng, sizes):
     # argument errors (diagnostics.jl:194-202)
     with pytest.raises(Exception):
         eng.checkpsd(ps, A[:-1] if p > 1 else A + A)
+
+
+# ---- eigvecs (src/vectors.jl:25-138; test/vectors.jl, checker test/testfuncs.jl:424-436) ----------------------------
+def ev_check(As, Vs, lams, left=True, tol=np.sqrt(pt.EPS)):
+    """test/testfuncs.jl:424-436 (left orientation): A_l v_l = mu v_{l+1}, mu = lambda^(1/p); for the right orientation
+    the sequence runs the other way (A_l v_{l+1} = mu v_l)."""
+    p = len(As)
+    for k in range(Vs[0].shape[1]):
+        mu = complex(lams[k]) ** (1.0 / p)
+        for l in range(p):
+            l1 = (l + 1) % p
+            if left:
+                ref = abs(mu) * np.linalg.norm(Vs[l1][:, k])
+                err = np.linalg.norm(As[l] @ Vs[l][:, k] - mu * Vs[l1][:, k])
+            else:
+                ref = abs(mu) * np.linalg.norm(Vs[l][:, k])
+                err = np.linalg.norm(As[l] @ Vs[l1][:, k] - mu * Vs[l][:, k])
+            assert err < tol * ref, (k, l, err, ref)
+
+
+def _distinct_real_factors(n, p, cplx, seed):
+    # test/vectors.jl:4-21: diagonal 2^(2j/p) in every factor, small strict upper part, unitary similarity chain
+    rs = np.random.RandomState(seed)
+    dt = np.complex128 if cplx else np.float64
+    A = []
+    for _ in range(p):
+        u = rs.rand(n, n) + (1j * rs.rand(n, n) if cplx else 0)
+        A.append(0.01 * np.triu(u).astype(dt))
+    for j in range(n):
+        mu = 2.0 ** (2 * (j + 1) / p)
+        for l in range(p):
+            A[l][j, j] = mu
+    for l in range(p):
+        g = rs.randn(n, n) + (1j * rs.randn(n, n) if cplx else 0)
+        q, _ = np.linalg.qr(g)
+        A[l] = q @ A[l]
+        l1 = (l + 1) % p
+        A[l1] = A[l1] @ q.conj().T
+    return [np.asfortranarray(a) for a in A]
+
+
+def case_eigvecs(eng):
+    for cplx in (False, True):
+        for p in (5, 1):
+            n, nsel = 7, 2
+            A = _distinct_real_factors(n, p, cplx, seed=60 + p + 10 * cplx)
+            ps0 = eng.pschur(A, "L")
+            lam0 = np.array(ps0.values)
+            T0 = [t.copy() for t in ps0.Ts]
+            for rev in (False, True):  # smallest, largest (test/vectors.jl:25-42)
+                idx = np.argsort(-np.abs(lam0) if rev else np.abs(lam0), kind="stable")
+                select = np.zeros(n, dtype=bool)
+                select[idx[:nsel]] = True
+                Vs = eng.eigvecs(ps0, select)
+                assert len(Vs) == p and Vs[0].shape == (n, nsel)
+                ev_check(A, Vs, lam0[select])
+                V1 = eng.eigvecs(ps0, select, shifted=False)
+                assert len(V1) == 1 and np.allclose(V1[0], Vs[0])
+            assert all(np.array_equal(a, b) for a, b in zip(T0, ps0.Ts))  # ps0 is not modified
+    # conjugate pairs of a real decomposition (the 2x2 cyclic problem, vectors.jl:73-112) and a right-oriented one
+    for lr in ("L", "R"):
+        A = pt.bench_factors(12, 3, seed=91)
+        ps0 = eng.pschur(A, lr)
+        lam0 = np.array(ps0.values)
+        cidx = [j for j in range(12) if lam0[j].imag > 0]
+        assert cidx, "test matrix has no complex pair"
+        select = np.zeros(12, dtype=bool)
+        select[cidx[0]] = True  # one member: eigvecs completes the pair
+        ridx = [j for j in range(12) if lam0[j].imag == 0]
+        if ridx:
+            select[ridx[-1]] = True
+        Vs = eng.eigvecs(ps0, select)
+        full = select.copy()
+        full[cidx[0] + 1] = True
+        # eigenvalues in the order the vectors come: selected ones top to bottom after the first ordschur!
+        ps1 = eng.ordschur_(type(ps0)([t.copy(order="F") for t in ps0.Ts], [z.copy(order="F") for z in ps0.Z],
+                                      lam0.copy(), ps0.orientation, ps0.schurindex), full)
+        lams = ps1.values[: int(full.sum())]
+        ev_check(A, Vs, lams, left=(lr == "L"))
+    # argument errors (vectors.jl:30-36)
+    with pytest.raises(ValueError):
+        eng.eigvecs(ps0, [True] * 5)

@@ -182,3 +182,9 @@ def test_phessenberg_lookahead_vs_oracle(gpu_engine, n, p):
         assert np.allclose(tau[j], tauo[j], rtol=0, atol=1e-11)
         Ax = Qo[j] @ Hs[j] @ Qo[(j + 1) % p].T
         assert np.linalg.norm(A[j] - Ax) < 1e-10 * max(np.linalg.norm(A[j]), 1.0)
+
+
+def test_eigvecs(gpu_engine):
+    """eigvecs(ps, select; shifted) (src/vectors.jl:25-138) on top of the device ordschur!: the reference's own test
+    (test/vectors.jl) plus conjugate pairs and the right orientation"""
+    ec.case_eigvecs(gpu_engine)

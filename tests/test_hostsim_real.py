@@ -83,3 +83,7 @@ def test_trains(sim_engine):
 def test_checkpsd(sim_engine):
     ec.case_checkpsd(sim_engine, [(12, 3, "R", "d"), (17, 4, "L", "d"), (10, 2, "R", "z"), (14, 3, "L", "z"),
                                   (12, 4, "R", "dg")])
+
+
+def test_eigvecs(sim_engine):
+    ec.case_eigvecs(sim_engine)
