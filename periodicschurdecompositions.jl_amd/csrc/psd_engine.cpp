@@ -169,6 +169,8 @@ struct psd_ctx {
     psd_rglobal* tgl = nullptr;
     int* tslotw = nullptr;  // role[PSD_SLOTS] | epoch[PSD_SLOTS] | cdone[PSD_SLOTS]
     int mblock = 1;         // PSD_MB=0: one active range at a time, as the reference
+    int train_mb_m = 64;    // bulges per train under the multi-block scheduler (PSD_TRAIN_MB)
+    int cgap = 1;           // ticks between the cursors of a train under the multi-block scheduler (PSD_CGAP=2: two windows)
     int treserve(int p) {
         if (tcst && p <= tcap_p) return 0;
         trelease();
@@ -731,7 +733,10 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     }
     int train_oc = 104;
     if (const char* e = getenv("PSD_TRAIN_OC")) train_oc = atoi(e);  // (tuning hook)
-    PSD_LAUNCH(psd_rq_init, psd_dim3(p), 256, 256 * 8, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, M, train_oc, mb ? 1 : 0);
+    int Mw = M;
+    if (mb && c->train_mb_m > Mw && c->train_m >= 32) Mw = (c->train_mb_m > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : c->train_mb_m;
+    PSD_LAUNCH(psd_rq_init, psd_dim3(p), 256, 256 * 8, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, Mw, train_oc, mb ? 1 : 0,
+               mb ? c->cgap : 2);
     const size_t lds_apply = apply_lds_bytes();
     const int tiles = (n + PSD_APPLY_NT - 1) / PSD_APPLY_NT;
     const int batch = 32;
@@ -953,6 +958,8 @@ int psd_create(psd_ctx** ctx, int device) {
     if (const char* e = getenv("PSD_HESS_LOOKAHEAD")) c->hess_lookahead = atoi(e);
 #endif
     if (const char* e = getenv("PSD_MB")) c->mblock = atoi(e);
+    if (const char* e = getenv("PSD_TRAIN_MB")) c->train_mb_m = atoi(e);
+    if (const char* e = getenv("PSD_CGAP")) c->cgap = (atoi(e) == 2) ? 2 : 1;
     if (const char* e = getenv("PSD_APPLY_WL")) c->apply_worklist = atoi(e);
     if (const char* e = getenv("PSD_APPLY_WL_GRID")) c->apply_wl_grid = atoi(e) > 0 ? atoi(e) : 2048;
 #ifdef PSD_HOSTSIM
@@ -967,7 +974,7 @@ int psd_create(psd_ctx** ctx, int device) {
 
 int psd_set_train(psd_ctx* c, int bulges) {
     if (!c) return -1;
-    c->train_m = (bulges < 0) ? 0 : ((bulges > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : bulges);
+    c->train_m = (bulges < 0) ? 0 : ((bulges > 32) ? 32 : bulges);
     c->ztrain_m = c->gtrain_m = c->train_m;
     return 0;
 }
@@ -975,13 +982,13 @@ int psd_set_train(psd_ctx* c, int bulges) {
 int psd_get_train(psd_ctx* c) { return c ? c->train_m : -1; }
 int psd_set_train_z(psd_ctx* c, int bulges) {
     if (!c) return -1;
-    c->ztrain_m = (bulges < 0) ? 0 : ((bulges > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : bulges);
+    c->ztrain_m = (bulges < 0) ? 0 : ((bulges > 32) ? 32 : bulges);
     return 0;
 }
 int psd_get_train_z(psd_ctx* c) { return c ? c->ztrain_m : -1; }
 int psd_set_train_g(psd_ctx* c, int bulges) {
     if (!c) return -1;
-    c->gtrain_m = (bulges == -2) ? -2 : ((bulges < 0) ? 0 : ((bulges > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : bulges));
+    c->gtrain_m = (bulges == -2) ? -2 : ((bulges < 0) ? 0 : ((bulges > 32) ? 32 : bulges));
     return 0;
 }
 int psd_get_train_g(psd_ctx* c) { return c ? c->gtrain_m : -1; }

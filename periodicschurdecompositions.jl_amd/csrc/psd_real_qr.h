@@ -38,7 +38,7 @@ enum { PSD_TR_R3 = 3, PSD_TR_H2 = 2, PSD_TR_R2 = 4, PSD_TR_G = 5 };
 #define PSD_TR_CAP 64     // transform-list capacity per owner and window
 #define PSD_STEP_NT 64    // the chase runs in one wavefront
 #define PSD_APPLY_NT 128  // threads (= tile rows / tile columns) of the bulk-apply kernel
-#define PSD_TRAIN_MAX 32  // bulges (cursors) of a multishift train
+#define PSD_TRAIN_MAX 64  // bulges (cursors) of a multishift train
 #define PSD_SLOTS 64      // workgroup slots of the multi-block scheduler (leaders of independent active blocks + cursors)
 enum { PSD_ROLE_FREE = 0, PSD_ROLE_CLAIMED = 1, PSD_ROLE_LEADER = 2, PSD_ROLE_CURSOR = 3 };
 #define PSD_EPOCH_NEVER 0x7fffffff
@@ -107,6 +107,14 @@ struct psd_rstate {
     // the range this leader owns (the reference works bottom-up through ONE range 1..n, PSD.jl:1057-1060; here the part
     // above a negligible subdiagonal is handed to another workgroup as soon as it is found), the running train's key
     int mb, slot, parent, lo, train_key;
+    // ticks between the starts of consecutive cursors of a train: 2 = two whole windows apart; 1 = one tick apart, the
+    // cursor's first window 4 positions short, so that its rows end above the window of the cursor ahead (cursors are
+    // then nb + 4 positions apart instead of 2 nb: more bulges fit a block, the train fills and drains faster).
+    // cgap: what the context asks for; tgap: what the running train uses (1 needs windows of >= 6 positions).
+    // All cursors advance nb positions per tick, so the spacing s (2 nb, or nb + 4) holds for the whole sweep if cursor
+    // b sits at K_0(t) - b s: it enters the block in the first tick in which that window reaches past l (cstart), with
+    // the part of the window that lies inside the block (cfirst positions).
+    int cgap, tgap, cstart, cfirst;
     int cslots[PSD_TRAIN_MAX];  // slots of the running train's cursors (entry 0 unused)
 };
 
@@ -779,10 +787,13 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
             int nb = st.Wmax - 4, m = 1;
             double best = 1e300;
             for (int nbc = (st.Wmax - 4 < 8) ? ((st.Wmax > 5) ? st.Wmax - 4 : 1) : 8; nbc <= st.Wmax - 4; ++nbc) {
-                int mc = 1 + (w - nbc) / (2 * nbc);
+                const int gap = (st.cgap == 1 && nbc >= 6) ? 1 : 2;
+                int mc = 1 + (w - nbc) / ((gap == 1) ? (nbc + 4) : (2 * nbc));
                 if (mc > mt) mc = mt;
                 if (mc < 2) break;
-                const double cost = (double)((w + nbc - 1) / nbc + 2 * (mc - 1)) * (double)(nbc * st.p + st.train_oc) / mc;
+                const int spc = (gap == 1) ? (nbc + 4) : (2 * nbc);
+                const double cost = (double)((w + nbc - 1) / nbc + ((mc - 1) * spc + nbc - 1) / nbc) *
+                                    (double)(nbc * st.p + st.train_oc) / mc;
                 if (cost < best) {
                     best = cost;
                     nb = nbc;
@@ -828,6 +839,7 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
                 if (*okf && mgot >= 2) {
                     m = mgot;
                     st.W = nb + 4;
+                    st.tgap = (st.cgap == 1 && nb >= 6) ? 1 : 2;
                     st.train_n = m;
                     st.train_tick0 = P.tick;
                     st.train_id += 1;
@@ -878,6 +890,17 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
                 cs.nsweeps = cs.nwindows = cs.nlog = 0;
                 cs.maxlog = 0;
                 for (int q = 0; q < 6; ++q) cs.cyc[q] = 0;
+                {  // entry tick and first window of cursor b (see psd_rstate::cstart)
+                    const int nbw = st.W - 4;
+                    const int spc = (st.tgap == 1) ? (nbw + 4) : (2 * nbw);
+                    int d = (b * spc - nbw + 1 + nbw - 1) / nbw;  // ceil((b s - nb + 1) / nb)
+                    if (d < 1) d = 1;
+                    int x = nbw * d - b * spc + nbw;
+                    if (x > nbw) x = nbw;
+                    if (x < 1) x = 1;
+                    cs.cstart = st.train_tick0 + d;
+                    cs.cfirst = x;
+                }
                 if (st.mb) {  // (the slot's workgroup picks the state up in the next launch: epoch < tick)
                     cs.parent = st.slot;
                     cs.slot = st.cslots[b];
@@ -1140,8 +1163,9 @@ PSD_D void psd_win_reflect(const psd_rparams& P, const psd_win& w, int jl, int j
 // PSD.jl:806-886: one window (steps kcur .. kcur+nb-1) of the double-shift periodic QR sweep
 PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, int* lcnt) {
     const int n = st.n, p = st.p, i = st.i, l = st.l, i1 = st.i1, i2 = st.i2;
-    const int nb = st.W - 4;
     const int ks = st.kcur;
+    // (a cursor one tick behind its predecessor chases 4 positions less in its first window: see psd_rstate::tgap)
+    const int nb = (st.cursor > 0 && ks == l) ? st.cfirst : (st.W - 4);
     const int ke = (ks + nb - 1 < i - 1) ? (ks + nb - 1) : (i - 1);
     psd_win w;
     w.b = ldsd;
@@ -1610,7 +1634,7 @@ PSD_D void psd_rq_cursor_body(const psd_rparams& P, int b) {
         // in four positions, so two ticks put a whole finished window (chase and bulk update, both complete at the
         // tick barrier) between neighbours.  A fixed offset, not a look at the predecessor's progress: the
         // predecessor's state is being written while this kernel runs.
-        if (P.tick < st.train_tick0 + 2 * b) return;
+        if (P.tick < st.cstart) return;
         double h11, h12, h21, h22, h32;
         psd_rq_topband(P, st.n, st.p, st.l, st.i, h11, h12, h21, h22, h32);
         psd_rq_startvec(h11, h12, h21, h22, h32, P.tshift + 4 * b, st.v);
@@ -2107,7 +2131,7 @@ PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride
 // hnorms[j] = ulp*n*opnorm(H_j, 1), column-1 / sub-Hessenberg clean-up (PSD.jl:379-388,406), and
 // state initialisation.  grid = p blocks.
 PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W, int maxitfac, int maxlog,
-                       int train_want, int train_oc, int mb) {
+                       int train_want, int train_oc, int mb, int cgap) {
     PSD_LDS_DECL;
     double* red = (double*)psd_lds;
     const int j = PSD_BLOCK_X + 1;
@@ -2139,6 +2163,9 @@ PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W,
             ulpx *= s;
             st.ulpx = ulpx;
             st.mb = mb;
+            st.cgap = cgap;
+            st.tgap = 2;
+            st.cstart = st.cfirst = 0;
             st.slot = 0;
             st.parent = -1;
             st.lo = 1;
