@@ -1960,43 +1960,152 @@ PSD_D void psd_wl_stream(double* L, int S, const psd_tr* ltr, int cnt, int plo) 
     }
 }
 
+// lane t's share of a 64-line tile, HBM <-> 32 registers <-> LDS.  Rows role (lines = columns l0.., elements = rows
+// plo..phi, contiguous in memory): lane = (row pair 2 (t & 15), column t >> 4 of every group of four), sixteen 16-byte
+// accesses.  Column roles (lines = rows l0.., elements = columns plo..): lane = row l0 + t, one 8-byte access per
+// element, 512 contiguous bytes per wavefront and column.
+PSD_D void psd_wl_load(bool rowsrole, const psd_mat<double>& Mx, int plo, int S, int l0, int nl, int t, double (&v)[32]) {
+    if (rowsrole) {
+        const int rr = 2 * (t & 15), cq = t >> 4;
+        const bool pair = rr + 1 < S;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int c = 4 * u + cq;
+            v[2 * u] = v[2 * u + 1] = 0.0;
+            if (rr < S && c < nl) {
+                const double* src = &Mx(plo + rr, l0 + c);
+                if (pair) {
+                    const psd_pair x = psd_pair_load(src);
+                    v[2 * u] = x.a;
+                    v[2 * u + 1] = x.b;
+                } else {
+                    v[2 * u] = src[0];
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = (t < nl && u < S) ? Mx(l0 + t, plo + u) : 0.0;
+    }
+}
+PSD_D void psd_wl_to_tile(bool rowsrole, double* tile, int S, int nl, int t, const double (&v)[32]) {
+    const int LD = PSD_WL_LD;
+    if (rowsrole) {
+        const int rr = 2 * (t & 15), cq = t >> 4;
+        if (rr < S) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int c = 4 * u + cq;
+                tile[c * LD + rr] = v[2 * u];
+                if (rr + 1 < S) tile[c * LD + rr + 1] = v[2 * u + 1];
+            }
+        }
+    } else if (t < nl) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u)
+            if (u < S) tile[t * LD + u] = v[u];
+    }
+}
+PSD_D void psd_wl_store(bool rowsrole, const psd_mat<double>& Mx, const double* tile, int plo, int S, int l0, int nl, int t) {
+    const int LD = PSD_WL_LD;
+    if (rowsrole) {
+        const int rr = 2 * (t & 15), cq = t >> 4;
+        if (rr < S) {
+            const bool pair = rr + 1 < S;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int c = 4 * u + cq;
+                if (c < nl) {
+                    double* dst = &Mx(plo + rr, l0 + c);
+                    if (pair) {
+                        psd_pair x;
+                        x.a = tile[c * LD + rr];
+                        x.b = tile[c * LD + rr + 1];
+                        psd_pair_store(dst, x);
+                    } else {
+                        dst[0] = tile[c * LD + rr];
+                    }
+                }
+            }
+        }
+    } else if (t < nl) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u)
+            if (u < S) Mx(l0 + t, plo + u) = tile[t * LD + u];
+    }
+}
+PSD_D void psd_wl_compute(double* tile, int S, int nl, int t, int order, const psd_tr* ltr, int cnt, int plo) {
+    if (t >= nl) return;
+    double* L = tile + t * PSD_WL_LD;
+    if (order > 0) {
+        psd_wl_stream<true>(L, S, ltr, cnt, plo);
+    } else if (order < 0) {
+        psd_wl_stream<false>(L, S, ltr, cnt, plo);
+    } else {
+        for (int e = 0; e < cnt; ++e) {
+            const psd_tr tr = ltr[e];
+            const int r = tr.pos - plo;
+            const int len = psd_tr_len(tr);
+            double a1 = L[r], a2 = L[r + 1], a3 = (len == 3) ? L[r + 2] : 0.0;
+            psd_tr_apply(tr, a1, a2, a3);
+            L[r] = a1;
+            L[r + 1] = a2;
+            if (len == 3) L[r + 2] = a3;
+        }
+    }
+}
+
 // zlo..zhi: the owners m (1-based) whose Z_m this context holds (period-sharded contexts: the Z role of the others is
 // some other rank's work; 1..p otherwise)
+#define PSD_WL_GROUP 4  // 64-line tiles per item: the owner's list is staged once for all of them
 PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride, int pass, int M, int zlo, int zhi) {
     PSD_LDS_DECL;
     psd_tr* ltr = (psd_tr*)psd_lds;
     int* flags = (int*)(psd_lds + sizeof(psd_tr) * PSD_TR_LDS_RECS);
     double* tile = (double*)(psd_lds + PSD_TR_LDS_BYTES);
-    int* ioff = (int*)(tile + (size_t)PSD_WL_LINES * PSD_WL_LD);  // [M + 1] item offsets, [M] tiles A, [M] tiles B
+    int* ioff = (int*)(tile + (size_t)PSD_WL_LINES * PSD_WL_LD);  // [M + 1] item offsets, [M] groups A, [M] groups B
     int* tA = ioff + PSD_SLOTS + 2;
     int* tB = tA + PSD_SLOTS;
-    const int TL = PSD_WL_LINES, LD = PSD_WL_LD;
-    // item table: cursor b contributes p * (tiles of role A + tiles of role B) items (pass 0: A = rows, B = Z;
-    // pass 1: A = columns, B = none)
-    PSD_PAR_FOR(b, M) {
-        const psd_apply_desc d = P.desc[b];
-        int a = 0, z = 0;
-        if (d.active) {
-            if (pass == 0) {
-                a = (d.lc1 >= d.lc0) ? ((d.lc1 - d.lc0 + 1 + TL - 1) / TL) : 0;
-                z = (d.zr1 >= d.zr0) ? ((d.zr1 - d.zr0 + 1 + TL - 1) / TL) : 0;
-            } else {
-                a = (d.rr1 >= d.rr0) ? ((d.rr1 - d.rr0 + 1 + TL - 1) / TL) : 0;
+    const int TL = PSD_WL_LINES;
+    // item table: slot b contributes p * (groups of role A + groups of role B) items (pass 0: A = rows, B = Z;
+    // pass 1: A = columns, B = none); a group = up to PSD_WL_GROUP tiles of 64 lines.  The group size adapts to the
+    // tick: whole groups only while they still leave every workgroup of the grid a few items (a tick of one small
+    // window must spread over the chip, a tick of sixty windows must not stage a list per 8 KiB)
+    int GL = TL;
+    for (int trial = 0; trial < 2; ++trial) {
+        PSD_PAR_FOR(b, M) {
+            const psd_apply_desc d = P.desc[b];
+            int a = 0, z = 0;
+            if (d.active) {
+                if (pass == 0) {
+                    a = (d.lc1 >= d.lc0) ? ((d.lc1 - d.lc0 + 1 + GL - 1) / GL) : 0;
+                    z = (d.zr1 >= d.zr0) ? ((d.zr1 - d.zr0 + 1 + GL - 1) / GL) : 0;
+                } else {
+                    a = (d.rr1 >= d.rr0) ? ((d.rr1 - d.rr0 + 1 + GL - 1) / GL) : 0;
+                }
             }
+            tA[b] = a;
+            tB[b] = z;
         }
-        tA[b] = a;
-        tB[b] = z;
-    }
-    PSD_SYNC();
-    PSD_ONE {
-        int acc = 0;
-        for (int b = 0; b < M; ++b) {
-            ioff[b] = acc;
-            acc += p * (tA[b] + tB[b]);
+        PSD_SYNC();
+        PSD_ONE {
+            int acc = 0;
+            for (int b = 0; b < M; ++b) {
+                ioff[b] = acc;
+                acc += p * (tA[b] + tB[b]);
+            }
+            ioff[M] = acc;
         }
-        ioff[M] = acc;
+        PSD_SYNC();
+        if (trial == 1) break;
+        const int tiles = ioff[M];
+        int grp = 1;
+        if (tiles >= 4 * PSD_WL_GROUP * PSD_GRID_X) grp = PSD_WL_GROUP;
+        else if (tiles >= 8 * PSD_GRID_X) grp = 2;
+        PSD_SYNC();
+        if (grp == 1) break;
+        GL = TL * grp;
     }
-    PSD_SYNC();
     const int total = ioff[M];
     for (int item = PSD_BLOCK_X; item < total; item += PSD_GRID_X) {
         int b = 0;
@@ -2005,7 +2114,7 @@ PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride
         const int q = item - ioff[b];
         const int m = q / per + 1, tt = q - (m - 1) * per;
         const int role = (pass == 0) ? ((tt < tA[b]) ? 0 : 2) : 1;
-        const int tix = (role == 2) ? (tt - tA[b]) : tt;
+        const int gix = (role == 2) ? (tt - tA[b]) : tt;
         if (role == 2 && (m < zlo || m > zhi)) continue;
         const psd_apply_desc d = P.desc[b];
         int cnt = P.cnt[(size_t)b * cstride + (m - 1)];
@@ -2013,8 +2122,6 @@ PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride
         if (cnt <= 0) continue;
         const psd_tr* gtr = P.tr + ((size_t)b * p + (m - 1)) * PSD_TR_CAP;
         const int S = d.phi - d.plo + 1;
-        PSD_SYNC();  // (the previous item's tile and list are no longer in use)
-        const int order = psd_tr_stage(gtr, cnt, ltr, flags);
         int lo, hi;
         double* base;
         int jm;
@@ -2025,106 +2132,50 @@ PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride
         } else {
             lo = d.zr0; hi = d.zr1; base = P.Z; jm = m;
         }
-        const int l0 = lo + tix * TL;  // first line (1-based column for the rows role, row for the column roles)
-        const int nl = (hi - l0 + 1 < TL) ? (hi - l0 + 1) : TL;
+        const int g0 = lo + gix * GL;  // first line of the group (1-based column for the rows role, row otherwise)
+        const int gl = (hi - g0 + 1 < GL) ? (hi - g0 + 1) : GL;
+        const int ns = (gl + TL - 1) / TL;
         const psd_mat<double> Mx = psd_mat<double>{base + (size_t)(jm - 1) * n * n, n};
-        if (role == 0) {
-            // rows panel: line = column l0 + c, elements = rows plo .. phi (contiguous): a lane moves two rows of a column,
-            // 16 lanes a column, four columns per step
-            PSD_PAR_FOR(t, PSD_WL_NT) {
-                const int rr = 2 * (t & 15), cq = t >> 4;
-                if (rr < S) {
-                    const bool pair = rr + 1 < S;
-                    for (int k = 0; k < TL / 4; k += 8) {
-                        psd_pair v[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int c = 4 * (k + u) + cq;
-                            v[u].a = v[u].b = 0.0;
-                            if (c < nl) {
-                                const double* src = &Mx(d.plo + rr, l0 + c);
-                                if (pair) v[u] = psd_pair_load(src);
-                                else v[u].a = src[0];
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int c = 4 * (k + u) + cq;
-                            tile[c * LD + rr] = v[u].a;
-                            if (pair) tile[c * LD + rr + 1] = v[u].b;
-                        }
-                    }
-                }
+        const bool rowsrole = role == 0;
+#ifndef PSD_HOSTSIM
+        // the next tile's loads are in flight while this one is computed on: a lane keeps them in 32 registers
+        const int t = PSD_TID;
+        double v[32];
+        psd_wl_load(rowsrole, Mx, d.plo, S, g0, (gl < TL) ? gl : TL, t, v);
+        PSD_SYNC();  // (the previous item's tile and list are no longer in use)
+        const int order = psd_tr_stage(gtr, cnt, ltr, flags);
+        for (int k = 0; k < ns; ++k) {
+            const int l0 = g0 + k * TL;
+            const int nl = (gl - k * TL < TL) ? (gl - k * TL) : TL;
+            psd_wl_to_tile(rowsrole, tile, S, nl, t, v);
+            PSD_SYNC();
+            if (k + 1 < ns) {
+                const int nl1 = (gl - (k + 1) * TL < TL) ? (gl - (k + 1) * TL) : TL;
+                psd_wl_load(rowsrole, Mx, d.plo, S, l0 + TL, nl1, t, v);
             }
-        } else {
-            // columns panel: line = row l0 + t, elements = columns plo .. phi (a wavefront reads 512 contiguous bytes
-            // per column); all loads of the line are in flight together
-            PSD_PAR_FOR(t, PSD_WL_NT) {
-                if (t < nl) {
-                    double v[32];
-#pragma unroll
-                    for (int u = 0; u < 32; ++u) v[u] = (u < S) ? Mx(l0 + t, d.plo + u) : 0.0;
-#pragma unroll
-                    for (int u = 0; u < 32; ++u)
-                        if (u < S) tile[t * LD + u] = v[u];
-                }
-            }
+            psd_wl_compute(tile, S, nl, t, order, ltr, cnt, d.plo);
+            PSD_SYNC();
+            psd_wl_store(rowsrole, Mx, tile, d.plo, S, l0, nl, t);
+            PSD_SYNC();
         }
+#else
         PSD_SYNC();
-        PSD_PAR_FOR(t, PSD_WL_NT) {
-            {
-                const int line = t;
-                if (line >= nl) continue;
-                double* L = tile + line * LD;
-                if (order > 0) {
-                    psd_wl_stream<true>(L, S, ltr, cnt, d.plo);
-                } else if (order < 0) {
-                    psd_wl_stream<false>(L, S, ltr, cnt, d.plo);
-                } else {
-                    for (int e = 0; e < cnt; ++e) {
-                        const psd_tr tr = ltr[e];
-                        const int r = tr.pos - d.plo;
-                        const int len = psd_tr_len(tr);
-                        double a1 = L[r], a2 = L[r + 1], a3 = (len == 3) ? L[r + 2] : 0.0;
-                        psd_tr_apply(tr, a1, a2, a3);
-                        L[r] = a1;
-                        L[r + 1] = a2;
-                        if (len == 3) L[r + 2] = a3;
-                    }
-                }
-            }
-        }
-        PSD_SYNC();
-        if (role == 0) {
+        const int order = psd_tr_stage(gtr, cnt, ltr, flags);
+        for (int k = 0; k < ns; ++k) {
+            const int l0 = g0 + k * TL;
+            const int nl = (gl - k * TL < TL) ? (gl - k * TL) : TL;
             PSD_PAR_FOR(t, PSD_WL_NT) {
-                const int rr = 2 * (t & 15), cq = t >> 4;
-                if (rr < S) {
-                    const bool pair = rr + 1 < S;
-                    for (int k = 0; k < TL / 4; ++k) {
-                        const int c = 4 * k + cq;
-                        if (c < nl) {
-                            double* dst = &Mx(d.plo + rr, l0 + c);
-                            if (pair) {
-                                psd_pair x;
-                                x.a = tile[c * LD + rr];
-                                x.b = tile[c * LD + rr + 1];
-                                psd_pair_store(dst, x);
-                            } else {
-                                dst[0] = tile[c * LD + rr];
-                            }
-                        }
-                    }
-                }
+                double v[32];
+                psd_wl_load(rowsrole, Mx, d.plo, S, l0, nl, t, v);
+                psd_wl_to_tile(rowsrole, tile, S, nl, t, v);
             }
-        } else {
-            PSD_PAR_FOR(t, PSD_WL_NT) {
-                if (t < nl) {
-#pragma unroll
-                    for (int u = 0; u < 32; ++u)
-                        if (u < S) Mx(l0 + t, d.plo + u) = tile[t * LD + u];
-                }
-            }
+            PSD_SYNC();
+            PSD_PAR_FOR(t, PSD_WL_NT) { psd_wl_compute(tile, S, nl, t, order, ltr, cnt, d.plo); }
+            PSD_SYNC();
+            PSD_PAR_FOR(t, PSD_WL_NT) { psd_wl_store(rowsrole, Mx, tile, d.plo, S, l0, nl, t); }
+            PSD_SYNC();
         }
+#endif
     }
 }
 
