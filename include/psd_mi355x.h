@@ -119,6 +119,15 @@ int psd_d_pschur_hess(psd_ctx* ctx, int n, int p, double* const* H, double* cons
                       int maxitfac, double* wr, double* wi, psd_stats* stats, int32_t* sweeplog, int64_t maxlog,
                       int* info);
 
+/* nb Hessenberg-triangular problems of the same shape (n, p) in ONE call — what the Krylov driver of the reference issues
+ * one by one (krylov.jl:575-592,645,710,800-829: projected problems of order <= 40): pschur!(H1, Hs; wantT, wantZ, Q,
+ * maxitfac) for each.  H / Q: nb * p pointers, problem q's factor j at [q * p + j] (H[q * p] upper Hessenberg, the
+ * others upper triangular); Q may be NULL when !wantZ, otherwise it holds Q_j on entry and Z_j on exit.  wr / wi: nb * n
+ * eigenvalues, problem by problem.  infos[nb] (may be NULL): per-problem info; the return value is the first non-zero
+ * one.  nb <= 32.  The problems run side by side on the slot scheduler of the real iteration. */
+int psd_d_pschur_hess_batch(psd_ctx* ctx, int nb, int n, int p, double* const* H, double* const* Q, int wantT, int wantZ,
+                            int maxitfac, double* wr, double* wi, int* infos, psd_stats* stats, int* info);
+
 /* Device-resident variant of psd_d_pschur: dA, dZ are device pointers to [p][n][n] blocks in user
  * order (dZ may be NULL when !wantZ).  wr/wi/sweeplog are host buffers. */
 int psd_d_pschur_dev(psd_ctx* ctx, int n, int p, double* dA, char orient, int wantT, int wantZ, int maxitfac,

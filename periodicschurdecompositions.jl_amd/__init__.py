@@ -185,6 +185,8 @@ class Engine:
                                        C.c_double, C.c_int, dp, dp, dp, ip, ip]
         lib.psd_d_checkpsd_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, u8p,
                                            C.c_char, C.c_int, C.c_double, C.c_int, dp, dp, dp, ip, ip]
+        lib.psd_d_pschur_hess_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, dpp, dpp, C.c_int, C.c_int, C.c_int,
+                                                dp, dp, ip, C.POINTER(Stats), ip]
         lib.psd_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.psd_shard_owned.argtypes = [C.c_void_p, C.c_int, C.c_char, u8p]
         self.ctx = C.c_void_p()
@@ -583,6 +585,46 @@ class Engine:
             Ts = [H[p - l] for l in range(1, p)] + [H[0]]
             return PeriodicSchur(Ts, Zr, lam, "L", p, st, slog)
         return PeriodicSchur(H, Z, lam, "R", 1, st, slog)
+
+    def pschur_hess_batch_(self, problems, wantT=True, wantZ=True, maxitfac=30):
+        """pschur!(H1, Hs; wantT, wantZ, Q, maxitfac) (src/PeriodicSchurDecompositions.jl:322-330) for a list of
+        problems of equal shape in ONE call (psd_d_pschur_hess_batch: what src/krylov.jl:575-592,800-829 issues one
+        by one).  `problems`: list of (H1, Hs) or (H1, Hs, Q); matrices are overwritten.  Returns a list of
+        PeriodicSchur; a problem that fails to converge raises like the single call, after all have run."""
+        nb = len(problems)
+        if nb == 0:
+            return []
+        Hall, Qall = [], []
+        n = problems[0][0].shape[0]
+        p = len(problems[0][1]) + 1
+        for pr in problems:
+            H = [pr[0]] + list(pr[1])
+            if len(H) != p or _check_square(H) != n:
+                raise DimensionMismatch("the problems of a batch must have equal order and period")
+            self._as_work(H)
+            Hall += H
+            if wantZ:
+                Q = list(pr[2]) if len(pr) > 2 and pr[2] is not None else [np.asfortranarray(np.eye(n)) for _ in range(p)]
+                self._as_work(Q)
+                Qall += Q
+        wr = np.zeros((nb, n))
+        wi = np.zeros((nb, n))
+        infos = (C.c_int * nb)()
+        st = Stats()
+        info = C.c_int(0)
+        dp = C.POINTER(C.c_double)
+        self.lib.psd_d_pschur_hess_batch(self.ctx, nb, n, p, self._ptrs(Hall), self._ptrs(Qall) if wantZ else None,
+                                         int(wantT), int(wantZ), int(maxitfac), wr.ctypes.data_as(dp),
+                                         wi.ctypes.data_as(dp), infos, C.byref(st), C.byref(info))
+        if info.value < 0 or info.value >= INFO_NOTIMPL:
+            self._raise(info.value)
+        out = []
+        for q in range(nb):
+            Z = Qall[q * p:(q + 1) * p] if wantZ else []
+            out.append(PeriodicSchur(Hall[q * p:(q + 1) * p], Z, wr[q] + 1j * wi[q], "R", 1, st))
+        for q in range(nb):
+            self._raise(infos[q])
+        return out
 
     def ordschur_(self, P, select, wantZ=True, Z=None):
         """LinearAlgebra.ordschur!(P, select; wantZ, Z) — src/ordschur.jl:11-73 (ComplexF64).  Mutates and returns P.

@@ -134,3 +134,80 @@ int psd_d_checkpsd_dev(psd_ctx* c, int n, int p, const double* dT, const double*
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Batch of small Hessenberg-triangular problems in ONE call (the projected problems of the
+// Krylov driver, krylov.jl:575-592,800-829, are <= 40 x 40 — one such problem per launch chain is the worst case for a
+// launch-bound design).  The slot scheduler of the real iteration (psd_rq_step_mb) runs the problems side by side: each
+// starts as one range with its own leader, its own factors, band arrays, eigenvalues and sweep budget; splits and
+// trains take further slots as in a single problem.
+extern "C" {
+int psd_d_pschur_hess_batch(psd_ctx* c, int nb, int n, int p, double* const* H, double* const* Q, int wantT, int wantZ,
+                            int maxitfac, double* wr, double* wi, int* infos, psd_stats* stats, int* info) {
+    int dummy;
+    if (!info) info = &dummy;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!c) return *info = -1;
+    if (nb < 1 || nb > PSD_SLOTS / 2) return *info = -2;
+    if ((*info = check_dims(n, p)) != 0) return *info - 1;
+    if (!H) return *info = -5;
+    if (wantZ && !Q) return *info = -6;
+    if (maxitfac < 1) return *info = -9;
+    if (!wr || !wi) return *info = -10;
+    const int mlog = 2 * maxitfac * n * nb + n * nb + 16;
+    if ((*info = c->reserve(n, p, false, mlog)) != 0) return *info;
+    const size_t nn = (size_t)n * n, sb = (size_t)nb * (n + 8);
+    double *dH = nullptr, *dZ = nullptr, *bws = nullptr;
+    PSD_CHECK(psd_rt_malloc((void**)&dH, nn * p * nb * sizeof(double)));
+    if (wantZ) PSD_CHECK(psd_rt_malloc((void**)&dZ, nn * p * nb * sizeof(double)));
+    PSD_CHECK(psd_rt_malloc((void**)&bws, (8 * sb + (size_t)nb * (p + 8)) * sizeof(double)));
+    PSD_CHECK(psd_rt_memset(bws, 0, (8 * sb + (size_t)nb * (p + 8)) * sizeof(double), c->stream));
+    for (int q = 0; q < nb; ++q)
+        for (int j = 0; j < p; ++j) {
+            PSD_CHECK(psd_rt_h2d(dH + ((size_t)q * p + j) * nn, H[(size_t)q * p + j], nn * 8, c->stream));
+            if (wantZ) PSD_CHECK(psd_rt_h2d(dZ + ((size_t)q * p + j) * nn, Q[(size_t)q * p + j], nn * 8, c->stream));
+        }
+    psd_stats local;
+    memset(&local, 0, sizeof(local));
+    psd_stats* s = stats ? stats : &local;
+    Timer t;
+    t.start(c->stream);
+    psd_rstate st;
+    std::vector<int> pinfo(nb, 0);
+    int rc = 0;
+    if (n == 1) {  // PSD.jl:333-352
+        for (int q = 0; q < nb; ++q) {
+            PSD_LAUNCH(psd_scalar_product, psd_dim3(1), 64, 0, c->stream, (const double*)(dH + (size_t)q * p), p,
+                       bws + 6 * sb + (size_t)q * (n + 8), bws + 7 * sb + (size_t)q * (n + 8));
+        }
+    } else {
+        rc = iterate_dev(c, n, p, dH, dZ, wantT, wantZ, maxitfac, &st, s, mlog, nb, bws, pinfo.data());
+        if (rc == 0) stats_from_state(s, st);
+    }
+    s->ms_iter = s->ms_total = t.stop(c->stream);
+    if (rc == 0) {
+        for (int q = 0; q < nb; ++q) {
+            PSD_CHECK(psd_rt_d2h(wr + (size_t)q * n, bws + 6 * sb + (size_t)q * (n + 8), sizeof(double) * n, c->stream));
+            PSD_CHECK(psd_rt_d2h(wi + (size_t)q * n, bws + 7 * sb + (size_t)q * (n + 8), sizeof(double) * n, c->stream));
+            for (int j = 0; j < p; ++j) {
+                PSD_CHECK(psd_rt_d2h(H[(size_t)q * p + j], dH + ((size_t)q * p + j) * nn, nn * 8, c->stream));
+                if (wantZ) PSD_CHECK(psd_rt_d2h(Q[(size_t)q * p + j], dZ + ((size_t)q * p + j) * nn, nn * 8, c->stream));
+            }
+        }
+        PSD_CHECK(psd_rt_sync(c->stream));
+    }
+    psd_rt_free(dH);
+    if (dZ) psd_rt_free(dZ);
+    psd_rt_free(bws);
+    if (rc != 0) return *info = rc;
+    int worst = 0;
+    for (int q = 0; q < nb; ++q) {
+        const int iq = (pinfo[q] == PSD_LIST_OVERFLOW) ? (PSD_INFO_RUNTIME + 77) : ((pinfo[q] != 0) ? (PSD_INFO_NOCONV + pinfo[q]) : 0);
+        if (infos) infos[q] = iq;
+        if (iq != 0 && worst == 0) worst = iq;
+    }
+    if (worst == 0 && st.info != 0)
+        worst = (st.info == PSD_LIST_OVERFLOW) ? (PSD_INFO_RUNTIME + 77) : (PSD_INFO_NOCONV + st.info);
+    return *info = worst;
+}
+}  // extern "C"

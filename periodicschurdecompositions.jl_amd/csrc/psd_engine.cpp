@@ -662,8 +662,12 @@ int formq_dev(psd_ctx* c, int n, int p, const double* dH, const double* dtau, do
 }
 
 // PSD.jl:322-1096 on device.  dH: H_1 Hessenberg, H_j triangular; dZ: Q_j (or identity) or null.
+// nprob > 1 (batch, psd_d_pschur_hess_batch): dH / dZ hold nprob problems back to back, bws the per-problem band arrays
+// hdiag | hsub | hsup | Pd | Pe | Pf | wr | wi (nprob (n + 8) doubles each) and hnorms (nprob (p + 8)); pinfo_out: info per
+// problem
 int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int wantZ, int maxitfac,
-                psd_rstate* st_out, psd_stats* stats, int maxlog) {
+                psd_rstate* st_out, psd_stats* stats, int maxlog, int nprob = 1, double* bws = nullptr,
+                int* pinfo_out = nullptr) {
     const int W = choose_window(p);
     if (W == 0) return PSD_INFO_NOTIMPL;
     psd_rparams P;
@@ -701,12 +705,22 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     P.gl = nullptr;
     P.cep = nullptr;
     P.role = P.epoch = P.cdone = nullptr;
+    P.nprob = 1;
+    if (bws) {
+        if (nprob < 1 || nprob > PSD_SLOTS / 2) return -3;
+        const size_t sb = (size_t)nprob * (n + 8);
+        P.hdiag = bws; P.hsub = bws + sb; P.hsup = bws + 2 * sb; P.Pd = bws + 3 * sb; P.Pe = bws + 4 * sb;
+        P.Pf = bws + 5 * sb; P.wr = bws + 6 * sb; P.wi = bws + 7 * sb;
+        P.hnorms = bws + 8 * sb;
+        P.nprob = nprob;
+    }
     // multi-block scheduler (default with trains on; PSD_MB=0: one active range at a time): PSD_SLOTS workgroup slots,
     // leaders of independent active ranges and the cursors of their trains
-    const bool mb = (M > 1) && c->mblock;
+    const bool mb = ((M > 1) && c->mblock) || bws != nullptr;  // (a batch always runs on the slot scheduler)
     const int NSL = mb ? PSD_SLOTS : M;
-    if (M > 1) {
+    if (M > 1 || mb) {
         PSD_CHECK(c->treserve(p));
+        PSD_CHECK(psd_rt_memset(c->tgl, 0, sizeof(psd_rglobal), c->stream));
         PSD_CHECK(psd_rt_memset(c->tcst, 0, sizeof(psd_rstate) * PSD_SLOTS, c->stream));
         PSD_CHECK(psd_rt_memset(c->tdesc, 0, sizeof(psd_apply_desc) * PSD_SLOTS, c->stream));
         P.cst = c->tcst;
@@ -735,8 +749,8 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     if (const char* e = getenv("PSD_TRAIN_OC")) train_oc = atoi(e);  // (tuning hook)
     int Mw = M;
     if (mb && c->train_mb_m > Mw && c->train_m >= 32) Mw = (c->train_mb_m > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : c->train_mb_m;
-    PSD_LAUNCH(psd_rq_init, psd_dim3(p), 256, 256 * 8, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, Mw, train_oc, mb ? 1 : 0,
-               mb ? c->cgap : 2);
+    PSD_LAUNCH(psd_rq_init, psd_dim3(p, nprob), 256, 256 * 8, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, Mw, train_oc,
+               mb ? 1 : 0, mb ? c->cgap : 2);
     const size_t lds_apply = apply_lds_bytes();
     const int tiles = (n + PSD_APPLY_NT - 1) / PSD_APPLY_NT;
     const int batch = 32;
@@ -768,7 +782,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
             }
 #endif
             P.tick = (int)launched;
-            if (M == 1)
+            if (M == 1 && !mb)
                 PSD_LAUNCH(psd_rq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
             else if (mb)  // every slot of the scheduler in one launch
                 PSD_LAUNCH(psd_rq_step_mb, psd_dim3(PSD_SLOTS), PSD_STEP_NT, lds_step, c->stream, P, p, p + 8);
@@ -780,7 +794,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 pend.emplace_back(ev0, ev1);
             }
 #endif
-            if (c->apply_worklist || c->shard_world > 1) {
+            if (c->apply_worklist || c->shard_world > 1 || mb) {
                 // work-list form: one grid of single-wave workgroups loops over the items of the tick
                 const int wl_grid = c->apply_wl_grid;
                 PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, P, n, p, p + 8, 0, NSL,
@@ -816,6 +830,8 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 hst.ntrains = hgl.ntrains;
                 hst.ntrainsweeps = hgl.ntrainsweeps;
                 for (int q = 0; q < 6; ++q) hst.cyc[q] = hgl.cyc[q];
+                if (pinfo_out)
+                    for (int q = 0; q < nprob; ++q) pinfo_out[q] = hgl.pinfo[q];
                 break;
             }
             if (launched > cap || (getenv("PSD_DBG_CAP") && launched > atoll(getenv("PSD_DBG_CAP")))) {

@@ -76,6 +76,7 @@ PSD_HD int psd_tr_len(const psd_tr& t) { return t.kind == PSD_TR_R3 ? 3 : 2; }
 
 struct psd_apply_desc {
     int active;
+    int prob;      // batch: problem the window belongs to
     int plo, phi;  // span of positions touched by the lists
     int lc0, lc1;  // left role: columns of H_m
     int rr0, rr1;  // right role: rows of H_{m-1}
@@ -107,6 +108,7 @@ struct psd_rstate {
     // the range this leader owns (the reference works bottom-up through ONE range 1..n, PSD.jl:1057-1060; here the part
     // above a negligible subdiagonal is handed to another workgroup as soon as it is found), the running train's key
     int mb, slot, parent, lo, train_key;
+    int prob;  // batch: the problem (its own factors, Schur vectors, band arrays, eigenvalues) this range belongs to
     // ticks between the starts of consecutive cursors of a train: 2 = two whole windows apart; 1 = one tick apart, the
     // cursor's first window 4 positions short, so that its rows end above the window of the cursor ahead (cursors are
     // then nb + 4 positions apart instead of 2 nb: more bulges fit a block, the train fills and drains faster).
@@ -124,7 +126,10 @@ struct psd_rglobal {
     int nactive;    // leaders alive
     int nlog;       // entries of the shared sweep log
     int train_seq;  // train keys
-    int itbudget;   // the reference's maxitleft (PSD.jl:471,1057): ONE budget of maxitfac * n sweeps for all ranges
+    int itbudget;   // (unused since the budget became per problem: pbudget)
+    // batch (psd_d_pschur_hess_batch): leaders alive, sweep budget (the reference's maxitleft, PSD.jl:471,1057: ONE
+    // budget of maxitfac * n sweeps for all ranges of a problem) and info per problem
+    int pactive[PSD_SLOTS], pbudget[PSD_SLOTS], pinfo[PSD_SLOTS];
     int nsweeps, nrqpass, ndefl1, ndefl2, nwindows, ntrains, ntrainsweeps, maxits, nspawn, nslotmax;
     long long niter;
     long long cyc[6];
@@ -158,6 +163,8 @@ struct psd_rparams {
                  // of finished cursors
     int* role;   // [PSD_SLOTS] PSD_ROLE_*
     int* epoch;  // [PSD_SLOTS] tick at which a claimed slot's state was written (PSD_EPOCH_NEVER while free)
+    int nprob;   // batch: problems in this call; problem q's arrays start q * (stride) behind problem 0's: factors and
+                 // Schur vectors p n n, band arrays / eigenvalues n + 8, hnorms p + 8
     int* cdone;  // [PSD_SLOTS] per LEADER slot: cursors of its running train that have finished (a cursor's own slot
                  // may be reused by another train before the leader looks)
 };
@@ -392,7 +399,7 @@ PSD_D void psd_mb_spawn(const psd_rparams& P, psd_rstate& st, int* bc) {
             cs.i = st.l - 1;
             cs.l = st.lo;
             cs.its = 1;
-            cs.maxitleft = psd_atomic_load(&P.gl->itbudget);
+            cs.maxitleft = psd_atomic_load(&P.gl->pbudget[st.prob]);
             cs.exc_dec = 0;
             cs.kcur = 0;
             cs.phase = PSD_PH_DECIDE;
@@ -405,6 +412,7 @@ PSD_D void psd_mb_spawn(const psd_rparams& P, psd_rstate& st, int* bc) {
             for (int q = 0; q < 6; ++q) cs.cyc[q] = 0;
             P.cst[s] = cs;
             psd_atomic_add(&P.gl->nactive, 1);
+            psd_atomic_add(&P.gl->pactive[st.prob], 1);
             psd_atomic_add(&P.gl->nspawn, 1);
             psd_atomic_store(P.epoch + s, P.tick);
         }
@@ -431,18 +439,21 @@ PSD_D void psd_mb_finish_leader(const psd_rparams& P, psd_rstate& st, int* bc) {
         psd_atomic_add_ll(&g->niter, st.niter);
         for (int q = 0; q < 6; ++q) psd_atomic_add_ll(&g->cyc[q], st.cyc[q]);
         psd_release_fence();  // (eigenvalues of this range are read by whoever finishes last)
+        bc[1] = psd_atomic_add(&g->pactive[st.prob], -1) - 1;
         bc[0] = psd_atomic_add(&g->nactive, -1) - 1;
     }
     PSD_SYNC();
-    const int left = bc[0];
+    const int left = bc[0], leftp = bc[1];
     PSD_SYNC();
-    if (left == 0) {
+    if (leftp == 0) {  // last range of this problem: PSD.jl:1066-1073
         psd_acquire_fence();
         const psd_mat<double> H1 = psd_fac(P, st.n, 1);
         PSD_PAR_FOR(q, st.n - 1) {
             if (P.wi[q] == 0.0) H1(q + 2, q + 1) = 0.0;
         }
         PSD_SYNC();
+    }
+    if (left == 0) {
         PSD_ONE { psd_atomic_store(&P.gl->done, 1); }
     }
     st.phase = PSD_PH_DONE;  // (psd_rq_step_body hands the slot back after its last store)
@@ -481,6 +492,7 @@ PSD_D void psd_rq_decide(const psd_rparams& P, psd_rstate& st, double* red, int*
         if (st.mb) {
             PSD_ONE {
                 psd_atomic_store(&P.gl->info, i);
+                psd_atomic_store(&P.gl->pinfo[st.prob], i);
                 psd_atomic_store(&P.gl->abort, 1);
                 psd_atomic_store(&P.gl->done, 1);
             }
@@ -936,6 +948,7 @@ PSD_D void psd_desc_write(const psd_rparams& P, psd_rstate& st, const int* lcnt,
     PSD_ONE {
         psd_apply_desc d;
         d.active = over ? 0 : 1;
+        d.prob = st.prob;
         d.plo = plo;
         d.phi = phi;
         d.lc0 = lc0;
@@ -1567,7 +1580,7 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
             case PSD_PH_NEXT:  // PSD.jl:1057-1060
                 if (st.mb) {  // the budget is shared by all ranges
                     PSD_SYNC();
-                    PSD_ONE { redi[0] = psd_atomic_add(&P.gl->itbudget, -st.its); }
+                    PSD_ONE { redi[0] = psd_atomic_add(&P.gl->pbudget[st.prob], -st.its); }
                     PSD_SYNC();
                     st.maxitleft = redi[0];  // (value before the subtraction: the line below takes `its` off)
                     PSD_SYNC();
@@ -1693,6 +1706,16 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rq_step_mb(psd_rparams P, int p, int cstride) {
         // written in an earlier launch: the slot goes live (only this workgroup ever changes a claimed slot's role)
         role = (P.cst[s].cursor > 0) ? PSD_ROLE_CURSOR : PSD_ROLE_LEADER;
         PSD_ONE { psd_atomic_store(P.role + s, role); }
+    }
+    if (P.nprob > 1 && (role == PSD_ROLE_LEADER || role == PSD_ROLE_CURSOR)) {
+        const int pr = P.cst[s].prob, n_ = P.cst[s].n;
+        const size_t sm = (size_t)p * n_ * n_, sb = (size_t)n_ + 8;
+        Q.H = P.H + pr * sm;
+        if (P.Z) Q.Z = P.Z + pr * sm;
+        Q.hdiag = P.hdiag + pr * sb; Q.hsub = P.hsub + pr * sb; Q.hsup = P.hsup + pr * sb;
+        Q.Pd = P.Pd + pr * sb; Q.Pe = P.Pe + pr * sb; Q.Pf = P.Pf + pr * sb;
+        Q.wr = P.wr + pr * sb; Q.wi = P.wi + pr * sb;
+        Q.hnorms = P.hnorms + (size_t)pr * (p + 8);
     }
     if (role == PSD_ROLE_LEADER) {
         Q.lead = Q.st;
@@ -2135,7 +2158,7 @@ PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride
         const int g0 = lo + gix * GL;  // first line of the group (1-based column for the rows role, row otherwise)
         const int gl = (hi - g0 + 1 < GL) ? (hi - g0 + 1) : GL;
         const int ns = (gl + TL - 1) / TL;
-        const psd_mat<double> Mx = psd_mat<double>{base + (size_t)(jm - 1) * n * n, n};
+        const psd_mat<double> Mx = psd_mat<double>{base + ((size_t)d.prob * p + (jm - 1)) * n * n, n};
         const bool rowsrole = role == 0;
 #ifndef PSD_HOSTSIM
         // the next tile's loads are in flight while this one is computed on: a lane keeps them in 32 registers
@@ -2186,8 +2209,9 @@ PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W,
     PSD_LDS_DECL;
     double* red = (double*)psd_lds;
     const int j = PSD_BLOCK_X + 1;
+    const int pr = PSD_BLOCK_Y;  // problem of the batch (grid.y = nprob; 1 otherwise)
     const int NT = PSD_NTHREADS;
-    const psd_mat<double> Hj = psd_mat<double>{P.H + (size_t)(j - 1) * n * n, n};
+    const psd_mat<double> Hj = psd_mat<double>{P.H + ((size_t)pr * p + (j - 1)) * n * n, n};
     if (j == 1) {
         // _gethess!: zero below the first subdiagonal
         PSD_PAR_FOR(c, n) {
@@ -2217,26 +2241,31 @@ PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W,
             st.cgap = cgap;
             st.tgap = 2;
             st.cstart = st.cfirst = 0;
-            st.slot = 0;
+            st.slot = pr;
             st.parent = -1;
             st.lo = 1;
             st.train_key = 0;
+            st.prob = pr;
             for (int q = 0; q < PSD_TRAIN_MAX; ++q) st.cslots[q] = 0;
-            *P.st = st;
-            P.desc->active = 0;
-            if (mb) {  // slot 0 leads the whole range; every other slot is free
-                psd_rglobal g;
-                memset(&g, 0, sizeof(g));
-                g.nactive = 1;
-                g.nslotmax = 1;
-                g.itbudget = maxitfac * n;
-                *P.gl = g;
-                for (int q = 0; q < PSD_SLOTS; ++q) {
-                    P.role[q] = (q == 0) ? PSD_ROLE_LEADER : PSD_ROLE_FREE;
-                    P.epoch[q] = PSD_EPOCH_NEVER;
-                    P.cdone[q] = 0;
-                    P.desc[q].active = 0;
+            if (mb) {
+                // (the host zeroed psd_rglobal and the slot words: roles FREE) problem pr starts as one range led by slot
+                // pr; block 0 sets what is shared
+                P.cst[pr] = st;
+                P.gl->pactive[pr] = 1;
+                P.gl->pbudget[pr] = maxitfac * n;
+                P.role[pr] = PSD_ROLE_LEADER;
+                if (pr == 0) {
+                    P.gl->nactive = P.nprob;
+                    P.gl->nslotmax = P.nprob;
+                    for (int q = 0; q < PSD_SLOTS; ++q) {
+                        P.epoch[q] = PSD_EPOCH_NEVER;
+                        P.cdone[q] = 0;
+                        P.desc[q].active = 0;
+                    }
                 }
+            } else {
+                *P.st = st;
+                P.desc->active = 0;
             }
         }
     } else {
@@ -2256,7 +2285,7 @@ PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W,
             double best = 0.0;
             for (int t = 0; t < NT; ++t)
                 if (red[t] > best) best = red[t];
-            P.hnorms[j] = PSD_DBL_EPS * n * best;
+            P.hnorms[(size_t)pr * (p + 8) + j] = PSD_DBL_EPS * n * best;
         }
     }
 }

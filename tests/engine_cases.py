@@ -1327,3 +1327,41 @@ def case_eigvecs(eng):
     # argument errors (vectors.jl:30-36)
     with pytest.raises(ValueError):
         eng.eigvecs(ps0, [True] * 5)
+
+
+# ---- batch of small Hessenberg-triangular problems (psd_d_pschur_hess_batch; krylov.jl:575-592,800-829) ------------
+def _hess_ut_problem(n, p, seed):
+    A = [np.asfortranarray(np.triu(a)) for a in pt.bench_factors(n, p, seed=seed)]
+    A[0] = np.asfortranarray(np.triu(pt.bench_factors(n, 1, seed=seed + 977)[0], -1))
+    return A
+
+
+def case_pschur_hess_batch(eng, shapes):
+    for (nb, n, p) in shapes:
+        probs = [_hess_ut_problem(n, p, 300 + 7 * q + n + p) for q in range(nb)]
+        # one by one (the reference's order of work) ...
+        single = []
+        for A in probs:
+            W = [a.copy(order="F") for a in A]
+            single.append(eng.pschur_hess_(W[0], W[1:]))
+        # ... and all in one call
+        Ws = [[a.copy(order="F") for a in A] for A in probs]
+        batch = eng.pschur_hess_batch_([(W[0], W[1:]) for W in Ws])
+        assert len(batch) == nb
+        for q in range(nb):
+            A = probs[q]
+            pt.pschur_check(A, batch[q], tol=100 * max(1.0, np.sqrt(n / 32)), check_lam=False)
+            P = pt.product(A)
+            sc = np.linalg.norm(P, 2)
+            assert pt.match_eigs(np.linalg.eigvals(P), batch[q].values) <= 1e-10 * sc * max(1.0, np.linalg.cond(P) * 1e-6)
+            # same iteration as the single call when no trains / splits reorder it; always the same spectrum
+            assert pt.match_eigs(single[q].values, batch[q].values) <= 1e-10 * sc
+    # wantZ = False, and a batch of one equals the plain call
+    A = _hess_ut_problem(12, 3, 5)
+    W = [a.copy(order="F") for a in A]
+    b1 = eng.pschur_hess_batch_([(W[0], W[1:])], wantZ=False)
+    W2 = [a.copy(order="F") for a in A]
+    s1 = eng.pschur_hess_(W2[0], W2[1:], wantZ=False)
+    assert pt.match_eigs(s1.values, b1[0].values) <= 1e-10 * np.linalg.norm(pt.product(A), 2)
+    with pytest.raises(Exception):
+        eng.pschur_hess_batch_([(W[0], W[1:]), (W[0][:5, :5].copy(order="F"), [w[:5, :5].copy(order="F") for w in W[1:]])])

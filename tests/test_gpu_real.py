@@ -207,3 +207,8 @@ def test_residual_growth_oracle_vs_device(gpu_engine, n, p):
     assert ok and oko
     assert erro.max() > 100 * 0.5 or n < 256  # the reference algorithm itself is beyond half its n = 32 tolerance here
     assert err.max() <= 2.0 * erro.max() + 20.0
+
+
+def test_pschur_hess_batch(gpu_engine):
+    """many small Hessenberg-triangular problems in one call on the slot scheduler"""
+    ec.case_pschur_hess_batch(gpu_engine, [(3, 10, 2), (16, 40, 4), (32, 24, 3), (6, 64, 8)])

@@ -87,3 +87,7 @@ def test_checkpsd(sim_engine):
 
 def test_eigvecs(sim_engine):
     ec.case_eigvecs(sim_engine)
+
+
+def test_pschur_hess_batch(sim_engine):
+    ec.case_pschur_hess_batch(sim_engine, [(3, 10, 2), (5, 20, 3), (4, 33, 1)])
