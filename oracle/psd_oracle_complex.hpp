@@ -176,7 +176,7 @@ inline void givens_algorithm_z(cplx f, cplx g, double& cs, cplx& sn, cplx& r) {
         }
     }
     const double f2 = std::norm(fs), g2 = std::norm(gs);
-    if (f2 <= std::max(g2, 1.0) * safmin) {
+    if (f2 <= std::max(g2, (double)1.0) * safmin) {
         if (f == cplx(0.0)) {
             cs = 0.0;
             r = cplx(std::hypot(g.real(), g.imag()));

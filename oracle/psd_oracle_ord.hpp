@@ -50,11 +50,11 @@ template <class T> bool qr_solve(int K, std::vector<T>& M /*col-major*/, std::ve
             for (int c = k; c < K; ++c) {
                 T d = T(0.0);
                 for (int r = k; r < K; ++r) d += Sc<T>::conj(v[r - k]) * at(r, c);
-                for (int r = k; r < K; ++r) at(r, c) -= 2.0 * v[r - k] * d;
+                for (int r = k; r < K; ++r) at(r, c) -= (double)2.0 * v[r - k] * d;
             }
             T d = T(0.0);
             for (int r = k; r < K; ++r) d += Sc<T>::conj(v[r - k]) * b[r];
-            for (int r = k; r < K; ++r) b[r] -= 2.0 * v[r - k] * d;
+            for (int r = k; r < K; ++r) b[r] -= (double)2.0 * v[r - k] * d;
         }
     }
     for (int k = 0; k < K; ++k)

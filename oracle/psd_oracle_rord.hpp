@@ -382,11 +382,11 @@ inline bool sanitize_reigpair(cplx* alpha, double* scal) {
         }
         const double misr = std::hypot(cst, zt1.imag());
         const double misc = std::abs(zt2) / 2;
-        const double cs = std::max(std::abs(alpha[0]), std::max(1.0, std::abs(alpha[1])));
+        const double cs = std::max(std::abs(alpha[0]), std::max((double)1.0, std::abs(alpha[1])));
         good = std::min(misr, misc) <= cs * std::sqrt(ulp);
         if (misr > misc) {
             const int j = (scal[0] >= scal[1]) ? 0 : 1;
-            const cplx at = (alpha[j] + std::conj(zt1)) / 2.0;
+            const cplx at = (alpha[j] + std::conj(zt1)) / (double)2.0;
             const double ai = std::fabs(at.imag());
             alpha[0] = cplx(at.real(), ai);
             alpha[1] = std::conj(alpha[0]);
