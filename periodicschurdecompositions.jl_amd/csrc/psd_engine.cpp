@@ -176,9 +176,11 @@ struct psd_ctx {
         trelease();
         PSD_CHECK(psd_rt_malloc((void**)&tcst, sizeof(psd_rstate) * PSD_SLOTS));
         PSD_CHECK(psd_rt_malloc((void**)&tshift, sizeof(double) * PSD_TSHIFT_STRIDE * PSD_SLOTS));
-        PSD_CHECK(psd_rt_malloc((void**)&tdesc, sizeof(psd_apply_desc) * PSD_SLOTS));
-        PSD_CHECK(psd_rt_malloc((void**)&tcnt, sizeof(int) * PSD_SLOTS * (size_t)(p + 8)));
-        PSD_CHECK(psd_rt_malloc((void**)&ttr, sizeof(psd_tr) * PSD_SLOTS * (size_t)p * PSD_TR_CAP));
+        // (descriptors, counts and lists twice: ticks alternate between the two sets, so that the far part of a tick's
+        //  bulk update can still read its lists while the next tick's chases write theirs)
+        PSD_CHECK(psd_rt_malloc((void**)&tdesc, 2 * sizeof(psd_apply_desc) * PSD_SLOTS));
+        PSD_CHECK(psd_rt_malloc((void**)&tcnt, 2 * sizeof(int) * PSD_SLOTS * (size_t)(p + 8)));
+        PSD_CHECK(psd_rt_malloc((void**)&ttr, 2 * sizeof(psd_tr) * PSD_SLOTS * (size_t)p * PSD_TR_CAP));
         PSD_CHECK(psd_rt_malloc((void**)&tgl, sizeof(psd_rglobal)));
         PSD_CHECK(psd_rt_malloc((void**)&tslotw, sizeof(int) * 3 * PSD_SLOTS));
         tcap_p = p;
@@ -211,6 +213,15 @@ struct psd_ctx {
         lo = shard_rank * base + (shard_rank < rem ? shard_rank : rem);
         hi = lo + base + (shard_rank < rem ? 1 : 0);
     }
+    // PSD_OVERLAP=1: the far part of a tick's bulk update on a second stream beside the next tick's chases
+    // (psd_rq_apply_wl modes).  Off by default: measured the far parts do run beside the chases and
+    // a train tick drops from 610 to 445 us at n = 1024, p = 64, but two more launches and two cross-stream events per tick
+    // cost 15-25 us on every tick, and most ticks are small: 811 vs 817 ms at that size, 249 vs 224 ms at n = 512, p = 16
+    int overlap = 0;
+#ifndef PSD_HOSTSIM
+    hipStream_t stream2 = nullptr;  // the far parts of the bulk updates (beside the next tick's chases)
+    hipEvent_t evE[2] = {nullptr, nullptr}, evF[2] = {nullptr, nullptr};
+#endif
     int apply_worklist = 1;   // PSD_APPLY_WL=0: the grid-per-cursor bulk-apply kernels
     int apply_wl_grid = 2048; // workgroups of the work-list bulk apply (PSD_APPLY_WL_GRID)
     psd_rostate* rost = nullptr;
@@ -718,11 +729,12 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     // leaders of independent active ranges and the cursors of their trains
     const bool mb = ((M > 1) && c->mblock) || bws != nullptr;  // (a batch always runs on the slot scheduler)
     const int NSL = mb ? PSD_SLOTS : M;
+    const bool ovl = mb && c->overlap && wantT;  // far bulk updates beside the next tick's chases (psd_rq_apply_wl modes)
     if (M > 1 || mb) {
         PSD_CHECK(c->treserve(p));
         PSD_CHECK(psd_rt_memset(c->tgl, 0, sizeof(psd_rglobal), c->stream));
         PSD_CHECK(psd_rt_memset(c->tcst, 0, sizeof(psd_rstate) * PSD_SLOTS, c->stream));
-        PSD_CHECK(psd_rt_memset(c->tdesc, 0, sizeof(psd_apply_desc) * PSD_SLOTS, c->stream));
+        PSD_CHECK(psd_rt_memset(c->tdesc, 0, 2 * sizeof(psd_apply_desc) * PSD_SLOTS, c->stream));
         P.cst = c->tcst;
         P.cep = c->tslotw;  // (single-range train mode; the multi-block scheduler uses the same words as role/epoch/cdone)
         PSD_CHECK(psd_rt_memset(c->tslotw, 0, sizeof(int) * 3 * PSD_SLOTS, c->stream));
@@ -782,10 +794,21 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
             }
 #endif
             P.tick = (int)launched;
+            // ticks alternate between two sets of descriptors / counts / lists (multi-block mode)
+            const int par = mb ? (int)(launched & 1) : 0;
+            psd_rparams Pq = P, Pprev = P;
+            if (mb) {
+                Pq.desc = P.desc + (size_t)par * PSD_SLOTS;
+                Pq.cnt = P.cnt + (size_t)par * PSD_SLOTS * (p + 8);
+                Pq.tr = P.tr + (size_t)par * PSD_SLOTS * p * PSD_TR_CAP;
+                Pprev.desc = P.desc + (size_t)(par ^ 1) * PSD_SLOTS;
+                Pprev.cnt = P.cnt + (size_t)(par ^ 1) * PSD_SLOTS * (p + 8);
+                Pprev.tr = P.tr + (size_t)(par ^ 1) * PSD_SLOTS * p * PSD_TR_CAP;
+            }
             if (M == 1 && !mb)
                 PSD_LAUNCH(psd_rq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
             else if (mb)  // every slot of the scheduler in one launch
-                PSD_LAUNCH(psd_rq_step_mb, psd_dim3(PSD_SLOTS), PSD_STEP_NT, lds_step, c->stream, P, p, p + 8);
+                PSD_LAUNCH(psd_rq_step_mb, psd_dim3(PSD_SLOTS), PSD_STEP_NT, lds_step, c->stream, Pq, p, p + 8);
             else  // every cursor of the tick in one launch, one workgroup each
                 PSD_LAUNCH(psd_rq_step_train, psd_dim3(M), PSD_STEP_NT, lds_step, c->stream, P, p, p + 8);
 #ifndef PSD_HOSTSIM
@@ -794,13 +817,45 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 pend.emplace_back(ev0, ev1);
             }
 #endif
-            if (c->apply_worklist || c->shard_world > 1 || mb) {
+            if (ovl) {
+                // Far part of the PREVIOUS tick's bulk update: beside this tick's chases, on the second stream, behind
+                // the previous tick's near part (evE) — a rows-role far block of one window meets the column role of
+                // another, which belongs to the near part.  The serial simulation runs it right here, i.e. in the latest
+                // order the streams allow.
+                const int wl_grid = c->apply_wl_grid;
+                if (launched > 0) {
+#ifndef PSD_HOSTSIM
+                    PSD_CHECK(hipStreamWaitEvent(c->stream2, c->evE[par ^ 1], 0));
+                    hipLaunchKernelGGL(psd_rq_apply_wl, dim3(wl_grid), dim3(PSD_WL_NT), psd_wl_lds_bytes(), c->stream2, Pprev, n, p,
+                                       p + 8, 0, NSL, zlo1, zhi1, 2);
+                    PSD_CHECK(hipEventRecord(c->evF[par ^ 1], c->stream2));
+                    PSD_CHECK(hipStreamWaitEvent(c->stream, c->evF[par ^ 1], 0));
+#else
+                    if (!getenv("PSD_OVL_DBG"))
+                        PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pprev, n, p, p + 8, 0,
+                                   NSL, zlo1, zhi1, 2);
+#endif
+                }
+                // near part of this tick's update, before the next tick's chases
+                PSD_LAUNCH(psd_rq_cuts, psd_dim3(1), PSD_WL_NT, PSD_SLOTS * sizeof(int), c->stream, Pq, NSL);
+                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 0, NSL,
+                           zlo1, zhi1, 1);
+                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 1, NSL,
+                           zlo1, zhi1, 1);
+#ifndef PSD_HOSTSIM
+                PSD_CHECK(hipEventRecord(c->evE[par], c->stream));
+#else
+                if (getenv("PSD_OVL_DBG"))
+                    PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 0, NSL,
+                               zlo1, zhi1, 2);
+#endif
+            } else if (c->apply_worklist || c->shard_world > 1 || mb) {
                 // work-list form: one grid of single-wave workgroups loops over the items of the tick
                 const int wl_grid = c->apply_wl_grid;
-                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, P, n, p, p + 8, 0, NSL,
-                           zlo1, zhi1);
-                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, P, n, p, p + 8, 1, NSL,
-                           zlo1, zhi1);
+                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 0, NSL,
+                           zlo1, zhi1, 0);
+                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 1, NSL,
+                           zlo1, zhi1, 0);
             } else if (M == 1) {
                 PSD_LAUNCH(psd_rq_apply, psd_dim3(tiles, p, 3), PSD_APPLY_NT, lds_apply, c->stream, P, n, p);
             } else {
@@ -869,6 +924,9 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
             return PSD_INFO_RUNTIME + 0xfffe;
         }
     }
+#ifndef PSD_HOSTSIM
+    if (ovl) PSD_CHECK(hipStreamSynchronize(c->stream2));
+#endif
 #ifndef PSD_HOSTSIM
     PSD_CHECK(poller.finish(pend));
 #endif
@@ -964,15 +1022,22 @@ int psd_create(psd_ctx** ctx, int device) {
     }
     for (int q = 0; q < 2; ++q) {
         if (hipHostMalloc(&c->pin[q], 4096, hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&c->pev[q], hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&c->pev[q], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->evE[q], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->evF[q], hipEventDisableTiming) != hipSuccess) {
             psd_destroy(c);
             return PSD_INFO_RUNTIME + 5;
         }
+    }
+    if (hipStreamCreate(&c->stream2) != hipSuccess) {
+        psd_destroy(c);
+        return PSD_INFO_RUNTIME + 4;
     }
 #endif
 #ifndef PSD_HOSTSIM
     if (const char* e = getenv("PSD_HESS_LOOKAHEAD")) c->hess_lookahead = atoi(e);
 #endif
+    if (const char* e = getenv("PSD_OVERLAP")) c->overlap = atoi(e);
     if (const char* e = getenv("PSD_MB")) c->mblock = atoi(e);
     if (const char* e = getenv("PSD_TRAIN_MB")) c->train_mb_m = atoi(e);
     if (const char* e = getenv("PSD_CGAP")) c->cgap = (atoi(e) == 2) ? 2 : 1;
@@ -1023,8 +1088,11 @@ int psd_destroy(psd_ctx* c) {
 #ifndef PSD_HOSTSIM
     for (int q = 0; q < 2; ++q) {
         if (c->pev[q]) (void)hipEventDestroy(c->pev[q]);
+        if (c->evE[q]) (void)hipEventDestroy(c->evE[q]);
+        if (c->evF[q]) (void)hipEventDestroy(c->evF[q]);
         if (c->pin[q]) (void)hipHostFree(c->pin[q]);
     }
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
 #endif
     delete c;

@@ -77,6 +77,9 @@ PSD_HD int psd_tr_len(const psd_tr& t) { return t.kind == PSD_TR_R3 ? 3 : 2; }
 struct psd_apply_desc {
     int active;
     int prob;      // batch: problem the window belongs to
+    int cut;       // first far column of a split window (psd_rq_cuts)
+    int split;     // 1: a window in the middle of a sweep: the far part of its bulk update (the rows role beyond the next
+                   // PSD_WL_EDGE columns and the whole Z role) may run while the next tick chases (psd_rq_apply_wl modes)
     int plo, phi;  // span of positions touched by the lists
     int lc0, lc1;  // left role: columns of H_m
     int rr0, rr1;  // right role: rows of H_{m-1}
@@ -169,6 +172,7 @@ struct psd_rparams {
                  // may be reused by another train before the leader looks)
 };
 #define PSD_TSHIFT_STRIDE (4 * PSD_TRAIN_MAX + 8)
+#define PSD_WL_EDGE 64  // columns right of a mid-sweep window that the next windows of the sweep can reach
 
 PSD_HD psd_mat<double> psd_fac(const psd_rparams& P, int n, int j) {
     return psd_mat<double>{P.H + (size_t)(j - 1) * n * n, n};
@@ -930,7 +934,7 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
 }
 
 PSD_D void psd_desc_write(const psd_rparams& P, psd_rstate& st, const int* lcnt, int plo, int phi, int lc0,
-                          int lc1, int rr0, int rr1) {
+                          int lc1, int rr0, int rr1, int split = 0) {
     PSD_SYNC();
     const bool over = psd_list_overflow(lcnt, st.p, PSD_TR_CAP);
     if (over) {  // never apply truncated lists
@@ -949,6 +953,8 @@ PSD_D void psd_desc_write(const psd_rparams& P, psd_rstate& st, const int* lcnt,
         psd_apply_desc d;
         d.active = over ? 0 : 1;
         d.prob = st.prob;
+        d.split = (split && st.wantT) ? 1 : 0;
+        d.cut = lc0 + PSD_WL_EDGE;
         d.plo = plo;
         d.phi = phi;
         d.lc0 = lc0;
@@ -1266,7 +1272,8 @@ PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
     st.cyc[2] += tc2 - tc1;
     st.cyc[3] += tc3 - tc2;
     const int phi = (ke + 2 < i) ? (ke + 2) : i;
-    psd_desc_write(P, st, lcnt, ks, phi, w.be + 1, i2, i1, w.bs - 1);
+    // (the sweep goes on below this window: nothing reads the far part of this window's update before the sweep ends)
+    psd_desc_write(P, st, lcnt, ks, phi, w.be + 1, i2, i1, w.bs - 1, (ke < i - 1) ? 1 : 0);
     st.nwindows += 1;
     st.kcur = ke + 1;
     if (ke >= i - 1) {  // sweep complete (PSD.jl:887)
@@ -2080,8 +2087,68 @@ PSD_D void psd_wl_compute(double* tile, int S, int nl, int t, int order, const p
 
 // zlo..zhi: the owners m (1-based) whose Z_m this context holds (period-sharded contexts: the Z role of the others is
 // some other rank's work; 1..p otherwise)
+// line ranges of a window's three roles under an apply mode (see psd_rq_apply_wl); cut: first far column
+PSD_HD void psd_wl_ranges(psd_apply_desc& d, int mode, int cut) {
+    if (mode == 0) return;
+    if (mode == 1) {
+        if (d.split) {
+            if (d.lc1 > cut - 1) d.lc1 = cut - 1;
+            d.zr1 = d.zr0 - 1;
+        }
+    } else {
+        if (d.split) {
+            d.lc0 = cut;
+        } else {
+            d.lc1 = d.lc0 - 1;
+            d.zr1 = d.zr0 - 1;
+        }
+        d.rr1 = d.rr0 - 1;
+    }
+}
+// First far column of slot b's rows role: PSD_WL_EDGE columns right of the window — moved right past the column range of
+// any other window of the tick it would cut.  (Another window's column update R mixes its columns plo..phi; this
+// window's row update L commutes with it only applied to ALL of those columns on the same side of R: near = L before R,
+// far = L after R.  A cut through plo..phi would apply L twice to what R carries across it.)
+PSD_D int psd_wl_cut(const psd_apply_desc* desc, int M, int b) {
+    const psd_apply_desc d = desc[b];
+    int cut = d.lc0 + PSD_WL_EDGE;
+    for (int rep = 0; rep < M; ++rep) {
+        bool moved = false;
+        for (int o = 0; o < M; ++o) {
+            if (o == b) continue;
+            const psd_apply_desc e = desc[o];
+            if (!e.active || e.prob != d.prob) continue;
+            if (e.plo < cut && cut <= e.phi) {
+                cut = e.phi + 1;
+                moved = true;
+            }
+        }
+        if (!moved) break;
+    }
+    return cut;
+}
+// the first far column of every split window of the tick (one workgroup; see psd_wl_cut)
+PSD_KERNEL_B(PSD_WL_NT) psd_rq_cuts(psd_rparams P, int M) {
+    PSD_LDS_DECL;
+    int* cutc = (int*)psd_lds;
+    PSD_PAR_FOR(b, M) { cutc[b] = (P.desc[b].active && P.desc[b].split) ? psd_wl_cut(P.desc, M, b) : 0; }
+    PSD_SYNC();
+    PSD_PAR_FOR(b, M) {
+        if (P.desc[b].active && P.desc[b].split) P.desc[b].cut = cutc[b];
+    }
+}
+
 #define PSD_WL_GROUP 4  // 64-line tiles per item: the owner's list is staged once for all of them
-PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride, int pass, int M, int zlo, int zhi) {
+// mode 0: everything.  Modes 1 / 2 split a tick's bulk update so that most of it runs beside the NEXT tick's chases:
+//   mode 1 ("near", before the next chase): windows that end a sweep, RQ and deflation windows completely; mid-sweep
+//           windows (desc.split): the rows role on the next PSD_WL_EDGE columns (what the sweep's next windows load)
+//           and the column role;
+//   mode 2 ("far", beside the next chase, pass 0 only): mid-sweep windows: the rows role beyond the edge and the Z role.
+// Nothing a chase, a deflation search or a shift computation reads lies in a far part: those read diagonal window
+// blocks and near-diagonal bands of their own range, the far parts are rows of a window x columns >= 64 to its right
+// and Schur vectors.
+PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride, int pass, int M, int zlo, int zhi,
+                                        int mode) {
     PSD_LDS_DECL;
     psd_tr* ltr = (psd_tr*)psd_lds;
     int* flags = (int*)(psd_lds + sizeof(psd_tr) * PSD_TR_LDS_RECS);
@@ -2097,9 +2164,10 @@ PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride
     int GL = TL;
     for (int trial = 0; trial < 2; ++trial) {
         PSD_PAR_FOR(b, M) {
-            const psd_apply_desc d = P.desc[b];
+            psd_apply_desc d = P.desc[b];
             int a = 0, z = 0;
             if (d.active) {
+                psd_wl_ranges(d, mode, d.cut);
                 if (pass == 0) {
                     a = (d.lc1 >= d.lc0) ? ((d.lc1 - d.lc0 + 1 + GL - 1) / GL) : 0;
                     z = (d.zr1 >= d.zr0) ? ((d.zr1 - d.zr0 + 1 + GL - 1) / GL) : 0;
@@ -2139,7 +2207,8 @@ PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride
         const int role = (pass == 0) ? ((tt < tA[b]) ? 0 : 2) : 1;
         const int gix = (role == 2) ? (tt - tA[b]) : tt;
         if (role == 2 && (m < zlo || m > zhi)) continue;
-        const psd_apply_desc d = P.desc[b];
+        psd_apply_desc d = P.desc[b];
+        psd_wl_ranges(d, mode, d.cut);
         int cnt = P.cnt[(size_t)b * cstride + (m - 1)];
         if (cnt > PSD_TR_CAP) cnt = PSD_TR_CAP;
         if (cnt <= 0) continue;

@@ -91,3 +91,25 @@ def test_eigvecs(sim_engine):
 
 def test_pschur_hess_batch(sim_engine):
     ec.case_pschur_hess_batch(sim_engine, [(3, 10, 2), (5, 20, 3), (4, 33, 1)])
+
+
+def test_far_apply_overlap_order(built, monkeypatch):
+    """PSD_OVERLAP=1 (opt-in): the far part of a tick's bulk update — the rows role beyond the columns the next windows
+    reach, cut so that it never splits another window's column range, and the Z role — is applied one tick late, after
+    the next tick's chases (the latest order the two streams of the HIP build allow); same invariants."""
+    import os
+
+    import numpy as np
+    import psd_amd
+    import psdtest as pt
+
+    monkeypatch.setenv("PSD_OVERLAP", "1")
+    eng = psd_amd.Engine(libpath=os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim", "_build",
+                                              "libpsd_hostsim.so"))
+    for (n, p, lr) in [(100, 1, "R"), (150, 7, "L"), (200, 2, "R")]:
+        A = pt.bench_factors(n, p, seed=7)
+        ps = eng.pschur(A, lr)
+        ok, err = pt.checkpsd(ps, A, thresh=100 * np.sqrt(n / 32))
+        assert ok, (n, p, err.max())
+        P = pt.product(A, left=(lr == "L"))
+        assert pt.match_eigs(np.linalg.eigvals(P), ps.values) <= 1e-10 * np.linalg.norm(P, 2)
