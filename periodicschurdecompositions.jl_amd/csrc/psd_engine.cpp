@@ -3,6 +3,7 @@
 // serial simulation for the CPU-only test tier; the package never loads that build.
 #include "psd_hess.h"
 #include "psd_hess2.h"
+#include "psd_formq2.h"
 #include "psd_real_qr.h"
 #include "psd_zhess.h"
 #include "psd_zqz.h"
@@ -198,6 +199,10 @@ struct psd_ctx {
         tgl = nullptr; tslotw = nullptr;
         tcap_p = 0;
     }
+    // blocked Q formation (psd_formq2.h): the T factors of all blocks of all factors
+    double* fqT = nullptr;
+    size_t fqT_doubles = 0;
+    int formq_blocked = 1;
 #ifndef PSD_HOSTSIM
     hipGraphExec_t hess_exec = nullptr;
     int hess_graph_n = 0, hess_graph_p = 0;
@@ -217,7 +222,8 @@ struct psd_ctx {
     // (psd_rq_apply_wl modes).  Off by default: measured the far parts do run beside the chases and
     // a train tick drops from 610 to 445 us at n = 1024, p = 64, but two more launches and two cross-stream events per tick
     // cost 15-25 us on every tick, and most ticks are small: 811 vs 817 ms at that size, 249 vs 224 ms at n = 512, p = 16
-    int overlap = 0;
+    int overlap = 3;  // 0 off, 1 far/near split of the H updates, 2 Schur-vector updates on stream2, 3 = 2 for n >= 1024
+    int far_grid = 0;  // grid of the far bulk-update launches (0: apply_wl_grid)
 #ifndef PSD_HOSTSIM
     hipStream_t stream2 = nullptr;  // the far parts of the bulk updates (beside the next tick's chases)
     hipEvent_t evE[2] = {nullptr, nullptr}, evF[2] = {nullptr, nullptr};
@@ -374,6 +380,9 @@ struct psd_ctx {
         h2ring = nullptr;
         h2ring_n = 0;
 #endif
+        if (fqT) psd_rt_free(fqT);
+        fqT = nullptr;
+        fqT_doubles = 0;
         void* ptrs[] = {dH, dZ, tau, vbuf, hdiag, hsub, hsup, Pd, Pe, Pf, hnorms, wr, wi, st, desc, tr, cnt, log};
         for (void* q : ptrs)
             if (q) psd_rt_free(q);
@@ -664,6 +673,37 @@ int formq_dev(psd_ctx* c, int n, int p, const double* dH, const double* dtau, do
     c->slice(p, jlo, jhi);
     if (jhi <= jlo) return 0;
     PSD_LAUNCH(psd_set_identity, psd_dim3(n, jhi - jlo), 64, 0, c->stream, dQ + (size_t)jlo * n * n, n);
+    if (c->formq_blocked && n >= 2 * PSD_FQ_KB) {
+        // compact-WY blocks of 32 reflectors on the matrix cores (psd_formq2.h)
+        const int nfac = jhi - jlo;
+        const int nblk = (n - 1 + PSD_FQ_KB - 1) / PSD_FQ_KB;
+        const size_t need = (size_t)nblk * nfac * PSD_FQ_KB * PSD_FQ_KB;
+        if (c->fqT_doubles < need) {
+            if (c->fqT) psd_rt_free(c->fqT);
+            c->fqT = nullptr;
+            c->fqT_doubles = 0;
+            PSD_CHECK(psd_rt_malloc((void**)&c->fqT, need * sizeof(double)));
+            c->fqT_doubles = need;
+        }
+        psd_fq_args g;
+        g.Hp = dH;
+        g.tau = dtau;
+        g.Q = dQ;
+        g.T = c->fqT;
+        g.n = n;
+        g.j0 = jlo;
+        g.nblk = nblk;
+        PSD_LAUNCH(psd_fq_tfactor, psd_dim3(nblk, nfac), PSD_FQ_NT, (64 * 33 + 2 * 32 * 33 + 32) * sizeof(double), c->stream, g);
+        for (int b = nblk - 1; b >= 0; --b) {
+#ifdef PSD_HOSTSIM
+            psd_fq_apply_sim(g, b, nfac);
+#else
+            const int tiles = (n - b * PSD_FQ_KB + PSD_FQ_TN - 1) / PSD_FQ_TN;
+            hipLaunchKernelGGL(psd_fq_apply, dim3(tiles, nfac), dim3(PSD_FQ_NT), 0, c->stream, g, b);
+#endif
+        }
+        return 0;
+    }
     const size_t lds = PSD_HESS_NT * 8;
     for (int i = n - 1; i >= 1; --i) {
         const int tiles = (n - i + 1 + 3) / 4;
@@ -729,7 +769,8 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     // leaders of independent active ranges and the cursors of their trains
     const bool mb = ((M > 1) && c->mblock) || bws != nullptr;  // (a batch always runs on the slot scheduler)
     const int NSL = mb ? PSD_SLOTS : M;
-    const bool ovl = mb && c->overlap && wantT;  // far bulk updates beside the next tick's chases (psd_rq_apply_wl modes)
+    const bool zdef = mb && wantZ && (c->overlap == 2 || (c->overlap == 3 && n >= 1024));  // Schur-vector updates on the second stream, beside the next chases
+    const bool ovl = mb && c->overlap == 1 && wantT;  // far bulk updates beside the next tick's chases (psd_rq_apply_wl modes)
     if (M > 1 || mb) {
         PSD_CHECK(c->treserve(p));
         PSD_CHECK(psd_rt_memset(c->tgl, 0, sizeof(psd_rglobal), c->stream));
@@ -786,6 +827,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     for (;;) {
         for (int b = 0; b < batch; ++b) {
 #ifndef PSD_HOSTSIM
+            if (zdef && launched >= 2) PSD_CHECK(hipStreamWaitEvent(c->stream, c->evF[(int)(launched & 1)], 0));
             const bool sample = c->profile && ((launched & 15) == 0);
             if (sample) {
                 (void)hipEventCreate(&ev0);
@@ -817,7 +859,27 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 pend.emplace_back(ev0, ev1);
             }
 #endif
-            if (ovl) {
+            if (zdef) {
+                // Schur-vector updates one stream over (psd_rq_apply_wl modes 3 / 4): the Z launch of this tick starts on
+                // stream2 when the tick's H updates are done (evE) — beside the NEXT tick's chases, which leave most of the
+                // chip idle — and its lists must not be rewritten before it is done (evF, awaited in front of the chase
+                // that reuses this parity's lists, two ticks on).  The serial simulation runs the Z launch last.
+                const int wl_grid = c->apply_wl_grid;
+                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 0, NSL,
+                           zlo1, zhi1, 3);
+                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 1, NSL,
+                           zlo1, zhi1, 3);
+#ifndef PSD_HOSTSIM
+                PSD_CHECK(hipEventRecord(c->evE[par], c->stream));
+                PSD_CHECK(hipStreamWaitEvent(c->stream2, c->evE[par], 0));
+                hipLaunchKernelGGL(psd_rq_apply_wl, dim3(c->far_grid > 0 ? c->far_grid : wl_grid), dim3(PSD_WL_NT),
+                                   psd_wl_lds_bytes(), c->stream2, Pq, n, p, p + 8, 0, NSL, zlo1, zhi1, 4);
+                PSD_CHECK(hipEventRecord(c->evF[par], c->stream2));
+#else
+                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 0, NSL,
+                           zlo1, zhi1, 4);
+#endif
+            } else if (ovl) {
                 // Far part of the PREVIOUS tick's bulk update: beside this tick's chases, on the second stream, behind
                 // the previous tick's near part (evE) — a rows-role far block of one window meets the column role of
                 // another, which belongs to the near part.  The serial simulation runs it right here, i.e. in the latest
@@ -826,8 +888,8 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 if (launched > 0) {
 #ifndef PSD_HOSTSIM
                     PSD_CHECK(hipStreamWaitEvent(c->stream2, c->evE[par ^ 1], 0));
-                    hipLaunchKernelGGL(psd_rq_apply_wl, dim3(wl_grid), dim3(PSD_WL_NT), psd_wl_lds_bytes(), c->stream2, Pprev, n, p,
-                                       p + 8, 0, NSL, zlo1, zhi1, 2);
+                    hipLaunchKernelGGL(psd_rq_apply_wl, dim3(c->far_grid > 0 ? c->far_grid : wl_grid), dim3(PSD_WL_NT),
+                                       psd_wl_lds_bytes(), c->stream2, Pprev, n, p, p + 8, 0, NSL, zlo1, zhi1, 2);
                     PSD_CHECK(hipEventRecord(c->evF[par ^ 1], c->stream2));
                     PSD_CHECK(hipStreamWaitEvent(c->stream, c->evF[par ^ 1], 0));
 #else
@@ -925,7 +987,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
         }
     }
 #ifndef PSD_HOSTSIM
-    if (ovl) PSD_CHECK(hipStreamSynchronize(c->stream2));
+    if (ovl || zdef) PSD_CHECK(hipStreamSynchronize(c->stream2));
 #endif
 #ifndef PSD_HOSTSIM
     PSD_CHECK(poller.finish(pend));
@@ -1029,15 +1091,38 @@ int psd_create(psd_ctx** ctx, int device) {
             return PSD_INFO_RUNTIME + 5;
         }
     }
-    if (hipStreamCreate(&c->stream2) != hipSuccess) {
-        psd_destroy(c);
-        return PSD_INFO_RUNTIME + 4;
+    if (const char* e = getenv("PSD_OVERLAP")) c->overlap = atoi(e);
+    {
+        // The far bulk updates run beside the next tick's chases.  A chase workgroup takes the whole LDS of a compute
+        // unit (p*W*(W+1) doubles), so it can only start on a CU that holds no bulk-update workgroup: the second stream
+        // is confined to the CUs the chases do not need (CU mask), PSD_OVERLAP_CUS of them stay free for the slots.
+        int ncu = 0;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+        int keep = PSD_SLOTS;
+        if (const char* e = getenv("PSD_OVERLAP_CUS")) keep = atoi(e);
+        hipError_t rc = hipErrorInvalidValue;
+        if (c->overlap && ncu > keep + 32 && keep > 0 && ncu <= 1024) {
+            uint32_t mask[32];
+            memset(mask, 0, sizeof(mask));
+            for (int q = keep; q < ncu; ++q) mask[q >> 5] |= (1u << (q & 31));
+            rc = hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)((ncu + 31) / 32), mask);
+            if (rc == hipSuccess) c->far_grid = (ncu - keep) * 8;
+            if (const char* e = getenv("PSD_FAR_GRID")) c->far_grid = atoi(e);  // (tuning hook)
+        }
+        if (rc != hipSuccess) rc = hipStreamCreate(&c->stream2);
+        if (rc != hipSuccess) {
+            psd_destroy(c);
+            return PSD_INFO_RUNTIME + 4;
+        }
     }
 #endif
 #ifndef PSD_HOSTSIM
     if (const char* e = getenv("PSD_HESS_LOOKAHEAD")) c->hess_lookahead = atoi(e);
 #endif
+#ifdef PSD_HOSTSIM
     if (const char* e = getenv("PSD_OVERLAP")) c->overlap = atoi(e);
+#endif
+    if (const char* e = getenv("PSD_FORMQ_BLOCKED")) c->formq_blocked = atoi(e);
     if (const char* e = getenv("PSD_MB")) c->mblock = atoi(e);
     if (const char* e = getenv("PSD_TRAIN_MB")) c->train_mb_m = atoi(e);
     if (const char* e = getenv("PSD_CGAP")) c->cgap = (atoi(e) == 2) ? 2 : 1;

@@ -195,6 +195,7 @@ struct psd_win {
 // writes (Hessenberg / triangular factors plus a 3x3 bulge): they are neither loaded nor stored.  (The simulated tier
 // poisons LDS with NaNs, so a read outside the band would surface there.)
 #define PSD_WIN_BAND 3
+#define PSD_WIN_LF 4  // factors whose window loads are in flight together (16-byte loads, 8 per factor and lane)
 struct alignas(8) psd_pair {
     double a, b;
 };
@@ -225,12 +226,12 @@ PSD_D void psd_win_load(const psd_rparams& P, const psd_win& w, int n, int p) {
             const bool pair = r + 1 < m;
             const int back = (pair || r == 0) ? 0 : 1;  // (m == 1: the single element twice, second copy dropped)
             const bool one = !pair && r == 0;
-            for (int j = 0; j < p; j += 2) {
+            for (int j = 0; j < p; j += PSD_WIN_LF) {
                 const double* src = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r - back);
                 double* dst = w.b + j * w.bsz + r;
-                psd_pair v[2][8];
+                psd_pair v[PSD_WIN_LF][8];
 #pragma unroll
-                for (int f = 0; f < 2; ++f) {
+                for (int f = 0; f < PSD_WIN_LF; ++f) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int c = g + 4 * u;
@@ -245,7 +246,7 @@ PSD_D void psd_win_load(const psd_rparams& P, const psd_win& w, int n, int p) {
                     }
                 }
 #pragma unroll
-                for (int f = 0; f < 2; ++f) {
+                for (int f = 0; f < PSD_WIN_LF; ++f) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int c = g + 4 * u;
@@ -2090,6 +2091,15 @@ PSD_D void psd_wl_compute(double* tile, int S, int nl, int t, int order, const p
 // line ranges of a window's three roles under an apply mode (see psd_rq_apply_wl); cut: first far column
 PSD_HD void psd_wl_ranges(psd_apply_desc& d, int mode, int cut) {
     if (mode == 0) return;
+    if (mode == 3) {  // everything but the Schur vectors
+        d.zr1 = d.zr0 - 1;
+        return;
+    }
+    if (mode == 4) {  // the Schur vectors only (pass 0)
+        d.lc1 = d.lc0 - 1;
+        d.rr1 = d.rr0 - 1;
+        return;
+    }
     if (mode == 1) {
         if (d.split) {
             if (d.lc1 > cut - 1) d.lc1 = cut - 1;
@@ -2147,6 +2157,9 @@ PSD_KERNEL_B(PSD_WL_NT) psd_rq_cuts(psd_rparams P, int M) {
 // Nothing a chase, a deflation search or a shift computation reads lies in a far part: those read diagonal window
 // blocks and near-diagonal bands of their own range, the far parts are rows of a window x columns >= 64 to its right
 // and Schur vectors.
+// Modes 3 / 4 split off the Schur vectors alone: mode 3 = the two H roles (both passes), mode 4 = the Z role (pass 0).
+// Nothing reads Z_m before the iteration ends and only owner m's lists touch it, so the Z updates of a tick only have to
+// stay in tick order among themselves: they run on a second stream beside the following ticks' chases.
 PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride, int pass, int M, int zlo, int zhi,
                                         int mode) {
     PSD_LDS_DECL;

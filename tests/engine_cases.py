@@ -1365,3 +1365,22 @@ def case_pschur_hess_batch(eng, shapes):
     assert pt.match_eigs(s1.values, b1[0].values) <= 1e-10 * np.linalg.norm(pt.product(A), 2)
     with pytest.raises(Exception):
         eng.pschur_hess_batch_([(W[0], W[1:]), (W[0][:5, :5].copy(order="F"), [w[:5, :5].copy(order="F") for w in W[1:]])])
+
+
+def case_formq_blocked(make_engine, sizes):
+    """Blocked (compact-WY, csrc/psd_formq2.h) against reflector-by-reflector (csrc/psd_hess.h) materialisation of the
+    Q_j (PSD.jl:136-143): both engines reduce and iterate the same H, so their Z_j differ by the rounding of Q_j only.
+    make_engine(env) -> Engine created with that environment."""
+    blocked = make_engine({"PSD_FORMQ_BLOCKED": "1"})
+    plain = make_engine({"PSD_FORMQ_BLOCKED": "0"})
+    for (n, p, lr) in sizes:
+        A = pt.bench_factors(n, p, seed=300 + n + p)
+        pb = blocked.pschur(A, lr)
+        pp = plain.pschur(A, lr)
+        assert np.array_equal(pb.values, pp.values)  # (the iteration never sees Q)
+        for j in range(p):
+            assert np.array_equal(pb.Ts[j], pp.Ts[j])
+            d = np.abs(pb.Z[j] - pp.Z[j]).max()
+            assert d < 50 * pt.EPS * np.sqrt(n), (n, p, j, d)
+            orth = np.linalg.norm(pb.Z[j].T @ pb.Z[j] - np.eye(n))
+            assert orth < 10 * pt.EPS * n, (n, p, j, orth)

@@ -212,3 +212,19 @@ def test_residual_growth_oracle_vs_device(gpu_engine, n, p):
 def test_pschur_hess_batch(gpu_engine):
     """many small Hessenberg-triangular problems in one call on the slot scheduler"""
     ec.case_pschur_hess_batch(gpu_engine, [(3, 10, 2), (16, 40, 4), (32, 24, 3), (6, 64, 8)])
+
+
+def test_formq_blocked(monkeypatch):
+    """compact-WY Q formation on the matrix cores (csrc/psd_formq2.h) against the reflector-by-reflector kernel:
+    identical T and eigenvalues, Z equal to rounding, orthogonal to 10 eps n; sizes off the 32 / 64 tiling"""
+    import torch
+
+    torch.cuda.init()
+    import psd_amd
+
+    def make(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        return psd_amd.Engine(device=0)
+
+    ec.case_formq_blocked(make, [(64, 3, "R"), (97, 2, "L"), (130, 1, "R"), (257, 5, "R"), (512, 4, "L")])

@@ -113,3 +113,47 @@ def test_far_apply_overlap_order(built, monkeypatch):
         assert ok, (n, p, err.max())
         P = pt.product(A, left=(lr == "L"))
         assert pt.match_eigs(np.linalg.eigvals(P), ps.values) <= 1e-10 * np.linalg.norm(P, 2)
+
+
+def test_schur_vector_updates_deferred(built, monkeypatch):
+    """PSD_OVERLAP=2 (what the HIP build does by itself for n >= 1024): the Z role of a tick's bulk update is its own
+    launch (psd_rq_apply_wl mode 4) behind the two H passes (mode 3) — on the GPU it runs on a second stream beside the
+    next tick's chases.  Same invariants, and the same T and Z as the one-stream order to the last bit: the Z role
+    commutes with everything else because only owner m's lists touch Z_m."""
+    import os
+
+    import numpy as np
+    import psd_amd
+    import psdtest as pt
+
+    lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim", "_build", "libpsd_hostsim.so")
+    monkeypatch.setenv("PSD_OVERLAP", "0")
+    ref = psd_amd.Engine(libpath=lib)
+    monkeypatch.setenv("PSD_OVERLAP", "2")
+    eng = psd_amd.Engine(libpath=lib)
+    for (n, p, lr) in [(100, 1, "R"), (150, 7, "L"), (200, 2, "R")]:
+        A = pt.bench_factors(n, p, seed=11)
+        ps = eng.pschur(A, lr)
+        ok, err = pt.checkpsd(ps, A, thresh=100 * np.sqrt(n / 32))
+        assert ok, (n, p, err.max())
+        pr = ref.pschur(A, lr)
+        for j in range(p):
+            assert np.array_equal(ps.Z[j], pr.Z[j])
+        assert np.array_equal(ps.values, pr.values)
+
+
+def test_formq_blocked(built, monkeypatch):
+    """compact-WY Q formation (T factors by the device code, the matrix-core step by its plain-loop stand-in) against
+    the reflector-by-reflector form: n not a multiple of the block, p = 1 (H_1 alone: reflectors one row lower)"""
+    import os
+
+    import psd_amd
+
+    lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim", "_build", "libpsd_hostsim.so")
+
+    def make(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        return psd_amd.Engine(libpath=lib)
+
+    ec.case_formq_blocked(make, [(64, 3, "R"), (97, 2, "L"), (130, 1, "R")])
