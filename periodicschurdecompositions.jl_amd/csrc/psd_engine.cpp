@@ -209,6 +209,8 @@ struct psd_ctx {
     // look-ahead reduction (psd_hess2.h)
     double* h2ring = nullptr;
     int h2ring_n = 0;
+    std::vector<hipEvent_t> h2ev;
+    int hess_async = -1;  // links per panel-update launch of the two-stream form (0: off, < 0: by size)
     int hess_lookahead = 1;  // PSD_HESS_LOOKAHEAD=0: the two-launch form of psd_hess.h
 #endif
     // period sharding (psd_set_shard): this context holds the Schur vectors Z_j of a contiguous slice of the period
@@ -226,6 +228,7 @@ struct psd_ctx {
     int far_grid = 0;  // grid of the far bulk-update launches (0: apply_wl_grid)
 #ifndef PSD_HOSTSIM
     hipStream_t stream2 = nullptr;  // the far parts of the bulk updates (beside the next tick's chases)
+    hipStream_t stream3 = nullptr;  // the panel updates of the Hessenberg reduction (beside its chain)
     hipEvent_t evE[2] = {nullptr, nullptr}, evF[2] = {nullptr, nullptr};
 #endif
     int apply_worklist = 1;   // PSD_APPLY_WL=0: the grid-per-cursor bulk-apply kernels
@@ -590,19 +593,82 @@ int hessenberg2_launches(psd_ctx* c, int n, int p, const psd_hess2_args& ha) {
     link(n, p - 1);
     return 0;
 }
+// Two-stream form: the chain launches carry no bulk part; the panel updates of K consecutive links (K distinct
+// matrices) are ONE launch on the CU-masked second stream, up to p - K links behind the chain.  What the chain needs of a
+// matrix — its update by the previous link on it, p links earlier — is awaited by event before the launch that reads it.
+template <int NK, int CR>
+int hessenberg2_async(psd_ctx* c, int n, int p, const psd_hess2_args& ha, int K) {
+    const int nC = (n + CR - 1) / CR + 1, nT = (n + PSD_H2_ROWS - 1) / PSD_H2_ROWS, nB = (n + 3) / 4;
+    const size_t lds = ((size_t)n + 8 + 2 * PSD_H2_NT + 64) * sizeof(double);
+    const int Q = (n - 1) * p;
+    const int nbatch = Q / K + 1;  // link indices 0 .. Q (Q: the drain position)
+    if ((int)c->h2ev.size() < 16) {
+        c->h2ev.resize(16, nullptr);
+        for (auto& e : c->h2ev) PSD_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    // (an event is re-recorded 8 batches later; the chain awaits batch b while at most (p - K) / K < 8 later ones exist)
+    hipEvent_t* evA = c->h2ev.data();      // [8]: chain reached the end of a batch
+    hipEvent_t* evB = c->h2ev.data() + 8;  // [8]: a batch of panel updates is done
+    // order against whatever ran on the main stream before
+    PSD_CHECK(hipEventRecord(evA[0], c->stream));
+    PSD_CHECK(hipStreamWaitEvent(c->stream3, evA[0], 0));
+    hipLaunchKernelGGL((psd_hess2_link<NK, CR>), dim3(nC), dim3(PSD_H2_NT), lds, c->stream, ha, n, 0, 1, nC, 0);  // staging
+    // (PSD_HESS_LAG: a batch is launched that many links later than it could be — tuning hook)
+    int lag = 0;
+    if (const char* e = getenv("PSD_HESS_LAG")) lag = atoi(e);
+    if (lag < 0) lag = 0;
+    if (lag > p - K - 1) lag = p - K - 1;
+    int nextb = 0;  // next batch to launch
+    auto batch = [&](int b) -> int {
+        PSD_CHECK(hipEventRecord(evA[b & 7], c->stream));
+        PSD_CHECK(hipStreamWaitEvent(c->stream3, evA[b & 7], 0));
+        hipLaunchKernelGGL((psd_hess2_bulk<NK>), dim3(nT + nB, K), dim3(PSD_H2_NT), lds, c->stream3, ha, n, b * K, nT);
+        PSD_CHECK(hipEventRecord(evB[b & 7], c->stream3));
+        return 0;
+    };
+    int idx = 0;
+    for (int i = 1; i <= n - 1; ++i)
+        for (int j = p; j >= 1; --j, ++idx) {
+            // chain#idx reads the matrix of link idx + 1, last updated by B(idx + 1 - p): batch (idx + 1 - p) / K
+            const int need = idx + 1 - p;
+            if (need >= 0 && need % K == 0) PSD_CHECK(hipStreamWaitEvent(c->stream, evB[(need / K) & 7], 0));
+            hipLaunchKernelGGL((psd_hess2_link<NK, CR>), dim3(nC), dim3(PSD_H2_NT), lds, c->stream, ha, n, i, j, nC, 0);
+            // links nextb K .. nextb K + K - 1 have their reflectors once the chain has passed the last of them
+            if (idx >= nextb * K + K - 1 + lag) {
+                PSD_CHECK(batch(nextb));
+                ++nextb;
+            }
+        }
+    for (; nextb < nbatch; ++nextb) PSD_CHECK(batch(nextb));  // the rest, up to the drain position Q
+    PSD_CHECK(hipStreamWaitEvent(c->stream, evB[(nbatch - 1) & 7], 0));
+    return 0;
+}
 int hessenberg2_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
     if (!c->h2ring || c->h2ring_n < n) {
         if (c->h2ring) psd_rt_free(c->h2ring);
         c->h2ring = nullptr;
-        PSD_CHECK(psd_rt_malloc((void**)&c->h2ring, 4 * psd_h2_slot_doubles(n) * sizeof(double)));
+        PSD_CHECK(psd_rt_malloc((void**)&c->h2ring, PSD_H2_RING * psd_h2_slot_doubles(n) * sizeof(double)));
         c->h2ring_n = n;
     }
-    PSD_CHECK(psd_rt_memset(c->h2ring, 0, 4 * psd_h2_slot_doubles(c->h2ring_n) * sizeof(double), c->stream));
+    PSD_CHECK(psd_rt_memset(c->h2ring, 0, PSD_H2_RING * psd_h2_slot_doubles(c->h2ring_n) * sizeof(double), c->stream));
     psd_hess2_args ha;
     ha.H = dH;
     ha.tau = dtau;
     ha.ring = c->h2ring;
     ha.p = p;
+    ha.ringmask = 3;
+    // two-stream form: K links per panel-update launch; the chain may run p - K links ahead of the updates and the ring
+    // keeps every link the pending updates still read (p + K + 2 <= PSD_H2_RING)
+    int K = c->hess_async;
+    if (K < 0) K = (p >= 32 && n >= 512) ? 16 : 0;
+    if (K > 0 && p >= 9 * K) K = (p + 7) / 8;
+    if (K > 0 && p >= 2 * K && p + K + 2 <= PSD_H2_RING && c->stream3) {
+        ha.ringmask = PSD_H2_RING - 1;
+        if (n <= 256) return hessenberg2_async<4, 8>(c, n, p, ha, K);
+        if (n <= 512) return hessenberg2_async<8, 8>(c, n, p, ha, K);
+        if (n <= 1024) return hessenberg2_async<16, 4>(c, n, p, ha, K);
+        return hessenberg2_async<32, 8>(c, n, p, ha, K);
+    }
     if (n <= 256) return hessenberg2_launches<4, 8>(c, n, p, ha);
     if (n <= 512) return hessenberg2_launches<8, 8>(c, n, p, ha);
     if (n <= 1024) return hessenberg2_launches<16, 4>(c, n, p, ha);
@@ -1114,10 +1180,27 @@ int psd_create(psd_ctx** ctx, int device) {
             psd_destroy(c);
             return PSD_INFO_RUNTIME + 4;
         }
+        // the same for the panel updates of the Hessenberg reduction: its chain launches are HBM-latency chains that
+        // slow down under the panel traffic; half of the chip for the panels measured best (PSD_HESS_CUS)
+        int keeph = 128;
+        if (const char* e = getenv("PSD_HESS_CUS")) keeph = atoi(e);
+        rc = hipErrorInvalidValue;
+        if (ncu > keeph + 32 && keeph > 0 && ncu <= 1024) {
+            uint32_t mask[32];
+            memset(mask, 0, sizeof(mask));
+            for (int q = keeph; q < ncu; ++q) mask[q >> 5] |= (1u << (q & 31));
+            rc = hipExtStreamCreateWithCUMask(&c->stream3, (uint32_t)((ncu + 31) / 32), mask);
+        }
+        if (rc != hipSuccess) rc = hipStreamCreate(&c->stream3);
+        if (rc != hipSuccess) {
+            psd_destroy(c);
+            return PSD_INFO_RUNTIME + 4;
+        }
     }
 #endif
 #ifndef PSD_HOSTSIM
     if (const char* e = getenv("PSD_HESS_LOOKAHEAD")) c->hess_lookahead = atoi(e);
+    if (const char* e = getenv("PSD_HESS_ASYNC")) c->hess_async = atoi(e);
 #endif
 #ifdef PSD_HOSTSIM
     if (const char* e = getenv("PSD_OVERLAP")) c->overlap = atoi(e);
@@ -1177,7 +1260,10 @@ int psd_destroy(psd_ctx* c) {
         if (c->evF[q]) (void)hipEventDestroy(c->evF[q]);
         if (c->pin[q]) (void)hipHostFree(c->pin[q]);
     }
+    for (auto& e : c->h2ev)
+        if (e) (void)hipEventDestroy(e);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream) (void)hipStreamDestroy(c->stream);
 #endif
     delete c;

@@ -27,20 +27,22 @@
 #ifndef PSD_HOSTSIM
 #define PSD_H2_NT 256
 #define PSD_H2_ROWS 8
+#define PSD_H2_RING 256  // slots of the per-link ring (power of two)
 
 struct psd_hess2_args {
     double* H;     // [p][n][n]
     double* tau;   // [p][n]
-    double* ring;  // 4 slots of psd_h2_slot_doubles(n)
+    double* ring;  // ringmask + 1 slots of psd_h2_slot_doubles(n)
     int p;         // period
+    int ringmask;  // slots - 1 (a power of two minus one: 3 when the panel updates ride one launch behind the chain)
 };
 // slot layout: v[n+8] | w[n+8] | col[n+8] | hdr[8] (tau, beta) | part[2 * (n/4 + 2)]
 PSD_HD size_t psd_h2_slot_doubles(int n) { return 3 * (size_t)(n + 8) + 8 + 2 * (size_t)(n / 4 + 2); }
 struct psd_h2_slot {
     double *v, *w, *col, *hdr, *part;
 };
-PSD_D psd_h2_slot psd_h2_get(double* ring, int n, int q) {
-    double* b = ring + (size_t)(q & 3) * psd_h2_slot_doubles(n);
+PSD_D psd_h2_slot psd_h2_get(const psd_hess2_args* G, int n, int q) {
+    double* b = G->ring + (size_t)(q & G->ringmask) * psd_h2_slot_doubles(n);
     psd_h2_slot s;
     s.v = b;
     s.w = b + (n + 8);
@@ -149,6 +151,117 @@ PSD_D void psd_h2_larfg(double alpha, double xnorm, double& tau, double& beta, d
     for (int q = 0; q < kount; ++q) beta *= sfmin;
 }
 
+// The deferred update of the matrix of link Lb: M <- H(v_Lb)' (M H(v_La)), La the link before Lb (either may lie outside
+// the chain: first link / drain).  bb: block index inside the update (nT row strips above the reflector, then the
+// 4-column groups of the bottom part); slotb: ring position of Lb.
+template <int NK>
+PSD_D void psd_h2_bulk_body(const psd_hess2_args* G, int n, const psd_h2_link Lb, const psd_h2_link La, int slotb, int bb, int nT,
+                            double* vs, double* red) {
+    const int p = G->p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (!Lb.valid && !La.valid) return;
+    // matrix of link qb (after the last link: the matrix the last reflector acts on from the right, A_p)
+    const int jb = Lb.valid ? Lb.j : p;
+    double* M = G->H + (size_t)(jb - 1) * n * n;
+    const psd_h2_slot SR = psd_h2_get(G, n, slotb - 1), SL = psd_h2_get(G, n, slotb);
+    const double tauR = La.valid ? SR.hdr[0] : 0.0;
+    const double tauL = Lb.valid ? SL.hdr[0] : 0.0;
+    const int rR = La.valid ? (La.r0 - 1) : 0;      // right reflector acts on columns rR..n-1
+    const int mR = n - rR;
+    const int R0 = Lb.valid ? (Lb.r0 - 1) : n;      // left reflector acts on rows R0..n-1
+    if (bb < nT) {
+        // rows above the left reflector: fused GEMV + rank-one update, 8-row strips (right reflector only)
+        if (tauR == 0.0) return;
+        const int t = bb;
+        if (PSD_H2_ROWS * t >= R0) return;
+        const int rp = tid & 3, cl = tid >> 2;
+        const int r = PSD_H2_ROWS * t + 2 * rp;
+        const bool ok0 = r < R0, ok1 = r + 1 < R0;
+        double a0[NK], a1[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {  // the panel is requested before the reflector is staged
+            const int cc = cl + 64 * k;
+            a0[k] = a1[k] = 0.0;
+            if (cc < mR) psd_h2_ld2(M, n, r, rR + cc, ok0, ok1, a0[k], a1[k]);
+        }
+        for (int k = tid; k < mR; k += PSD_H2_NT) vs[k] = SR.v[k];
+        __syncthreads();
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int cc = cl + 64 * k;
+            if (cc < mR) {
+                const double vv = vs[cc];
+                acc0 += a0[k] * vv;
+                acc1 += a1[k] * vv;
+            }
+        }
+#pragma unroll
+        for (int s = 4; s < 64; s <<= 1) {
+            acc0 += __shfl_xor(acc0, s, 64);
+            acc1 += __shfl_xor(acc1, s, 64);
+        }
+        if (lane < 4) {
+            red[(wave * 4 + lane) * 2] = acc0;
+            red[(wave * 4 + lane) * 2 + 1] = acc1;
+        }
+        __syncthreads();
+        const int k0 = rp * 2;
+        const double w0 = tauR * (red[k0] + red[8 + k0] + red[16 + k0] + red[24 + k0]);
+        const double w1 = tauR * (red[k0 + 1] + red[8 + k0 + 1] + red[16 + k0 + 1] + red[24 + k0 + 1]);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int cc = cl + 64 * k;
+            if (cc < mR) {
+                const double vv = vs[cc];
+                psd_h2_st2(M, n, r, rR + cc, ok0, ok1, a0[k] - w0 * vv, a1[k] - w1 * vv);
+            }
+        }
+        return;
+    }
+    // rows R0..n-1: one wavefront per column, the column in registers: a <- a - tauR w v_c, then the left reflector
+    if (!Lb.valid) return;
+    if (tauR == 0.0 && tauL == 0.0) return;
+    const int c = Lb.i + 4 * (bb - nT) + wave;  // 0-based column: the columns right of the reflector's (Lb.i - 1)
+    if (c >= n) return;
+    const int mL = n - R0;
+    constexpr int NKC = (NK + 1) / 2;  // row pairs per lane: 128 rows per step
+    double a0[NKC], a1[NKC];
+    const double vc = (tauR != 0.0 && c >= rR) ? tauR * SR.v[c - rR] : 0.0;
+    double z = 0.0;
+#pragma unroll
+    for (int k = 0; k < NKC; ++k) {
+        const int rr = 2 * lane + 128 * k;  // offset inside the reflector
+        a0[k] = a1[k] = 0.0;
+        if (rr < mL) {
+            const bool ok1 = rr + 1 < mL;
+            psd_h2_ld2(M, n, R0 + rr, c, true, ok1, a0[k], a1[k]);
+            if (vc != 0.0) {
+                a0[k] -= vc * SR.w[R0 + rr];
+                if (ok1) a1[k] -= vc * SR.w[R0 + rr + 1];
+            }
+            if (tauL != 0.0) {
+                z += a0[k] * SL.v[rr];
+                if (ok1) z += a1[k] * SL.v[rr + 1];
+            }
+        }
+    }
+    z = tauL * psd_h2_wave_sum(z);
+#pragma unroll
+    for (int k = 0; k < NKC; ++k) {
+        const int rr = 2 * lane + 128 * k;
+        if (rr < mL) {
+            const bool ok1 = rr + 1 < mL;
+            double x0 = a0[k], x1 = a1[k];
+            if (tauL != 0.0) {
+                x0 -= z * SL.v[rr];
+                if (ok1) x1 -= z * SL.v[rr + 1];
+            }
+            psd_h2_st2(M, n, R0 + rr, c, true, ok1, x0, x1);
+        }
+    }
+}
+
 // One launch = chain#q + bulk B(q-1).  The link index q is a launch argument (no dependent load in front of the data
 // loads; the launches are issued one by one: at 5-15 us each the host keeps up).  NK: ceil(n / 64) rounded up
 // (register panel depth); CR: rows per chain strip (8, or 4 for large n: twice the workgroups on the GEMV).
@@ -172,7 +285,7 @@ __global__ void __launch_bounds__(PSD_H2_NT, (NK > 16 ? 2 : 4)) psd_hess2_link(c
         if (!L.valid && qi > 1) return;
         const int q = L.valid ? 0 : -1;  // (q = -1: the very first column is only staged)
         const int slot = qi * p - qj;    // ring position: any number that advances by one per link
-        const psd_h2_slot S = psd_h2_get(G->ring, n, slot), Sn = psd_h2_get(G->ring, n, slot + 1);
+        const psd_h2_slot S = psd_h2_get(G, n, slot), Sn = psd_h2_get(G, n, slot + 1);
         const int r0 = L.r0 - 1;  // 0-based first row of v_q
         const int m = (q >= 0) ? (n - r0) : 0;
         constexpr int RP = CR / 2;                  // row pairs of a strip = lanes per column
@@ -323,109 +436,28 @@ __global__ void __launch_bounds__(PSD_H2_NT, (NK > 16 ? 2 : 4)) psd_hess2_link(c
         return;
     }
     // ---------------------------------------------------------------------- bulk B(q-1) on M_{q-1}
-    const psd_h2_link Lb = psd_h2_linkat(qi, qj, -1, n, p), La = psd_h2_linkat(qi, qj, -2, n, p);
-    if (!Lb.valid && !La.valid) return;
-    const int slotb = qi * p - qj - 1;
-    // matrix of link qb (after the last link: the matrix the last reflector acts on from the right, A_p)
-    const int jb = Lb.valid ? Lb.j : p;
-    double* M = G->H + (size_t)(jb - 1) * n * n;
-    const psd_h2_slot SR = psd_h2_get(G->ring, n, slotb - 1), SL = psd_h2_get(G->ring, n, slotb);
-    const double tauR = La.valid ? SR.hdr[0] : 0.0;
-    const double tauL = Lb.valid ? SL.hdr[0] : 0.0;
-    const int rR = La.valid ? (La.r0 - 1) : 0;      // right reflector acts on columns rR..n-1
-    const int mR = n - rR;
-    const int R0 = Lb.valid ? (Lb.r0 - 1) : n;      // left reflector acts on rows R0..n-1
-    if (b < nC + nT) {
-        // rows above the left reflector: fused GEMV + rank-one update, 8-row strips (right reflector only)
-        if (tauR == 0.0) return;
-        const int t = b - nC;
-        if (PSD_H2_ROWS * t >= R0) return;
-        const int rp = tid & 3, cl = tid >> 2;
-        const int r = PSD_H2_ROWS * t + 2 * rp;
-        const bool ok0 = r < R0, ok1 = r + 1 < R0;
-        double a0[NK], a1[NK];
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {  // the panel is requested before the reflector is staged
-            const int cc = cl + 64 * k;
-            a0[k] = a1[k] = 0.0;
-            if (cc < mR) psd_h2_ld2(M, n, r, rR + cc, ok0, ok1, a0[k], a1[k]);
-        }
-        for (int k = tid; k < mR; k += PSD_H2_NT) vs[k] = SR.v[k];
-        __syncthreads();
-        double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int cc = cl + 64 * k;
-            if (cc < mR) {
-                const double vv = vs[cc];
-                acc0 += a0[k] * vv;
-                acc1 += a1[k] * vv;
-            }
-        }
-#pragma unroll
-        for (int s = 4; s < 64; s <<= 1) {
-            acc0 += __shfl_xor(acc0, s, 64);
-            acc1 += __shfl_xor(acc1, s, 64);
-        }
-        if (lane < 4) {
-            red[(wave * 4 + lane) * 2] = acc0;
-            red[(wave * 4 + lane) * 2 + 1] = acc1;
-        }
-        __syncthreads();
-        const int k0 = rp * 2;
-        const double w0 = tauR * (red[k0] + red[8 + k0] + red[16 + k0] + red[24 + k0]);
-        const double w1 = tauR * (red[k0 + 1] + red[8 + k0 + 1] + red[16 + k0 + 1] + red[24 + k0 + 1]);
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int cc = cl + 64 * k;
-            if (cc < mR) {
-                const double vv = vs[cc];
-                psd_h2_st2(M, n, r, rR + cc, ok0, ok1, a0[k] - w0 * vv, a1[k] - w1 * vv);
-            }
-        }
-        return;
-    }
-    // rows R0..n-1: one wavefront per column, the column in registers: a <- a - tauR w v_c, then the left reflector
-    if (!Lb.valid) return;
-    if (tauR == 0.0 && tauL == 0.0) return;
-    const int c = Lb.i + 4 * (b - nC - nT) + wave;  // 0-based column: the columns right of the reflector's (Lb.i - 1)
-    if (c >= n) return;
-    const int mL = n - R0;
-    constexpr int NKC = (NK + 1) / 2;  // row pairs per lane: 128 rows per step
-    double a0[NKC], a1[NKC];
-    const double vc = (tauR != 0.0 && c >= rR) ? tauR * SR.v[c - rR] : 0.0;
-    double z = 0.0;
-#pragma unroll
-    for (int k = 0; k < NKC; ++k) {
-        const int rr = 2 * lane + 128 * k;  // offset inside the reflector
-        a0[k] = a1[k] = 0.0;
-        if (rr < mL) {
-            const bool ok1 = rr + 1 < mL;
-            psd_h2_ld2(M, n, R0 + rr, c, true, ok1, a0[k], a1[k]);
-            if (vc != 0.0) {
-                a0[k] -= vc * SR.w[R0 + rr];
-                if (ok1) a1[k] -= vc * SR.w[R0 + rr + 1];
-            }
-            if (tauL != 0.0) {
-                z += a0[k] * SL.v[rr];
-                if (ok1) z += a1[k] * SL.v[rr + 1];
-            }
-        }
-    }
-    z = tauL * psd_h2_wave_sum(z);
-#pragma unroll
-    for (int k = 0; k < NKC; ++k) {
-        const int rr = 2 * lane + 128 * k;
-        if (rr < mL) {
-            const bool ok1 = rr + 1 < mL;
-            double x0 = a0[k], x1 = a1[k];
-            if (tauL != 0.0) {
-                x0 -= z * SL.v[rr];
-                if (ok1) x1 -= z * SL.v[rr + 1];
-            }
-            psd_h2_st2(M, n, R0 + rr, c, true, ok1, x0, x1);
-        }
-    }
+    psd_h2_bulk_body<NK>(G, n, psd_h2_linkat(qi, qj, -1, n, p), psd_h2_linkat(qi, qj, -2, n, p), qi * p - qj - 1, b - nC, nT, vs, red);
+}
+
+// The updates of K consecutive links in one launch (K distinct matrices: K <= p), for the two-stream form in which the
+// chain launches carry no bulk part.  idx0: chain index of the first link ((i - 1) p + (p - j)); Q = (n - 1) p itself is
+// the drain position (the last right reflector on A_p).  grid = (nT + nB, K).
+template <int NK>
+__global__ void __launch_bounds__(PSD_H2_NT, (NK > 16 ? 2 : 4)) psd_hess2_bulk(const psd_hess2_args Gv, int n, int idx0, int nT) {
+    extern __shared__ __attribute__((aligned(16))) char psd_lds[];
+    double* vs = (double*)psd_lds;
+    double* red = vs + (n + 8);
+    const int p = Gv.p;
+    const int idx = idx0 + (int)blockIdx.y;
+    const int Q = (n - 1) * p;
+    if (idx > Q) return;
+    psd_h2_link Lb, La;
+    Lb.i = idx / p + 1;
+    Lb.j = p - idx % p;
+    Lb.valid = (idx < Q) ? 1 : 0;
+    Lb.r0 = (Lb.j == 1) ? (Lb.i + 1) : Lb.i;
+    La = psd_h2_linkat(Lb.i, Lb.j, -1, n, p);
+    psd_h2_bulk_body<NK>(&Gv, n, Lb, La, idx, (int)blockIdx.x, nT, vs, red);
 }
 
 #endif

@@ -228,3 +228,25 @@ def test_formq_blocked(monkeypatch):
         return psd_amd.Engine(device=0)
 
     ec.case_formq_blocked(make, [(64, 3, "R"), (97, 2, "L"), (130, 1, "R"), (257, 5, "R"), (512, 4, "L")])
+
+
+@pytest.mark.parametrize("n,p,K", [(33, 8, 4), (130, 9, 4), (257, 16, 8), (300, 40, 16), (64, 70, 16), (96, 150, 16)])
+def test_phessenberg_two_stream_vs_oracle(monkeypatch, n, p, K):
+    """The two-stream form of the look-ahead reduction (chain launches alone on the main stream, the panel updates of K
+    consecutive links as one launch on the second stream, awaited by event p - 1 links later; by itself only for
+    p >= 32, n >= 512) forced on small problems: periods that are not multiples of K, a last batch that is only the
+    drain position, p >= 9 K (K is raised), against the oracle's packed storage and tau."""
+    import torch
+
+    torch.cuda.init()
+    import psd_amd
+
+    monkeypatch.setenv("PSD_HESS_ASYNC", str(K))
+    eng = psd_amd.Engine(device=0)
+    A = pt.bench_factors(n, p, seed=170 + n + p)
+    W = [a.copy(order="F") for a in A]
+    Hs, tau, _ = eng.phessenberg_(W)
+    Ho, Qo, packed, tauo = pt.oracle_phessenberg(A)
+    for j in range(p):
+        assert np.linalg.norm(W[j] - packed[j]) < 1e-11 * max(np.linalg.norm(packed[j]), 1.0), (j,)
+        assert np.allclose(tau[j], tauo[j], rtol=0, atol=1e-11)
