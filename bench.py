@@ -235,6 +235,26 @@ def main():
     elapsed_max, sweeps_all = aggregate(dist if world > 1 else None, elapsed, sweeps, device)
     if sharded:
         sweeps_all = sweeps  # ONE problem: every rank ran the same (replicated) chain, its sweeps count once
+    # Beside the sharded line: the same K steps as N independent replicas (one problem per rank, no collective) — the
+    # throughput mode of a path whose chains do not shard.  Reported as an extra object.
+    replicas = None
+    if sharded:
+        eng.set_shard(0, 1)
+        rb = [host.to(device) for _ in range(args.steps)]
+        rz = [torch.zeros_like(rb[0]) for _ in range(args.steps)]
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        rres = [eng.pschur_dev(rb[k].data_ptr(), n, p, "R", dZ_ptr=rz[k].data_ptr()) for k in range(args.steps)]
+        torch.cuda.synchronize()
+        dist.barrier()
+        el_r = time.perf_counter() - t1
+        sw_r = sum(st.nsweeps for (_, _, st, _) in rres)
+        el_r_max, sw_r_all = aggregate(dist, el_r, sw_r, device)
+        replicas = {"value": sw_r_all / el_r_max, "unit": "sweeps/s", "scaling": "weak", "ms_per_step": 1e3 * el_r_max / args.steps,
+                    "parallelism": "replicas x%d (one independent problem per rank, no collective)" % world}
+        del rb, rz
+        eng.set_shard(rank, world)
 
     if rank == 0:
         st = results[-1][2]
@@ -322,6 +342,8 @@ def main():
                          "orth_max_over_eps_n": float(orth.max() / (pt.EPS * n)), "evaluated": "device (psd_d_checkpsd_dev)"},
             "roofline": roof,
         }
+        if replicas is not None:
+            out["replicas"] = replicas
         if world == 1 and not args.no_cpu_baseline:
             positions = sum(int((lg[lg[:, 0] == 0][:, 2] - lg[lg[:, 0] == 0][:, 1] + 1).sum()) for (_, _, _, lg) in results)
             out["sweep_positions_per_step"] = positions / args.steps
