@@ -183,7 +183,7 @@ struct psd_ctx {
         PSD_CHECK(psd_rt_malloc((void**)&tcnt, 2 * sizeof(int) * PSD_SLOTS * (size_t)(p + 8)));
         PSD_CHECK(psd_rt_malloc((void**)&ttr, 2 * sizeof(psd_tr) * PSD_SLOTS * (size_t)p * PSD_TR_CAP));
         PSD_CHECK(psd_rt_malloc((void**)&tgl, sizeof(psd_rglobal)));
-        PSD_CHECK(psd_rt_malloc((void**)&tslotw, sizeof(int) * 3 * PSD_SLOTS));
+        PSD_CHECK(psd_rt_malloc((void**)&tslotw, sizeof(int) * 6 * PSD_SLOTS));
         tcap_p = p;
         return 0;
     }
@@ -224,6 +224,7 @@ struct psd_ctx {
     // (psd_rq_apply_wl modes).  Off by default: measured the far parts do run beside the chases and
     // a train tick drops from 610 to 445 us at n = 1024, p = 64, but two more launches and two cross-stream events per tick
     // cost 15-25 us on every tick, and most ticks are small: 811 vs 817 ms at that size, 249 vs 224 ms at n = 512, p = 16
+    int band_helper = 1;  // PSD_BAND_HELPER=0: a leader computes the product band of its decisions itself
     int overlap = 3;  // 0 off, 1 far/near split of the H updates, 2 Schur-vector updates on stream2, 3 = 2 for n >= 1024
     int far_grid = 0;  // grid of the far bulk-update launches (0: apply_wl_grid)
 #ifndef PSD_HOSTSIM
@@ -666,6 +667,7 @@ int hessenberg2_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
         ha.ringmask = PSD_H2_RING - 1;
         if (n <= 256) return hessenberg2_async<4, 8>(c, n, p, ha, K);
         if (n <= 512) return hessenberg2_async<8, 8>(c, n, p, ha, K);
+        if (n <= 1024 && getenv("PSD_H2_CR8")) return hessenberg2_async<16, 8>(c, n, p, ha, K);  // (experiment)
         if (n <= 1024) return hessenberg2_async<16, 4>(c, n, p, ha, K);
         return hessenberg2_async<32, 8>(c, n, p, ha, K);
     }
@@ -823,6 +825,19 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     P.cep = nullptr;
     P.role = P.epoch = P.cdone = nullptr;
     P.nprob = 1;
+    P.ticklog = nullptr;
+    P.ticklog_n = 0;
+    P.bandinfo = nullptr;
+    const char* ticklog_path = getenv("PSD_TICKLOG");  // diagnostics: per tick the longest workgroup of the chase launch
+    const int ticklog_cap = 1 << 16;
+    if (ticklog_path && nprob == 1) {
+        if (psd_rt_malloc((void**)&P.ticklog, sizeof(int) * ticklog_cap) == 0) {
+            PSD_CHECK(psd_rt_memset(P.ticklog, 0, sizeof(int) * ticklog_cap, c->stream));
+            P.ticklog_n = ticklog_cap;
+        } else {
+            P.ticklog = nullptr;
+        }
+    }
     if (bws) {
         if (nprob < 1 || nprob > PSD_SLOTS / 2) return -3;
         const size_t sb = (size_t)nprob * (n + 8);
@@ -844,6 +859,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
         PSD_CHECK(psd_rt_memset(c->tdesc, 0, 2 * sizeof(psd_apply_desc) * PSD_SLOTS, c->stream));
         P.cst = c->tcst;
         P.cep = c->tslotw;  // (single-range train mode; the multi-block scheduler uses the same words as role/epoch/cdone)
+        PSD_CHECK(psd_rt_memset(c->tslotw, 0xff, sizeof(int) * 6 * PSD_SLOTS, c->stream));  // (band info: tick -1)
         PSD_CHECK(psd_rt_memset(c->tslotw, 0, sizeof(int) * 3 * PSD_SLOTS, c->stream));
         P.tshift = c->tshift;
         P.desc = c->tdesc;  // slot 0 of the cursor arrays: the fused bulk-update kernel indexes them by cursor
@@ -856,6 +872,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
             P.role = c->tslotw;
             P.epoch = c->tslotw + PSD_SLOTS;
             P.cdone = c->tslotw + 2 * PSD_SLOTS;
+            if (c->band_helper) P.bandinfo = c->tslotw + 3 * PSD_SLOTS;
         }
 #ifndef PSD_HOSTSIM
         PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_rq_step_train),
@@ -915,8 +932,11 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
             }
             if (M == 1 && !mb)
                 PSD_LAUNCH(psd_rq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
-            else if (mb)  // every slot of the scheduler in one launch
+            else if (mb) {  // every slot of the scheduler in one launch
+                // (in front of it: the product bands of the wide decisions pending, spread over the chip)
+                if (Pq.bandinfo) PSD_LAUNCH(psd_rq_band, psd_dim3((n + 63) / 64, PSD_SLOTS), 64, 0, c->stream, Pq, n, p);
                 PSD_LAUNCH(psd_rq_step_mb, psd_dim3(PSD_SLOTS), PSD_STEP_NT, lds_step, c->stream, Pq, p, p + 8);
+            }
             else  // every cursor of the tick in one launch, one workgroup each
                 PSD_LAUNCH(psd_rq_step_train, psd_dim3(M), PSD_STEP_NT, lds_step, c->stream, P, p, p + 8);
 #ifndef PSD_HOSTSIM
@@ -1059,6 +1079,19 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     PSD_CHECK(poller.finish(pend));
 #endif
     PSD_CHECK(psd_rt_last_error());
+    if (P.ticklog) {
+        std::vector<int> tl((size_t)ticklog_cap);
+        PSD_CHECK(psd_rt_d2h(tl.data(), P.ticklog, sizeof(int) * ticklog_cap, c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+        fprintf(stderr, "psd ticklog: phase cycles (decide, spawn, train shifts, small QR, claims, cursor states, deflate, RQ window):");
+        for (int q = 0; q < 8; ++q) fprintf(stderr, " %lld/%d", hgl.dbg[q], hgl.dbgn[q]);
+        fprintf(stderr, "\n");
+        if (FILE* fh = fopen(ticklog_path, "w")) {
+            for (long long t = 0; t < launched && t < ticklog_cap; ++t) fprintf(fh, "%lld %d %d\n", t, tl[(size_t)t] >> 12, tl[(size_t)t] & 0xfff);
+            fclose(fh);
+        }
+        psd_rt_free(P.ticklog);
+    }
     *st_out = hst;
     if (stats) {
         stats->nlaunch_step = (int32_t)launched;
@@ -1206,6 +1239,7 @@ int psd_create(psd_ctx** ctx, int device) {
     if (const char* e = getenv("PSD_OVERLAP")) c->overlap = atoi(e);
 #endif
     if (const char* e = getenv("PSD_FORMQ_BLOCKED")) c->formq_blocked = atoi(e);
+    if (const char* e = getenv("PSD_BAND_HELPER")) c->band_helper = atoi(e);
     if (const char* e = getenv("PSD_MB")) c->mblock = atoi(e);
     if (const char* e = getenv("PSD_TRAIN_MB")) c->train_mb_m = atoi(e);
     if (const char* e = getenv("PSD_CGAP")) c->cgap = (atoi(e) == 2) ? 2 : 1;

@@ -136,6 +136,11 @@ struct psd_rglobal {
     int nsweeps, nrqpass, ndefl1, ndefl2, nwindows, ntrains, ntrainsweeps, maxits, nspawn, nslotmax;
     long long niter;
     long long cyc[6];
+    // diagnostics (PSD_TICKLOG): shader cycles and calls of the phases of a launch that are not window work:
+    // [0] decide, [1] split / spawn, [2] train shifts: staging + product, [3] small QR, [4] slot claims,
+    // [5] cursor states, [6] deflate, [7] RQ window; dbgn: calls
+    long long dbg[8];
+    int dbgn[8];
 };
 
 struct psd_rparams {
@@ -170,10 +175,29 @@ struct psd_rparams {
                  // Schur vectors p n n, band arrays / eigenvalues n + 8, hnorms p + 8
     int* cdone;  // [PSD_SLOTS] per LEADER slot: cursors of its running train that have finished (a cursor's own slot
                  // may be reused by another train before the leader looks)
+    // diagnostics (nullptr by default, PSD_TICKLOG): per tick the longest workgroup of the chase launch,
+    // (100 MHz ticks << 12) | bit mask of the phases it ran (1 << PSD_PH_*)
+    int* ticklog;
+    int ticklog_n;
+    // multi-block: [3][PSD_SLOTS] tick, first and last row of the product band psd_rq_band computed for a slot's
+    // pending decision (nullptr otherwise)
+    int* bandinfo;
 };
 #define PSD_TSHIFT_STRIDE (4 * PSD_TRAIN_MAX + 8)
+#define PSD_DECIDE_YIELD 128  // active-range width from which the band of a decision comes from psd_rq_band (multi-block mode)
 #define PSD_WL_EDGE 64  // columns right of a mid-sweep window that the next windows of the sweep can reach
 
+// diagnostics: add shader cycles since t0 to counter k of psd_rglobal (multi-block mode with a tick log only)
+#define PSD_DBG_T0() const long long _dbg0 = (P.ticklog != nullptr) ? psd_clock() : 0
+#define PSD_DBG_ADD(k)                                                        \
+    do {                                                                      \
+        if (P.ticklog != nullptr && P.gl != nullptr) {                        \
+            PSD_ONE {                                                         \
+                psd_atomic_add_ll(&P.gl->dbg[k], psd_clock() - _dbg0);        \
+                psd_atomic_add(&P.gl->dbgn[k], 1);                            \
+            }                                                                 \
+        }                                                                     \
+    } while (0)
 PSD_HD psd_mat<double> psd_fac(const psd_rparams& P, int n, int j) {
     return psd_mat<double>{P.H + (size_t)(j - 1) * n * n, n};
 }
@@ -383,6 +407,35 @@ PSD_D int psd_mb_claim(const psd_rparams& P, int self) {  // (one lane)
     }
     return -1;
 }
+// Up to `want` free slots at once, one lane per slot (a train of 64 bulges claimed them one by one before: 63 scans of
+// the role words by one lane, milliseconds of dependent atomics).  flags: PSD_SLOTS ints of LDS scratch; the slots go to
+// list[0..], the count is returned in *count (both LDS).  Slots taken beyond `want` are handed back untouched.
+PSD_D void psd_mb_claim_many(const psd_rparams& P, int self, int want, int* flags, int* list, int* count) {
+    PSD_SYNC();
+    PSD_PAR_FOR(s, PSD_SLOTS) {
+        int got = 0;
+        if (s != self && psd_atomic_load(P.role + s) == PSD_ROLE_FREE &&
+            psd_atomic_cas(P.role + s, PSD_ROLE_FREE, PSD_ROLE_CLAIMED) == PSD_ROLE_FREE)
+            got = 1;
+        flags[s] = got;
+    }
+    PSD_SYNC();
+    PSD_ONE {
+        int k = 0, top = 0;
+        for (int s = 0; s < PSD_SLOTS; ++s) {
+            if (!flags[s]) continue;
+            if (k < want) {
+                list[k++] = s;
+                top = s + 1;
+            } else {
+                psd_atomic_store(P.role + s, PSD_ROLE_FREE);
+            }
+        }
+        if (k > 0) psd_atomic_max(&P.gl->nslotmax, top);
+        *count = k;
+    }
+    PSD_SYNC();
+}
 // hands a slot back: everything this workgroup stored must be out before another workgroup may reuse the slot
 PSD_D void psd_mb_release_slot(const psd_rparams& P, int s) {  // (one lane)
     psd_release_fence();
@@ -464,6 +517,50 @@ PSD_D void psd_mb_finish_leader(const psd_rparams& P, psd_rstate& st, int* bc) {
     st.phase = PSD_PH_DONE;  // (psd_rq_step_body hands the slot back after its last store)
 }
 
+// Product band of the decisions pending at the start of a tick, all slots, 64 rows per workgroup (multi-block mode).
+// A leader that computes the band of a wide range itself walks p * w scattered cache lines with one wavefront: 1 ms at
+// w = 1024, p = 64, three windows' worth of chase with every other slot waiting for the tick to end.  Here the same
+// rows are spread over the chip in front of the chase launch; psd_rq_decide finds them through P.bandinfo.  Same
+// recurrence, same order of operations per row (PSD.jl:475-495,507-516).  grid = (ceil(n / 64), PSD_SLOTS), 64 threads.
+PSD_KERNEL_B(64) psd_rq_band(psd_rparams P, int n, int p) {
+    const int s = PSD_BLOCK_Y, chunk = PSD_BLOCK_X;
+    // (a leader, or a slot a leader was spawned into in an earlier launch: it goes live with the chase launch behind this one)
+    const int role = psd_atomic_load(P.role + s);
+    if (role != PSD_ROLE_LEADER && role != PSD_ROLE_CLAIMED) return;
+    if (psd_atomic_load(P.epoch + s) >= P.tick) return;  // (state still being written / not this slot's turn yet)
+    if (psd_atomic_load(&P.gl->done) || psd_atomic_load(&P.gl->abort)) return;
+    const psd_rstate* st = P.cst + s;
+    if (st->phase != PSD_PH_DECIDE || st->cursor != 0) return;
+    const int lo = st->l, i = st->i;
+    if (i - lo + 1 < PSD_DECIDE_YIELD) return;
+    const int a0 = lo + 64 * chunk;
+    if (a0 > i) return;
+    const size_t sb = (size_t)st->prob * (n + 8);
+    double* H = P.H + (size_t)st->prob * p * n * n;
+    PSD_PAR_FOR(t, 64) {
+        const int a = a0 + t;
+        if (a <= i) {
+            double d = 1.0, e = 0.0, f = 0.0;
+            for (int j = 2; j <= p; ++j) {
+                const psd_mat<double> Hj = psd_mat<double>{H + (size_t)(j - 1) * n * n, n};
+                if (a + 2 <= i) f = d * Hj(a, a + 2) + e * Hj(a + 1, a + 2) + f * Hj(a + 2, a + 2);
+                if (a + 1 <= i) e = d * Hj(a, a + 1) + e * Hj(a + 1, a + 1);
+                d *= Hj(a, a);
+            }
+            P.Pd[sb + a] = d;
+            P.Pe[sb + a] = e;
+            P.Pf[sb + a] = f;
+        }
+    }
+    if (chunk == 0) {
+        PSD_ONE {
+            P.bandinfo[s] = P.tick;
+            P.bandinfo[PSD_SLOTS + s] = lo;
+            P.bandinfo[2 * PSD_SLOTS + s] = i;
+        }
+    }
+}
+
 // opnorm(view(H1, lo:hi, lo:hi), 1) — PSD.jl:537,596 fallback when a diagonal pair is exactly zero
 PSD_D double psd_h1_opnorm(const psd_rparams& P, const psd_rstate& st, double* red, int lo, int hi) {
     const psd_mat<double> H1 = psd_fac(P, st.n, 1);
@@ -488,7 +585,8 @@ PSD_D double psd_h1_opnorm(const psd_rparams& P, const psd_rstate& st, double* r
 
 // ------------------------------------------------------------------------------------------------
 // PSD.jl:471-672: product band, deflation search, RQ decision
-PSD_D void psd_rq_decide(const psd_rparams& P, psd_rstate& st, double* red, int* redi) {
+// stage: LDS free during the decision (the window area), stage_doubles of it
+PSD_D void psd_rq_decide(const psd_rparams& P, psd_rstate& st, double* red, int* redi, double* stage, size_t stage_doubles) {
     const int n = st.n, p = st.p, i = st.i, lo = st.l;
     const int NT = PSD_NTHREADS;
     if (!(st.its < st.maxitleft)) {  // PSD.jl:471,891-893
@@ -505,19 +603,64 @@ PSD_D void psd_rq_decide(const psd_rparams& P, psd_rstate& st, double* red, int*
         return;
     }
     const psd_mat<double> H1 = psd_fac(P, n, 1);
-    // band of P = H_2 H_3 ... H_p on rows lo..i (PSD.jl:475-495,507-516, evaluated per row)
-    PSD_PAR_FOR(t, i - lo + 1) {
-        const int a = lo + t;
-        double d = 1.0, e = 0.0, f = 0.0;
-        for (int j = 2; j <= p; ++j) {
-            const psd_mat<double> Hj = psd_fac(P, n, j);
-            if (a + 2 <= i) f = d * Hj(a, a + 2) + e * Hj(a + 1, a + 2) + f * Hj(a + 2, a + 2);
-            if (a + 1 <= i) e = d * Hj(a, a + 1) + e * Hj(a + 1, a + 1);
-            d *= Hj(a, a);
+    // band of P = H_2 H_3 ... H_p on rows lo..i (PSD.jl:475-495,507-516, evaluated per row).  The entries a row needs —
+    // Hj(a, a..a+2), Hj(a+1, a+1..a+2), Hj(a+2, a+2) — are the last three of columns a, a+1, a+2 above the diagonal:
+    // 24 contiguous bytes per (column, factor).  They are staged through LDS in chunks of R rows with ALL the loads of a
+    // chunk independent of each other (a lane that walks j with the recurrence in front of every load pays the HBM
+    // latency p times per row: 1 ms for a full-width block at p = 64), then the recurrence runs out of LDS.
+    bool have = false;  // psd_rq_band has the band of rows lo..i (same H: nothing was emitted since)
+    if (P.bandinfo != nullptr && st.mb) {
+        have = P.bandinfo[st.slot] == P.tick && P.bandinfo[PSD_SLOTS + st.slot] <= lo && i <= P.bandinfo[2 * PSD_SLOTS + st.slot];
+    }
+    if (!have) {
+        const int pj = p - 1;  // factors 2..p
+        int R = (pj > 0) ? (int)(stage_doubles / (3 * (size_t)pj)) - 2 : NT;
+        if (R > NT) R = NT;
+        if (pj > 0 && R >= 1) {
+            for (int a0 = lo; a0 <= i; a0 += R) {
+                const int a1 = (a0 + R - 1 < i) ? (a0 + R - 1) : i;  // rows a0..a1, columns a0..min(a1 + 2, i)
+                const int c1 = (a1 + 2 < i) ? (a1 + 2) : i;
+                const int nc = c1 - a0 + 1;
+                PSD_SYNC();
+                PSD_PAR_FOR(t, nc * pj) {
+                    const int cc = t % nc, jj = t / nc;  // (consecutive lanes: consecutive columns of one factor)
+                    const int c = a0 + cc;
+                    const psd_mat<double> Hj = psd_fac(P, n, jj + 2);
+                    double* q = stage + 3 * (size_t)t;
+                    q[0] = Hj(c, c);
+                    q[1] = (c - 1 >= lo) ? Hj(c - 1, c) : 0.0;
+                    q[2] = (c - 2 >= lo) ? Hj(c - 2, c) : 0.0;
+                }
+                PSD_SYNC();
+                PSD_PAR_FOR(t, a1 - a0 + 1) {
+                    const int a = a0 + t;
+                    double d = 1.0, e = 0.0, f = 0.0;
+                    for (int jj = 0; jj < pj; ++jj) {
+                        const double* q0 = stage + 3 * ((size_t)jj * nc + t);  // column a: (a,a), (a-1,a), (a-2,a)
+                        if (a + 2 <= i) f = d * q0[8] + e * q0[7] + f * q0[6];     // column a+2: (a,a+2), (a+1,a+2), (a+2,a+2)
+                        if (a + 1 <= i) e = d * q0[4] + e * q0[3];                 // column a+1: (a,a+1), (a+1,a+1)
+                        d *= q0[0];
+                    }
+                    P.Pd[a] = d;
+                    P.Pe[a] = e;
+                    P.Pf[a] = f;
+                }
+            }
+        } else {
+            PSD_PAR_FOR(t, i - lo + 1) {
+                const int a = lo + t;
+                double d = 1.0, e = 0.0, f = 0.0;
+                for (int j = 2; j <= p; ++j) {
+                    const psd_mat<double> Hj = psd_fac(P, n, j);
+                    if (a + 2 <= i) f = d * Hj(a, a + 2) + e * Hj(a + 1, a + 2) + f * Hj(a + 2, a + 2);
+                    if (a + 1 <= i) e = d * Hj(a, a + 1) + e * Hj(a + 1, a + 1);
+                    d *= Hj(a, a);
+                }
+                P.Pd[a] = d;
+                P.Pe[a] = e;
+                P.Pf[a] = f;
+            }
         }
-        P.Pd[a] = d;
-        P.Pe[a] = e;
-        P.Pf[a] = f;
     }
     PSD_SYNC();
     // tridiagonal band of the product (PSD.jl:485-488,517-528)
@@ -692,8 +835,22 @@ PSD_D void psd_rq_train_shifts(const psd_rparams& P, int n, int p, int i, int m,
         T[q] = acc;
     }
     PSD_SYNC();
+#ifndef PSD_HOSTSIM
+    const long long _hq0 = psd_clock();
+    const bool okw = psd_hqr_wave(T, K, K, wr, wi, PSD_TID);  // (the workgroup is one wavefront)
+    if (P.ticklog != nullptr && P.gl != nullptr) {
+        PSD_ONE {
+            psd_atomic_add_ll(&P.gl->dbg[3], psd_clock() - _hq0);
+            psd_atomic_add(&P.gl->dbgn[3], 1);
+        }
+    }
+#endif
     PSD_ONE {
+#ifndef PSD_HOSTSIM
+        bool ok = okw;
+#else
         bool ok = psd_hqr(T, K, K, wr, wi);
+#endif
         int np = 0, nre = 0;
         // conjugate pairs first, then the real eigenvalues in ascending order two by two
         for (int q = 0; ok && q < K; ++q) {
@@ -728,14 +885,22 @@ PSD_D void psd_rq_train_shifts(const psd_rparams& P, int n, int p, int i, int m,
 }
 
 // PSD.jl:668-803: split test, shifts, first column of the shifted product
-PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int* bc) {
+// Returns true when the shift pairs of a multishift train were computed (trailing blocks of all factors, their product,
+// a small Hessenberg-QR in one lane: as long as a window's chase) — the multi-block driver then ends this workgroup's
+// launch there, so that the tick is not stretched for all the other slots; the sweep starts with the next launch.
+PSD_D bool psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int* bc) {
     const int n = st.n, i = st.i, l = st.l;
+    bool heavy = false;
     // (after the RQ clean-up at l, which still touches position l - 1; a block that deflates at once is not worth a
     //  hand-over: the range above it simply stays with this leader, as in the reference)
-    if (st.mb && st.l > st.lo && st.l < i - 1) psd_mb_spawn(P, st, bc);
+    if (st.mb && st.l > st.lo && st.l < i - 1) {
+        PSD_DBG_T0();
+        psd_mb_spawn(P, st, bc);
+        PSD_DBG_ADD(1);
+    }
     if (l >= i - 1) {
         st.phase = PSD_PH_DEFLATE;
-        return;
+        return false;
     }
     if (!st.wantT) {
         st.i1 = l;
@@ -824,7 +989,12 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
             if (ms < m && ms < PSD_HQR_MAX / 2) m = ms;
             if (m >= 2 && 2 * m + 2 <= w) {
                 int* okf = (int*)P.tshift + 8 * PSD_TRAIN_MAX;  // (flag word behind the pairs)
-                psd_rq_train_shifts(P, n, st.p, i, ms, work, okf);
+                {
+                    PSD_DBG_T0();
+                    psd_rq_train_shifts(P, n, st.p, i, ms, work, okf);
+                    PSD_DBG_ADD(2);
+                }
+                heavy = st.mb != 0;
                 if (*okf && m > ms) {
                     PSD_ONE {
                         for (int b = ms; b < m; ++b)
@@ -834,16 +1004,11 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
                 }
                 int mgot = m;
                 if (*okf && st.mb) {  // the cursors need slots: as many as are free
-                    PSD_SYNC();
+                    PSD_DBG_T0();
+                    psd_mb_claim_many(P, st.slot, m - 1, (int*)work, bc + 3, bc);  // (the staging area of the shifts is free again)
+                    PSD_DBG_ADD(4);
                     PSD_ONE {
-                        int got = 1;
-                        for (int b = 1; b < m; ++b) {
-                            const int sl = psd_mb_claim(P, st.slot);
-                            if (sl < 0) break;
-                            bc[2 + b] = sl;
-                            ++got;
-                        }
-                        bc[0] = got;
+                        bc[0] += 1;  // (with the leader)
                         bc[1] = psd_atomic_add(&P.gl->train_seq, 1) + 1;
                         psd_atomic_store(P.cdone + st.slot, 0);  // (no cursor of an earlier train of this leader is left)
                     }
@@ -858,7 +1023,7 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
                     st.W = nb + 4;
                     st.tgap = (st.cgap == 1 && nb >= 6) ? 1 : 2;
                     st.train_n = m;
-                    st.train_tick0 = P.tick;
+                    st.train_tick0 = P.tick + (heavy ? 1 : 0);  // (the leader's first window runs in the next launch)
                     st.train_id += 1;
                     st.ntrains += 1;
                     st.ntrainsweeps += m;
@@ -896,6 +1061,7 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
     st.phase = PSD_PH_QR;
     st.kcur = l;
     if (st.train_n > 1) {  // the cursors behind the leader start from this state
+        PSD_DBG_T0();
         PSD_SYNC();
         PSD_ONE {
             if (!st.mb) psd_atomic_store(P.cep + PSD_TRAIN_MAX, 0);  // finished cursors of this train
@@ -931,7 +1097,9 @@ PSD_D void psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
             }
         }
         PSD_SYNC();
+        PSD_DBG_ADD(5);
     }
+    return heavy;
 }
 
 PSD_D void psd_desc_write(const psd_rparams& P, psd_rstate& st, const int* lcnt, int plo, int phi, int lc0,
@@ -1538,29 +1706,42 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
     const long long tk0 = psd_clock(), tw0 = psd_wallclock();
     bool emitted = false;
     int guard = 0;
+    int phmask = 0;
     while (!emitted && st.phase != PSD_PH_DONE && guard < 4 * st.n + 16) {
         ++guard;
+        phmask |= 1 << st.phase;
         switch (st.phase) {
             case PSD_PH_DECIDE: {
                 const long long td0 = psd_clock();
-                psd_rq_decide(P, st, red, redi);
+                {
+                    PSD_DBG_T0();
+                    psd_rq_decide(P, st, red, redi, ldsd, winb);
+                    PSD_DBG_ADD(0);
+                }
                 st.cyc[0] += psd_clock() - td0;
+
                 break;
             }
-            case PSD_PH_RQ:
+            case PSD_PH_RQ: {
+                PSD_DBG_T0();
                 psd_rq_rq_window(P, st, ldsd, lcnt);
+                PSD_DBG_ADD(7);
                 emitted = true;
                 break;
+            }
             case PSD_PH_SHIFT:
-                psd_rq_shift(P, st, ldsd, redi);
+                if (psd_rq_shift(P, st, ldsd, redi)) emitted = true;  // (no transformations: the descriptor stays inactive)
                 break;
             case PSD_PH_QR:
                 psd_rq_qr_window(P, st, ldsd, lcnt);
                 emitted = true;
                 break;
-            case PSD_PH_DEFLATE:
+            case PSD_PH_DEFLATE: {
+                PSD_DBG_T0();
                 emitted = psd_rq_deflate(P, st, ldsd, lcnt);
+                PSD_DBG_ADD(6);
                 break;
+            }
             case PSD_PH_TWAIT: {  // the leader's sweep is done: wait for the cursors of the train, then go on
                 bool all = true;
                 if (st.mb) {  // a cursor adds one to its leader's counter after its last window
@@ -1601,6 +1782,8 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
                 st.its = 1;
                 st.exc_dec = 0;
                 st.phase = (st.i >= st.l) ? PSD_PH_DECIDE : PSD_PH_FINAL;
+                // (a wide rest of the range: its product band is the job of psd_rq_band in front of the next launch)
+                if (st.mb && P.bandinfo != nullptr && st.phase == PSD_PH_DECIDE && st.i - st.l + 1 >= PSD_DECIDE_YIELD) emitted = true;
                 break;
             case PSD_PH_FINAL: {  // PSD.jl:1066-1073
                 if (st.mb) {
@@ -1623,6 +1806,9 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
     }
     st.cyc[4] += psd_clock() - tk0;
     st.cyc[5] += psd_wallclock() - tw0;
+    if (P.ticklog && P.tick < P.ticklog_n) {
+        PSD_ONE { psd_atomic_max(P.ticklog + P.tick, (int)(((psd_wallclock() - tw0) << 12) | (phmask & 0xfff))); }
+    }
     if (st.info == PSD_LIST_OVERFLOW) st.phase = PSD_PH_DONE;  // (a window that overran a list ends the call)
     PSD_SYNC();
     PSD_ONE {
