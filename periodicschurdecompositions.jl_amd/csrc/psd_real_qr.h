@@ -2361,6 +2361,51 @@ PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride
     // tick: whole groups only while they still leave every workgroup of the grid a few items (a tick of one small
     // window must spread over the chip, a tick of sixty windows must not stage a list per 8 KiB)
     int GL = TL;
+#ifndef PSD_HOSTSIM
+    {
+        // lane b = slot b (M <= 64): one read of the descriptor, group counts for the chosen group size, offsets by a
+        // wavefront scan (a serial prefix over 64 slots in LDS and a second pass over the descriptors cost every
+        // workgroup of every launch several microseconds before its first item)
+        const int b = PSD_TID;
+        psd_apply_desc d;
+        d.active = 0;
+        if (b < M) d = P.desc[b];
+        int la = 0, lz = 0;  // lines of role A / B
+        if (b < M && d.active) {
+            psd_wl_ranges(d, mode, d.cut);
+            if (pass == 0) {
+                la = (d.lc1 >= d.lc0) ? (d.lc1 - d.lc0 + 1) : 0;
+                lz = (d.zr1 >= d.zr0) ? (d.zr1 - d.zr0 + 1) : 0;
+            } else {
+                la = (d.rr1 >= d.rr0) ? (d.rr1 - d.rr0 + 1) : 0;
+            }
+        }
+        int a = (la + TL - 1) / TL, z = (lz + TL - 1) / TL;
+        int tiles = p * (a + z);
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) tiles += __shfl_xor(tiles, sft, 64);
+        int grp = 1;
+        if (tiles >= 4 * PSD_WL_GROUP * PSD_GRID_X) grp = PSD_WL_GROUP;
+        else if (tiles >= 8 * PSD_GRID_X) grp = 2;
+        GL = TL * grp;
+        a = (la + GL - 1) / GL;
+        z = (lz + GL - 1) / GL;
+        const int mine = p * (a + z);
+        int incl = mine;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const int up = __shfl_up(incl, sft, 64);
+            if (b >= sft) incl += up;
+        }
+        if (b < M) {
+            tA[b] = a;
+            tB[b] = z;
+            ioff[b] = incl - mine;
+        }
+        if (b == 63) ioff[M] = incl;  // (lanes >= M contribute nothing)
+        PSD_SYNC();
+    }
+#else
     for (int trial = 0; trial < 2; ++trial) {
         PSD_PAR_FOR(b, M) {
             psd_apply_desc d = P.desc[b];
@@ -2396,10 +2441,19 @@ PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride
         if (grp == 1) break;
         GL = TL * grp;
     }
+#endif
     const int total = ioff[M];
     for (int item = PSD_BLOCK_X; item < total; item += PSD_GRID_X) {
         int b = 0;
-        while (b + 1 < M && ioff[b + 1] <= item) ++b;
+        {  // the slot whose items contain `item`: last b with ioff[b] <= item (binary search; empty slots repeat an offset)
+            int lo_ = 0, hi_ = M - 1;
+            while (lo_ < hi_) {
+                const int mid = (lo_ + hi_ + 1) >> 1;
+                if (ioff[mid] <= item) lo_ = mid;
+                else hi_ = mid - 1;
+            }
+            b = lo_;
+        }
         const int per = tA[b] + tB[b];
         const int q = item - ioff[b];
         const int m = q / per + 1, tt = q - (m - 1) * per;
