@@ -304,7 +304,9 @@ def main():
                                         "frac": hess_gbs / HBM_PEAK_GBS if hess_gbs else None,
                                         "alg_bytes_per_launch": st.bytes_hess / links if links else None,
                                         "avg_launch_ms": st.ms_hess / links if links else None,
-                                        "note": "one launch per chain link; algorithmic bytes 16*(m*(m+1) + n*m) per link"},
+                                        "note": "one chain launch per link on the main stream (the panel updates of 16 links per launch run on a "
+                                                "second, CU-masked stream beside it); algorithmic bytes 16*(m*(m+1) + n*m) per link / "
+                                                "HIP-event duration of the reduction per link"},
                     "note": "algorithmic bytes of the sweep windows one tick chases (one window of every bulge in flight: "
                             "the cursors of the multishift trains of all active ranges; 2*8*p*w*(2n+1) per sweep) / "
                             "HIP-event duration of the tick; every bulge is latency-bound on its serial reflector chain, "
