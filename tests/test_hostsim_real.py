@@ -157,3 +157,30 @@ def test_formq_blocked(built, monkeypatch):
         return psd_amd.Engine(libpath=lib)
 
     ec.case_formq_blocked(make, [(64, 3, "R"), (97, 2, "L"), (130, 1, "R")])
+
+
+def test_band_helper_same_decisions(built, monkeypatch):
+    """psd_rq_band (the product bands of wide pending decisions computed in front of the chase launch, found by
+    psd_rq_decide through bandinfo) against leaders that compute their bands themselves (PSD_BAND_HELPER=0): the same
+    recurrence in the same order per row, so the same decisions — T, Z and the eigenvalues are bit-identical in the
+    serial simulation.  n >= 128 so that the helper has wide ranges to serve."""
+    import os
+
+    import numpy as np
+    import psd_amd
+    import psdtest as pt
+
+    lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim", "_build", "libpsd_hostsim.so")
+    monkeypatch.setenv("PSD_BAND_HELPER", "0")
+    plain = psd_amd.Engine(libpath=lib)
+    monkeypatch.setenv("PSD_BAND_HELPER", "1")
+    helped = psd_amd.Engine(libpath=lib)
+    for (n, p, lr) in [(200, 3, "R"), (260, 2, "L")]:
+        A = pt.bench_factors(n, p, seed=31)
+        ph = helped.pschur(A, lr)
+        pp = plain.pschur(A, lr)
+        assert np.array_equal(ph.values, pp.values)
+        for j in range(p):
+            assert np.array_equal(ph.Ts[j], pp.Ts[j]) and np.array_equal(ph.Z[j], pp.Z[j])
+        ok, err = pt.checkpsd(ph, A, thresh=100 * np.sqrt(n / 32))
+        assert ok, (n, p, err.max())
