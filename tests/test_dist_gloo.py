@@ -98,10 +98,10 @@ def test_period_sharded_pschur_gloo_world2(tmp_path):
     """The period-sharded engine (psd_set_shard: Z_j of a contiguous slice of the period per rank, chains replicated,
     one all-gather of the slices at the end) on two ranks: same decomposition as one rank, bit for bit, both
     orientations, a period the ranks split evenly and one they do not."""
-    res = _run_sharded(tmp_path, 2, [(24, 4, "R"), (30, 5, "L"), (40, 3, "R")], 29541)
+    res = _run_sharded(tmp_path, 2, [(24, 4, "R"), (30, 5, "L"), (40, 3, "R"), (70, 4, "L")], 29541)  # (n >= 64: blocked Q formation of a slice)
     assert res["24x4R"]["owned"] == 2 and res["30x5L"]["owned"] == 3 and res["40x3R"]["owned"] == 2
 
 
 def test_period_sharded_pschur_gloo_world3(tmp_path):
-    res = _run_sharded(tmp_path, 3, [(20, 7, "R"), (18, 2, "L")], 29543)
+    res = _run_sharded(tmp_path, 3, [(20, 7, "R"), (18, 2, "L"), (66, 5, "R")], 29543)
     assert res["20x7R"]["owned"] == 3 and res["18x2L"]["owned"] == 1
