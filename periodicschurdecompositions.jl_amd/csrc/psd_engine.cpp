@@ -911,12 +911,6 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
         for (int b = 0; b < batch; ++b) {
 #ifndef PSD_HOSTSIM
             if (zdef && launched >= 2) PSD_CHECK(hipStreamWaitEvent(c->stream, c->evF[(int)(launched & 1)], 0));
-            const bool sample = c->profile && ((launched & 15) == 0);
-            if (sample) {
-                (void)hipEventCreate(&ev0);
-                (void)hipEventCreate(&ev1);
-                (void)hipEventRecord(ev0, c->stream);
-            }
 #endif
             P.tick = (int)launched;
             // ticks alternate between two sets of descriptors / counts / lists (multi-block mode)
@@ -930,13 +924,20 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 Pprev.cnt = P.cnt + (size_t)(par ^ 1) * PSD_SLOTS * (p + 8);
                 Pprev.tr = P.tr + (size_t)(par ^ 1) * PSD_SLOTS * p * PSD_TR_CAP;
             }
+            // (multi-block: in front of the chase launch the product bands of the wide decisions pending, spread over the chip)
+            if (mb && Pq.bandinfo) PSD_LAUNCH(psd_rq_band, psd_dim3((n + 63) / 64, PSD_SLOTS), 64, 0, c->stream, Pq, n, p);
+#ifndef PSD_HOSTSIM
+            const bool sample = c->profile && ((launched & 15) == 0);  // HIP events around the chase launch alone
+            if (sample) {
+                (void)hipEventCreate(&ev0);
+                (void)hipEventCreate(&ev1);
+                (void)hipEventRecord(ev0, c->stream);
+            }
+#endif
             if (M == 1 && !mb)
                 PSD_LAUNCH(psd_rq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
-            else if (mb) {  // every slot of the scheduler in one launch
-                // (in front of it: the product bands of the wide decisions pending, spread over the chip)
-                if (Pq.bandinfo) PSD_LAUNCH(psd_rq_band, psd_dim3((n + 63) / 64, PSD_SLOTS), 64, 0, c->stream, Pq, n, p);
+            else if (mb)  // every slot of the scheduler in one launch
                 PSD_LAUNCH(psd_rq_step_mb, psd_dim3(PSD_SLOTS), PSD_STEP_NT, lds_step, c->stream, Pq, p, p + 8);
-            }
             else  // every cursor of the tick in one launch, one workgroup each
                 PSD_LAUNCH(psd_rq_step_train, psd_dim3(M), PSD_STEP_NT, lds_step, c->stream, P, p, p + 8);
 #ifndef PSD_HOSTSIM
