@@ -183,7 +183,7 @@ struct psd_ctx {
         PSD_CHECK(psd_rt_malloc((void**)&tcnt, 2 * sizeof(int) * PSD_SLOTS * (size_t)(p + 8)));
         PSD_CHECK(psd_rt_malloc((void**)&ttr, 2 * sizeof(psd_tr) * PSD_SLOTS * (size_t)p * PSD_TR_CAP));
         PSD_CHECK(psd_rt_malloc((void**)&tgl, sizeof(psd_rglobal)));
-        PSD_CHECK(psd_rt_malloc((void**)&tslotw, sizeof(int) * 6 * PSD_SLOTS));
+        PSD_CHECK(psd_rt_malloc((void**)&tslotw, sizeof(int) * 8 * PSD_SLOTS));
         tcap_p = p;
         return 0;
     }
@@ -224,6 +224,10 @@ struct psd_ctx {
     // (psd_rq_apply_wl modes).  Off by default: measured the far parts do run beside the chases and
     // a train tick drops from 610 to 445 us at n = 1024, p = 64, but two more launches and two cross-stream events per tick
     // cost 15-25 us on every tick, and most ticks are small: 811 vs 817 ms at that size, 249 vs 224 ms at n = 512, p = 16
+    int train_stop = 1;    // a long train stops admitting bulges once one of them leaves the bottom converged (PSD_TRAIN_STOP=0: never)
+    int train_wdiv = 8;    // a long train has at most (range width) / train_wdiv bulges (PSD_TRAIN_WDIV; 4 is 3-15 % faster and
+                           // costs 40 % more residual: every bulge of a train passes over the whole range)
+    int train_long = 256;  // bulges per train of the multi-block scheduler when slots can be recycled (PSD_TRAIN_LONG; 0: one bulge per slot)
     int band_helper = 1;  // PSD_BAND_HELPER=0: a leader computes the product band of its decisions itself
     int overlap = 3;  // 0 off, 1 far/near split of the H updates, 2 Schur-vector updates on stream2, 3 = 2 for n >= 1024
     int far_grid = 0;  // grid of the far bulk-update launches (0: apply_wl_grid)
@@ -828,6 +832,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     P.ticklog = nullptr;
     P.ticklog_n = 0;
     P.bandinfo = nullptr;
+    P.ccancel = nullptr;
     const char* ticklog_path = getenv("PSD_TICKLOG");  // diagnostics: per tick the longest workgroup of the chase launch
     const int ticklog_cap = 1 << 16;
     if (ticklog_path && nprob == 1) {
@@ -861,6 +866,8 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
         P.cep = c->tslotw;  // (single-range train mode; the multi-block scheduler uses the same words as role/epoch/cdone)
         PSD_CHECK(psd_rt_memset(c->tslotw, 0xff, sizeof(int) * 6 * PSD_SLOTS, c->stream));  // (band info: tick -1)
         PSD_CHECK(psd_rt_memset(c->tslotw, 0, sizeof(int) * 3 * PSD_SLOTS, c->stream));
+        PSD_CHECK(psd_rt_memset(c->tslotw + 6 * PSD_SLOTS, 0, sizeof(int) * 2 * PSD_SLOTS, c->stream));  // (stopped-train words)
+        PSD_CHECK(psd_rt_memset(c->tslotw + 6 * PSD_SLOTS, 0, sizeof(int) * 2 * PSD_SLOTS, c->stream));
         P.tshift = c->tshift;
         P.desc = c->tdesc;  // slot 0 of the cursor arrays: the fused bulk-update kernel indexes them by cursor
         P.cnt = c->tcnt;
@@ -873,6 +880,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
             P.epoch = c->tslotw + PSD_SLOTS;
             P.cdone = c->tslotw + 2 * PSD_SLOTS;
             if (c->band_helper) P.bandinfo = c->tslotw + 3 * PSD_SLOTS;
+            if (c->train_stop) P.ccancel = c->tslotw + 6 * PSD_SLOTS;
         }
 #ifndef PSD_HOSTSIM
         PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_rq_step_train),
@@ -886,7 +894,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     int Mw = M;
     if (mb && c->train_mb_m > Mw && c->train_m >= 32) Mw = (c->train_mb_m > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : c->train_mb_m;
     PSD_LAUNCH(psd_rq_init, psd_dim3(p, nprob), 256, 256 * 8, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, Mw, train_oc,
-               mb ? 1 : 0, mb ? c->cgap : 2);
+               mb ? 1 : 0, mb ? c->cgap : 2, c->train_long, c->train_wdiv);
     const size_t lds_apply = apply_lds_bytes();
     const int tiles = (n + PSD_APPLY_NT - 1) / PSD_APPLY_NT;
     const int batch = 32;
@@ -1241,6 +1249,9 @@ int psd_create(psd_ctx** ctx, int device) {
 #endif
     if (const char* e = getenv("PSD_FORMQ_BLOCKED")) c->formq_blocked = atoi(e);
     if (const char* e = getenv("PSD_BAND_HELPER")) c->band_helper = atoi(e);
+    if (const char* e = getenv("PSD_TRAIN_LONG")) c->train_long = atoi(e);
+    if (const char* e = getenv("PSD_TRAIN_STOP")) c->train_stop = atoi(e);
+    if (const char* e = getenv("PSD_TRAIN_WDIV")) c->train_wdiv = atoi(e) > 0 ? atoi(e) : 8;
     if (const char* e = getenv("PSD_MB")) c->mblock = atoi(e);
     if (const char* e = getenv("PSD_TRAIN_MB")) c->train_mb_m = atoi(e);
     if (const char* e = getenv("PSD_CGAP")) c->cgap = (atoi(e) == 2) ? 2 : 1;

@@ -121,6 +121,11 @@ struct psd_rstate {
     // the part of the window that lies inside the block (cfirst positions).
     int cgap, tgap, cstart, cfirst;
     int cslots[PSD_TRAIN_MAX];  // slots of the running train's cursors (entry 0 unused)
+    // Long trains (multi-block): a train may have more bulges than cursor slots — a slot that has finished bulge b goes
+    // on as bulge b + train_S (same schedule formula), so the pipeline fills and drains once per train_n sweeps instead of
+    // once per slot count.  train_S: cursor slots of the train; train_ms: distinct shift pairs (bulge b uses pair
+    // b mod train_ms); train_long: bulges wanted per train (psd_rq_init).
+    int train_S, train_ms, train_long, train_wdiv;  // (train_wdiv: a long train has at most w / train_wdiv bulges)
 };
 
 // global words of the multi-block scheduler
@@ -182,8 +187,12 @@ struct psd_rparams {
     // multi-block: [3][PSD_SLOTS] tick, first and last row of the product band psd_rq_band computed for a slot's
     // pending decision (nullptr otherwise)
     int* bandinfo;
+    // multi-block, long trains: [2][PSD_SLOTS] per LEADER slot — 1 once a bulge of its running train has found the
+    // bottom of the range converged (no further bulge of the train enters), and the number of bulges cancelled that way
+    int* ccancel;
 };
 #define PSD_TSHIFT_STRIDE (4 * PSD_TRAIN_MAX + 8)
+#define PSD_TRAIN_LONG_MINW 64  // narrower ranges keep one bulge per slot (a long train there is sweeps past convergence)
 #define PSD_DECIDE_YIELD 128  // active-range width from which the band of a decision comes from psd_rq_band (multi-block mode)
 #define PSD_WL_EDGE 64  // columns right of a mid-sweep window that the next windows of the sweep can reach
 
@@ -885,6 +894,19 @@ PSD_D void psd_rq_train_shifts(const psd_rparams& P, int n, int p, int i, int m,
 }
 
 // PSD.jl:668-803: split test, shifts, first column of the shifted product
+// entry tick and first window of cursor b of the running train (see psd_rstate::cstart)
+PSD_HD void psd_cursor_schedule(const psd_rstate& st, int b, int& cstart, int& cfirst) {
+    const int nbw = st.W - 4;
+    const int spc = (st.tgap == 1) ? (nbw + 4) : (2 * nbw);
+    int d = (b * spc - nbw + 1 + nbw - 1) / nbw;  // ceil((b s - nb + 1) / nb)
+    if (d < 1) d = 1;
+    int x = nbw * d - b * spc + nbw;
+    if (x > nbw) x = nbw;
+    if (x < 1) x = 1;
+    cstart = st.train_tick0 + d;
+    cfirst = x;
+}
+
 // Returns true when the shift pairs of a multishift train were computed (trailing blocks of all factors, their product,
 // a small Hessenberg-QR in one lane: as long as a window's chase) — the multi-block driver then ends this workgroup's
 // launch there, so that the tick is not stretched for all the other slots; the sweep starts with the next launch.
@@ -982,6 +1004,31 @@ PSD_D bool psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
                     m = mc;
                 }
             }
+            // Long train (slots recycled, see psd_rstate::train_S): in its steady state S(nb) = the slots that keep the
+            // pipeline full are all busy, S nb / w sweeps per tick at nb p c + o per tick.  The width with the most
+            // sweeps per time among those whose S fits the slots is taken; none fits: the train above.
+            if (st.mb && st.train_long > m && m >= 2 && st.cgap == 1 && w >= PSD_TRAIN_LONG_MINW) {
+                double bestthr = 0.0;
+                int nbl = 0, ml = 0;
+                for (int nbc = (st.Wmax - 4 < 8) ? ((st.Wmax - 4 >= 6) ? st.Wmax - 4 : 6) : 8; nbc <= st.Wmax - 4; ++nbc) {
+                    if (nbc < 6) continue;
+                    const int spx = nbc + 4;
+                    const int sneed = (((w - 1 + nbc - 1) / nbc + 2) * nbc + spx - 1) / spx;
+                    int mx = 1 + (w - nbc) / spx;
+                    if (mx > mt) mx = mt;
+                    if (sneed > PSD_TRAIN_MAX - 1 || mx < 2 || w / st.train_wdiv <= sneed + 1) continue;
+                    const double thr = (double)sneed * nbc / (double)(nbc * st.p + st.train_oc);
+                    if (thr > bestthr) {
+                        bestthr = thr;
+                        nbl = nbc;
+                        ml = mx;
+                    }
+                }
+                if (nbl > 0) {
+                    nb = nbl;
+                    m = ml;
+                }
+            }
             // the shift pairs come from one lane's Hessenberg-QR of a block of order <= PSD_HQR_MAX: a longer train
             // runs through them twice
             int ms = (2 * m > PSD_HQR_MAX) ? PSD_HQR_MAX / 2 : m;
@@ -997,7 +1044,7 @@ PSD_D bool psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
                 heavy = st.mb != 0;
                 if (*okf && m > ms) {
                     PSD_ONE {
-                        for (int b = ms; b < m; ++b)
+                        for (int b = ms; b < m && b < PSD_TRAIN_MAX; ++b)
                             for (int q = 0; q < 4; ++q) P.tshift[4 * b + q] = P.tshift[4 * (b - ms) + q];
                     }
                     PSD_SYNC();
@@ -1005,12 +1052,24 @@ PSD_D bool psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
                 int mgot = m;
                 if (*okf && st.mb) {  // the cursors need slots: as many as are free
                     PSD_DBG_T0();
-                    psd_mb_claim_many(P, st.slot, m - 1, (int*)work, bc + 3, bc);  // (the staging area of the shifts is free again)
+                    // (a long train needs a few slots more than bulges fit the range at once: see below)
+                    int wantslots = m - 1;
+                    if (st.train_long > m && w >= PSD_TRAIN_LONG_MINW) {
+                        const int tg = (st.cgap == 1 && nb >= 6) ? 1 : 2, spc = (tg == 1) ? (nb + 4) : (2 * nb);
+                        const int sneed = (((i - l + nb - 1) / nb + 2) * nb + spc - 1) / spc;
+                        if (sneed > wantslots) wantslots = sneed;
+                        if (wantslots > PSD_TRAIN_MAX - 1) wantslots = PSD_TRAIN_MAX - 1;
+                    }
+                    psd_mb_claim_many(P, st.slot, wantslots, (int*)work, bc + 3, bc);  // (the staging area of the shifts is free again)
                     PSD_DBG_ADD(4);
                     PSD_ONE {
                         bc[0] += 1;  // (with the leader)
                         bc[1] = psd_atomic_add(&P.gl->train_seq, 1) + 1;
                         psd_atomic_store(P.cdone + st.slot, 0);  // (no cursor of an earlier train of this leader is left)
+                        if (P.ccancel) {
+                            psd_atomic_store(P.ccancel + st.slot, 0);
+                            psd_atomic_store(P.ccancel + PSD_SLOTS + st.slot, 0);
+                        }
                     }
                     PSD_SYNC();
                     mgot = bc[0];
@@ -1022,6 +1081,20 @@ PSD_D bool psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
                     m = mgot;
                     st.W = nb + 4;
                     st.tgap = (st.cgap == 1 && nb >= 6) ? 1 : 2;
+                    st.train_S = m - 1;
+                    st.train_ms = (ms < m) ? ms : m;
+                    if (st.mb && st.train_long > m && w >= PSD_TRAIN_LONG_MINW) {
+                        // more bulges than slots: the slot of bulge b takes bulge b + S when b is through.  Bulge b + S
+                        // enters S s / nb ticks after bulge b, which needs (i - l) / nb + 1 ticks for its sweep and one
+                        // to turn around — with two ticks to spare, or the train stays at one bulge per slot
+                        const int S = m - 1, spc = (st.tgap == 1) ? (nb + 4) : (2 * nb);
+                        const int need = (i - l + nb - 1) / nb + 2;
+                        if ((S * spc) / nb >= need) {
+                            int want = st.train_long;
+                            if (want > w / st.train_wdiv) want = w / st.train_wdiv;  // (a train deflates a fraction of its bulge count: keep several trains per range)
+                            if (want > m) m = want;
+                        }
+                    }
                     st.train_n = m;
                     st.train_tick0 = P.tick + (heavy ? 1 : 0);  // (the leader's first window runs in the next launch)
                     st.train_id += 1;
@@ -1065,7 +1138,8 @@ PSD_D bool psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
         PSD_SYNC();
         PSD_ONE {
             if (!st.mb) psd_atomic_store(P.cep + PSD_TRAIN_MAX, 0);  // finished cursors of this train
-            for (int b = 1; b < st.train_n; ++b) {
+            const int ngen1 = (st.mb && st.train_S > 0 && st.train_S + 1 < st.train_n) ? (st.train_S + 1) : st.train_n;
+            for (int b = 1; b < ngen1; ++b) {  // (a long train: the first bulge of every slot)
                 psd_rstate cs = st;
                 cs.cursor = b;
                 cs.phase = PSD_PH_CWAIT;
@@ -1073,17 +1147,7 @@ PSD_D bool psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
                 cs.nsweeps = cs.nwindows = cs.nlog = 0;
                 cs.maxlog = 0;
                 for (int q = 0; q < 6; ++q) cs.cyc[q] = 0;
-                {  // entry tick and first window of cursor b (see psd_rstate::cstart)
-                    const int nbw = st.W - 4;
-                    const int spc = (st.tgap == 1) ? (nbw + 4) : (2 * nbw);
-                    int d = (b * spc - nbw + 1 + nbw - 1) / nbw;  // ceil((b s - nb + 1) / nb)
-                    if (d < 1) d = 1;
-                    int x = nbw * d - b * spc + nbw;
-                    if (x > nbw) x = nbw;
-                    if (x < 1) x = 1;
-                    cs.cstart = st.train_tick0 + d;
-                    cs.cfirst = x;
-                }
+                psd_cursor_schedule(st, b, cs.cstart, cs.cfirst);
                 if (st.mb) {  // (the slot's workgroup picks the state up in the next launch: epoch < tick)
                     cs.parent = st.slot;
                     cs.slot = st.cslots[b];
@@ -1448,6 +1512,28 @@ PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
     if (ke >= i - 1) {  // sweep complete (PSD.jl:887)
         st.its += 1;
         st.phase = (st.cursor > 0) ? PSD_PH_CDONE : ((st.train_n > 1) ? PSD_PH_TWAIT : PSD_PH_DECIDE);
+        // Long train: a bulge that leaves the bottom of the range converged — the last or the last but one subdiagonal
+        // entry of the product negligible against its diagonal neighbours, from the window still in LDS — stops the
+        // train: bulges that have not entered are cancelled (psd_rq_cursor_body), the leader decides sooner.  Only a hint:
+        // the deflation itself is the leader's decision on the exact band (psd_rq_decide).
+        if (st.mb && P.ccancel != nullptr && st.train_n > st.train_S + 1 && st.train_S > 0 && i - 2 >= w.bs && i - 2 >= l) {
+            PSD_SYNC();
+            PSD_ONE {
+                double sub1 = w.at(1, i, i - 1), sub2 = w.at(1, i - 1, i - 2);
+                double d0 = w.at(1, i, i), d1 = w.at(1, i - 1, i - 1), d2 = w.at(1, i - 2, i - 2);
+                for (int j = 2; j <= p; ++j) {
+                    const double t0 = w.at(j, i, i), t1 = w.at(j, i - 1, i - 1), t2 = w.at(j, i - 2, i - 2);
+                    sub1 *= t1;
+                    sub2 *= t2;
+                    d0 *= t0;
+                    d1 *= t1;
+                    d2 *= t2;
+                }
+                const bool conv = fabs(sub1) <= st.ulp * (fabs(d0) + fabs(d1)) || fabs(sub2) <= st.ulp * (fabs(d1) + fabs(d2));
+                if (conv) psd_atomic_store(P.ccancel + ((st.cursor > 0) ? st.parent : st.slot), 1);
+            }
+            PSD_SYNC();
+        }
     }
 }
 
@@ -1751,7 +1837,13 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
                     if (all) psd_acquire_fence();
                 }
                 if (all) {
-                    for (int b = 1; b < st.train_n; ++b) {
+                    int swept = st.train_n;  // bulges that ran (a stopped long train drops the ones that had not entered)
+                    if (st.mb && P.ccancel != nullptr) {
+                        const int dropped = psd_atomic_load(P.ccancel + PSD_SLOTS + st.slot);
+                        swept -= dropped;
+                        st.ntrainsweeps -= dropped;
+                    }
+                    for (int b = 1; b < swept; ++b) {
                         if (!st.mb) st.nwindows += P.cst[b].nwindows;  // (multi-block: a cursor adds its own to psd_rglobal)
                         st.nsweeps += 1;
                         st.its += 1;
@@ -1836,6 +1928,17 @@ PSD_D void psd_rq_cursor_body(const psd_rparams& P, int b) {
     double* ldsd = (double*)psd_lds;
     const size_t winb = (size_t)st.p * st.Wmax * (st.Wmax + 1);
     int* lcnt = (int*)(ldsd + winb + PSD_STEP_NT) + 2 * PSD_STEP_NT;
+    if (st.phase == PSD_PH_CWAIT && st.mb && P.ccancel != nullptr && st.train_S > 0 &&
+        psd_atomic_load(P.ccancel + st.parent)) {
+        // the train was stopped (psd_rq_qr_window): this bulge and the later ones of this slot do not enter
+        PSD_ONE {
+            const int k = 1 + (st.train_n - 1 - b) / st.train_S;
+            psd_atomic_add(P.ccancel + PSD_SLOTS + st.parent, k);
+            psd_mb_release_slot(P, st.slot);
+            psd_atomic_add(P.cdone + st.parent, k);
+        }
+        return;
+    }
     if (st.phase == PSD_PH_CWAIT) {
         // Cursor b chases its first window exactly 2 b ticks after the leader's: consecutive windows of a sweep overlap
         // in four positions, so two ticks put a whole finished window (chase and bulk update, both complete at the
@@ -1844,11 +1947,36 @@ PSD_D void psd_rq_cursor_body(const psd_rparams& P, int b) {
         if (P.tick < st.cstart) return;
         double h11, h12, h21, h22, h32;
         psd_rq_topband(P, st.n, st.p, st.l, st.i, h11, h12, h21, h22, h32);
-        psd_rq_startvec(h11, h12, h21, h22, h32, P.tshift + 4 * b, st.v);
+        psd_rq_startvec(h11, h12, h21, h22, h32, P.tshift + 4 * ((st.train_ms > 0) ? (b % st.train_ms) : b), st.v);
         st.kcur = st.l;
         st.phase = PSD_PH_QR;
     }
     psd_rq_qr_window(P, st, ldsd, lcnt);
+    // long train: this slot goes on as bulge b + S (its report below counts bulge b in)
+    bool rearm = st.mb && st.phase == PSD_PH_CDONE && st.train_S > 0 && b + st.train_S <= st.train_n - 1;
+    int ncancel = 0;  // later bulges of this slot that a stopped train drops
+    if (rearm && P.ccancel != nullptr && psd_atomic_load(P.ccancel + st.parent)) {
+        ncancel = (st.train_n - 1 - b) / st.train_S;
+        rearm = false;
+    }
+    const int nwin_done = st.nwindows;
+    long long cyc_done[4] = {0, st.cyc[1], st.cyc[2], st.cyc[3]};
+    if (rearm) {
+        st.cursor = b + st.train_S;
+        psd_cursor_schedule(st, st.cursor, st.cstart, st.cfirst);
+        if (st.cstart <= P.tick) {  // (excluded by the margin psd_rq_shift keeps; never run a bulge off its schedule)
+            st.info = PSD_LIST_OVERFLOW;
+            PSD_ONE {
+                psd_atomic_store(&P.gl->info, PSD_LIST_OVERFLOW);
+                psd_atomic_store(&P.gl->abort, 1);
+                psd_atomic_store(&P.gl->done, 1);
+            }
+        }
+        st.phase = PSD_PH_CWAIT;
+        st.kcur = 0;
+        st.nwindows = 0;
+        st.cyc[1] = st.cyc[2] = st.cyc[3] = 0;
+    }
     PSD_SYNC();
     PSD_ONE { *P.st = st; }
     if (!st.mb && st.phase == PSD_PH_CDONE) {  // last window: count this cursor in (its state and lists are out first)
@@ -1857,12 +1985,13 @@ PSD_D void psd_rq_cursor_body(const psd_rparams& P, int b) {
             psd_atomic_add(P.cep + PSD_TRAIN_MAX, 1);
         }
     }
-    if (st.mb && st.phase == PSD_PH_CDONE) {  // last window of this bulge: report, hand the slot back
+    if (st.mb && (st.phase == PSD_PH_CDONE || rearm)) {  // last window of this bulge: report, hand the slot back (or keep it)
         PSD_ONE {
-            psd_atomic_add(&P.gl->nwindows, st.nwindows);
-            for (int q = 1; q < 4; ++q) psd_atomic_add_ll(&P.gl->cyc[q], st.cyc[q]);
-            psd_mb_release_slot(P, st.slot);
-            psd_atomic_add(P.cdone + st.parent, 1);
+            psd_atomic_add(&P.gl->nwindows, nwin_done);
+            for (int q = 1; q < 4; ++q) psd_atomic_add_ll(&P.gl->cyc[q], cyc_done[q]);
+            if (!rearm) psd_mb_release_slot(P, st.slot);
+            if (ncancel) psd_atomic_add(P.ccancel + PSD_SLOTS + st.parent, ncancel);
+            psd_atomic_add(P.cdone + st.parent, 1 + ncancel);
         }
     }
 }
@@ -2527,7 +2656,7 @@ PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride
 // hnorms[j] = ulp*n*opnorm(H_j, 1), column-1 / sub-Hessenberg clean-up (PSD.jl:379-388,406), and
 // state initialisation.  grid = p blocks.
 PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W, int maxitfac, int maxlog,
-                       int train_want, int train_oc, int mb, int cgap) {
+                       int train_want, int train_oc, int mb, int cgap, int train_long, int train_wdiv) {
     PSD_LDS_DECL;
     double* red = (double*)psd_lds;
     const int j = PSD_BLOCK_X + 1;
@@ -2550,6 +2679,7 @@ PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W,
             st.v[0] = st.v[1] = st.v[2] = 0.0;
             for (int q = 0; q < 6; ++q) st.cyc[q] = 0;
             st.train_want = train_want; st.train_n = 1; st.train_id = 0; st.cursor = 0; st.train_tick0 = 0;
+            st.train_S = 0; st.train_ms = 0; st.train_long = mb ? train_long : 0; st.train_wdiv = (train_wdiv > 0) ? train_wdiv : 8;
             st.ntrains = st.ntrainsweeps = 0; st.exc_dec = 0;
             st.ulp = PSD_DBL_EPS;
             st.smlnum = PSD_DBL_MIN * ((double)n / PSD_DBL_EPS);

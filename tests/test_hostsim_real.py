@@ -162,8 +162,8 @@ def test_formq_blocked(built, monkeypatch):
 def test_band_helper_same_decisions(built, monkeypatch):
     """psd_rq_band (the product bands of wide pending decisions computed in front of the chase launch, found by
     psd_rq_decide through bandinfo) against leaders that compute their bands themselves (PSD_BAND_HELPER=0): the same
-    recurrence in the same order per row, so the same decisions — T, Z and the eigenvalues are bit-identical in the
-    serial simulation.  n >= 128 so that the helper has wide ranges to serve."""
+    recurrence in the same order per row, so the same decisions: the same number of sweeps and the same eigenvalues to
+    rounding in the serial simulation.  n >= 128 so that the helper has wide ranges to serve."""
     import os
 
     import numpy as np
@@ -179,8 +179,11 @@ def test_band_helper_same_decisions(built, monkeypatch):
         A = pt.bench_factors(n, p, seed=31)
         ph = helped.pschur(A, lr)
         pp = plain.pschur(A, lr)
-        assert np.array_equal(ph.values, pp.values)
-        for j in range(p):
-            assert np.array_equal(ph.Ts[j], pp.Ts[j]) and np.array_equal(ph.Z[j], pp.Z[j])
-        ok, err = pt.checkpsd(ph, A, thresh=100 * np.sqrt(n / 32))
-        assert ok, (n, p, err.max())
+        # (the same sweeps; a leader that ends its launch for the helper shifts its range's ticks against the other
+        #  ranges', so updates of different ranges may reach a shared off-diagonal element in the other order: equal to
+        #  rounding, not to the bit)
+        assert ph.stats.nsweeps == pp.stats.nsweeps
+        assert pt.match_eigs(pp.values, ph.values) <= 1e-13 * np.abs(pp.values).max()
+        for res in (ph, pp):
+            ok, err = pt.checkpsd(res, A, thresh=100 * np.sqrt(n / 32))
+            assert ok, (n, p, err.max())
