@@ -224,6 +224,7 @@ struct psd_ctx {
     // (psd_rq_apply_wl modes).  Off by default: measured the far parts do run beside the chases and
     // a train tick drops from 610 to 445 us at n = 1024, p = 64, but two more launches and two cross-stream events per tick
     // cost 15-25 us on every tick, and most ticks are small: 811 vs 817 ms at that size, 249 vs 224 ms at n = 512, p = 16
+    int ovl_what = 3;      // far/near split (PSD_OVERLAP=1): bit 0 rows roles, bit 1 column roles (PSD_OVL_WHAT)
     int train_stop = 1;    // a long train stops admitting bulges once one of them leaves the bottom converged (PSD_TRAIN_STOP=0: never)
     int train_wdiv = 8;    // a long train has at most (range width) / train_wdiv bulges (PSD_TRAIN_WDIV; 4 is 3-15 % faster and
                            // costs 40 % more residual: every bulge of a train passes over the whole range)
@@ -985,16 +986,22 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                     PSD_CHECK(hipStreamWaitEvent(c->stream2, c->evE[par ^ 1], 0));
                     hipLaunchKernelGGL(psd_rq_apply_wl, dim3(c->far_grid > 0 ? c->far_grid : wl_grid), dim3(PSD_WL_NT),
                                        psd_wl_lds_bytes(), c->stream2, Pprev, n, p, p + 8, 0, NSL, zlo1, zhi1, 2);
+                    if (c->ovl_what & 2)
+                        hipLaunchKernelGGL(psd_rq_apply_wl, dim3(c->far_grid > 0 ? c->far_grid : wl_grid), dim3(PSD_WL_NT),
+                                           psd_wl_lds_bytes(), c->stream2, Pprev, n, p, p + 8, 1, NSL, zlo1, zhi1, 2);
                     PSD_CHECK(hipEventRecord(c->evF[par ^ 1], c->stream2));
                     PSD_CHECK(hipStreamWaitEvent(c->stream, c->evF[par ^ 1], 0));
 #else
-                    if (!getenv("PSD_OVL_DBG"))
+                    if (!getenv("PSD_OVL_DBG")) {
                         PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pprev, n, p, p + 8, 0,
                                    NSL, zlo1, zhi1, 2);
+                        PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pprev, n, p, p + 8, 1,
+                                   NSL, zlo1, zhi1, 2);
+                    }
 #endif
                 }
                 // near part of this tick's update, before the next tick's chases
-                PSD_LAUNCH(psd_rq_cuts, psd_dim3(1), PSD_WL_NT, PSD_SLOTS * sizeof(int), c->stream, Pq, NSL);
+                PSD_LAUNCH(psd_rq_cuts, psd_dim3(1), PSD_WL_NT, 3 * PSD_SLOTS * sizeof(int), c->stream, Pq, NSL, W + 2, c->ovl_what);
                 PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 0, NSL,
                            zlo1, zhi1, 1);
                 PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 1, NSL,
@@ -1002,9 +1009,12 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
 #ifndef PSD_HOSTSIM
                 PSD_CHECK(hipEventRecord(c->evE[par], c->stream));
 #else
-                if (getenv("PSD_OVL_DBG"))
+                if (getenv("PSD_OVL_DBG")) {
                     PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 0, NSL,
                                zlo1, zhi1, 2);
+                    PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 1, NSL,
+                               zlo1, zhi1, 2);
+                }
 #endif
             } else if (c->apply_worklist || c->shard_world > 1 || mb) {
                 // work-list form: one grid of single-wave workgroups loops over the items of the tick
@@ -1251,6 +1261,7 @@ int psd_create(psd_ctx** ctx, int device) {
     if (const char* e = getenv("PSD_BAND_HELPER")) c->band_helper = atoi(e);
     if (const char* e = getenv("PSD_TRAIN_LONG")) c->train_long = atoi(e);
     if (const char* e = getenv("PSD_TRAIN_STOP")) c->train_stop = atoi(e);
+    if (const char* e = getenv("PSD_OVL_WHAT")) c->ovl_what = atoi(e) & 3;
     if (const char* e = getenv("PSD_TRAIN_WDIV")) c->train_wdiv = atoi(e) > 0 ? atoi(e) : 8;
     if (const char* e = getenv("PSD_MB")) c->mblock = atoi(e);
     if (const char* e = getenv("PSD_TRAIN_MB")) c->train_mb_m = atoi(e);
