@@ -253,6 +253,40 @@ PSD_D void psd_pair_store(double* q, const psd_pair& x) {
 #endif
 PSD_D void psd_win_load(const psd_rparams& P, const psd_win& w, int n, int p) {
     const int m = w.be - w.bs + 1;
+#ifndef PSD_HOSTSIM
+    if ((w.ld & 1) == 0 && w.ld <= 64) {
+        // LDS-DMA (global_load_lds_dwordx4): a lane's 16 bytes — two consecutive rows of a column — go straight to LDS
+        // at wave-uniform base + 16 lane, no VGPRs, so every load of the window can be in flight at once (the register
+        // path holds 32 per lane and is bounded by that: 42 us of a 376 us window at p = 64).  A column of the window
+        // image is ld = W + 1 doubles = ld / 2 lanes, so one instruction fills 64 / (ld / 2) whole columns; needs ld even
+        // (W = 17 at p = 64).  The odd last row at the bottom edge of the matrix (its pair would leave the allocation)
+        // comes by an ordinary load.
+        const int lpc = w.ld >> 1, cpi = 64 / lpc;
+        const int lane = PSD_TID;
+        const int cl = lane / lpc, r = 2 * (lane - cl * lpc);
+        const bool on = cl < cpi && r < m;
+        const bool pair_ok = (r + 1 < m) || (w.bs - 1 + r + 1 < n);  // (the second row exists in the matrix)
+        const size_t fstride = (size_t)n * n;
+        for (int c0 = 0; c0 < m; c0 += cpi) {  // (column group outside, factors inside: the inner loop is a pointer step and the load)
+            const int c = c0 + cl;
+            const bool act = on && c < m && c + PSD_WIN_BAND >= r;
+            const double* q = P.H + (size_t)(w.bs - 1 + (act ? c : 0)) * n + (w.bs - 1 + (act ? r : 0));
+            double* dst = w.b + c0 * w.ld;
+            if (act && pair_ok) {
+                for (int j = 0; j < p; ++j) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)q,
+                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                    q += fstride;
+                    dst += w.bsz;
+                }
+            } else if (act) {
+                for (int j = 0; j < p; ++j) w.b[j * w.bsz + c * w.ld + r] = q[(size_t)j * fstride];
+            }
+        }
+        PSD_SYNC();
+        return;
+    }
+#endif
     PSD_PAR_FOR(t, PSD_STEP_NT) {
         const int r = 2 * (t & 15), g = t >> 4;
         if (r < m) {
