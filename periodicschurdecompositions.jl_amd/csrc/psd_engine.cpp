@@ -65,8 +65,9 @@ struct Timer {
 #endif
 };
 
-size_t step_lds_bytes(int p, int W, int esize);
-int choose_window(int p, int esize = 8) {
+size_t step_lds_bytes(int p, int W, int esize, bool even);
+// even: the window area is laid out for an even column pitch (real standard engine: psd_win_area)
+int choose_window(int p, int esize = 8, bool even = false) {
     // largest W <= 32 with p blocks of W x (W+1) elements (+ scratch) inside the 160 KiB LDS of one CU;
     // PSD_WINDOW (test hook) lowers it
     int cap = 32;
@@ -75,11 +76,12 @@ int choose_window(int p, int esize = 8) {
         if (w >= 6 && w < cap) cap = w;
     }
     for (int W = cap; W >= 6; --W)
-        if (step_lds_bytes(p, W, esize) <= (size_t)160 * 1024) return W;
+        if (step_lds_bytes(p, W, esize, even) <= (size_t)160 * 1024) return W;
     return 0;
 }
-size_t step_lds_bytes(int p, int W, int esize = 8) {
-    size_t b = (size_t)p * W * (W + 1) * esize + PSD_STEP_NT * 8 + (2 * PSD_STEP_NT + (size_t)p) * 4;
+size_t step_lds_bytes(int p, int W, int esize = 8, bool even = false) {
+    const size_t area = even ? (size_t)psd_win_area(W) : (size_t)W * (W + 1);
+    size_t b = (size_t)p * area * esize + PSD_STEP_NT * 8 + (2 * PSD_STEP_NT + (size_t)p) * 4;
     return (b + 15) & ~(size_t)15;
 }
 // ordschur! alignments (ordschur.jl:20-33, rordschur.jl:15-27, utils.jl:6-85): the swap kernels work on the right-
@@ -792,7 +794,7 @@ int formq_dev(psd_ctx* c, int n, int p, const double* dH, const double* dtau, do
 int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int wantZ, int maxitfac,
                 psd_rstate* st_out, psd_stats* stats, int maxlog, int nprob = 1, double* bws = nullptr,
                 int* pinfo_out = nullptr) {
-    const int W = choose_window(p);
+    const int W = choose_window(p, 8, true);
     if (W == 0) return PSD_INFO_NOTIMPL;
     psd_rparams P;
     P.H = dH;
@@ -811,7 +813,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     P.wr = c->wr;
     P.wi = c->wi;
     P.log = c->log;
-    const size_t lds_step = step_lds_bytes(p, W);
+    const size_t lds_step = step_lds_bytes(p, W, 8, true);
 #ifndef PSD_HOSTSIM
     if (lds_step > c->step_lds_set) {
         PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_rq_step),

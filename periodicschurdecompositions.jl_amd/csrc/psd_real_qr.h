@@ -213,6 +213,14 @@ PSD_HD psd_mat<double> psd_fac(const psd_rparams& P, int n, int j) {
 
 // ------------------------------------------------------------------------------------------------
 // LDS window: blocks [bs..be]^2 of all p factors, column-major with leading dimension W+1
+// Column pitch of a window image of width W inside an area laid out for Wmax x (Wmax + 1) per factor: W + 1, or W + 2
+// when that makes it even and still fits — an even pitch is what the LDS-DMA window load needs (psd_win_load).
+// (the area itself is laid out for an even pitch at Wmax: Wmax x (Wmax + 1) or Wmax x (Wmax + 2) doubles per factor)
+PSD_HD int psd_win_area(int Wmax) { return Wmax * ((((Wmax + 1) & 1) == 0) ? (Wmax + 1) : (Wmax + 2)); }
+PSD_HD int psd_win_pitch(int W, int Wmax) {
+    if (((W + 1) & 1) == 0) return W + 1;
+    return (W * (W + 2) <= psd_win_area(Wmax)) ? (W + 2) : (W + 1);
+}
 struct psd_win {
     double* b;
     int W, ld, bsz, bs, be;
@@ -1066,7 +1074,7 @@ PSD_D bool psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
             // the shift pairs come from one lane's Hessenberg-QR of a block of order <= PSD_HQR_MAX: a longer train
             // runs through them twice
             int ms = (2 * m > PSD_HQR_MAX) ? PSD_HQR_MAX / 2 : m;
-            while (ms >= 2 && psd_rq_train_doubles(st.p, ms) > (size_t)st.p * st.Wmax * (st.Wmax + 1)) --ms;  // LDS of the staging
+            while (ms >= 2 && psd_rq_train_doubles(st.p, ms) > (size_t)st.p * psd_win_area(st.Wmax)) --ms;  // LDS of the staging
             if (ms < m && ms < PSD_HQR_MAX / 2) m = ms;
             if (m >= 2 && 2 * m + 2 <= w) {
                 int* okf = (int*)P.tshift + 8 * PSD_TRAIN_MAX;  // (flag word behind the pairs)
@@ -1457,8 +1465,8 @@ PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
     psd_win w;
     w.b = ldsd;
     w.W = st.W;
-    w.ld = st.W + 1;
-    w.bsz = st.W * (st.W + 1);
+    w.ld = psd_win_pitch(st.W, st.Wmax);
+    w.bsz = st.W * w.ld;
     w.bs = (ks > l) ? (ks - 1) : l;
     w.be = (ke + 3 < i) ? (ke + 3) : i;
     const long long tc0 = psd_clock();
@@ -1581,8 +1589,8 @@ PSD_D void psd_rq_rq_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
     psd_win w;
     w.b = ldsd;
     w.W = st.W;
-    w.ld = st.W + 1;
-    w.bsz = st.W * (st.W + 1);
+    w.ld = psd_win_pitch(st.W, st.Wmax);
+    w.bsz = st.W * w.ld;
     w.bs = ke - 1;
     w.be = (ks + 1 < i) ? (ks + 1) : i;
     PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
@@ -1664,8 +1672,8 @@ PSD_D bool psd_rq_deflate(const psd_rparams& P, psd_rstate& st, double* ldsd, in
     psd_win w;
     w.b = ldsd;
     w.W = st.W;
-    w.ld = st.W + 1;
-    w.bsz = st.W * (st.W + 1);
+    w.ld = psd_win_pitch(st.W, st.Wmax);
+    w.bsz = st.W * w.ld;
     w.bs = i - 1;
     w.be = i;
     double hh11, hh12, hh21, hh22;
@@ -1819,7 +1827,7 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
     }
     const int NT = PSD_NTHREADS;
     double* ldsd = (double*)psd_lds;
-    const size_t winb = (size_t)st.p * st.Wmax * (st.Wmax + 1);
+    const size_t winb = (size_t)st.p * psd_win_area(st.Wmax);
     double* red = ldsd + winb;
     int* redi = (int*)(red + NT);
     int* lcnt = redi + 2 * NT;
@@ -1961,7 +1969,7 @@ PSD_D void psd_rq_cursor_body(const psd_rparams& P, int b) {
     if (st.cursor != b) return;
     if (st.phase != PSD_PH_CWAIT && st.phase != PSD_PH_QR) return;
     double* ldsd = (double*)psd_lds;
-    const size_t winb = (size_t)st.p * st.Wmax * (st.Wmax + 1);
+    const size_t winb = (size_t)st.p * psd_win_area(st.Wmax);
     int* lcnt = (int*)(ldsd + winb + PSD_STEP_NT) + 2 * PSD_STEP_NT;
     if (st.phase == PSD_PH_CWAIT && st.mb && P.ccancel != nullptr && st.train_S > 0 &&
         psd_atomic_load(P.ccancel + st.parent)) {

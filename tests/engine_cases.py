@@ -149,14 +149,16 @@ def case_edge(eng):
 
 
 def expected_window(p, esize=8):
-    """The engine's rule (psd_engine.cpp choose_window): the largest W <= 32 whose p window blocks of W x (W+1)
-    elements plus the chase scratch fit the 160 KiB LDS of one CU; PSD_WINDOW (test hook) lowers the cap."""
+    """The engine's rule (psd_engine.cpp choose_window): the largest W <= 32 whose p window blocks plus the chase
+    scratch fit the 160 KiB LDS of one CU; a block is W x (W+1) elements, or W x (W+2) where that makes the column
+    pitch even (real standard engine: the LDS-DMA window load wants it); PSD_WINDOW (test hook) lowers the cap."""
     cap = 32
     e = os.environ.get("PSD_WINDOW")
     if e and 6 <= int(e) < cap:
         cap = int(e)
     for W in range(cap, 5, -1):
-        need = p * W * (W + 1) * esize + 64 * 8 + (2 * 64 + p) * 4
+        pitch = W + 1 if (esize != 8 or (W + 1) % 2 == 0) else W + 2
+        need = p * W * pitch * esize + 64 * 8 + (2 * 64 + p) * 4
         if (need + 15) // 16 * 16 <= 160 * 1024:
             return W
     return 0
