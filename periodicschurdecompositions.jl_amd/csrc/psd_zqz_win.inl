@@ -5,6 +5,34 @@
 // factors j0, j0 + jstep, ... (0-based) only
 PSD_D void psd_zwin_load(const psd_zparams& P, const psd_zwin& w, int n, int p, int j0 = 0, int jstep = 1) {
     const int m = w.be - w.bs + 1;
+#ifndef PSD_HOSTSIM
+    if (PSD_NTHREADS == 64 && w.ld <= 64) {
+        // LDS-DMA (global_load_lds_dwordx4, as psd_win_load of the real engine): a lane's element (16 bytes) goes straight
+        // to the window image at wave-uniform base + 16 lane, no VGPR destination, so every load of the window is in
+        // flight at once; one instruction fills 64 / ld whole columns of one factor (lanes in image order).
+        const int cpi = 64 / w.ld;
+        const int lane = PSD_TID;
+        const int cl = lane / w.ld, r = lane - cl * w.ld;
+        const bool on = cl < cpi && r < m;
+        const size_t fstride = (size_t)n * n;
+        for (int c0 = 0; c0 < m; c0 += cpi) {
+            const int c = c0 + cl;
+            const bool act = on && c < m;
+            const psd_z* q = P.H + (size_t)j0 * fstride + (size_t)(w.bs - 1 + (act ? c : 0)) * n + (w.bs - 1 + (act ? r : 0));
+            psd_z* dst = w.b + j0 * w.bsz + c0 * w.ld;
+            if (act) {
+                for (int j = j0; j < p; j += jstep) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)q,
+                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                    q += (size_t)jstep * fstride;
+                    dst += jstep * w.bsz;
+                }
+            }
+        }
+        PSD_SYNC();
+        return;
+    }
+#endif
     const int RW = (m > 16) ? 32 : 16, sh = (m > 16) ? 5 : 4, ncg = PSD_STEP_NT / RW;
     if (m <= 16) {
         // narrow windows (many factors): 16 rows x 4 column groups, a lane has at most 4 elements per factor, so four
