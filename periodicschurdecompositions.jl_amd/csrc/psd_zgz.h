@@ -737,12 +737,27 @@ PSD_D void psd_zgq_train_shifts(const psd_zgparams& P, int n, int p, int ilast, 
         T[q] = acc;
     }
     PSD_SYNC();
+#ifndef PSD_HOSTSIM
+    const psd_z lastw = T[(K - 1) * K + (K - 1)];
+    const bool wave1 = PSD_NTHREADS == 64;  // (the workgroup is one wavefront: all of it runs the small QR)
+    bool finw = true;
+    for (int q = 0; q < K * K; ++q)
+        if (!(zabs1(T[q]) < 1e300)) finw = false;
+    bool okw = false;
+    if (wave1 && finw) okw = psd_zhqr_wave(T, K, K, w, PSD_TID);
+#endif
     PSD_ONE {
+#ifndef PSD_HOSTSIM
+        bool ok = finw;
+        const psd_z last = lastw;
+        ok = ok && (wave1 ? okw : psd_zhqr(T, K, K, w));
+#else
         bool ok = true;
         for (int q = 0; q < K * K; ++q)
             if (!(zabs1(T[q]) < 1e300)) ok = false;
         const psd_z last = T[(K - 1) * K + (K - 1)];
         ok = ok && psd_zhqr(T, K, K, w);
+#endif
         for (int a = 0; ok && a < K; ++a)
             if (!(zabs1(w[a]) < 1e300)) ok = false;
         if (ok) {

@@ -293,9 +293,20 @@ PSD_D void psd_zq_train_shifts(const psd_zparams& P, int n, int p, int ilast, in
         T[q] = acc;
     }
     PSD_SYNC();
+#ifndef PSD_HOSTSIM
+    const psd_z lastw = T[(K - 1) * K + (K - 1)];
+    const bool wave1 = PSD_NTHREADS == 64;  // (the workgroup is one wavefront: all of it runs the small QR)
+    bool okw = false;
+    if (wave1) okw = psd_zhqr_wave(T, K, K, w, PSD_TID);
+#endif
     PSD_ONE {
+#ifndef PSD_HOSTSIM
+        const psd_z last = lastw;
+        bool ok = wave1 ? okw : psd_zhqr(T, K, K, w);
+#else
         const psd_z last = T[(K - 1) * K + (K - 1)];
         bool ok = psd_zhqr(T, K, K, w);
+#endif
         for (int a = 0; ok && a < K; ++a)
             if (!(zabs1(w[a]) < 1e300)) ok = false;
         if (ok) {
