@@ -1049,7 +1049,7 @@ PSD_D bool psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
             // Long train (slots recycled, see psd_rstate::train_S): in its steady state S(nb) = the slots that keep the
             // pipeline full are all busy, S nb / w sweeps per tick at nb p c + o per tick.  The width with the most
             // sweeps per time among those whose S fits the slots is taken; none fits: the train above.
-            if (st.mb && st.train_long > m && m >= 2 && st.cgap == 1 && w >= PSD_TRAIN_LONG_MINW) {
+            if (st.mb && st.train_long > m && m >= 2 && st.cgap == 1 && w >= PSD_TRAIN_LONG_MINW && st.train_want >= PSD_TRAIN_MAX) {
                 double bestthr = 0.0;
                 int nbl = 0, ml = 0;
                 for (int nbc = (st.Wmax - 4 < 8) ? ((st.Wmax - 4 >= 6) ? st.Wmax - 4 : 6) : 8; nbc <= st.Wmax - 4; ++nbc) {
@@ -1096,7 +1096,7 @@ PSD_D bool psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
                     PSD_DBG_T0();
                     // (a long train needs a few slots more than bulges fit the range at once: see below)
                     int wantslots = m - 1;
-                    if (st.train_long > m && w >= PSD_TRAIN_LONG_MINW) {
+                    if (st.train_long > m && w >= PSD_TRAIN_LONG_MINW && st.train_want >= PSD_TRAIN_MAX) {  // (a caller's cap on the bulges in flight stands)
                         const int tg = (st.cgap == 1 && nb >= 6) ? 1 : 2, spc = (tg == 1) ? (nb + 4) : (2 * nb);
                         const int sneed = (((i - l + nb - 1) / nb + 2) * nb + spc - 1) / spc;
                         if (sneed > wantslots) wantslots = sneed;
@@ -1125,7 +1125,7 @@ PSD_D bool psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
                     st.tgap = (st.cgap == 1 && nb >= 6) ? 1 : 2;
                     st.train_S = m - 1;
                     st.train_ms = (ms < m) ? ms : m;
-                    if (st.mb && st.train_long > m && w >= PSD_TRAIN_LONG_MINW) {
+                    if (st.mb && st.train_long > m && w >= PSD_TRAIN_LONG_MINW && st.train_want >= PSD_TRAIN_MAX) {
                         // more bulges than slots: the slot of bulge b takes bulge b + S when b is through.  Bulge b + S
                         // enters S s / nb ticks after bulge b, which needs (i - l) / nb + 1 ticks for its sweep and one
                         // to turn around — with two ticks to spare, or the train stays at one bulge per slot
