@@ -27,7 +27,8 @@ enum {
     PSD_PH_NEXT = 5,
     PSD_PH_FINAL = 6,
     PSD_PH_DONE = 7,
-    // multishift trains (on by default: up to 32 bulges, psd_set_train / PSD_TRAIN): the leader waits for the cursors
+    // multishift trains (on by default: up to 32 bulges in the single-range mode, 64 cursor slots and longer trains under
+    // the multi-block scheduler; psd_set_train / PSD_TRAIN): the leader waits for the cursors
     // behind it (TWAIT); a cursor waits for its start (CWAIT), runs QR windows, and ends in CDONE
     PSD_PH_TWAIT = 8,
     PSD_PH_CWAIT = 9,
@@ -801,7 +802,7 @@ PSD_D void psd_rq_decide(const psd_rparams& P, psd_rstate& st, double* red, int*
 // ------------------------------------------------------------------------------------------------
 // Multishift trains (the default iteration strategy on large active blocks, psd_set_train / PSD_TRAIN).
 // A train is m double-shift sweeps whose shift pairs are the eigenvalues of the trailing 2m x 2m block of the product,
-// fixed before the first sweep starts.  The sweeps run as m cursors two windows apart: cursor 0 is the ordinary state
+// fixed before the first sweep starts.  The sweeps run as m cursors nb + 4 positions (or two windows) apart: cursor 0 is the ordinary state
 // machine (the leader), cursors 1..m-1 are psd_rq_cursor_step launches with their own state, lists and descriptor.
 
 // first column of (P - s1)(P - s2) at the top of the active block (PSD.jl:768-803) for the shift pair `sh`
@@ -1019,7 +1020,7 @@ PSD_D bool psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
                 rt1i = rt2i = 0.0;
             }
         }
-        // multishift train: m bulges if the active block leaves room for cursors two windows apart
+        // multishift train: m bulges if the active block leaves room for cursors nb + 4 positions (cgap 2: two windows) apart
         st.train_n = 1;
         if (st.train_want >= 2 && P.cst != nullptr) {
             // Window width of this train: nb positions per window cost a tick of about nb p c + o (c: one position of one
@@ -1983,9 +1984,8 @@ PSD_D void psd_rq_cursor_body(const psd_rparams& P, int b) {
         return;
     }
     if (st.phase == PSD_PH_CWAIT) {
-        // Cursor b chases its first window exactly 2 b ticks after the leader's: consecutive windows of a sweep overlap
-        // in four positions, so two ticks put a whole finished window (chase and bulk update, both complete at the
-        // tick barrier) between neighbours.  A fixed offset, not a look at the predecessor's progress: the
+        // Cursor b enters at the tick its schedule says (psd_cursor_schedule: nb + 4 positions, or two whole windows, behind
+        // its predecessor for the whole sweep).  A fixed schedule, not a look at the predecessor's progress: the
         // predecessor's state is being written while this kernel runs.
         if (P.tick < st.cstart) return;
         double h11, h12, h21, h22, h32;
