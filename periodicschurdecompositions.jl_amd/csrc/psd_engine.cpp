@@ -936,7 +936,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 Pprev.tr = P.tr + (size_t)(par ^ 1) * PSD_SLOTS * p * PSD_TR_CAP;
             }
             // (multi-block: in front of the chase launch the product bands of the wide decisions pending, spread over the chip)
-            if (mb && Pq.bandinfo) PSD_LAUNCH(psd_rq_band, psd_dim3((n + 63) / 64, PSD_SLOTS), 64, 0, c->stream, Pq, n, p);
+            if (mb && Pq.bandinfo && n >= PSD_DECIDE_YIELD) PSD_LAUNCH(psd_rq_band, psd_dim3((n + 63) / 64, PSD_SLOTS), 64, 0, c->stream, Pq, n, p);
 #ifndef PSD_HOSTSIM
             const bool sample = c->profile && ((launched & 15) == 0);  // HIP events around the chase launch alone
             if (sample) {
