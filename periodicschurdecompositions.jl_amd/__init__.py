@@ -586,11 +586,13 @@ class Engine:
             return PeriodicSchur(Ts, Zr, lam, "L", p, st, slog)
         return PeriodicSchur(H, Z, lam, "R", 1, st, slog)
 
-    def pschur_hess_batch_(self, problems, wantT=True, wantZ=True, maxitfac=30):
+    def pschur_hess_batch_(self, problems, wantT=True, wantZ=True, maxitfac=30, infos_out=None):
         """pschur!(H1, Hs; wantT, wantZ, Q, maxitfac) (src/PeriodicSchurDecompositions.jl:322-330) for a list of
         problems of equal shape in ONE call (psd_d_pschur_hess_batch: what src/krylov.jl:575-592,800-829 issues one
         by one).  `problems`: list of (H1, Hs) or (H1, Hs, Q); matrices are overwritten.  Returns a list of
-        PeriodicSchur; a problem that fails to converge raises like the single call, after all have run."""
+        PeriodicSchur; a problem that fails to converge raises like the single call, after all have run — the other
+        problems of the batch are complete then (a failure ends only the problem it occurs in).  `infos_out`: a list
+        that receives the per-problem info codes instead (nothing is raised for a failed problem then)."""
         nb = len(problems)
         if nb == 0:
             return []
@@ -622,6 +624,9 @@ class Engine:
         for q in range(nb):
             Z = Qall[q * p:(q + 1) * p] if wantZ else []
             out.append(PeriodicSchur(Hall[q * p:(q + 1) * p], Z, wr[q] + 1j * wi[q], "R", 1, st))
+        if infos_out is not None:
+            infos_out[:] = [int(infos[q]) for q in range(nb)]
+            return out
         for q in range(nb):
             self._raise(infos[q])
         return out

@@ -3,6 +3,16 @@
 
 namespace {
 
+// device allocation freed on every way out of the function that owns it
+struct psd_devbuf {
+    void* p = nullptr;
+    ~psd_devbuf() {
+        if (p) psd_rt_free(p);
+    }
+    int alloc(size_t bytes) { return psd_rt_malloc(&p, bytes); }
+    double* d() const { return (double*)p; }
+};
+
 // T, Z, A: [p][n][n] device blocks in USER order (ES doubles per element).  err[p] (host) receives the normalized
 // factorization errors, orth[p] / tri[p] (host, optional) the orthogonality and triangularity norms.
 template <bool CPLX>
@@ -11,9 +21,10 @@ int checkpsd_dev(psd_ctx* c, int n, int p, const double* dT, const double* dZ, c
                  double* tri, int* ok) {
     constexpr int E = CPLX ? 2 : 1;
     const size_t nn = (size_t)n * n * E;
-    double *dW = nullptr, *dacc = nullptr;
-    PSD_CHECK(psd_rt_malloc((void**)&dW, nn * sizeof(double)));
-    PSD_CHECK(psd_rt_malloc((void**)&dacc, sizeof(double) * 5 * (size_t)p));
+    psd_devbuf bW, bacc;
+    PSD_CHECK(bW.alloc(nn * sizeof(double)));
+    PSD_CHECK(bacc.alloc(sizeof(double) * 5 * (size_t)p));
+    double *dW = bW.d(), *dacc = bacc.d();
     PSD_CHECK(psd_rt_memset(dacc, 0, sizeof(double) * 5 * (size_t)p, c->stream));
     const bool left = orient == 'L';
     const int tiles = (n + PSD_CK_TM - 1) / PSD_CK_TM;
@@ -48,8 +59,6 @@ int checkpsd_dev(psd_ctx* c, int n, int p, const double* dT, const double* dZ, c
     PSD_CHECK(psd_rt_d2h(acc.data(), dacc, sizeof(double) * 5 * (size_t)p, c->stream));
     PSD_CHECK(psd_rt_sync(c->stream));
     PSD_CHECK(psd_rt_last_error());
-    psd_rt_free(dW);
-    psd_rt_free(dacc);
     const double eps = PSD_DBL_EPS;
     bool good = true;
     for (int l = 0; l < p; ++l) {
@@ -82,24 +91,22 @@ int checkpsd_host(psd_ctx* c, int n, int p, double* const* T, double* const* Z, 
     if (!err) return *info = -13;
     constexpr int E = CPLX ? 2 : 1;
     const size_t nn = (size_t)n * n * E;
-    double *dT = nullptr, *dZ = nullptr, *dA = nullptr, *dwi = nullptr;
-    PSD_CHECK(psd_rt_malloc((void**)&dT, nn * p * sizeof(double)));
-    PSD_CHECK(psd_rt_malloc((void**)&dZ, nn * p * sizeof(double)));
-    PSD_CHECK(psd_rt_malloc((void**)&dA, nn * p * sizeof(double)));
+    psd_devbuf bT, bZ, bA, bwi;
+    PSD_CHECK(bT.alloc(nn * p * sizeof(double)));
+    PSD_CHECK(bZ.alloc(nn * p * sizeof(double)));
+    PSD_CHECK(bA.alloc(nn * p * sizeof(double)));
+    double *dT = bT.d(), *dZ = bZ.d(), *dA = bA.d(), *dwi = nullptr;
     for (int l = 0; l < p; ++l) {
         PSD_CHECK(psd_rt_h2d(dT + l * nn, T[l], nn * 8, c->stream));
         PSD_CHECK(psd_rt_h2d(dZ + l * nn, Z[l], nn * 8, c->stream));
         PSD_CHECK(psd_rt_h2d(dA + l * nn, A[l], nn * 8, c->stream));
     }
     if (wi && !CPLX) {
-        PSD_CHECK(psd_rt_malloc((void**)&dwi, sizeof(double) * (size_t)n));
+        PSD_CHECK(bwi.alloc(sizeof(double) * (size_t)n));
+        dwi = bwi.d();
         PSD_CHECK(psd_rt_h2d(dwi, wi, sizeof(double) * (size_t)n, c->stream));
     }
     const int rc = checkpsd_dev<CPLX>(c, n, p, dT, dZ, dA, S, orient, schurindex, dwi, thresh, strict, err, orth, tri, ok);
-    psd_rt_free(dT);
-    psd_rt_free(dZ);
-    psd_rt_free(dA);
-    if (dwi) psd_rt_free(dwi);
     return *info = rc;
 }
 

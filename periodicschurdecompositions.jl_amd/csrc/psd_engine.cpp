@@ -185,7 +185,7 @@ struct psd_ctx {
         PSD_CHECK(psd_rt_malloc((void**)&tcnt, 2 * sizeof(int) * PSD_SLOTS * (size_t)(p + 8)));
         PSD_CHECK(psd_rt_malloc((void**)&ttr, 2 * sizeof(psd_tr) * PSD_SLOTS * (size_t)p * PSD_TR_CAP));
         PSD_CHECK(psd_rt_malloc((void**)&tgl, sizeof(psd_rglobal)));
-        PSD_CHECK(psd_rt_malloc((void**)&tslotw, sizeof(int) * 8 * PSD_SLOTS));
+        PSD_CHECK(psd_rt_malloc((void**)&tslotw, sizeof(int) * (8 * PSD_SLOTS + PSD_PLAN_INTS)));
         tcap_p = p;
         return 0;
     }
@@ -836,6 +836,22 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     P.ticklog_n = 0;
     P.bandinfo = nullptr;
     P.ccancel = nullptr;
+    P.plan = nullptr;
+    // Every way out of this function (the runaway cap, a failed runtime call) first waits for the second stream — its
+    // Schur-vector launches read the caller's dZ and the lists — and frees the tick log.
+    struct ExitGuard {
+        psd_ctx* c;
+        int** ticklog;
+        ~ExitGuard() {
+#ifndef PSD_HOSTSIM
+            if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+#endif
+            if (*ticklog) {
+                psd_rt_free(*ticklog);
+                *ticklog = nullptr;
+            }
+        }
+    } exit_guard{c, &P.ticklog};
     const char* ticklog_path = getenv("PSD_TICKLOG");  // diagnostics: per tick the longest workgroup of the chase launch
     const int ticklog_cap = 1 << 16;
     if (ticklog_path && nprob == 1) {
@@ -870,7 +886,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
         PSD_CHECK(psd_rt_memset(c->tslotw, 0xff, sizeof(int) * 6 * PSD_SLOTS, c->stream));  // (band info: tick -1)
         PSD_CHECK(psd_rt_memset(c->tslotw, 0, sizeof(int) * 3 * PSD_SLOTS, c->stream));
         PSD_CHECK(psd_rt_memset(c->tslotw + 6 * PSD_SLOTS, 0, sizeof(int) * 2 * PSD_SLOTS, c->stream));  // (stopped-train words)
-        PSD_CHECK(psd_rt_memset(c->tslotw + 6 * PSD_SLOTS, 0, sizeof(int) * 2 * PSD_SLOTS, c->stream));
+        PSD_CHECK(psd_rt_memset(c->tslotw + 8 * PSD_SLOTS, 0xff, sizeof(int) * PSD_PLAN_INTS, c->stream));  // (slot plan: tick -1)
         P.tshift = c->tshift;
         P.desc = c->tdesc;  // slot 0 of the cursor arrays: the fused bulk-update kernel indexes them by cursor
         P.cnt = c->tcnt;
@@ -884,6 +900,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
             P.cdone = c->tslotw + 2 * PSD_SLOTS;
             if (c->band_helper) P.bandinfo = c->tslotw + 3 * PSD_SLOTS;
             if (c->train_stop) P.ccancel = c->tslotw + 6 * PSD_SLOTS;
+            P.plan = c->tslotw + 8 * PSD_SLOTS;
         }
 #ifndef PSD_HOSTSIM
         PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_rq_step_train),
@@ -936,7 +953,12 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 Pprev.tr = P.tr + (size_t)(par ^ 1) * PSD_SLOTS * p * PSD_TR_CAP;
             }
             // (multi-block: in front of the chase launch the product bands of the wide decisions pending, spread over the chip)
-            if (mb && Pq.bandinfo && n >= PSD_DECIDE_YIELD) PSD_LAUNCH(psd_rq_band, psd_dim3((n + 63) / 64, PSD_SLOTS), 64, 0, c->stream, Pq, n, p);
+            // and the slot plan of the tick (last row of the grid; problems narrower than the band threshold launch that row alone)
+            if (mb) {
+                const bool bands = Pq.bandinfo && n >= PSD_DECIDE_YIELD;
+                PSD_LAUNCH(psd_rq_band, psd_dim3(bands ? (n + 63) / 64 : 1, bands ? PSD_SLOTS + 1 : 1), 64,
+                           sizeof(int) * PSD_PLAN_LDS_INTS, c->stream, Pq, n, p);
+            }
 #ifndef PSD_HOSTSIM
             const bool sample = c->profile && ((launched & 15) == 0);  // HIP events around the chase launch alone
             if (sample) {
@@ -1054,8 +1076,9 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 hst.ntrains = hgl.ntrains;
                 hst.ntrainsweeps = hgl.ntrainsweeps;
                 for (int q = 0; q < 6; ++q) hst.cyc[q] = hgl.cyc[q];
-                if (pinfo_out)
-                    for (int q = 0; q < nprob; ++q) pinfo_out[q] = hgl.pinfo[q];
+                if (pinfo_out)  // (a call-wide abort — a list overflow — leaves the problems still active unfinished: say so)
+                    for (int q = 0; q < nprob; ++q)
+                        pinfo_out[q] = (hgl.abort && hgl.pinfo[q] == 0 && hgl.pactive[q] > 0) ? hgl.info : hgl.pinfo[q];
                 break;
             }
             if (launched > cap || (getenv("PSD_DBG_CAP") && launched > atoll(getenv("PSD_DBG_CAP")))) {
@@ -1111,7 +1134,6 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
             for (long long t = 0; t < launched && t < ticklog_cap; ++t) fprintf(fh, "%lld %d %d\n", t, tl[(size_t)t] >> 12, tl[(size_t)t] & 0xfff);
             fclose(fh);
         }
-        psd_rt_free(P.ticklog);
     }
     *st_out = hst;
     if (stats) {

@@ -36,6 +36,7 @@ extern psd_simctx psd_sim;  // the block currently being simulated (serial)
 #define PSD_BLOCK_Y (psd_sim.block.y)
 #define PSD_BLOCK_Z (psd_sim.block.z)
 #define PSD_GRID_X (psd_sim.grid.x)
+#define PSD_GRID_Y (psd_sim.grid.y)
 #define PSD_NTHREADS (psd_sim.nthreads)
 #define PSD_LDS_DECL char* psd_lds = psd_sim.lds
 #define PSD_SYNC() ((void)0)
@@ -128,6 +129,7 @@ typedef dim3 psd_dim3;
 #define PSD_BLOCK_Y ((int)blockIdx.y)
 #define PSD_BLOCK_Z ((int)blockIdx.z)
 #define PSD_GRID_X ((int)gridDim.x)
+#define PSD_GRID_Y ((int)gridDim.y)
 #define PSD_NTHREADS ((int)blockDim.x)
 #define PSD_LDS_DECL extern __shared__ __attribute__((aligned(16))) char psd_lds[]
 #define PSD_SYNC() __syncthreads()

@@ -128,6 +128,8 @@ struct psd_rstate {
     // once per slot count.  train_S: cursor slots of the train; train_ms: distinct shift pairs (bulge b uses pair
     // b mod train_ms); train_long: bulges wanted per train (psd_rq_init).
     int train_S, train_ms, train_long, train_wdiv;  // (train_wdiv: a long train has at most w / train_wdiv bulges)
+    // slots of this leader's share of the tick's slot plan (psd_rq_plan) already taken in launch plan_tick
+    int plan_tick, plan_used;
 };
 
 // global words of the multi-block scheduler
@@ -192,7 +194,20 @@ struct psd_rparams {
     // multi-block, long trains: [2][PSD_SLOTS] per LEADER slot — 1 once a bulge of its running train has found the
     // bottom of the range converged (no further bulge of the train enters), and the number of bulges cancelled that way
     int* ccancel;
+    // multi-block: the slot plan of the tick, written by psd_rq_plan in front of every chase launch from the slot words
+    // as the previous launch left them (see PSD_PLAN_*): which free slots each leader may claim in this launch, and
+    // the snapshots of cdone / ccancel the workgroups of the launch read.  Nothing a workgroup decides in a launch
+    // depends on what another workgroup of the SAME launch has done so far: the schedule is reproducible run to run.
+    int* plan;
 };
+// layout of psd_rparams::plan (ints): share of leader slot s = free slots PSD_PLAN_FREE[first[s] .. first[s] + count[s])
+#define PSD_PLAN_FIRST 0
+#define PSD_PLAN_COUNT (PSD_SLOTS)
+#define PSD_PLAN_FREE (2 * PSD_SLOTS)
+#define PSD_PLAN_CDONE (3 * PSD_SLOTS)
+#define PSD_PLAN_CCANCEL (4 * PSD_SLOTS)
+#define PSD_PLAN_TICK (5 * PSD_SLOTS)
+#define PSD_PLAN_INTS (5 * PSD_SLOTS + 8)
 #define PSD_TSHIFT_STRIDE (4 * PSD_TRAIN_MAX + 8)
 #define PSD_TRAIN_LONG_MINW 64  // narrower ranges keep one bulge per slot (a long train there is sweeps past convergence)
 #define PSD_DECIDE_YIELD 128  // active-range width from which the band of a decision comes from psd_rq_band (multi-block mode)
@@ -448,44 +463,44 @@ PSD_D void psd_log(const psd_rparams& P, psd_rstate& st, int kind, int l, int i)
 // leader's train.  A slot's workgroup is the only one that reads its state, and it starts doing so in the launch AFTER
 // the one that wrote it (epoch < tick), so state never crosses workgroups inside a launch; what does are the role
 // words (agent-scope CAS), the per-leader counters of finished cursors and the counters of psd_rglobal.
-PSD_D int psd_mb_claim(const psd_rparams& P, int self) {  // (one lane)
-    for (int s = 0; s < PSD_SLOTS; ++s) {
-        if (s == self) continue;
-        if (psd_atomic_load(P.role + s) != PSD_ROLE_FREE) continue;
-        if (psd_atomic_cas(P.role + s, PSD_ROLE_FREE, PSD_ROLE_CLAIMED) == PSD_ROLE_FREE) {
-            psd_atomic_max(&P.gl->nslotmax, s + 1);
-            return s;
-        }
-    }
-    return -1;
+// Claims come out of the leader's share of the tick's plan (psd_rq_plan): the slots of a share were FREE when the
+// previous launch ended and belong to no other share, so no claim of this launch competes with another (round 2 took
+// whatever a CAS scan found free at that moment: train sizes, and with them sweep counts, changed from run to run).
+PSD_D int psd_mb_share_left(const psd_rparams& P, const psd_rstate& st, int& base) {  // (any lane; uniform)
+    if (P.plan == nullptr || P.plan[PSD_PLAN_TICK] != P.tick) return 0;
+    const int used = (st.plan_tick == P.tick) ? st.plan_used : 0;
+    base = P.plan[PSD_PLAN_FIRST + st.slot] + used;
+    const int left = P.plan[PSD_PLAN_COUNT + st.slot] - used;
+    return (left > 0) ? left : 0;
 }
-// Up to `want` free slots at once, one lane per slot (a train of 64 bulges claimed them one by one before: 63 scans of
-// the role words by one lane, milliseconds of dependent atomics).  flags: PSD_SLOTS ints of LDS scratch; the slots go to
-// list[0..], the count is returned in *count (both LDS).  Slots taken beyond `want` are handed back untouched.
-PSD_D void psd_mb_claim_many(const psd_rparams& P, int self, int want, int* flags, int* list, int* count) {
+PSD_D void psd_mb_share_take(const psd_rparams& P, psd_rstate& st, int k) {  // (every lane, uniform)
+    if (k <= 0) return;
+    st.plan_used = ((st.plan_tick == P.tick) ? st.plan_used : 0) + k;
+    st.plan_tick = P.tick;
+}
+PSD_D int psd_mb_claim(const psd_rparams& P, const psd_rstate& st) {  // (one lane; the caller books it with psd_mb_share_take)
+    int base = 0;
+    if (psd_mb_share_left(P, st, base) < 1) return -1;
+    const int s = P.plan[PSD_PLAN_FREE + base];
+    psd_atomic_store(P.role + s, PSD_ROLE_CLAIMED);
+    psd_atomic_max(&P.gl->nslotmax, s + 1);
+    return s;
+}
+// Up to `want` slots of the share at once.  The slots go to list[0..], the count is returned in *count (both LDS).
+PSD_D void psd_mb_claim_many(const psd_rparams& P, psd_rstate& st, int want, int* list, int* count) {
     PSD_SYNC();
-    PSD_PAR_FOR(s, PSD_SLOTS) {
-        int got = 0;
-        if (s != self && psd_atomic_load(P.role + s) == PSD_ROLE_FREE &&
-            psd_atomic_cas(P.role + s, PSD_ROLE_FREE, PSD_ROLE_CLAIMED) == PSD_ROLE_FREE)
-            got = 1;
-        flags[s] = got;
+    int base = 0;
+    int k = psd_mb_share_left(P, st, base);
+    if (k > want) k = want;
+    if (k < 0) k = 0;
+    PSD_PAR_FOR(q, k) {
+        const int s = P.plan[PSD_PLAN_FREE + base + q];
+        psd_atomic_store(P.role + s, PSD_ROLE_CLAIMED);
+        list[q] = s;
+        if (q == k - 1) psd_atomic_max(&P.gl->nslotmax, s + 1);  // (the free list ascends)
     }
-    PSD_SYNC();
-    PSD_ONE {
-        int k = 0, top = 0;
-        for (int s = 0; s < PSD_SLOTS; ++s) {
-            if (!flags[s]) continue;
-            if (k < want) {
-                list[k++] = s;
-                top = s + 1;
-            } else {
-                psd_atomic_store(P.role + s, PSD_ROLE_FREE);
-            }
-        }
-        if (k > 0) psd_atomic_max(&P.gl->nslotmax, top);
-        *count = k;
-    }
+    PSD_ONE { *count = k; }
+    psd_mb_share_take(P, st, k);
     PSD_SYNC();
 }
 // hands a slot back: everything this workgroup stored must be out before another workgroup may reuse the slot
@@ -500,7 +515,7 @@ PSD_D void psd_mb_release_slot(const psd_rparams& P, int s) {  // (one lane)
 PSD_D void psd_mb_spawn(const psd_rparams& P, psd_rstate& st, int* bc) {
     PSD_SYNC();
     PSD_ONE {
-        const int s = psd_mb_claim(P, st.slot);
+        const int s = psd_mb_claim(P, st);
         if (s >= 0) {
             psd_rstate cs = st;
             cs.slot = s;
@@ -519,6 +534,8 @@ PSD_D void psd_mb_spawn(const psd_rparams& P, psd_rstate& st, int* bc) {
             cs.maxits = 0;
             cs.nsweeps = cs.nrqpass = cs.ndefl1 = cs.ndefl2 = cs.nwindows = cs.nlog = 0;
             cs.ntrains = cs.ntrainsweeps = 0;
+            cs.plan_tick = -1;
+            cs.plan_used = 0;
             for (int q = 0; q < 6; ++q) cs.cyc[q] = 0;
             P.cst[s] = cs;
             psd_atomic_add(&P.gl->nactive, 1);
@@ -529,7 +546,10 @@ PSD_D void psd_mb_spawn(const psd_rparams& P, psd_rstate& st, int* bc) {
         bc[0] = s;
     }
     PSD_SYNC();
-    if (bc[0] >= 0) st.lo = st.l;
+    if (bc[0] >= 0) {
+        st.lo = st.l;
+        psd_mb_share_take(P, st, 1);
+    }
     PSD_SYNC();
 }
 // a leader whose range is exhausted: totals to psd_rglobal, the last one alive finishes the decomposition
@@ -574,7 +594,84 @@ PSD_D void psd_mb_finish_leader(const psd_rparams& P, psd_rstate& st, int* bc) {
 // w = 1024, p = 64, three windows' worth of chase with every other slot waiting for the tick to end.  Here the same
 // rows are spread over the chip in front of the chase launch; psd_rq_decide finds them through P.bandinfo.  Same
 // recurrence, same order of operations per row (PSD.jl:475-495,507-516).  grid = (ceil(n / 64), PSD_SLOTS), 64 threads.
+// The slot plan of a tick (one workgroup of 64 lanes = slots, the last row of psd_rq_band's grid; runs between two chase
+// launches, so the slot words and states it reads are at rest).  Candidates are the leaders that may start a train or
+// hand a range over in the coming launch (any phase from which PSD_PH_SHIFT can be reached before the workgroup
+// emits); each gets a share of the free slots sized by the widest range it can decide on, the widest range first.
+#define PSD_PLAN_LDS_INTS (5 * PSD_SLOTS)
+PSD_D void psd_rq_plan_body(const psd_rparams& P) {
+    PSD_LDS_DECL;
+    int* isfree = (int*)psd_lds;
+    int* cw = isfree + PSD_SLOTS;     // width of a candidate's range (0: no candidate)
+    int* need = cw + PSD_SLOTS;       // slots it may ask for
+    int* order = need + PSD_SLOTS;    // candidates by rank
+    int* nfree = order + PSD_SLOTS;   // [0] free slots
+    PSD_PAR_FOR(s, PSD_SLOTS) {
+        const int role = psd_atomic_load(P.role + s);
+        const int ep = psd_atomic_load(P.epoch + s);
+        isfree[s] = (role == PSD_ROLE_FREE) ? 1 : 0;
+        int w = 0, nd = 0;
+        if (role == PSD_ROLE_LEADER || (role == PSD_ROLE_CLAIMED && ep < P.tick)) {
+            const psd_rstate* x = P.cst + s;
+            const int ph = x->phase;
+            if (x->cursor == 0 && (ph == PSD_PH_DECIDE || ph == PSD_PH_SHIFT || ph == PSD_PH_DEFLATE || ph == PSD_PH_NEXT)) {
+                w = x->i - x->lo + 1;
+                if (w < 1) w = 1;
+                // most slots psd_rq_shift can ask for on a range of width <= w: the long-train pipeline at the
+                // narrowest window it considers, plus one for a hand-over (psd_mb_spawn)
+                int nbm = x->Wmax - 4;
+                if (nbm > 8) nbm = 8;
+                if (nbm < 1) nbm = 1;
+                nd = (w + 4 * nbm + 3) / (nbm + 4) + 1;
+                if (nd > x->train_want) nd = x->train_want;
+                if (nd > PSD_TRAIN_MAX - 1) nd = PSD_TRAIN_MAX - 1;
+                if (nd < 0) nd = 0;
+                nd += 1;
+            }
+        }
+        cw[s] = w;
+        need[s] = nd;
+        P.plan[PSD_PLAN_CDONE + s] = psd_atomic_load(P.cdone + s);
+        P.plan[PSD_PLAN_CCANCEL + s] = (P.ccancel != nullptr) ? psd_atomic_load(P.ccancel + s) : 0;
+    }
+    PSD_SYNC();
+    PSD_PAR_FOR(s, PSD_SLOTS) {
+        // position of slot s among the free slots (ascending) and among the candidates (widest first, then by slot)
+        int fidx = 0, rank = 0;
+        const int w = cw[s];
+        for (int t = 0; t < PSD_SLOTS; ++t) {
+            if (t < s && isfree[t]) fidx += 1;
+            if (w > 0 && cw[t] > 0 && (cw[t] > w || (cw[t] == w && t < s))) rank += 1;
+        }
+        if (isfree[s]) P.plan[PSD_PLAN_FREE + fidx] = s;
+        if (s == PSD_SLOTS - 1) nfree[0] = fidx + isfree[s];
+        if (w > 0) order[rank] = s;
+    }
+    PSD_SYNC();
+    PSD_PAR_FOR(s, PSD_SLOTS) {
+        int first = 0, cnt = 0;
+        const int w = cw[s];
+        if (w > 0) {
+            int rank = 0;
+            for (int t = 0; t < PSD_SLOTS; ++t)
+                if (cw[t] > 0 && (cw[t] > w || (cw[t] == w && t < s))) rank += 1;
+            for (int r = 0; r < rank; ++r) first += need[order[r]];
+            const int nf = nfree[0];
+            if (first > nf) first = nf;
+            cnt = need[s];
+            if (cnt > nf - first) cnt = nf - first;
+        }
+        P.plan[PSD_PLAN_FIRST + s] = first;
+        P.plan[PSD_PLAN_COUNT + s] = cnt;
+    }
+    PSD_ONE { P.plan[PSD_PLAN_TICK] = P.tick; }
+}
+
 PSD_KERNEL_B(64) psd_rq_band(psd_rparams P, int n, int p) {
+    if (P.plan != nullptr && PSD_BLOCK_Y == PSD_GRID_Y - 1) {  // (grid.y = slots with a band row + 1)
+        if (PSD_BLOCK_X == 0) psd_rq_plan_body(P);
+        return;
+    }
     const int s = PSD_BLOCK_Y, chunk = PSD_BLOCK_X;
     // (a leader, or a slot a leader was spawned into in an earlier launch: it goes live with the chase launch behind this one)
     const int role = psd_atomic_load(P.role + s);
@@ -642,6 +739,13 @@ PSD_D void psd_rq_decide(const psd_rparams& P, psd_rstate& st, double* red, int*
     const int n = st.n, p = st.p, i = st.i, lo = st.l;
     const int NT = PSD_NTHREADS;
     if (!(st.its < st.maxitleft)) {  // PSD.jl:471,891-893
+        if (st.mb && P.nprob > 1) {
+            // batch: only this problem has failed.  Its info word says so; this range ends like an exhausted one (the
+            // leader counts itself out, the slot goes back), the other problems of the call run on.
+            PSD_ONE { psd_atomic_store(&P.gl->pinfo[st.prob], i); }
+            st.phase = PSD_PH_FINAL;
+            return;
+        }
         st.info = i;
         st.phase = PSD_PH_DONE;
         if (st.mb) {
@@ -1103,7 +1207,7 @@ PSD_D bool psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
                         if (sneed > wantslots) wantslots = sneed;
                         if (wantslots > PSD_TRAIN_MAX - 1) wantslots = PSD_TRAIN_MAX - 1;
                     }
-                    psd_mb_claim_many(P, st.slot, wantslots, (int*)work, bc + 3, bc);  // (the staging area of the shifts is free again)
+                    psd_mb_claim_many(P, st, wantslots, bc + 3, bc);
                     PSD_DBG_ADD(4);
                     PSD_ONE {
                         bc[0] += 1;  // (with the leader)
@@ -1874,8 +1978,8 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
             }
             case PSD_PH_TWAIT: {  // the leader's sweep is done: wait for the cursors of the train, then go on
                 bool all = true;
-                if (st.mb) {  // a cursor adds one to its leader's counter after its last window
-                    all = psd_atomic_load(P.cdone + st.slot) == st.train_n - 1;
+                if (st.mb) {  // a cursor adds one to its leader's counter after its last window (read as the previous launch left it)
+                    all = ((P.plan != nullptr) ? P.plan[PSD_PLAN_CDONE + st.slot] : psd_atomic_load(P.cdone + st.slot)) == st.train_n - 1;
                 } else {  // a cursor counts itself in after its last store; its slot's state is then complete
                     all = psd_atomic_load(P.cep + PSD_TRAIN_MAX) == st.train_n - 1;
                     if (all) psd_acquire_fence();
@@ -1972,8 +2076,11 @@ PSD_D void psd_rq_cursor_body(const psd_rparams& P, int b) {
     double* ldsd = (double*)psd_lds;
     const size_t winb = (size_t)st.p * psd_win_area(st.Wmax);
     int* lcnt = (int*)(ldsd + winb + PSD_STEP_NT) + 2 * PSD_STEP_NT;
-    if (st.phase == PSD_PH_CWAIT && st.mb && P.ccancel != nullptr && st.train_S > 0 &&
-        psd_atomic_load(P.ccancel + st.parent)) {
+    // (the stop word as the previous launch left it: a bulge that stops the train in THIS launch is seen from the next one
+    //  on by every workgroup alike, whatever the order the workgroups of a launch happen to run in)
+    const bool stopped = st.mb && P.ccancel != nullptr &&
+                         ((P.plan != nullptr) ? P.plan[PSD_PLAN_CCANCEL + st.parent] : psd_atomic_load(P.ccancel + st.parent)) != 0;
+    if (st.phase == PSD_PH_CWAIT && st.train_S > 0 && stopped) {
         // the train was stopped (psd_rq_qr_window): this bulge and the later ones of this slot do not enter
         PSD_ONE {
             const int k = 1 + (st.train_n - 1 - b) / st.train_S;
@@ -1998,7 +2105,7 @@ PSD_D void psd_rq_cursor_body(const psd_rparams& P, int b) {
     // long train: this slot goes on as bulge b + S (its report below counts bulge b in)
     bool rearm = st.mb && st.phase == PSD_PH_CDONE && st.train_S > 0 && b + st.train_S <= st.train_n - 1;
     int ncancel = 0;  // later bulges of this slot that a stopped train drops
-    if (rearm && P.ccancel != nullptr && psd_atomic_load(P.ccancel + st.parent)) {
+    if (rearm && stopped) {
         ncancel = (st.train_n - 1 - b) / st.train_S;
         rearm = false;
     }
@@ -2757,6 +2864,8 @@ PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W,
             st.parent = -1;
             st.lo = 1;
             st.train_key = 0;
+            st.plan_tick = -1;
+            st.plan_used = 0;
             st.prob = pr;
             for (int q = 0; q < PSD_TRAIN_MAX; ++q) st.cslots[q] = 0;
             if (mb) {

@@ -1369,6 +1369,34 @@ def case_pschur_hess_batch(eng, shapes):
         eng.pschur_hess_batch_([(W[0], W[1:]), (W[0][:5, :5].copy(order="F"), [w[:5, :5].copy(order="F") for w in W[1:]])])
 
 
+def case_pschur_hess_batch_one_fails(eng, n=24, p=3):
+    """A batch in which ONE problem exhausts its sweep budget (maxitfac = 2: 2 n sweeps, PSD.jl:471,891-893; every deflation
+    step takes at least one off it, PSD.jl:1057-1060): its info says
+    so, the other problems of the call are complete and correct (the failure used to stop the whole batch
+    with info = 0 for the unfinished problems)."""
+    def easy(seed):  # one 3 x 3 block in an otherwise triangular H1: a handful of sweeps
+        A = _hess_ut_problem(n, p, seed)
+        sub = np.diag(A[0], -1).copy()
+        keep = np.zeros_like(sub)
+        for k in (9, 10):
+            keep[k] = sub[k]
+        A[0] = np.asfortranarray(np.triu(A[0]) + np.diag(keep, -1))
+        return A
+    probs = [easy(41), _hess_ut_problem(n, p, 42), easy(43), easy(44)]
+    Ws = [[a.copy(order="F") for a in A] for A in probs]
+    infos = []
+    out = eng.pschur_hess_batch_([(W[0], W[1:]) for W in Ws], maxitfac=2, infos_out=infos)
+    assert len(infos) == 4 and infos[0] == 0 and infos[2] == 0 and infos[3] == 0, infos
+    assert infos[1] != 0, infos  # (a full random Hessenberg problem of order 24 needs more than 48 sweeps)
+    for q in (0, 2, 3):
+        pt.pschur_check(probs[q], out[q], tol=100, check_lam=False)
+        P = pt.product(probs[q])
+        assert pt.match_eigs(np.linalg.eigvals(P), out[q].values) <= 1e-10 * np.linalg.norm(P, 2)
+    with pytest.raises(Exception):  # the default form raises for the failed problem after all have run
+        Ws = [[a.copy(order="F") for a in A] for A in probs]
+        eng.pschur_hess_batch_([(W[0], W[1:]) for W in Ws], maxitfac=2)
+
+
 def case_formq_blocked(make_engine, sizes):
     """Blocked (compact-WY, csrc/psd_formq2.h) against reflector-by-reflector (csrc/psd_hess.h) materialisation of the
     Q_j (PSD.jl:136-143): both engines reduce and iterate the same H, so their Z_j differ by the rounding of Q_j only.

@@ -214,6 +214,11 @@ def test_pschur_hess_batch(gpu_engine):
     ec.case_pschur_hess_batch(gpu_engine, [(3, 10, 2), (16, 40, 4), (32, 24, 3), (6, 64, 8)])
 
 
+def test_pschur_hess_batch_one_fails(gpu_engine):
+    """a problem of a batch that exhausts its sweep budget ends alone; the others are complete"""
+    ec.case_pschur_hess_batch_one_fails(gpu_engine)
+
+
 def test_formq_blocked(monkeypatch):
     """compact-WY Q formation on the matrix cores (csrc/psd_formq2.h) against the reflector-by-reflector kernel:
     identical T and eigenvalues, Z equal to rounding, orthogonal to 10 eps n; sizes off the 32 / 64 tiling"""

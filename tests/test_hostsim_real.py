@@ -93,6 +93,10 @@ def test_pschur_hess_batch(sim_engine):
     ec.case_pschur_hess_batch(sim_engine, [(3, 10, 2), (5, 20, 3), (4, 33, 1)])
 
 
+def test_pschur_hess_batch_one_fails(sim_engine):
+    ec.case_pschur_hess_batch_one_fails(sim_engine)
+
+
 def test_far_apply_overlap_order(built, monkeypatch):
     """PSD_OVERLAP=1 (opt-in): the far part of a tick's bulk update — the rows role beyond the columns the next windows
     reach, cut so that it never splits another window's column range, and the Z role — is applied one tick late, after
