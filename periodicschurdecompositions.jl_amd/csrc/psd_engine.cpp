@@ -5,6 +5,7 @@
 #include "psd_hess2.h"
 #include "psd_formq2.h"
 #include "psd_real_qr.h"
+#include "psd_apply2.h"
 #include "psd_zhess.h"
 #include "psd_zqz.h"
 #include "psd_zord.h"
@@ -241,6 +242,10 @@ struct psd_ctx {
 #endif
     int apply_worklist = 1;   // PSD_APPLY_WL=0: the grid-per-cursor bulk-apply kernels
     int apply_wl_grid = 2048; // workgroups of the work-list bulk apply (PSD_APPLY_WL_GRID)
+    int apply_wl2 = 1;        // register-line form of the work-list bulk apply (psd_apply2.h; PSD_APPLY_WL2=0: round 2's kernel)
+    int apply_wl2_grid = 1024;  // its grid of four-wave workgroups (PSD_APPLY_WL2_GRID)
+    size_t wl2_lds_set[3] = {0, 0, 0};
+    int apply_wl2_wpe = 4;    // waves per SIMD its register allocation is held to at W <= 17 (PSD_APPLY_WL2_WPE=3: no spills)
     psd_rostate* rost = nullptr;
     psd_tq* rotq = nullptr;
     unsigned char* rosel = nullptr;
@@ -787,6 +792,38 @@ int formq_dev(psd_ctx* c, int n, int p, const double* dH, const double* dtau, do
     return 0;
 }
 
+// One launch of the work-list bulk apply (pass 0: rows + Z roles, pass 1: column roles; modes: psd_rq_apply_wl).  W: the
+// window width of the call (its spans are at most W).  grid_old: workgroups of the single-wave form.
+int launch_apply_wl(psd_ctx* c, psd_stream_t stream, const psd_rparams& Pq, int n, int p, int pass, int NSL, int zlo1, int zhi1,
+                    int mode, int W, int grid_old) {
+#ifndef PSD_HOSTSIM
+    if (c->apply_wl2) {
+        const int g = c->apply_wl2_grid;
+        void (*kern)(psd_rparams, int, int, int, int, int, int, int, int) = nullptr;
+        size_t lb = 0;
+        int slot = 0;
+        if (W <= 17) {
+            lb = psd_wl2_lds_bytes<17>();
+            if (c->apply_wl2_wpe == 3) { kern = psd_rq_apply_wl2<17, 3>; slot = 1; }
+            else { kern = psd_rq_apply_wl2<17, 4>; slot = 0; }
+        } else {
+            lb = psd_wl2_lds_bytes<32>();
+            kern = psd_rq_apply_wl2<32, 2>;
+            slot = 2;
+        }
+        if (lb > c->wl2_lds_set[slot]) {
+            PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+            c->wl2_lds_set[slot] = lb;
+        }
+        hipLaunchKernelGGL(kern, dim3(g), dim3(PSD_WL2_NT), lb, stream, Pq, n, p, p + 8, pass, NSL, zlo1, zhi1, mode);
+        return 0;
+    }
+#endif
+    (void)W;
+    PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(grid_old), PSD_WL_NT, psd_wl_lds_bytes(), stream, Pq, n, p, p + 8, pass, NSL, zlo1, zhi1, mode);
+    return 0;
+}
+
 // PSD.jl:322-1096 on device.  dH: H_1 Hessenberg, H_j triangular; dZ: Q_j (or identity) or null.
 // nprob > 1 (batch, psd_d_pschur_hess_batch): dH / dZ hold nprob problems back to back, bws the per-problem band arrays
 // hdiag | hsub | hsup | Pd | Pe | Pf | wr | wi (nprob (n + 8) doubles each) and hnorms (nprob (p + 8)); pinfo_out: info per
@@ -985,19 +1022,15 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 // chip idle — and its lists must not be rewritten before it is done (evF, awaited in front of the chase
                 // that reuses this parity's lists, two ticks on).  The serial simulation runs the Z launch last.
                 const int wl_grid = c->apply_wl_grid;
-                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 0, NSL,
-                           zlo1, zhi1, 3);
-                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 1, NSL,
-                           zlo1, zhi1, 3);
+                PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 3, W, wl_grid));
+                PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 1, NSL, zlo1, zhi1, 3, W, wl_grid));
 #ifndef PSD_HOSTSIM
                 PSD_CHECK(hipEventRecord(c->evE[par], c->stream));
                 PSD_CHECK(hipStreamWaitEvent(c->stream2, c->evE[par], 0));
-                hipLaunchKernelGGL(psd_rq_apply_wl, dim3(c->far_grid > 0 ? c->far_grid : wl_grid), dim3(PSD_WL_NT),
-                                   psd_wl_lds_bytes(), c->stream2, Pq, n, p, p + 8, 0, NSL, zlo1, zhi1, 4);
+                PSD_CHECK(launch_apply_wl(c, c->stream2, Pq, n, p, 0, NSL, zlo1, zhi1, 4, W, c->far_grid > 0 ? c->far_grid : wl_grid));
                 PSD_CHECK(hipEventRecord(c->evF[par], c->stream2));
 #else
-                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 0, NSL,
-                           zlo1, zhi1, 4);
+                PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 4, W, wl_grid));
 #endif
             } else if (ovl) {
                 // Far part of the PREVIOUS tick's bulk update: beside this tick's chases, on the second stream, behind
@@ -1008,45 +1041,35 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 if (launched > 0) {
 #ifndef PSD_HOSTSIM
                     PSD_CHECK(hipStreamWaitEvent(c->stream2, c->evE[par ^ 1], 0));
-                    hipLaunchKernelGGL(psd_rq_apply_wl, dim3(c->far_grid > 0 ? c->far_grid : wl_grid), dim3(PSD_WL_NT),
-                                       psd_wl_lds_bytes(), c->stream2, Pprev, n, p, p + 8, 0, NSL, zlo1, zhi1, 2);
+                    PSD_CHECK(launch_apply_wl(c, c->stream2, Pprev, n, p, 0, NSL, zlo1, zhi1, 2, W, c->far_grid > 0 ? c->far_grid : wl_grid));
                     if (c->ovl_what & 2)
-                        hipLaunchKernelGGL(psd_rq_apply_wl, dim3(c->far_grid > 0 ? c->far_grid : wl_grid), dim3(PSD_WL_NT),
-                                           psd_wl_lds_bytes(), c->stream2, Pprev, n, p, p + 8, 1, NSL, zlo1, zhi1, 2);
+                        PSD_CHECK(launch_apply_wl(c, c->stream2, Pprev, n, p, 1, NSL, zlo1, zhi1, 2, W, c->far_grid > 0 ? c->far_grid : wl_grid));
                     PSD_CHECK(hipEventRecord(c->evF[par ^ 1], c->stream2));
                     PSD_CHECK(hipStreamWaitEvent(c->stream, c->evF[par ^ 1], 0));
 #else
                     if (!getenv("PSD_OVL_DBG")) {
-                        PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pprev, n, p, p + 8, 0,
-                                   NSL, zlo1, zhi1, 2);
-                        PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pprev, n, p, p + 8, 1,
-                                   NSL, zlo1, zhi1, 2);
+                        PSD_CHECK(launch_apply_wl(c, c->stream, Pprev, n, p, 0, NSL, zlo1, zhi1, 2, W, wl_grid));
+                        PSD_CHECK(launch_apply_wl(c, c->stream, Pprev, n, p, 1, NSL, zlo1, zhi1, 2, W, wl_grid));
                     }
 #endif
                 }
                 // near part of this tick's update, before the next tick's chases
                 PSD_LAUNCH(psd_rq_cuts, psd_dim3(1), PSD_WL_NT, 3 * PSD_SLOTS * sizeof(int), c->stream, Pq, NSL, W + 2, c->ovl_what);
-                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 0, NSL,
-                           zlo1, zhi1, 1);
-                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 1, NSL,
-                           zlo1, zhi1, 1);
+                PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 1, W, wl_grid));
+                PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 1, NSL, zlo1, zhi1, 1, W, wl_grid));
 #ifndef PSD_HOSTSIM
                 PSD_CHECK(hipEventRecord(c->evE[par], c->stream));
 #else
                 if (getenv("PSD_OVL_DBG")) {
-                    PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 0, NSL,
-                               zlo1, zhi1, 2);
-                    PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 1, NSL,
-                               zlo1, zhi1, 2);
+                    PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 2, W, wl_grid));
+                    PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 1, NSL, zlo1, zhi1, 2, W, wl_grid));
                 }
 #endif
             } else if (c->apply_worklist || c->shard_world > 1 || mb) {
                 // work-list form: one grid of single-wave workgroups loops over the items of the tick
                 const int wl_grid = c->apply_wl_grid;
-                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 0, NSL,
-                           zlo1, zhi1, 0);
-                PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(wl_grid), PSD_WL_NT, psd_wl_lds_bytes(), c->stream, Pq, n, p, p + 8, 1, NSL,
-                           zlo1, zhi1, 0);
+                PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 0, W, wl_grid));
+                PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 1, NSL, zlo1, zhi1, 0, W, wl_grid));
             } else if (M == 1) {
                 PSD_LAUNCH(psd_rq_apply, psd_dim3(tiles, p, 3), PSD_APPLY_NT, lds_apply, c->stream, P, n, p);
             } else {
@@ -1292,6 +1315,9 @@ int psd_create(psd_ctx** ctx, int device) {
     if (const char* e = getenv("PSD_CGAP")) c->cgap = (atoi(e) == 2) ? 2 : 1;
     if (const char* e = getenv("PSD_APPLY_WL")) c->apply_worklist = atoi(e);
     if (const char* e = getenv("PSD_APPLY_WL_GRID")) c->apply_wl_grid = atoi(e) > 0 ? atoi(e) : 2048;
+    if (const char* e = getenv("PSD_APPLY_WL2")) c->apply_wl2 = atoi(e);
+    if (const char* e = getenv("PSD_APPLY_WL2_GRID")) c->apply_wl2_grid = atoi(e) > 0 ? atoi(e) : 1024;
+    if (const char* e = getenv("PSD_APPLY_WL2_WPE")) c->apply_wl2_wpe = atoi(e);
 #ifdef PSD_HOSTSIM
     c->apply_wl_grid = 3;  // (serial simulation: a few workgroups exercise the item loop)
 #endif
