@@ -16,8 +16,9 @@
 //     flight at once, no LDS tile, the position loop unrolled so that every register index is static;
 //   * rows role (left transforms on columns of H_m): 16-byte loads of row pairs as before, transposed through a
 //     per-wave LDS tile of pitch S + 1 (not 33), then the same register-line routine;
-//   * workgroups of four waves share one staged list (2 KiB) for up to eight tiles; the record that is being applied is
-//     wave-uniform: its position and kind go through v_readfirstlane, so the dispatch is scalar branches;
+//   * the unit of work is the wavefront (four per workgroup, each with its own staged list and tile: no workgroup
+//     barrier per item); the record that is being applied is wave-uniform and lives in scalar registers
+//     (v_readfirstlane), so the dispatch is scalar branches and the multiply-adds take a scalar operand;
 //   * occupancy follows from registers (SP = 17: four waves per SIMD), not from a 17 KiB tile per wave.
 #pragma once
 #ifndef PSD_HOSTSIM
@@ -28,8 +29,8 @@
 #define PSD_WL2_UNI(x) __builtin_amdgcn_readfirstlane(x)
 
 template <int SP>
-PSD_HD size_t psd_wl2_lds_bytes() {
-    return PSD_TR_LDS_BYTES + (size_t)PSD_WL2_WAVES * 64 * (SP + 1) * sizeof(double) + (size_t)(3 * PSD_SLOTS + 8) * sizeof(int);
+PSD_HD size_t psd_wl2_lds_bytes() {  // per wave: its copy of the list and its tile; per workgroup: the item table
+    return (size_t)PSD_WL2_WAVES * (PSD_TR_LDS_BYTES + (size_t)64 * (SP + 1) * sizeof(double)) + (size_t)(3 * PSD_SLOTS + 8) * sizeof(int);
 }
 
 // The record being applied is the same for every lane: all of it lives in scalar registers (v_readfirstlane after the
@@ -260,24 +261,54 @@ PSD_D void psd_wl2_generic_tile(bool rowsrole, const psd_mat<double>& Mx, double
     PSD_WL2_WAVE_FENCE();
 }
 
+// The owner's list into this wavefront's LDS copy (two sentinel records behind its end), classified: +1 positions
+// ascend, -1 descend, 0 neither.  One record per lane (cnt <= 64), no workgroup barrier.
+PSD_D int psd_wl2_stage_wave(const psd_tr* gtr, int cnt, psd_tr* ltr, int lane) {
+    psd_tr tr;
+    if (lane < cnt) {
+        tr = gtr[lane];
+    } else {
+        tr.pos = 0x3fffffff;
+        tr.kind = PSD_TR_G;
+        tr.c0 = 1.0;
+        tr.c1 = tr.c2 = 0.0;
+    }
+    ltr[lane] = tr;
+    if (lane < PSD_TR_LDS_RECS - 64) {
+        psd_tr se = tr;
+        se.pos = 0x3fffffff;
+        se.kind = PSD_TR_G;
+        se.c0 = 1.0;
+        se.c1 = se.c2 = 0.0;
+        ltr[64 + lane] = se;
+    }
+    const int nxt = __shfl_down(tr.pos, 1, 64);
+    const bool in = lane + 1 < cnt;
+    const unsigned long long down = __ballot(in && nxt < tr.pos), up = __ballot(in && nxt > tr.pos);
+    PSD_WL2_WAVE_FENCE();
+    return (down == 0ull) ? 1 : ((up == 0ull) ? -1 : 0);
+}
+
 // Same contract as psd_rq_apply_wl (passes, modes, zlo..zhi: see there).  SP: the largest window span the launch can
 // meet (17 or 32, from the window width the LDS of the chase kernel is laid out for); WPE: waves per SIMD the register
-// allocation is held to (SP = 17: 4 = 128 registers with 8 of them spilled, 3 = 154 without).  grid: any; 256 threads.
+// allocation is held to.  The unit of work is the WAVEFRONT: each of the four waves of a workgroup takes its own items
+// (up to `tpi` tiles of one (slot, owner, role)), stages the owner's list in its own LDS copy and never waits for the
+// others — the workgroup only shares the item table.  grid: any; 256 threads.
 template <int SP, int WPE>
 __global__ void __launch_bounds__(PSD_WL2_NT, WPE) psd_rq_apply_wl2(psd_rparams P, int n, int p, int cstride, int pass, int M, int zlo, int zhi,
                                                                int mode) {
     extern __shared__ __attribute__((aligned(16))) char psd_lds[];
-    psd_tr* ltr = (psd_tr*)psd_lds;
-    int* flags = (int*)(psd_lds + sizeof(psd_tr) * PSD_TR_LDS_RECS);
-    double* tiles = (double*)(psd_lds + PSD_TR_LDS_BYTES);
-    int* ioff = (int*)(tiles + (size_t)PSD_WL2_WAVES * 64 * (SP + 1));  // [M + 1] item offsets, [M] items of role A, [M] of role B
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = PSD_WL2_UNI(tid >> 6);
+    constexpr size_t WAVE_BYTES = PSD_TR_LDS_BYTES + (size_t)64 * (SP + 1) * sizeof(double);
+    psd_tr* ltr = (psd_tr*)(psd_lds + (size_t)wv * WAVE_BYTES);
+    double* tile = (double*)(psd_lds + (size_t)wv * WAVE_BYTES + PSD_TR_LDS_BYTES);
+    int* ioff = (int*)(psd_lds + (size_t)PSD_WL2_WAVES * WAVE_BYTES);  // [M + 1] item offsets, [M] items of role A, [M] of role B
     int* tA = ioff + PSD_SLOTS + 2;
     int* tB = tA + PSD_SLOTS;
     int* tpi_ = tB + PSD_SLOTS;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    double* tile = tiles + (size_t)wv * 64 * (SP + 1);
     const int TLA = (pass == 0) ? 64 : 128;  // lines per tile of role A (pass 0: rows role; pass 1: column role)
     const int TLB = 128;                      // role B: the Schur vectors
+    const int workers = (int)gridDim.x * PSD_WL2_WAVES;
     if (wv == 0) {
         // item table (lane b = slot b): an item = up to `tpi` tiles of one (slot, owner, role); tpi adapts to the tick —
         // a tick of one small window must spread over the chip, a tick of sixty windows must not stage a list per tile
@@ -299,7 +330,7 @@ __global__ void __launch_bounds__(PSD_WL2_NT, WPE) psd_rq_apply_wl2(psd_rparams 
 #pragma unroll
         for (int sft = 32; sft > 0; sft >>= 1) tl += __shfl_xor(tl, sft, 64);
         int tpi = 1;
-        while (tpi < PSD_WL2_TPI && tl >= 2 * (2 * tpi) * (int)gridDim.x) tpi *= 2;
+        while (tpi < PSD_WL2_TPI && tl >= 3 * (2 * tpi) * workers) tpi *= 2;
         const int a = (la + TLA * tpi - 1) / (TLA * tpi), z = (lz + TLB * tpi - 1) / (TLB * tpi);
         const int mine = p * (a + z);
         int incl = mine;
@@ -320,8 +351,7 @@ __global__ void __launch_bounds__(PSD_WL2_NT, WPE) psd_rq_apply_wl2(psd_rparams 
     }
     __syncthreads();
     const int total = PSD_WL2_UNI(ioff[M]), tpi = PSD_WL2_UNI(tpi_[0]);
-    const int wvu = PSD_WL2_UNI(wv);
-    for (int item = (int)blockIdx.x; item < total; item += (int)gridDim.x) {
+    for (int item = (int)blockIdx.x * PSD_WL2_WAVES + wv; item < total; item += workers) {
         int b = 0;
         {
             int lo_ = 0, hi_ = M - 1;
@@ -351,7 +381,7 @@ __global__ void __launch_bounds__(PSD_WL2_NT, WPE) psd_rq_apply_wl2(psd_rparams 
         const psd_tr* gtr = P.tr + ((size_t)b * p + (m - 1)) * PSD_TR_CAP;
         const int S = d.phi - d.plo + 1;
         if (S > SP) {  // (a window's span is at most the width this kernel was chosen for: fail loudly, never skip an update)
-            if (tid == 0 && P.gl != nullptr) {
+            if (lane == 0 && P.gl != nullptr) {
                 psd_atomic_store(&P.gl->info, PSD_LIST_OVERFLOW);
                 psd_atomic_store(&P.gl->abort, 1);
                 psd_atomic_store(&P.gl->done, 1);
@@ -372,11 +402,11 @@ __global__ void __launch_bounds__(PSD_WL2_NT, WPE) psd_rq_apply_wl2(psd_rparams 
         const int g0 = lo + gix * GL;
         const int gl = (hi - g0 + 1 < GL) ? (hi - g0 + 1) : GL;
         const psd_mat<double> Mx = psd_mat<double>{base + ((size_t)d.prob * p + (jm - 1)) * n * n, n};
-        __syncthreads();  // (the previous item's list is no longer in use)
-        const int order = PSD_WL2_UNI(psd_tr_stage(gtr, cnt, ltr, flags));
+        PSD_WL2_WAVE_FENCE();  // (this wave's reads of the previous item's list are done)
+        const int order = PSD_WL2_UNI(psd_wl2_stage_wave(gtr, cnt, ltr, lane));
         if (order != 0) {
             const int ns = (gl + TL - 1) / TL;
-            for (int k = wvu; k < ns; k += PSD_WL2_WAVES) {
+            for (int k = 0; k < ns; ++k) {
                 const int l0 = g0 + k * TL;
                 const int nl = (gl - k * TL < TL) ? (gl - k * TL) : TL;
                 // (one instantiation per direction and tile kind: joined behind a branch, the two directions' copies of
@@ -396,7 +426,7 @@ __global__ void __launch_bounds__(PSD_WL2_NT, WPE) psd_rq_apply_wl2(psd_rparams 
             }
         } else {
             const int ns = (gl + 63) / 64;
-            for (int k = wvu; k < ns; k += PSD_WL2_WAVES) {
+            for (int k = 0; k < ns; ++k) {
                 const int l0 = g0 + k * 64;
                 const int nl = (gl - k * 64 < 64) ? (gl - k * 64) : 64;
                 psd_wl2_generic_tile(role == 0, Mx, tile, SP + 1, d.plo, S, l0, nl, lane, ltr, cnt);

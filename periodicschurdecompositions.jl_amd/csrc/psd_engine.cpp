@@ -242,10 +242,11 @@ struct psd_ctx {
 #endif
     int apply_worklist = 1;   // PSD_APPLY_WL=0: the grid-per-cursor bulk-apply kernels
     int apply_wl_grid = 2048; // workgroups of the work-list bulk apply (PSD_APPLY_WL_GRID)
+    int chase2 = 1;           // two-wave chase of the real periodic QR sweep (psd_c2_run; PSD_C2=0: one wavefront per bulge)
     int apply_wl2 = 1;        // register-line form of the work-list bulk apply (psd_apply2.h; PSD_APPLY_WL2=0: round 2's kernel)
     int apply_wl2_grid = 1024;  // its grid of four-wave workgroups (PSD_APPLY_WL2_GRID)
     size_t wl2_lds_set[3] = {0, 0, 0};
-    int apply_wl2_wpe = 4;    // waves per SIMD its register allocation is held to at W <= 17 (PSD_APPLY_WL2_WPE=3: no spills)
+    int apply_wl2_wpe = 3;    // waves per SIMD its register allocation is held to at W <= 17 (3: what its LDS admits, no spills; PSD_APPLY_WL2_WPE=4)
     psd_rostate* rost = nullptr;
     psd_tq* rotq = nullptr;
     unsigned char* rosel = nullptr;
@@ -804,8 +805,8 @@ int launch_apply_wl(psd_ctx* c, psd_stream_t stream, const psd_rparams& Pq, int 
         int slot = 0;
         if (W <= 17) {
             lb = psd_wl2_lds_bytes<17>();
-            if (c->apply_wl2_wpe == 3) { kern = psd_rq_apply_wl2<17, 3>; slot = 1; }
-            else { kern = psd_rq_apply_wl2<17, 4>; slot = 0; }
+            if (c->apply_wl2_wpe == 4) { kern = psd_rq_apply_wl2<17, 4>; slot = 1; }
+            else { kern = psd_rq_apply_wl2<17, 3>; slot = 0; }
         } else {
             lb = psd_wl2_lds_bytes<32>();
             kern = psd_rq_apply_wl2<32, 2>;
@@ -874,6 +875,10 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     P.bandinfo = nullptr;
     P.ccancel = nullptr;
     P.plan = nullptr;
+    // two-wave chase (psd_c2_run): the command block sits in the reduction scratch behind the window image
+    P.c2off = (c->chase2 && p >= PSD_C2_MINP) ? (int)((size_t)p * psd_win_area(W) * sizeof(double)) : 0;
+    const int c2waves = P.c2off ? 2 : 1;
+    (void)c2waves;
     // Every way out of this function (the runaway cap, a failed runtime call) first waits for the second stream — its
     // Schur-vector launches read the caller's dZ and the lists — and frees the tick log.
     struct ExitGuard {
@@ -1005,11 +1010,11 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
             }
 #endif
             if (M == 1 && !mb)
-                PSD_LAUNCH(psd_rq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
+                PSD_LAUNCH2(psd_rq_step, psd_dim3(1), PSD_STEP_NT, c2waves, lds_step, c->stream, P);
             else if (mb)  // every slot of the scheduler in one launch
-                PSD_LAUNCH(psd_rq_step_mb, psd_dim3(PSD_SLOTS), PSD_STEP_NT, lds_step, c->stream, Pq, p, p + 8);
+                PSD_LAUNCH2(psd_rq_step_mb, psd_dim3(PSD_SLOTS), PSD_STEP_NT, c2waves, lds_step, c->stream, Pq, p, p + 8);
             else  // every cursor of the tick in one launch, one workgroup each
-                PSD_LAUNCH(psd_rq_step_train, psd_dim3(M), PSD_STEP_NT, lds_step, c->stream, P, p, p + 8);
+                PSD_LAUNCH2(psd_rq_step_train, psd_dim3(M), PSD_STEP_NT, c2waves, lds_step, c->stream, P, p, p + 8);
 #ifndef PSD_HOSTSIM
             if (sample) {
                 (void)hipEventRecord(ev1, c->stream);
@@ -1316,6 +1321,7 @@ int psd_create(psd_ctx** ctx, int device) {
     if (const char* e = getenv("PSD_APPLY_WL")) c->apply_worklist = atoi(e);
     if (const char* e = getenv("PSD_APPLY_WL_GRID")) c->apply_wl_grid = atoi(e) > 0 ? atoi(e) : 2048;
     if (const char* e = getenv("PSD_APPLY_WL2")) c->apply_wl2 = atoi(e);
+    if (const char* e = getenv("PSD_C2")) c->chase2 = atoi(e);
     if (const char* e = getenv("PSD_APPLY_WL2_GRID")) c->apply_wl2_grid = atoi(e) > 0 ? atoi(e) : 1024;
     if (const char* e = getenv("PSD_APPLY_WL2_WPE")) c->apply_wl2_wpe = atoi(e);
 #ifdef PSD_HOSTSIM
@@ -3163,5 +3169,88 @@ int psd_z_rphessenberg(psd_ctx* c, int m, int n, int p, double* Ap, double* cons
     return rphessenberg_host<psd_rh_cplx, 16>(c, m, n, p, Ap, A, Q, nq, nqc, info);
 }
 }  // extern "C"
+
+
+// Diagnostic (tools/apply_bench.py; not part of the drop-in boundary): the bulk-apply kernel alone on synthetic windows.
+// nwin windows of width W - 2 positions (two records per position and owner: the shape of a sweep window's lists)
+// spread over the diagonal of p factors of order n; which: 1 = rows role, 2 = column role, 4 = Schur vectors (each
+// timed on its own, reps launches, HIP events).  ms[3]: milliseconds per launch; bytes[3]: algorithmic bytes per launch.
+extern "C" int psd_dbg_apply_bench(psd_ctx* c, int n, int p, int nwin, int W, int which, int reps, double* ms, double* bytes) {
+#ifdef PSD_HOSTSIM
+    (void)c; (void)n; (void)p; (void)nwin; (void)W; (void)which; (void)reps; (void)ms; (void)bytes;
+    return PSD_INFO_NOTIMPL;
+#else
+    if (!c || nwin < 1 || nwin > PSD_SLOTS || W < 6 || W > 32) return -1;
+    PSD_CHECK(c->treserve(p));
+    const int nb = W - 4, S = nb + 2;
+    std::vector<psd_apply_desc> hd(PSD_SLOTS);
+    std::vector<int> hc((size_t)PSD_SLOTS * (p + 8), 0);
+    std::vector<psd_tr> ht((size_t)PSD_SLOTS * p * PSD_TR_CAP);
+    memset(hd.data(), 0, sizeof(psd_apply_desc) * PSD_SLOTS);
+    const int step = (nwin > 1) ? (n - S - 2) / (nwin - 1) : 0;
+    if (nwin > 1 && step < S + 2) return -2;
+    double br = 0, bc = 0, bz = 0;
+    for (int b = 0; b < nwin; ++b) {
+        psd_apply_desc& d = hd[b];
+        d.active = 1;
+        d.prob = 0;
+        d.plo = 2 + b * step;
+        d.phi = d.plo + S - 1;
+        d.lc0 = d.phi + 2; d.lc1 = n;
+        d.rr0 = 1; d.rr1 = d.plo - 2;
+        d.zr0 = 1; d.zr1 = n;
+        d.cut = d.lc1 + 1; d.rcut = d.rr0; d.split = 0;
+        br += 16.0 * p * S * (double)(d.lc1 >= d.lc0 ? d.lc1 - d.lc0 + 1 : 0);
+        bc += 16.0 * p * S * (double)(d.rr1 >= d.rr0 ? d.rr1 - d.rr0 + 1 : 0);
+        bz += 16.0 * p * S * (double)n;
+        for (int m = 0; m < p; ++m) {
+            int e = 0;
+            psd_tr* L = ht.data() + ((size_t)b * p + m) * PSD_TR_CAP;
+            const double v2 = 0.1, v3 = 0.05;
+            for (int k = 0; k < nb; ++k) {
+                L[e].pos = d.plo + k; L[e].kind = PSD_TR_R3; L[e].c0 = v2; L[e].c1 = v3; L[e].c2 = 2.0 / (1.0 + v2 * v2 + v3 * v3); ++e;
+                L[e].pos = d.plo + k + 1; L[e].kind = PSD_TR_H2; L[e].c0 = v2; L[e].c1 = 0.0; L[e].c2 = 2.0 / (1.0 + v2 * v2); ++e;
+            }
+            hc[(size_t)b * (p + 8) + m] = e;
+        }
+    }
+    double *dH = nullptr, *dZ = nullptr;
+    const size_t bytesM = (size_t)p * n * n * sizeof(double);
+    PSD_CHECK(psd_rt_malloc((void**)&dH, bytesM));
+    PSD_CHECK(psd_rt_malloc((void**)&dZ, bytesM));
+    PSD_CHECK(psd_rt_memset(dH, 0x3f, bytesM, c->stream));  // (every double 4.8e-4: orthogonal updates keep it bounded)
+    PSD_CHECK(psd_rt_memset(dZ, 0x3f, bytesM, c->stream));
+    PSD_CHECK(psd_rt_h2d(c->tdesc, hd.data(), sizeof(psd_apply_desc) * PSD_SLOTS, c->stream));
+    PSD_CHECK(psd_rt_h2d(c->tcnt, hc.data(), sizeof(int) * hc.size(), c->stream));
+    PSD_CHECK(psd_rt_h2d(c->ttr, ht.data(), sizeof(psd_tr) * ht.size(), c->stream));
+    psd_rparams P;
+    memset(&P, 0, sizeof(P));
+    P.H = dH; P.Z = dZ; P.desc = c->tdesc; P.cnt = c->tcnt; P.tr = c->ttr; P.nprob = 1;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const int cfg[3][2] = {{0, 3}, {1, 3}, {0, 4}};  // (pass, mode): rows role, column role, Schur vectors
+    const double by[3] = {br, bc, bz};
+    for (int q = 0; q < 3; ++q) {
+        ms[q] = 0.0;
+        bytes[q] = by[q];
+        if (!((which >> q) & 1)) continue;
+        for (int r = 0; r < 2; ++r) PSD_CHECK(launch_apply_wl(c, c->stream, P, n, p, cfg[q][0], PSD_SLOTS, 1, p, cfg[q][1], W, c->apply_wl_grid));
+        (void)hipEventRecord(e0, c->stream);
+        for (int r = 0; r < reps; ++r) PSD_CHECK(launch_apply_wl(c, c->stream, P, n, p, cfg[q][0], PSD_SLOTS, 1, p, cfg[q][1], W, c->apply_wl_grid));
+        (void)hipEventRecord(e1, c->stream);
+        PSD_CHECK(hipEventSynchronize(e1));
+        float t = 0;
+        (void)hipEventElapsedTime(&t, e0, e1);
+        ms[q] = (double)t / reps;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    psd_rt_free(dH);
+    psd_rt_free(dZ);
+    PSD_CHECK(psd_rt_last_error());
+    return 0;
+#endif
+}
 
 #include "psd_check_host.inl"

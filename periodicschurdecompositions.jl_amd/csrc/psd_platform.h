@@ -41,6 +41,9 @@ extern psd_simctx psd_sim;  // the block currently being simulated (serial)
 #define PSD_LDS_DECL char* psd_lds = psd_sim.lds
 #define PSD_SYNC() ((void)0)
 #define PSD_WAVE_SYNC() ((void)0)
+// two-wave workgroups of the chase kernels (block = 64 x 2): the simulation runs both roles one after the other
+#define PSD_WAVE_ROLE 0
+#define PSD_PAIR_BARRIER() ((void)0)
 // data-parallel loop over [0,count): iterations must be independent of each other
 #define PSD_PAR_FOR(t, count) for (int t = 0; t < (int)(count); ++t)
 #define PSD_ONE if (true)
@@ -90,6 +93,8 @@ typedef int psd_stream_t;
                 }                                                                     \
         free(_lds);                                                                   \
     } while (0)
+// (a block of nx x ny threads is nx simulated lanes: the second wavefront of a chase workgroup has no separate existence here)
+#define PSD_LAUNCH2(kern, grid_, nx_, ny_, ldsbytes_, stream_, ...) PSD_LAUNCH(kern, grid_, nx_, ldsbytes_, stream_, __VA_ARGS__)
 static inline int psd_rt_malloc(void** p, size_t bytes) {
     *p = malloc(bytes ? bytes : 16);
     return *p ? 0 : 1;
@@ -132,7 +137,23 @@ typedef dim3 psd_dim3;
 #define PSD_GRID_Y ((int)gridDim.y)
 #define PSD_NTHREADS ((int)blockDim.x)
 #define PSD_LDS_DECL extern __shared__ __attribute__((aligned(16))) char psd_lds[]
-#define PSD_SYNC() __syncthreads()
+// Workgroups with blockDim.x <= 64 are single wavefronts as far as the code written in terms of PSD_TID / PSD_SYNC is
+// concerned (blockDim.y = 2 adds a helper wavefront that such code never sees: the chase kernels, PSD_WAVE_ROLE): their
+// hand-offs through LDS and memory need the counters drained, not a hardware barrier.
+__device__ __forceinline__ void psd_sync() {
+    if (blockDim.x > 64) __syncthreads();
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+#define PSD_SYNC() psd_sync()
+#define PSD_WAVE_ROLE ((int)threadIdx.y)
+// the hardware barrier of the two wavefronts of a chase workgroup (everything either stored to LDS before it is visible
+// to the other behind it)
+#define PSD_PAIR_BARRIER()                                      \
+    do {                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+        __builtin_amdgcn_s_barrier();                           \
+        asm volatile("" ::: "memory");                          \
+    } while (0)
 // LDS hand-off between lanes of ONE wavefront (only valid in single-wave workgroups): DS operations
 // of a wave execute in order, so only the compiler has to be fenced; unlike __syncthreads() this does
 // not drain outstanding global stores (vmcnt), which would put their acknowledge latency on the chain.
@@ -225,6 +246,8 @@ __device__ __forceinline__ long long psd_wallclock() { return (long long)__built
 typedef hipStream_t psd_stream_t;
 #define PSD_LAUNCH(kern, grid_, nthreads_, ldsbytes_, stream_, ...) \
     hipLaunchKernelGGL(kern, (grid_), dim3(nthreads_), (ldsbytes_), (stream_), __VA_ARGS__)
+#define PSD_LAUNCH2(kern, grid_, nx_, ny_, ldsbytes_, stream_, ...) \
+    hipLaunchKernelGGL(kern, (grid_), dim3(nx_, ny_), (ldsbytes_), (stream_), __VA_ARGS__)
 static inline int psd_rt_malloc(void** p, size_t bytes) { return (int)hipMalloc(p, bytes ? bytes : 16); }
 static inline void psd_rt_free(void* p) { (void)hipFree(p); }
 static inline int psd_rt_memset(void* p, int v, size_t bytes, psd_stream_t s) {

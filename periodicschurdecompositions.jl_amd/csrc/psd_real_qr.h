@@ -199,6 +199,9 @@ struct psd_rparams {
     // the snapshots of cdone / ccancel the workgroups of the launch read.  Nothing a workgroup decides in a launch
     // depends on what another workgroup of the SAME launch has done so far: the schedule is reproducible run to run.
     int* plan;
+    // byte offset of the two-wave chase's command block in dynamic LDS (the reduction scratch behind the window image,
+    // idle while a window is chased); 0: the chase kernels run single wavefronts (psd_qr_micro3)
+    int c2off;
 };
 // layout of psd_rparams::plan (ints): share of leader slot s = free slots PSD_PLAN_FREE[first[s] .. first[s] + count[s])
 #define PSD_PLAN_FIRST 0
@@ -607,23 +610,25 @@ PSD_D void psd_rq_plan_body(const psd_rparams& P) {
     int* order = need + PSD_SLOTS;    // candidates by rank
     int* nfree = order + PSD_SLOTS;   // [0] free slots
     PSD_PAR_FOR(s, PSD_SLOTS) {
+        // (every word this lane needs is requested before the first is looked at: one memory round trip, not two —
+        //  a free slot's state is stale, never unmapped)
+        const psd_rstate* x = P.cst + s;
         const int role = psd_atomic_load(P.role + s);
         const int ep = psd_atomic_load(P.epoch + s);
+        const int ph = x->phase, xcur = x->cursor, xi = x->i, xlo = x->lo, xW = x->Wmax, xwant = x->train_want;
         isfree[s] = (role == PSD_ROLE_FREE) ? 1 : 0;
         int w = 0, nd = 0;
         if (role == PSD_ROLE_LEADER || (role == PSD_ROLE_CLAIMED && ep < P.tick)) {
-            const psd_rstate* x = P.cst + s;
-            const int ph = x->phase;
-            if (x->cursor == 0 && (ph == PSD_PH_DECIDE || ph == PSD_PH_SHIFT || ph == PSD_PH_DEFLATE || ph == PSD_PH_NEXT)) {
-                w = x->i - x->lo + 1;
+            if (xcur == 0 && (ph == PSD_PH_DECIDE || ph == PSD_PH_SHIFT || ph == PSD_PH_DEFLATE || ph == PSD_PH_NEXT)) {
+                w = xi - xlo + 1;
                 if (w < 1) w = 1;
                 // most slots psd_rq_shift can ask for on a range of width <= w: the long-train pipeline at the
                 // narrowest window it considers, plus one for a hand-over (psd_mb_spawn)
-                int nbm = x->Wmax - 4;
+                int nbm = xW - 4;
                 if (nbm > 8) nbm = 8;
                 if (nbm < 1) nbm = 1;
                 nd = (w + 4 * nbm + 3) / (nbm + 4) + 1;
-                if (nd > x->train_want) nd = x->train_want;
+                if (nd > xwant) nd = xwant;
                 if (nd > PSD_TRAIN_MAX - 1) nd = PSD_TRAIN_MAX - 1;
                 if (nd < 0) nd = 0;
                 nd += 1;
@@ -634,6 +639,48 @@ PSD_D void psd_rq_plan_body(const psd_rparams& P) {
         P.plan[PSD_PLAN_CDONE + s] = psd_atomic_load(P.cdone + s);
         P.plan[PSD_PLAN_CCANCEL + s] = (P.ccancel != nullptr) ? psd_atomic_load(P.ccancel + s) : 0;
     }
+#ifndef PSD_HOSTSIM
+    {
+        // one wavefront, lane = slot: positions among the free slots by a ballot, ranks among the candidates by a
+        // broadcast loop over the lanes' registers, the shares by a scan in rank order (the portable form below walks
+        // LDS 64 times per lane in three passes: 9 us in front of every chase launch)
+        const int s = PSD_TID;
+        const int w = cw[s], fr = isfree[s], nd = need[s];
+        const unsigned long long fmask = __ballot(fr != 0);
+        const int fidx = __popcll(fmask & ((1ull << s) - 1ull));
+        const int nf = __popcll(fmask);
+        if (fr) P.plan[PSD_PLAN_FREE + fidx] = s;
+        int rank = 0;
+        for (int t = 0; t < PSD_SLOTS; ++t) {
+            const int wt = __builtin_amdgcn_readlane(w, t);
+            if (w > 0 && wt > 0 && (wt > w || (wt == w && t < s))) rank += 1;
+        }
+        if (w > 0) order[rank] = nd;  // (need, by rank)
+        const unsigned long long cmask = __ballot(w > 0);
+        const int nc = __popcll(cmask);
+        PSD_SYNC();
+        int incl = (s < nc) ? order[s] : 0;
+        const int own = incl;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const int up = __shfl_up(incl, sft, 64);
+            if (s >= sft) incl += up;
+        }
+        PSD_SYNC();
+        if (s < nc) order[s] = incl - own;  // (first, by rank)
+        PSD_SYNC();
+        int first = 0, cnt = 0;
+        if (w > 0) {
+            first = order[rank];
+            if (first > nf) first = nf;
+            cnt = nd;
+            if (cnt > nf - first) cnt = nf - first;
+        }
+        P.plan[PSD_PLAN_FIRST + s] = first;
+        P.plan[PSD_PLAN_COUNT + s] = cnt;
+        (void)nfree;
+    }
+#else
     PSD_SYNC();
     PSD_PAR_FOR(s, PSD_SLOTS) {
         // position of slot s among the free slots (ascending) and among the candidates (widest first, then by slot)
@@ -664,6 +711,7 @@ PSD_D void psd_rq_plan_body(const psd_rparams& P) {
         P.plan[PSD_PLAN_FIRST + s] = first;
         P.plan[PSD_PLAN_COUNT + s] = cnt;
     }
+#endif
     PSD_ONE { P.plan[PSD_PLAN_TICK] = P.tick; }
 }
 
@@ -1560,6 +1608,273 @@ PSD_D void psd_win_reflect(const psd_rparams& P, const psd_win& w, int jl, int j
     PSD_SYNC();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two-wave chase (round 3).  The sweep's chain has two strands per position k (PSD.jl:844-883): the 3-reflectors
+// (H_1, then factors p..2: each from column k of H_j as the previous one's right update left it) and the 2-reflectors
+// (factors p..2: each from column k+1 of H_j after that factor's 3-reflector from the left and the previous factor's
+// 2-reflector from the right).  The 3-strand never reads anything a 2-reflector of the same position writes (column k
+// against columns k+1, k+2), so the two strands are two serial chains of the same length that only have to stay in
+// order where they touch the same factor from the same side.  psd_qr_micro3 runs both in one wavefront (~165
+// instructions per (position, factor), ~900 cycles: the wave is bound by its own issue rate, not by the dependency
+// chain).  Here wavefront A of a chase workgroup runs the 3-strand and wavefront B the 2-strand THREE links behind, one
+// hardware barrier per link:
+//   link q = (position k, t): t = 0 the H_1 step, t >= 1 factor j = p + 1 - t.  Step s: A does link s, B link s - 3.
+//   * same step, disjoint data: A(k,j) touches rows k..k+2 of H_j and columns k..k+2 of H_{j-1}, B(k,j+3) rows of
+//     H_{j+3} and columns of H_{j+2}; across the position wrap the factors differ as long as p >= 6 (p >= 8 is asked);
+//   * order where it matters (same factor, same side): A(k,j) before B(k,j) on rows of H_j and on columns of H_{j-1};
+//     B(k,j) before A(k+1,j) on both (p - 3 steps later);
+//   * a left and a right transformation of the same block commute, so B(k,j+1)'s column update of H_j may follow
+//     A(k,j)'s row update of it (the reference has them the other way round): same result up to rounding;
+//   * three links of lag (two would do for the hazards) let each wave fetch the operands of its NEXT link from LDS
+//     before the barrier, so no LDS latency sits on either chain: what B(k,j) reads was last written by A(k,j-1), one
+//     step before the step in which B prefetches it.
+// The helper wavefront (threadIdx.y = 1 of a 64 x 2 block) parks at the pair barrier between runs; code written in terms
+// of PSD_TID / PSD_SYNC never sees it.  The simulated tier runs A and B of a step one after the other.
+struct psd_c2 {
+    int cmd;                  // 0: the workgroup is done (helper leaves), 1: a run follows
+    int ld, bsz, bs, be;      // window image
+    int p, l, i, ks, npos;    // positions ks .. ks + npos - 1, all with three-row bulges (k <= i - 2)
+    int c1max, r0;
+    int n1, nj;               // list slots of the first position: owner 1, owners 2..p
+    double* wb;               // window image in LDS
+    psd_tr* tr;               // this slot's lists
+    double v0, v1, v2;        // the sweep's start vector (used when ks == l)
+};
+#define PSD_C2_MINP 8
+#define PSD_C2_LAG 3
+
+// operand layout of lane `ln` for A's link (k, t): offset of the first of its three operands, their stride, and the
+// lane classes [0, nl) left, [nl, nl + nrw) right, nl + nrw the lane that writes the annihilated column
+struct psd_c2_lay {
+    int nl, nrw, off, str;
+};
+PSD_D psd_c2_lay psd_c2_layA(const psd_c2& C, int k, int t, int ln) {
+    psd_c2_lay L;
+    const int rlim = (k + 3 < C.i) ? (k + 3) : C.i;
+    L.nrw = rlim - C.r0 + 1;
+    const int jl = (t == 0) ? 1 : (C.p + 1 - t);        // factor updated from the left
+    const int jr = (t == 0) ? C.p : (jl - 1);           // factor updated from the right
+    const int c0 = (t == 0) ? k : (k + 1);              // first column of the left lanes
+    L.nl = C.c1max - c0 + 1;
+    if (L.nl < 0) L.nl = 0;
+    if (ln < L.nl) {
+        L.off = (jl - 1) * C.bsz + (c0 + ln - C.bs) * C.ld + (k - C.bs);
+        L.str = 1;
+    } else if (ln < L.nl + L.nrw) {
+        L.off = (jr - 1) * C.bsz + (k - C.bs) * C.ld + (C.r0 + (ln - L.nl) - C.bs);
+        L.str = C.ld;
+    } else {  // column k - 1 of H_1 (t = 0) / column k of H_j
+        const int fc = (t == 0) ? (k - 1) : k;
+        L.off = (jl - 1) * C.bsz + (fc - C.bs) * C.ld + (k - C.bs);
+        L.str = 1;
+    }
+    return L;
+}
+// B's link (k, t >= 1), two operands per lane (rows k+1, k+2 / columns k+1, k+2); the last lane holds column k+1 of H_j:
+// the vector the 2-reflector is made from, then (beta, 0)
+PSD_D psd_c2_lay psd_c2_layB(const psd_c2& C, int k, int t, int ln) {
+    psd_c2_lay L;
+    const int rlim = (k + 3 < C.i) ? (k + 3) : C.i;
+    L.nrw = rlim - C.r0 + 1;
+    const int j = C.p + 1 - t;
+    L.nl = C.c1max - (k + 2) + 1;
+    if (L.nl < 0) L.nl = 0;
+    if (ln < L.nl) {
+        L.off = (j - 1) * C.bsz + (k + 2 + ln - C.bs) * C.ld + (k + 1 - C.bs);
+        L.str = 1;
+    } else if (ln < L.nl + L.nrw) {
+        L.off = (j - 2) * C.bsz + (k + 1 - C.bs) * C.ld + (C.r0 + (ln - L.nl) - C.bs);
+        L.str = C.ld;
+    } else {
+        L.off = (j - 1) * C.bsz + (k + 1 - C.bs) * C.ld + (k + 1 - C.bs);
+        L.str = 1;
+    }
+    return L;
+}
+
+// roles: bit 0 = A, bit 1 = B (a wavefront runs one; the simulated tier both)
+PSD_D void psd_c2_run(const psd_c2& C, int roles) {
+    const int p = C.p, L = C.npos * p;
+    double* const wb = C.wb;
+    // ---- A: state carried from link to link
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+    PSD_LANEVAR(double, a1);
+    PSD_LANEVAR(double, a2);
+    PSD_LANEVAR(double, a3);
+    // ---- B
+    PSD_LANEVAR(double, b2);
+    PSD_LANEVAR(double, b3);
+    if (roles & 1) {
+        if (C.ks > C.l) {
+            x0 = wb[(C.ks - 1 - C.bs) * C.ld + (C.ks - C.bs)];
+            x1 = wb[(C.ks - 1 - C.bs) * C.ld + (C.ks + 1 - C.bs)];
+            x2 = wb[(C.ks - 1 - C.bs) * C.ld + (C.ks + 2 - C.bs)];
+        } else {
+            x0 = C.v0;
+            x1 = C.v1;
+            x2 = C.v2;
+        }
+        PSD_PAR_ONCE(t, PSD_STEP_NT) {
+            const psd_c2_lay Y = psd_c2_layA(C, C.ks, 0, t);
+            PSD_LV(a1) = PSD_LV(a2) = PSD_LV(a3) = 0.0;
+            if (t < Y.nl + Y.nrw) {
+                PSD_LV(a1) = wb[Y.off];
+                PSD_LV(a2) = wb[Y.off + Y.str];
+                PSD_LV(a3) = wb[Y.off + 2 * Y.str];
+            }
+        }
+    }
+    for (int s = 0; s < L + PSD_C2_LAG; ++s) {
+        if ((roles & 1) && s < L) {
+            // ------------------------------------------------------------------ A: link s
+            const int kk = s / p, tq = s - kk * p, k = C.ks + kk;
+            const int j = (tq == 0) ? 1 : (p + 1 - tq);
+            const double tau = psd_refl3(x0, x1, x2);
+            const double beta = x0, v2 = x1, v3 = x2;
+            int nlq = 0, nrwq = 0;
+            PSD_PAR_ONCE(t, PSD_STEP_NT) {
+                const psd_c2_lay Y = psd_c2_layA(C, k, tq, t);
+                const int act = Y.nl + Y.nrw;
+                if (t < act) {
+                    const double xx = tau * (PSD_LV(a1) + v2 * PSD_LV(a2) + v3 * PSD_LV(a3));
+                    PSD_LV(a1) -= xx;
+                    PSD_LV(a2) -= xx * v2;
+                    PSD_LV(a3) -= xx * v3;
+                    wb[Y.off] = PSD_LV(a1);
+                    wb[Y.off + Y.str] = PSD_LV(a2);
+                    wb[Y.off + 2 * Y.str] = PSD_LV(a3);
+                } else if (t == act) {
+                    if (tq > 0 || k > C.l) {  // (the first position of a sweep has no column to annihilate in H_1)
+                        wb[Y.off] = beta;
+                        wb[Y.off + 1] = 0.0;
+                        wb[Y.off + 2] = 0.0;
+                    }
+                    psd_tr tr;
+                    tr.pos = k;
+                    tr.kind = PSD_TR_R3;
+                    tr.c0 = v2;
+                    tr.c1 = v3;
+                    tr.c2 = tau;
+                    const int slot = (tq == 0) ? (C.n1 + kk) : (C.nj + 2 * kk);
+                    if (slot < PSD_TR_CAP) C.tr[(size_t)(j - 1) * PSD_TR_CAP + slot] = tr;
+                }
+            }
+            {
+                const psd_c2_lay Y0 = psd_c2_layA(C, k, tq, 0);
+                nlq = Y0.nl;
+                nrwq = Y0.nrw;
+            }
+            (void)nrwq;
+            if (s + 1 < L) {
+                // the next link's vector: column k of the factor just updated from the right, rows k.. (same position) or
+                // rows k+1.. (tq = p - 1: the factor is H_1 and the next link is the H_1 step of position k + 1)
+                const int lk = nlq + (k - C.r0) + ((tq == p - 1) ? 1 : 0);
+                x0 = PSD_BCAST(a1, lk);
+                x1 = PSD_BCAST(a1, lk + 1);
+                x2 = PSD_BCAST(a1, lk + 2);
+                const int s1 = s + 1, kk1 = s1 / p, tq1 = s1 - kk1 * p;
+                PSD_PAR_ONCE(t, PSD_STEP_NT) {
+                    const psd_c2_lay Y = psd_c2_layA(C, C.ks + kk1, tq1, t);
+                    PSD_LV(a1) = PSD_LV(a2) = PSD_LV(a3) = 0.0;
+                    if (t < Y.nl + Y.nrw) {
+                        PSD_LV(a1) = wb[Y.off];
+                        PSD_LV(a2) = wb[Y.off + Y.str];
+                        PSD_LV(a3) = wb[Y.off + 2 * Y.str];
+                    }
+                }
+            }
+        }
+        if (roles & 2) {
+            // ------------------------------------------------------------------ B: link s - LAG
+            const int q = s - PSD_C2_LAG;
+            if (q >= 0) {
+                const int kk = q / p, tq = q - kk * p, k = C.ks + kk;
+                if (tq != 0) {
+                    const int j = p + 1 - tq;
+                    const psd_c2_lay Y0 = psd_c2_layB(C, k, tq, 0);
+                    const int fl = Y0.nl + Y0.nrw;  // the lane with column k + 1 of H_j
+                    double y0 = PSD_BCAST(b2, fl), y1 = PSD_BCAST(b3, fl);
+                    const double tau2 = psd_refl2(y0, y1);
+                    const double beta2 = y0, w2 = y1;
+                    PSD_PAR_ONCE(t, PSD_STEP_NT) {
+                        const psd_c2_lay Y = psd_c2_layB(C, k, tq, t);
+                        const int act = Y.nl + Y.nrw;
+                        if (t < act) {
+                            const double xx = tau2 * (PSD_LV(b2) + w2 * PSD_LV(b3));
+                            wb[Y.off] = PSD_LV(b2) - xx;
+                            wb[Y.off + Y.str] = PSD_LV(b3) - xx * w2;
+                        } else if (t == act) {
+                            wb[Y.off] = beta2;
+                            wb[Y.off + 1] = 0.0;
+                            psd_tr tr;
+                            tr.pos = k + 1;
+                            tr.kind = PSD_TR_H2;
+                            tr.c0 = w2;
+                            tr.c1 = 0.0;
+                            tr.c2 = tau2;
+                            const int slot = C.nj + 2 * kk + 1;
+                            if (slot < PSD_TR_CAP) C.tr[(size_t)(j - 1) * PSD_TR_CAP + slot] = tr;
+                        }
+                    }
+                }
+                const int q1 = q + 1;
+                if (q1 < L) {
+                    const int kk1 = q1 / p, tq1 = q1 - kk1 * p;
+                    if (tq1 != 0) {
+                        PSD_PAR_ONCE(t, PSD_STEP_NT) {
+                            const psd_c2_lay Y = psd_c2_layB(C, C.ks + kk1, tq1, t);
+                            PSD_LV(b2) = PSD_LV(b3) = 0.0;
+                            if (t <= Y.nl + Y.nrw) {
+                                PSD_LV(b2) = wb[Y.off];
+                                PSD_LV(b3) = wb[Y.off + Y.str];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        PSD_PAIR_BARRIER();
+    }
+}
+
+// wavefront A's side of a run: publish it, run it (the helper runs B), leave the helper parked
+PSD_D void psd_c2_lead(const psd_rparams& P, psd_c2& C) {
+#ifdef PSD_HOSTSIM
+    (void)P;
+    psd_c2_run(C, 3);
+#else
+    PSD_LDS_DECL;
+    psd_c2* cmd = (psd_c2*)(psd_lds + P.c2off);
+    C.cmd = 1;
+    PSD_ONE { *cmd = C; }
+    PSD_PAIR_BARRIER();
+    psd_c2_run(C, 1);
+    // (the helper is back at its command barrier or on its way there; the command word it finds if this wavefront
+    //  ever left without a word is "done")
+    PSD_ONE { cmd->cmd = 0; }
+#endif
+}
+#ifndef PSD_HOSTSIM
+// the helper wavefront of a chase workgroup (threadIdx.y == 1)
+PSD_D void psd_c2_helper(int c2off) {
+    PSD_LDS_DECL;
+    const psd_c2* cmd = (const psd_c2*)(psd_lds + c2off);
+    for (;;) {
+        PSD_PAIR_BARRIER();
+        const psd_c2 C = *cmd;
+        if (C.cmd == 0) return;
+        psd_c2_run(C, 2);
+    }
+}
+// wavefront A, last thing before it leaves the kernel
+PSD_D void psd_c2_release(int c2off) {
+    PSD_LDS_DECL;
+    psd_c2* cmd = (psd_c2*)(psd_lds + c2off);
+    PSD_ONE { cmd->cmd = 0; }
+    PSD_PAIR_BARRIER();
+}
+#endif
+
 // PSD.jl:806-886: one window (steps kcur .. kcur+nb-1) of the double-shift periodic QR sweep
 PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, int* lcnt) {
     const int n = st.n, p = st.p, i = st.i, l = st.l, i1 = st.i1, i2 = st.i2;
@@ -1580,7 +1895,29 @@ PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
     const int c1max = (w.be < i2) ? w.be : i2;
     const int r0 = (w.bs > i1) ? w.bs : i1;
     int n1 = 0, nj = 0;  // list lengths: owner 1, owners 2..p
-    for (int k = ks; k <= ke; ++k) {
+    int kfirst = ks;
+    if (P.c2off != 0 && p >= PSD_C2_MINP) {
+        // the positions with three-row bulges (all but possibly the last of a sweep) on the two-wave chase
+        const int klast = (ke < i - 2) ? ke : (i - 2);
+        if (klast >= ks) {
+            psd_c2 C;
+            C.cmd = 1;
+            C.ld = w.ld; C.bsz = w.bsz; C.bs = w.bs; C.be = w.be;
+            C.p = p; C.l = l; C.i = i; C.ks = ks; C.npos = klast - ks + 1;
+            C.c1max = c1max; C.r0 = r0;
+            C.n1 = 0; C.nj = 0;
+            C.wb = w.b;
+            C.tr = P.tr;
+            C.v0 = st.v[0]; C.v1 = st.v[1]; C.v2 = st.v[2];
+            PSD_SYNC();
+            psd_c2_lead(P, C);
+            PSD_SYNC();
+            n1 = C.npos;
+            nj = 2 * C.npos;
+            kfirst = klast + 1;
+        }
+    }
+    for (int k = kfirst; k <= ke; ++k) {
         const int nr = (3 < i - k + 1) ? 3 : (i - k + 1);
         const int rlim = (k + nr < i) ? (k + nr) : i;
         double x0, x1, x2 = 0.0;
@@ -2060,7 +2397,25 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
 // One launch of cursor b >= 1 of a multishift train (P.st = the cursor's state, P.lead = the main state, P.desc / P.cnt /
 // P.tr = the cursor's own descriptor and lists).  Starts two windows behind its predecessor, chases one window per
 // launch, ends in PSD_PH_CDONE.
-PSD_KERNEL_B(PSD_STEP_NT) psd_rq_step(psd_rparams P) { psd_rq_step_body(P); }
+// The chase kernels run blocks of 64 x 1 threads, or 64 x 2 when P.c2off != 0: the second wavefront is the helper of
+// the two-wave chase (psd_c2_helper) and takes no part in anything else.
+#ifndef PSD_HOSTSIM
+#define PSD_C2_ENTER(P)                                 \
+    if ((P).c2off != 0 && PSD_WAVE_ROLE == 1) {         \
+        psd_c2_helper((P).c2off);                       \
+        return;                                         \
+    }
+#define PSD_C2_LEAVE(P) \
+    if ((P).c2off != 0) psd_c2_release((P).c2off)
+#else
+#define PSD_C2_ENTER(P) ((void)0)
+#define PSD_C2_LEAVE(P) ((void)0)
+#endif
+PSD_KERNEL_B(2 * PSD_STEP_NT) psd_rq_step(psd_rparams P) {
+    PSD_C2_ENTER(P);
+    psd_rq_step_body(P);
+    PSD_C2_LEAVE(P);
+}
 
 PSD_D void psd_rq_cursor_body(const psd_rparams& P, int b) {
     PSD_LDS_DECL;
@@ -2149,23 +2504,25 @@ PSD_D void psd_rq_cursor_body(const psd_rparams& P, int b) {
 // All cursors of a tick in ONE launch: workgroup 0 is the ordinary state machine (the leader), workgroup b >= 1 is cursor
 // b.  P holds the leader's state and slot 0 of the cursor arrays (see psd_rq_apply_train).  No cross-stream events: the
 // chases of a tick run side by side on different compute units, the tick ends with the kernel.
-PSD_KERNEL_B(PSD_STEP_NT) psd_rq_step_train(psd_rparams P, int p, int cstride) {
+PSD_KERNEL_B(2 * PSD_STEP_NT) psd_rq_step_train(psd_rparams P, int p, int cstride) {
+    PSD_C2_ENTER(P);
     const int b = PSD_BLOCK_X;
     if (b == 0) {
         psd_rq_step_body(P);
-        return;
+    } else {
+        psd_rparams Q = P;
+        Q.lead = P.st;
+        Q.st = P.cst + b;
+        Q.desc = P.desc + b;
+        Q.cnt = P.cnt + (size_t)b * cstride;
+        Q.tr = P.tr + (size_t)b * p * PSD_TR_CAP;
+        psd_rq_cursor_body(Q, b);
     }
-    psd_rparams Q = P;
-    Q.lead = P.st;
-    Q.st = P.cst + b;
-    Q.desc = P.desc + b;
-    Q.cnt = P.cnt + (size_t)b * cstride;
-    Q.tr = P.tr + (size_t)b * p * PSD_TR_CAP;
-    psd_rq_cursor_body(Q, b);
+    PSD_C2_LEAVE(P);
 }
 
 // Multi-block tick: workgroup s runs slot s (see psd_mb_claim).  P holds slot 0 of every per-slot array.
-PSD_KERNEL_B(PSD_STEP_NT) psd_rq_step_mb(psd_rparams P, int p, int cstride) {
+PSD_D void psd_rq_step_mb_body(const psd_rparams& P, int p, int cstride) {
     const int s = PSD_BLOCK_X;
     psd_rparams Q = P;
     Q.st = P.cst + s;
@@ -2200,6 +2557,11 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rq_step_mb(psd_rparams P, int p, int cstride) {
         Q.tshift = P.tshift + (size_t)parent * PSD_TSHIFT_STRIDE;
         psd_rq_cursor_body(Q, P.cst[s].cursor);
     }
+}
+PSD_KERNEL_B(2 * PSD_STEP_NT) psd_rq_step_mb(psd_rparams P, int p, int cstride) {
+    PSD_C2_ENTER(P);
+    psd_rq_step_mb_body(P, p, cstride);
+    PSD_C2_LEAVE(P);
 }
 
 // ------------------------------------------------------------------------------------------------
