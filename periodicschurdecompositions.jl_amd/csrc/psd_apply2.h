@@ -27,10 +27,12 @@
 #define PSD_WL2_WAVES 4
 #define PSD_WL2_TPI 8  // tiles per item at most
 #define PSD_WL2_UNI(x) __builtin_amdgcn_readfirstlane(x)
+// pitch of a wave's LDS tile in doubles: odd, so that 32 lanes reading 8 bytes at a stride of one pitch meet 32 bank pairs
+#define PSD_WL2_LD(SP) (((SP) + 1) | 1)
 
 template <int SP>
 PSD_HD size_t psd_wl2_lds_bytes() {  // per wave: its copy of the list and its tile; per workgroup: the item table
-    return (size_t)PSD_WL2_WAVES * (PSD_TR_LDS_BYTES + (size_t)64 * (SP + 1) * sizeof(double)) + (size_t)(3 * PSD_SLOTS + 8) * sizeof(int);
+    return (size_t)PSD_WL2_WAVES * (PSD_TR_LDS_BYTES + (size_t)64 * PSD_WL2_LD(SP) * sizeof(double)) + (size_t)(3 * PSD_SLOTS + 8) * sizeof(int);
 }
 
 // The record being applied is the same for every lane: all of it lives in scalar registers (v_readfirstlane after the
@@ -174,10 +176,10 @@ PSD_D void psd_wl2_cols_tile(const psd_mat<double>& Mx, int plo, int S, int l0, 
 
 // one tile of the rows role: columns l0 .. l0 + nl - 1 of Mx (nl <= 64), rows plo .. plo + S - 1 (contiguous in memory).
 // Memory side: lane = (row pair 2 (lane & 15), column lane >> 4 of every group of four), 16-byte accesses (the lane
-// with the odd last row: 8 bytes); LDS side: lane = line (column), pitch SP + 1 (odd: conflict-free both ways).
+// with the odd last row: 8 bytes); LDS side: lane = line (column), odd pitch (conflict-free both ways).
 template <int SP, bool UP>
 PSD_D void psd_wl2_rows_tile(const psd_mat<double>& Mx, double* tile, int plo, int S, int l0, int nl, int lane, const psd_tr* ltr) {
-    constexpr int LD = SP + 1;
+    constexpr int LD = PSD_WL2_LD(SP);
     constexpr int NU = 16;  // column groups of four
     const int rr = 2 * (lane & 15), cq = lane >> 4;
     const __amdgpu_buffer_rsrc_t rs = psd_wl2_rsrc(Mx);
@@ -299,7 +301,7 @@ __global__ void __launch_bounds__(PSD_WL2_NT, WPE) psd_rq_apply_wl2(psd_rparams 
                                                                int mode) {
     extern __shared__ __attribute__((aligned(16))) char psd_lds[];
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = PSD_WL2_UNI(tid >> 6);
-    constexpr size_t WAVE_BYTES = PSD_TR_LDS_BYTES + (size_t)64 * (SP + 1) * sizeof(double);
+    constexpr size_t WAVE_BYTES = PSD_TR_LDS_BYTES + (size_t)64 * PSD_WL2_LD(SP) * sizeof(double);
     psd_tr* ltr = (psd_tr*)(psd_lds + (size_t)wv * WAVE_BYTES);
     double* tile = (double*)(psd_lds + (size_t)wv * WAVE_BYTES + PSD_TR_LDS_BYTES);
     int* ioff = (int*)(psd_lds + (size_t)PSD_WL2_WAVES * WAVE_BYTES);  // [M + 1] item offsets, [M] items of role A, [M] of role B
@@ -421,7 +423,7 @@ __global__ void __launch_bounds__(PSD_WL2_NT, WPE) psd_rq_apply_wl2(psd_rparams 
                     if (order > 0) psd_wl2_cols_tile<SP, false, true>(Mx, d.plo, S, l0, nl, lane, ltr);
                     else psd_wl2_cols_tile<SP, false, false>(Mx, d.plo, S, l0, nl, lane, ltr);
                 } else {
-                    psd_wl2_generic_tile(false, Mx, tile, SP + 1, d.plo, S, l0, nl, lane, ltr, cnt);
+                    psd_wl2_generic_tile(false, Mx, tile, PSD_WL2_LD(SP), d.plo, S, l0, nl, lane, ltr, cnt);
                 }
             }
         } else {
@@ -429,7 +431,7 @@ __global__ void __launch_bounds__(PSD_WL2_NT, WPE) psd_rq_apply_wl2(psd_rparams 
             for (int k = 0; k < ns; ++k) {
                 const int l0 = g0 + k * 64;
                 const int nl = (gl - k * 64 < 64) ? (gl - k * 64) : 64;
-                psd_wl2_generic_tile(role == 0, Mx, tile, SP + 1, d.plo, S, l0, nl, lane, ltr, cnt);
+                psd_wl2_generic_tile(role == 0, Mx, tile, PSD_WL2_LD(SP), d.plo, S, l0, nl, lane, ltr, cnt);
             }
         }
     }

@@ -43,6 +43,7 @@ extern psd_simctx psd_sim;  // the block currently being simulated (serial)
 #define PSD_WAVE_SYNC() ((void)0)
 // two-wave workgroups of the chase kernels (block = 64 x 2): the simulation runs both roles one after the other
 #define PSD_WAVE_ROLE 0
+#define PSD_GLOBAL(T, ptr) (ptr)
 #define PSD_PAIR_BARRIER() ((void)0)
 // data-parallel loop over [0,count): iterations must be independent of each other
 #define PSD_PAR_FOR(t, count) for (int t = 0; t < (int)(count); ++t)
@@ -146,6 +147,9 @@ __device__ __forceinline__ void psd_sync() {
 }
 #define PSD_SYNC() psd_sync()
 #define PSD_WAVE_ROLE ((int)threadIdx.y)
+// a pointer known to point to device memory (one read from a structure is generic: stores through it would be FLAT
+// instructions, which count against the LDS counter as well)
+#define PSD_GLOBAL(T, ptr) ((__attribute__((address_space(1))) T*)(ptr))
 // the hardware barrier of the two wavefronts of a chase workgroup (everything either stored to LDS before it is visible
 // to the other behind it)
 #define PSD_PAIR_BARRIER()                                      \

@@ -1636,205 +1636,262 @@ struct psd_c2 {
     int p, l, i, ks, npos;    // positions ks .. ks + npos - 1, all with three-row bulges (k <= i - 2)
     int c1max, r0;
     int n1, nj;               // list slots of the first position: owner 1, owners 2..p
-    double* wb;               // window image in LDS
+    int wboff;                // window image: byte offset in dynamic LDS (a generic pointer would make the helper's
+                              // LDS traffic FLAT instructions)
     psd_tr* tr;               // this slot's lists
     double v0, v1, v2;        // the sweep's start vector (used when ks == l)
 };
 #define PSD_C2_MINP 8
 #define PSD_C2_LAG 3
+#ifdef PSD_HOSTSIM
+#define PSD_C2_UNI(x) (x)
+#else
+#define PSD_C2_UNI(x) __builtin_amdgcn_readfirstlane(x)
+#endif
 
-// operand layout of lane `ln` for A's link (k, t): offset of the first of its three operands, their stride, and the
-// lane classes [0, nl) left, [nl, nl + nrw) right, nl + nrw the lane that writes the annihilated column
-struct psd_c2_lay {
-    int nl, nrw, off, str;
-};
-PSD_D psd_c2_lay psd_c2_layA(const psd_c2& C, int k, int t, int ln) {
-    psd_c2_lay L;
-    const int rlim = (k + 3 < C.i) ? (k + 3) : C.i;
-    L.nrw = rlim - C.r0 + 1;
-    const int jl = (t == 0) ? 1 : (C.p + 1 - t);        // factor updated from the left
-    const int jr = (t == 0) ? C.p : (jl - 1);           // factor updated from the right
-    const int c0 = (t == 0) ? k : (k + 1);              // first column of the left lanes
-    L.nl = C.c1max - c0 + 1;
-    if (L.nl < 0) L.nl = 0;
-    if (ln < L.nl) {
-        L.off = (jl - 1) * C.bsz + (c0 + ln - C.bs) * C.ld + (k - C.bs);
-        L.str = 1;
-    } else if (ln < L.nl + L.nrw) {
-        L.off = (jr - 1) * C.bsz + (k - C.bs) * C.ld + (C.r0 + (ln - L.nl) - C.bs);
-        L.str = C.ld;
-    } else {  // column k - 1 of H_1 (t = 0) / column k of H_j
-        const int fc = (t == 0) ? (k - 1) : k;
-        L.off = (jl - 1) * C.bsz + (fc - C.bs) * C.ld + (k - C.bs);
-        L.str = 1;
-    }
-    return L;
-}
-// B's link (k, t >= 1), two operands per lane (rows k+1, k+2 / columns k+1, k+2); the last lane holds column k+1 of H_j:
-// the vector the 2-reflector is made from, then (beta, 0)
-PSD_D psd_c2_lay psd_c2_layB(const psd_c2& C, int k, int t, int ln) {
-    psd_c2_lay L;
-    const int rlim = (k + 3 < C.i) ? (k + 3) : C.i;
-    L.nrw = rlim - C.r0 + 1;
-    const int j = C.p + 1 - t;
-    L.nl = C.c1max - (k + 2) + 1;
-    if (L.nl < 0) L.nl = 0;
-    if (ln < L.nl) {
-        L.off = (j - 1) * C.bsz + (k + 2 + ln - C.bs) * C.ld + (k + 1 - C.bs);
-        L.str = 1;
-    } else if (ln < L.nl + L.nrw) {
-        L.off = (j - 2) * C.bsz + (k + 1 - C.bs) * C.ld + (C.r0 + (ln - L.nl) - C.bs);
-        L.str = C.ld;
-    } else {
-        L.off = (j - 1) * C.bsz + (k + 1 - C.bs) * C.ld + (k + 1 - C.bs);
-        L.str = 1;
-    }
-    return L;
-}
-
-// roles: bit 0 = A, bit 1 = B (a wavefront runs one; the simulated tier both)
-PSD_D void psd_c2_run(const psd_c2& C, int roles) {
-    const int p = C.p, L = C.npos * p;
-    double* const wb = C.wb;
-    // ---- A: state carried from link to link
+// roles: bit 0 = A, bit 1 = B (a wavefront runs one; the simulated tier both).  Lane classes of a link: 0 = an operand
+// triple / pair that takes the reflector, 1 = the lane that writes the annihilated column and the record, 2 = idle.
+// Operand addresses are fixed per position up to the factor's block: off + (j - 1) bsz (the right lanes carry -bsz).
+PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
+    PSD_LDS_DECL;
+    const int roles = PSD_C2_UNI(roles_);
+    // (wave-uniform words: scalar registers on the device)
+    const int p = PSD_C2_UNI(Cin.p), ld = PSD_C2_UNI(Cin.ld), bsz = PSD_C2_UNI(Cin.bsz), bs = PSD_C2_UNI(Cin.bs);
+    const int l = PSD_C2_UNI(Cin.l), ie = PSD_C2_UNI(Cin.i), ks = PSD_C2_UNI(Cin.ks), npos = PSD_C2_UNI(Cin.npos);
+    const int c1max = PSD_C2_UNI(Cin.c1max), r0 = PSD_C2_UNI(Cin.r0), n1 = PSD_C2_UNI(Cin.n1), nj = PSD_C2_UNI(Cin.nj);
+    double* const wb = (double*)(psd_lds + PSD_C2_UNI(Cin.wboff));
+    psd_tr* const trb = Cin.tr;
+    const int L = npos * p;
+    // ---- A
     double x0 = 0.0, x1 = 0.0, x2 = 0.0;
     PSD_LANEVAR(double, a1);
     PSD_LANEVAR(double, a2);
     PSD_LANEVAR(double, a3);
+    PSD_LANEVAR(int, offH);  // H_1 step of the current position: absolute offset, stride, class
+    PSD_LANEVAR(int, strH);
+    PSD_LANEVAR(int, clsH);
+    PSD_LANEVAR(int, offF);  // factor steps
+    PSD_LANEVAR(int, strF);
+    PSD_LANEVAR(int, clsF);
+    int kA = ks, tA = 0, lkH = 0, lkF = 0;
     // ---- B
     PSD_LANEVAR(double, b2);
     PSD_LANEVAR(double, b3);
+    PSD_LANEVAR(int, offB);
+    PSD_LANEVAR(int, strB);
+    PSD_LANEVAR(int, clsB);
+    int kB = ks, tB = 0, flB = 0;
+#define PSD_C2_SETUP_A(k_)                                                                             \
+    do {                                                                                               \
+        const int k__ = (k_);                                                                          \
+        const int rlim__ = (k__ + 3 < ie) ? (k__ + 3) : ie;                                            \
+        const int nrw__ = rlim__ - r0 + 1;                                                             \
+        int nlh__ = c1max - k__ + 1, nlf__ = c1max - k__;                                              \
+        if (nlh__ < 0) nlh__ = 0;                                                                      \
+        if (nlf__ < 0) nlf__ = 0;                                                                      \
+        lkH = nlh__ + (k__ - r0);                                                                      \
+        lkF = nlf__ + (k__ - r0);                                                                      \
+        PSD_PAR_ONCE(t, PSD_STEP_NT) {                                                                 \
+            if (t < nlh__) {                                                                           \
+                PSD_LV(offH) = (k__ + t - bs) * ld + (k__ - bs);                                       \
+                PSD_LV(strH) = 1;                                                                      \
+                PSD_LV(clsH) = 0;                                                                      \
+            } else if (t < nlh__ + nrw__) {                                                            \
+                PSD_LV(offH) = (p - 1) * bsz + (k__ - bs) * ld + (r0 + (t - nlh__) - bs);              \
+                PSD_LV(strH) = ld;                                                                     \
+                PSD_LV(clsH) = 0;                                                                      \
+            } else {                                                                                   \
+                PSD_LV(offH) = (k__ - 1 - bs) * ld + (k__ - bs);                                       \
+                PSD_LV(strH) = 1;                                                                      \
+                PSD_LV(clsH) = (t == nlh__ + nrw__) ? 1 : 2;                                           \
+            }                                                                                          \
+            if (t < nlf__) {                                                                           \
+                PSD_LV(offF) = (k__ + 1 + t - bs) * ld + (k__ - bs);                                   \
+                PSD_LV(strF) = 1;                                                                      \
+                PSD_LV(clsF) = 0;                                                                      \
+            } else if (t < nlf__ + nrw__) {                                                            \
+                PSD_LV(offF) = (k__ - bs) * ld + (r0 + (t - nlf__) - bs) - bsz;                        \
+                PSD_LV(strF) = ld;                                                                     \
+                PSD_LV(clsF) = 0;                                                                      \
+            } else {                                                                                   \
+                PSD_LV(offF) = (k__ - bs) * ld + (k__ - bs);                                           \
+                PSD_LV(strF) = 1;                                                                      \
+                PSD_LV(clsF) = (t == nlf__ + nrw__) ? 1 : 2;                                           \
+            }                                                                                          \
+        }                                                                                              \
+    } while (0)
+#define PSD_C2_SETUP_B(k_)                                                                             \
+    do {                                                                                               \
+        const int k__ = (k_);                                                                          \
+        const int rlim__ = (k__ + 3 < ie) ? (k__ + 3) : ie;                                            \
+        const int nrw__ = rlim__ - r0 + 1;                                                             \
+        int nlb__ = c1max - (k__ + 2) + 1;                                                             \
+        if (nlb__ < 0) nlb__ = 0;                                                                      \
+        flB = nlb__ + nrw__;                                                                           \
+        PSD_PAR_ONCE(t, PSD_STEP_NT) {                                                                 \
+            if (t < nlb__) {                                                                           \
+                PSD_LV(offB) = (k__ + 2 + t - bs) * ld + (k__ + 1 - bs);                               \
+                PSD_LV(strB) = 1;                                                                      \
+                PSD_LV(clsB) = 0;                                                                      \
+            } else if (t < nlb__ + nrw__) {                                                            \
+                PSD_LV(offB) = (k__ + 1 - bs) * ld + (r0 + (t - nlb__) - bs) - bsz;                    \
+                PSD_LV(strB) = ld;                                                                     \
+                PSD_LV(clsB) = 0;                                                                      \
+            } else {                                                                                   \
+                PSD_LV(offB) = (k__ + 1 - bs) * ld + (k__ + 1 - bs);                                   \
+                PSD_LV(strB) = 1;                                                                      \
+                PSD_LV(clsB) = (t == nlb__ + nrw__) ? 1 : 2;                                           \
+            }                                                                                          \
+        }                                                                                              \
+    } while (0)
     if (roles & 1) {
-        if (C.ks > C.l) {
-            x0 = wb[(C.ks - 1 - C.bs) * C.ld + (C.ks - C.bs)];
-            x1 = wb[(C.ks - 1 - C.bs) * C.ld + (C.ks + 1 - C.bs)];
-            x2 = wb[(C.ks - 1 - C.bs) * C.ld + (C.ks + 2 - C.bs)];
+        if (ks > l) {
+            x0 = wb[(ks - 1 - bs) * ld + (ks - bs)];
+            x1 = wb[(ks - 1 - bs) * ld + (ks + 1 - bs)];
+            x2 = wb[(ks - 1 - bs) * ld + (ks + 2 - bs)];
         } else {
-            x0 = C.v0;
-            x1 = C.v1;
-            x2 = C.v2;
+            x0 = Cin.v0;
+            x1 = Cin.v1;
+            x2 = Cin.v2;
         }
+        PSD_C2_SETUP_A(ks);
         PSD_PAR_ONCE(t, PSD_STEP_NT) {
-            const psd_c2_lay Y = psd_c2_layA(C, C.ks, 0, t);
             PSD_LV(a1) = PSD_LV(a2) = PSD_LV(a3) = 0.0;
-            if (t < Y.nl + Y.nrw) {
-                PSD_LV(a1) = wb[Y.off];
-                PSD_LV(a2) = wb[Y.off + Y.str];
-                PSD_LV(a3) = wb[Y.off + 2 * Y.str];
+            if (PSD_LV(clsH) == 0) {
+                const double* q = wb + PSD_LV(offH);
+                const int sd = PSD_LV(strH);
+                PSD_LV(a1) = q[0];
+                PSD_LV(a2) = q[sd];
+                PSD_LV(a3) = q[2 * sd];
             }
         }
     }
+    if (roles & 2) PSD_C2_SETUP_B(ks);
     for (int s = 0; s < L + PSD_C2_LAG; ++s) {
         if ((roles & 1) && s < L) {
-            // ------------------------------------------------------------------ A: link s
-            const int kk = s / p, tq = s - kk * p, k = C.ks + kk;
-            const int j = (tq == 0) ? 1 : (p + 1 - tq);
-            const double tau = psd_refl3(x0, x1, x2);
+            // ------------------------------------------------------------------ A: link (kA, tA)
+            const int j = (tA == 0) ? 1 : (p + 1 - tA);
+            const int jb = (j - 1) * bsz;
+            const double tau = psd_refl3_lean(x0, x1, x2);
             const double beta = x0, v2 = x1, v3 = x2;
-            int nlq = 0, nrwq = 0;
+            const bool fixon = tA > 0 || kA > l;  // (the first position of a sweep has no column to annihilate in H_1)
+            const int slot = (tA == 0) ? (n1 + (kA - ks)) : (nj + 2 * (kA - ks));
             PSD_PAR_ONCE(t, PSD_STEP_NT) {
-                const psd_c2_lay Y = psd_c2_layA(C, k, tq, t);
-                const int act = Y.nl + Y.nrw;
-                if (t < act) {
-                    const double xx = tau * (PSD_LV(a1) + v2 * PSD_LV(a2) + v3 * PSD_LV(a3));
-                    PSD_LV(a1) -= xx;
-                    PSD_LV(a2) -= xx * v2;
-                    PSD_LV(a3) -= xx * v3;
-                    wb[Y.off] = PSD_LV(a1);
-                    wb[Y.off + Y.str] = PSD_LV(a2);
-                    wb[Y.off + 2 * Y.str] = PSD_LV(a3);
-                } else if (t == act) {
-                    if (tq > 0 || k > C.l) {  // (the first position of a sweep has no column to annihilate in H_1)
-                        wb[Y.off] = beta;
-                        wb[Y.off + 1] = 0.0;
-                        wb[Y.off + 2] = 0.0;
-                    }
+                // one instruction stream for all lane classes (selects, then one masked store): a lone wavefront pays
+                // for every instruction of every divergent path
+                const int cls = (tA == 0) ? PSD_LV(clsH) : PSD_LV(clsF);
+                double* q = wb + ((tA == 0) ? PSD_LV(offH) : (PSD_LV(offF) + jb));
+                const int sd = (tA == 0) ? PSD_LV(strH) : PSD_LV(strF);
+                const double xx = tau * (PSD_LV(a1) + v2 * PSD_LV(a2) + v3 * PSD_LV(a3));
+                double m1 = PSD_LV(a1) - xx, m2 = PSD_LV(a2) - xx * v2, m3 = PSD_LV(a3) - xx * v3;
+                if (cls == 1) {
+                    m1 = beta;
+                    m2 = 0.0;
+                    m3 = 0.0;
+                }
+                PSD_LV(a1) = m1;
+                if (cls == 0 || (cls == 1 && fixon)) {
+                    q[0] = m1;
+                    q[sd] = m2;
+                    q[2 * sd] = m3;
+                }
+                if (cls == 1 && slot < PSD_TR_CAP) {
                     psd_tr tr;
-                    tr.pos = k;
+                    tr.pos = kA;
                     tr.kind = PSD_TR_R3;
                     tr.c0 = v2;
                     tr.c1 = v3;
                     tr.c2 = tau;
-                    const int slot = (tq == 0) ? (C.n1 + kk) : (C.nj + 2 * kk);
-                    if (slot < PSD_TR_CAP) C.tr[(size_t)(j - 1) * PSD_TR_CAP + slot] = tr;
+                    PSD_GLOBAL(psd_tr, trb)[(size_t)(j - 1) * PSD_TR_CAP + slot] = tr;
                 }
             }
-            {
-                const psd_c2_lay Y0 = psd_c2_layA(C, k, tq, 0);
-                nlq = Y0.nl;
-                nrwq = Y0.nrw;
-            }
-            (void)nrwq;
             if (s + 1 < L) {
                 // the next link's vector: column k of the factor just updated from the right, rows k.. (same position) or
-                // rows k+1.. (tq = p - 1: the factor is H_1 and the next link is the H_1 step of position k + 1)
-                const int lk = nlq + (k - C.r0) + ((tq == p - 1) ? 1 : 0);
+                // rows k+1.. (tA = p - 1: that factor is H_1 and the next link is the H_1 step of position k + 1)
+                const int lk = (tA == 0) ? lkH : (lkF + ((tA == p - 1) ? 1 : 0));
                 x0 = PSD_BCAST(a1, lk);
                 x1 = PSD_BCAST(a1, lk + 1);
                 x2 = PSD_BCAST(a1, lk + 2);
-                const int s1 = s + 1, kk1 = s1 / p, tq1 = s1 - kk1 * p;
+                if (tA == p - 1) {
+                    kA += 1;
+                    tA = 0;
+                    PSD_C2_SETUP_A(kA);
+                } else {
+                    tA += 1;
+                }
+                const int jbn = (p - tA) * bsz;  // (tA >= 1: factor p + 1 - tA)
                 PSD_PAR_ONCE(t, PSD_STEP_NT) {
-                    const psd_c2_lay Y = psd_c2_layA(C, C.ks + kk1, tq1, t);
+                    const int cls = (tA == 0) ? PSD_LV(clsH) : PSD_LV(clsF);
                     PSD_LV(a1) = PSD_LV(a2) = PSD_LV(a3) = 0.0;
-                    if (t < Y.nl + Y.nrw) {
-                        PSD_LV(a1) = wb[Y.off];
-                        PSD_LV(a2) = wb[Y.off + Y.str];
-                        PSD_LV(a3) = wb[Y.off + 2 * Y.str];
+                    if (cls == 0) {
+                        const double* q = wb + ((tA == 0) ? PSD_LV(offH) : (PSD_LV(offF) + jbn));
+                        const int sd = (tA == 0) ? PSD_LV(strH) : PSD_LV(strF);
+                        PSD_LV(a1) = q[0];
+                        PSD_LV(a2) = q[sd];
+                        PSD_LV(a3) = q[2 * sd];
                     }
                 }
             }
         }
-        if (roles & 2) {
-            // ------------------------------------------------------------------ B: link s - LAG
-            const int q = s - PSD_C2_LAG;
-            if (q >= 0) {
-                const int kk = q / p, tq = q - kk * p, k = C.ks + kk;
-                if (tq != 0) {
-                    const int j = p + 1 - tq;
-                    const psd_c2_lay Y0 = psd_c2_layB(C, k, tq, 0);
-                    const int fl = Y0.nl + Y0.nrw;  // the lane with column k + 1 of H_j
-                    double y0 = PSD_BCAST(b2, fl), y1 = PSD_BCAST(b3, fl);
-                    const double tau2 = psd_refl2(y0, y1);
-                    const double beta2 = y0, w2 = y1;
-                    PSD_PAR_ONCE(t, PSD_STEP_NT) {
-                        const psd_c2_lay Y = psd_c2_layB(C, k, tq, t);
-                        const int act = Y.nl + Y.nrw;
-                        if (t < act) {
-                            const double xx = tau2 * (PSD_LV(b2) + w2 * PSD_LV(b3));
-                            wb[Y.off] = PSD_LV(b2) - xx;
-                            wb[Y.off + Y.str] = PSD_LV(b3) - xx * w2;
-                        } else if (t == act) {
-                            wb[Y.off] = beta2;
-                            wb[Y.off + 1] = 0.0;
-                            psd_tr tr;
-                            tr.pos = k + 1;
-                            tr.kind = PSD_TR_H2;
-                            tr.c0 = w2;
-                            tr.c1 = 0.0;
-                            tr.c2 = tau2;
-                            const int slot = C.nj + 2 * kk + 1;
-                            if (slot < PSD_TR_CAP) C.tr[(size_t)(j - 1) * PSD_TR_CAP + slot] = tr;
-                        }
+        if ((roles & 2) && s >= PSD_C2_LAG) {
+            // ------------------------------------------------------------------ B: link (kB, tB), LAG steps behind A
+            if (tB != 0) {
+                const int j = p + 1 - tB;
+                const int jb = (j - 1) * bsz;
+                double y0 = PSD_BCAST(b2, flB), y1 = PSD_BCAST(b3, flB);
+                const double tau2 = psd_refl2_lean(y0, y1);
+                const double beta2 = y0, w2 = y1;
+                const int slot = nj + 2 * (kB - ks) + 1;
+                PSD_PAR_ONCE(t, PSD_STEP_NT) {
+                    const int cls = PSD_LV(clsB);
+                    double* q = wb + (PSD_LV(offB) + jb);
+                    const int sd = PSD_LV(strB);
+                    const double xx = tau2 * (PSD_LV(b2) + w2 * PSD_LV(b3));
+                    double m2 = PSD_LV(b2) - xx, m3 = PSD_LV(b3) - xx * w2;
+                    if (cls == 1) {
+                        m2 = beta2;
+                        m3 = 0.0;
+                    }
+                    if (cls != 2) {
+                        q[0] = m2;
+                        q[sd] = m3;
+                    }
+                    if (cls == 1 && slot < PSD_TR_CAP) {
+                        psd_tr tr;
+                        tr.pos = kB + 1;
+                        tr.kind = PSD_TR_H2;
+                        tr.c0 = w2;
+                        tr.c1 = 0.0;
+                        tr.c2 = tau2;
+                        PSD_GLOBAL(psd_tr, trb)[(size_t)(j - 1) * PSD_TR_CAP + slot] = tr;
                     }
                 }
-                const int q1 = q + 1;
-                if (q1 < L) {
-                    const int kk1 = q1 / p, tq1 = q1 - kk1 * p;
-                    if (tq1 != 0) {
-                        PSD_PAR_ONCE(t, PSD_STEP_NT) {
-                            const psd_c2_lay Y = psd_c2_layB(C, C.ks + kk1, tq1, t);
-                            PSD_LV(b2) = PSD_LV(b3) = 0.0;
-                            if (t <= Y.nl + Y.nrw) {
-                                PSD_LV(b2) = wb[Y.off];
-                                PSD_LV(b3) = wb[Y.off + Y.str];
-                            }
-                        }
+            }
+            // next link; its operands (the lane of class 1 holds column k + 1 of H_j: the vector of the 2-reflector)
+            if (tB == p - 1) {
+                kB += 1;
+                tB = 0;
+                if (kB < ks + npos) PSD_C2_SETUP_B(kB);
+            } else {
+                tB += 1;
+            }
+            if (tB != 0 && kB < ks + npos) {
+                const int jbn = (p - tB) * bsz;
+                PSD_PAR_ONCE(t, PSD_STEP_NT) {
+                    PSD_LV(b2) = PSD_LV(b3) = 0.0;
+                    if (PSD_LV(clsB) != 2) {
+                        const double* q = wb + (PSD_LV(offB) + jbn);
+                        const int sd = PSD_LV(strB);
+                        PSD_LV(b2) = q[0];
+                        PSD_LV(b3) = q[sd];
                     }
                 }
             }
         }
         PSD_PAIR_BARRIER();
     }
+#undef PSD_C2_SETUP_A
+#undef PSD_C2_SETUP_B
 }
 
 // wavefront A's side of a run: publish it, run it (the helper runs B), leave the helper parked
@@ -1906,7 +1963,10 @@ PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
             C.p = p; C.l = l; C.i = i; C.ks = ks; C.npos = klast - ks + 1;
             C.c1max = c1max; C.r0 = r0;
             C.n1 = 0; C.nj = 0;
-            C.wb = w.b;
+            {
+                PSD_LDS_DECL;
+                C.wboff = (int)((char*)w.b - (char*)psd_lds);
+            }
             C.tr = P.tr;
             C.v0 = st.v[0]; C.v1 = st.v[1]; C.v2 = st.v[2];
             PSD_SYNC();

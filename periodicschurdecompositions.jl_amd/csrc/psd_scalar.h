@@ -148,6 +148,71 @@ PSD_HD void psd_refl32_pair(double& x0, double& x1, double& x2, double& tau3, do
     }
 }
 
+// The same reflectors for a chain that must stay short in code as well as in time (psd_c2_run: one reflector per link
+// and wavefront): the fast path straight-line, ONE range test on the sums of squares behind it (as psd_refl32_pair), the
+// dlarfg path out of line.
+// (by value both ways: an argument passed by reference to a function that is not inlined lives in scratch memory, and
+//  its loads and stores would sit on the chain of every link)
+struct psd_refl_out {
+    double x0, x1, x2, tau;
+};
+PSD_D_NOINLINE psd_refl_out psd_refl3_slow(double x0, double x1, double x2) {
+    psd_refl_out o;
+    o.tau = psd_refl3(x0, x1, x2);
+    o.x0 = x0;
+    o.x1 = x1;
+    o.x2 = x2;
+    return o;
+}
+PSD_D_NOINLINE psd_refl_out psd_refl2_slow(double x0, double x1) {
+    psd_refl_out o;
+    o.tau = psd_refl2(x0, x1);
+    o.x0 = x0;
+    o.x1 = x1;
+    o.x2 = 0.0;
+    return o;
+}
+PSD_D double psd_refl3_lean(double& x0, double& x1, double& x2) {
+    const double tx2 = x1 * x1 + x2 * x2, nx2 = x0 * x0 + tx2;
+    double nx, rnx;
+    psd_sqrt_pair_fast(nx2, nx, rnx);
+    const double ax = fabs(x0);
+    double t3 = 1.0 + ax * rnx;
+    const double sx = psd_rcp_fast(copysign(ax + nx, x0));
+    double f0 = -copysign(nx, x0), f1 = x1 * sx, f2 = x2 * sx;
+    const bool ok = (nx2 < 1e280) & (tx2 > 1e-280);
+    if (!ok) {
+        const psd_refl_out o = psd_refl3_slow(x0, x1, x2);
+        f0 = o.x0;
+        f1 = o.x1;
+        f2 = o.x2;
+        t3 = o.tau;
+    }
+    x0 = f0;
+    x1 = f1;
+    x2 = f2;
+    return t3;
+}
+PSD_D double psd_refl2_lean(double& y0, double& y1) {
+    const double ty2 = y1 * y1, ny2 = y0 * y0 + ty2;
+    double ny, rny;
+    psd_sqrt_pair_fast(ny2, ny, rny);
+    const double ay = fabs(y0);
+    double t2 = 1.0 + ay * rny;
+    const double sy = psd_rcp_fast(copysign(ay + ny, y0));
+    double f0 = -copysign(ny, y0), f1 = y1 * sy;
+    const bool ok = (ny2 < 1e280) & (ty2 > 1e-280);
+    if (!ok) {
+        const psd_refl_out o = psd_refl2_slow(y0, y1);
+        f0 = o.x0;
+        f1 = o.x1;
+        t2 = o.tau;
+    }
+    y0 = f0;
+    y1 = f1;
+    return t2;
+}
+
 // stdlib LinearAlgebra.givensAlgorithm(f::Float64, g::Float64) (imported by the reference at
 // PSD.jl:9): (c, s, r) with [c s; -s c][f; g] = [r; 0].
 PSD_HD void psd_givens(double f, double g, double& cs, double& sn, double& r) {
