@@ -74,6 +74,19 @@ PSD_HD void psd_tr_apply(const psd_tr& t, double& a1, double& a2, double& a3) {
     }
 }
 PSD_HD int psd_tr_len(const psd_tr& t) { return t.kind == PSD_TR_R3 ? 3 : 2; }
+// a record to a list in device memory through a pointer that was read from a structure (generic to the compiler: a
+// plain assignment would be FLAT stores, which count against the LDS counter the chain waits on)
+PSD_D void psd_tr_store_global(psd_tr* dst, const psd_tr& tr) {
+#ifdef PSD_HOSTSIM
+    *dst = tr;
+#else
+    __attribute__((address_space(1))) double* q = (__attribute__((address_space(1))) double*)dst;
+    q[0] = __hiloint2double(tr.kind, tr.pos);  // (pos, kind: the first eight bytes)
+    q[1] = tr.c0;
+    q[2] = tr.c1;
+    q[3] = tr.c2;
+#endif
+}
 
 struct psd_apply_desc {
     int active;
@@ -1802,7 +1815,7 @@ PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
                     tr.c0 = v2;
                     tr.c1 = v3;
                     tr.c2 = tau;
-                    PSD_GLOBAL(psd_tr, trb)[(size_t)(j - 1) * PSD_TR_CAP + slot] = tr;
+                    psd_tr_store_global(trb + (size_t)(j - 1) * PSD_TR_CAP + slot, tr);
                 }
             }
             if (s + 1 < L) {
@@ -1863,7 +1876,7 @@ PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
                         tr.c0 = w2;
                         tr.c1 = 0.0;
                         tr.c2 = tau2;
-                        PSD_GLOBAL(psd_tr, trb)[(size_t)(j - 1) * PSD_TR_CAP + slot] = tr;
+                        psd_tr_store_global(trb + (size_t)(j - 1) * PSD_TR_CAP + slot, tr);
                     }
                 }
             }
