@@ -45,6 +45,8 @@ extern psd_simctx psd_sim;  // the block currently being simulated (serial)
 #define PSD_WAVE_ROLE 0
 #define PSD_GLOBAL(T, ptr) (ptr)
 #define PSD_PAIR_BARRIER() ((void)0)
+#define PSD_PAIR_BARRIER_KEEP(n) ((void)0)
+#define PSD_PAIR_BARRIER_BARE() ((void)0)
 // data-parallel loop over [0,count): iterations must be independent of each other
 #define PSD_PAR_FOR(t, count) for (int t = 0; t < (int)(count); ++t)
 #define PSD_ONE if (true)
@@ -52,6 +54,8 @@ extern psd_simctx psd_sim;  // the block currently being simulated (serial)
 // regions and can be broadcast from a given lane (v_readlane on the GPU, array slot here).
 #define PSD_MAXLANES 64
 #define PSD_PAR_ONCE(t, count) for (int t = 0; t < (int)(count); ++t)
+// every lane of a 64-lane block, no bound check
+#define PSD_PAR_ALL64(t) for (int t = 0; t < 64; ++t)
 // the wavefronts of a workgroup as independent workers (serial here; they touch disjoint data between two PSD_SYNCs)
 #define PSD_WAVES_FOR(g, G) for (int g = 0; g < (int)(G); ++g)
 #define PSD_LANEVAR(type, name) type name[PSD_MAXLANES]
@@ -158,6 +162,21 @@ __device__ __forceinline__ void psd_sync() {
         __builtin_amdgcn_s_barrier();                           \
         asm volatile("" ::: "memory");                          \
     } while (0)
+// the rendezvous alone (the caller argues which of its LDS operations are complete)
+#define PSD_PAIR_BARRIER_BARE()                                 \
+    do {                                                        \
+        asm volatile("" ::: "memory");                          \
+        __builtin_amdgcn_s_barrier();                           \
+        asm volatile("" ::: "memory");                          \
+    } while (0)
+// the same, but the n youngest LDS operations of this wavefront — loads it issued AFTER its last store, for its own next
+// step — may still be in flight behind the barrier (DS operations of a wave complete in order: the stores are out)
+#define PSD_PAIR_BARRIER_KEEP(n)                                \
+    do {                                                        \
+        asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
+        __builtin_amdgcn_s_barrier();                           \
+        asm volatile("" ::: "memory");                          \
+    } while (0)
 // LDS hand-off between lanes of ONE wavefront (only valid in single-wave workgroups): DS operations
 // of a wave execute in order, so only the compiler has to be fenced; unlike __syncthreads() this does
 // not drain outstanding global stores (vmcnt), which would put their acknowledge latency on the chain.
@@ -177,6 +196,7 @@ __device__ __forceinline__ void psd_sync() {
 #define PSD_ONE if (PSD_TID == 0)
 #define PSD_MAXLANES 64
 #define PSD_PAR_ONCE(t, count) if (const int t = PSD_TID; t < (int)(count))
+#define PSD_PAR_ALL64(t) if (const int t = PSD_TID; true)
 // the wavefronts of a workgroup as independent workers: g = wave index, runs for g < G
 #define PSD_WAVES_FOR(g, G) if (const int g = (int)threadIdx.x >> 6; g < (int)(G))
 #define PSD_LANEVAR(type, name) type name = type()

@@ -1665,6 +1665,13 @@ struct psd_c2 {
 // roles: bit 0 = A, bit 1 = B (a wavefront runs one; the simulated tier both).  Lane classes of a link: 0 = an operand
 // triple / pair that takes the reflector, 1 = the lane that writes the annihilated column and the record, 2 = idle.
 // Operand addresses are fixed per position up to the factor's block: off + (j - 1) bsz (the right lanes carry -bsz).
+//
+// A lone wavefront hides nothing: every taken branch is a fetch bubble, every dependent instruction waits out its
+// predecessor.  So the steps are straight-line blocks (selects and one masked store instead of per-class branches), a
+// step starts with its LDS loads and generates its reflector while they are in flight, both strands hand the next
+// link's vector over in registers (lane broadcasts from the lanes that just updated it) instead of reading it back from
+// LDS, and the loops over the factors carry no position logic.  Steps: s = 0 .. L + LAG - 1, a barrier in front of each
+// and one behind the last; A works in steps [0, L), B (link s - LAG) in [LAG, L + LAG).
 PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
     PSD_LDS_DECL;
     const int roles = PSD_C2_UNI(roles_);
@@ -1686,14 +1693,23 @@ PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
     PSD_LANEVAR(int, offF);  // factor steps
     PSD_LANEVAR(int, strF);
     PSD_LANEVAR(int, clsF);
-    int kA = ks, tA = 0, lkH = 0, lkF = 0;
+    int lkH = 0, lkF = 0;
+    // records of the factor steps, held by lane (j - 2) & 63 until the position (or a run of 64 factors) is through:
+    // one scattered store per 64 links instead of two global stores on every link's chain
+    PSD_LANEVAR(double, rc0);
+    PSD_LANEVAR(double, rc1);
+    PSD_LANEVAR(double, rc2);
+    PSD_LANEVAR(double, rd0);  // (B's: the simulated tier runs both strands in one function)
+    PSD_LANEVAR(double, rd1);
+    PSD_LANEVAR(double, rd2);
     // ---- B
+    double y0 = 0.0, y1 = 0.0;
     PSD_LANEVAR(double, b2);
     PSD_LANEVAR(double, b3);
     PSD_LANEVAR(int, offB);
     PSD_LANEVAR(int, strB);
     PSD_LANEVAR(int, clsB);
-    int kB = ks, tB = 0, flB = 0;
+    int flB = 0, lyB = 0;
 #define PSD_C2_SETUP_A(k_)                                                                             \
     do {                                                                                               \
         const int k__ = (k_);                                                                          \
@@ -1704,7 +1720,7 @@ PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
         if (nlf__ < 0) nlf__ = 0;                                                                      \
         lkH = nlh__ + (k__ - r0);                                                                      \
         lkF = nlf__ + (k__ - r0);                                                                      \
-        PSD_PAR_ONCE(t, PSD_STEP_NT) {                                                                 \
+        PSD_PAR_ALL64(t) {                                                                 \
             if (t < nlh__) {                                                                           \
                 PSD_LV(offH) = (k__ + t - bs) * ld + (k__ - bs);                                       \
                 PSD_LV(strH) = 1;                                                                      \
@@ -1741,7 +1757,8 @@ PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
         int nlb__ = c1max - (k__ + 2) + 1;                                                             \
         if (nlb__ < 0) nlb__ = 0;                                                                      \
         flB = nlb__ + nrw__;                                                                           \
-        PSD_PAR_ONCE(t, PSD_STEP_NT) {                                                                 \
+        lyB = nlb__ + (k__ + 1 - r0);                                                                  \
+        PSD_PAR_ALL64(t) {                                                                 \
             if (t < nlb__) {                                                                           \
                 PSD_LV(offB) = (k__ + 2 + t - bs) * ld + (k__ + 1 - bs);                               \
                 PSD_LV(strB) = 1;                                                                      \
@@ -1757,6 +1774,126 @@ PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
             }                                                                                          \
         }                                                                                              \
     } while (0)
+    // one link of A.  OFF / STR / CLS: the lane variables of the layout; JB: block offset added to OFF; JIDX: the factor
+    // that is updated from the left (list owner); FIXON: the class-1 lane writes its column; SLOT: list slot; LK: lane of
+    // the first of the three rows of the next link's vector.  (a1, a2, a3) <- operands; (x0, x1, x2) in: the vector to
+    // reflect, out: the next link's.
+#define PSD_C2_A_STEP(OFF, STR, CLS, JB, JIDX, FIXON, KPOS, SLOT, LK)                                  \
+    do {                                                                                               \
+        PSD_PAR_ALL64(t) {                                                                 \
+            PSD_LV(a1) = PSD_LV(a2) = PSD_LV(a3) = 0.0;                                                \
+            if (PSD_LV(CLS) == 0) {                                                                    \
+                const double* q = wb + (PSD_LV(OFF) + (JB));                                           \
+                const int sd = PSD_LV(STR);                                                            \
+                PSD_LV(a1) = q[0];                                                                     \
+                PSD_LV(a2) = q[sd];                                                                    \
+                PSD_LV(a3) = q[2 * sd];                                                                \
+            }                                                                                          \
+        }                                                                                              \
+        const double tau__ = psd_refl3_lean(x0, x1, x2);                                               \
+        const double beta__ = x0, v2__ = x1, v3__ = x2;                                                \
+        PSD_PAR_ALL64(t) {                                                                 \
+            const double xx = tau__ * (PSD_LV(a1) + v2__ * PSD_LV(a2) + v3__ * PSD_LV(a3));            \
+            PSD_LV(a1) -= xx;                                                                          \
+            PSD_LV(a2) -= xx * v2__;                                                                   \
+            PSD_LV(a3) -= xx * v3__;                                                                   \
+            if (PSD_LV(CLS) == 1) {                                                                    \
+                PSD_LV(a1) = beta__;                                                                   \
+                PSD_LV(a2) = 0.0;                                                                      \
+                PSD_LV(a3) = 0.0;                                                                      \
+            }                                                                                          \
+        }                                                                                              \
+        x0 = PSD_BCAST(a1, (LK));                                                                      \
+        x1 = PSD_BCAST(a1, (LK) + 1);                                                                  \
+        x2 = PSD_BCAST(a1, (LK) + 2);                                                                  \
+        PSD_PAR_ALL64(t) {                                                                 \
+            const int cls = PSD_LV(CLS);                                                               \
+            double* q = wb + (PSD_LV(OFF) + (JB));                                                     \
+            const int sd = PSD_LV(STR);                                                                \
+            if (cls == 0 || (cls == 1 && (FIXON))) {                                                   \
+                q[0] = PSD_LV(a1);                                                                     \
+                q[sd] = PSD_LV(a2);                                                                    \
+                q[2 * sd] = PSD_LV(a3);                                                                \
+            }                                                                                          \
+            if ((JIDX) == 1) {                                                                         \
+                if (cls == 1 && (SLOT) < PSD_TR_CAP) {                                                 \
+                    psd_tr tr;                                                                         \
+                    tr.pos = (KPOS);                                                                   \
+                    tr.kind = PSD_TR_R3;                                                               \
+                    tr.c0 = v2__;                                                                      \
+                    tr.c1 = v3__;                                                                      \
+                    tr.c2 = tau__;                                                                     \
+                    psd_tr_store_global(trb + (SLOT), tr);                                             \
+                }                                                                                      \
+            } else if (t == (((JIDX) - 2) & 63)) {                                                     \
+                PSD_LV(rc0) = v2__;                                                                    \
+                PSD_LV(rc1) = v3__;                                                                    \
+                PSD_LV(rc2) = tau__;                                                                   \
+            }                                                                                          \
+        }                                                                                              \
+    } while (0)
+    // one link of B (factor JIDX).  FIRST: the vector comes from the class-1 lane's operands (first factor of a
+    // position); otherwise (y0, y1) was handed over by the previous link.  Out: the next factor's vector, column k + 1
+    // of H_{j-1} on rows k+1, k+2 as this link's column update left it (lanes LY, LY + 1 of the right lanes).
+#define PSD_C2_B_STEP(JB, JIDX, FIRST, KPOS, SLOT)                                                     \
+    do {                                                                                               \
+        PSD_PAR_ALL64(t) {                                                                 \
+            PSD_LV(b2) = PSD_LV(b3) = 0.0;                                                             \
+            if (PSD_LV(clsB) != 2) {                                                                   \
+                const double* q = wb + (PSD_LV(offB) + (JB));                                          \
+                const int sd = PSD_LV(strB);                                                           \
+                PSD_LV(b2) = q[0];                                                                     \
+                PSD_LV(b3) = q[sd];                                                                    \
+            }                                                                                          \
+        }                                                                                              \
+        if (FIRST) {                                                                                   \
+            y0 = PSD_BCAST(b2, flB);                                                                   \
+            y1 = PSD_BCAST(b3, flB);                                                                   \
+        }                                                                                              \
+        const double tau2__ = psd_refl2_lean(y0, y1);                                                  \
+        const double beta2__ = y0, w2__ = y1;                                                          \
+        PSD_PAR_ALL64(t) {                                                                 \
+            const double xx = tau2__ * (PSD_LV(b2) + w2__ * PSD_LV(b3));                               \
+            PSD_LV(b2) -= xx;                                                                          \
+            PSD_LV(b3) -= xx * w2__;                                                                   \
+            if (PSD_LV(clsB) == 1) {                                                                   \
+                PSD_LV(b2) = beta2__;                                                                  \
+                PSD_LV(b3) = 0.0;                                                                      \
+            }                                                                                          \
+        }                                                                                              \
+        y0 = PSD_BCAST(b2, lyB);                                                                       \
+        y1 = PSD_BCAST(b2, lyB + 1);                                                                   \
+        PSD_PAR_ALL64(t) {                                                                 \
+            const int cls = PSD_LV(clsB);                                                              \
+            double* q = wb + (PSD_LV(offB) + (JB));                                                    \
+            const int sd = PSD_LV(strB);                                                               \
+            if (cls != 2) {                                                                            \
+                q[0] = PSD_LV(b2);                                                                     \
+                q[sd] = PSD_LV(b3);                                                                    \
+            }                                                                                          \
+            if (t == (((JIDX) - 2) & 63)) {                                                            \
+                PSD_LV(rd0) = w2__;                                                                    \
+                PSD_LV(rd1) = 0.0;                                                                     \
+                PSD_LV(rd2) = tau2__;                                                                  \
+            }                                                                                          \
+        }                                                                                              \
+    } while (0)
+    // the lane-held records of factors JLO .. min(JLO + 63, p) (JLO - 2 a multiple of 64) to their owners' lists
+#define PSD_C2_FLUSH(R0, R1, R2, JLO, KIND, POS, SLOT)                                                           \
+    do {                                                                                               \
+        PSD_PAR_ALL64(t) {                                                                             \
+            const int jj = (JLO) + t;                                                                  \
+            if (jj <= p && (SLOT) < PSD_TR_CAP) {                                                      \
+                psd_tr tr;                                                                             \
+                tr.pos = (POS);                                                                        \
+                tr.kind = (KIND);                                                                      \
+                tr.c0 = PSD_LV(R0);                                                                    \
+                tr.c1 = PSD_LV(R1);                                                                    \
+                tr.c2 = PSD_LV(R2);                                                                    \
+                psd_tr_store_global(trb + (size_t)(jj - 1) * PSD_TR_CAP + (SLOT), tr);                 \
+            }                                                                                          \
+        }                                                                                              \
+    } while (0)
     if (roles & 1) {
         if (ks > l) {
             x0 = wb[(ks - 1 - bs) * ld + (ks - bs)];
@@ -1767,144 +1904,84 @@ PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
             x1 = Cin.v1;
             x2 = Cin.v2;
         }
-        PSD_C2_SETUP_A(ks);
-        PSD_PAR_ONCE(t, PSD_STEP_NT) {
-            PSD_LV(a1) = PSD_LV(a2) = PSD_LV(a3) = 0.0;
-            if (PSD_LV(clsH) == 0) {
-                const double* q = wb + PSD_LV(offH);
-                const int sd = PSD_LV(strH);
-                PSD_LV(a1) = q[0];
-                PSD_LV(a2) = q[sd];
-                PSD_LV(a3) = q[2 * sd];
-            }
-        }
     }
-    if (roles & 2) PSD_C2_SETUP_B(ks);
-    for (int s = 0; s < L + PSD_C2_LAG; ++s) {
-        if ((roles & 1) && s < L) {
-            // ------------------------------------------------------------------ A: link (kA, tA)
-            const int j = (tA == 0) ? 1 : (p + 1 - tA);
-            const int jb = (j - 1) * bsz;
-            const double tau = psd_refl3_lean(x0, x1, x2);
-            const double beta = x0, v2 = x1, v3 = x2;
-            const bool fixon = tA > 0 || kA > l;  // (the first position of a sweep has no column to annihilate in H_1)
-            const int slot = (tA == 0) ? (n1 + (kA - ks)) : (nj + 2 * (kA - ks));
-            PSD_PAR_ONCE(t, PSD_STEP_NT) {
-                // one instruction stream for all lane classes (selects, then one masked store): a lone wavefront pays
-                // for every instruction of every divergent path
-                const int cls = (tA == 0) ? PSD_LV(clsH) : PSD_LV(clsF);
-                double* q = wb + ((tA == 0) ? PSD_LV(offH) : (PSD_LV(offF) + jb));
-                const int sd = (tA == 0) ? PSD_LV(strH) : PSD_LV(strF);
-                const double xx = tau * (PSD_LV(a1) + v2 * PSD_LV(a2) + v3 * PSD_LV(a3));
-                double m1 = PSD_LV(a1) - xx, m2 = PSD_LV(a2) - xx * v2, m3 = PSD_LV(a3) - xx * v3;
-                if (cls == 1) {
-                    m1 = beta;
-                    m2 = 0.0;
-                    m3 = 0.0;
-                }
-                PSD_LV(a1) = m1;
-                if (cls == 0 || (cls == 1 && fixon)) {
-                    q[0] = m1;
-                    q[sd] = m2;
-                    q[2 * sd] = m3;
-                }
-                if (cls == 1 && slot < PSD_TR_CAP) {
-                    psd_tr tr;
-                    tr.pos = kA;
-                    tr.kind = PSD_TR_R3;
-                    tr.c0 = v2;
-                    tr.c1 = v3;
-                    tr.c2 = tau;
-                    psd_tr_store_global(trb + (size_t)(j - 1) * PSD_TR_CAP + slot, tr);
-                }
+#ifndef PSD_HOSTSIM
+    if (roles == 1) {
+        for (int kk = 0; kk < npos; ++kk) {
+            const int k = ks + kk;
+            PSD_C2_SETUP_A(k);
+            PSD_PAIR_BARRIER_BARE();
+            PSD_C2_A_STEP(offH, strH, clsH, 0, 1, k > l, k, n1 + kk, lkH);
+            int jb = (p - 1) * bsz;
+            const int slot = nj + 2 * kk;
+            for (int j = p; j > 2; --j) {
+                PSD_PAIR_BARRIER_BARE();
+                PSD_C2_A_STEP(offF, strF, clsF, jb, j, true, k, slot, lkF);
+                if (((j - 2) & 63) == 0) PSD_C2_FLUSH(rc0, rc1, rc2, j, PSD_TR_R3, k, slot);
+                jb -= bsz;
             }
-            if (s + 1 < L) {
-                // the next link's vector: column k of the factor just updated from the right, rows k.. (same position) or
-                // rows k+1.. (tA = p - 1: that factor is H_1 and the next link is the H_1 step of position k + 1)
-                const int lk = (tA == 0) ? lkH : (lkF + ((tA == p - 1) ? 1 : 0));
-                x0 = PSD_BCAST(a1, lk);
-                x1 = PSD_BCAST(a1, lk + 1);
-                x2 = PSD_BCAST(a1, lk + 2);
-                if (tA == p - 1) {
-                    kA += 1;
-                    tA = 0;
-                    PSD_C2_SETUP_A(kA);
-                } else {
-                    tA += 1;
-                }
-                const int jbn = (p - tA) * bsz;  // (tA >= 1: factor p + 1 - tA)
-                PSD_PAR_ONCE(t, PSD_STEP_NT) {
-                    const int cls = (tA == 0) ? PSD_LV(clsH) : PSD_LV(clsF);
-                    PSD_LV(a1) = PSD_LV(a2) = PSD_LV(a3) = 0.0;
-                    if (cls == 0) {
-                        const double* q = wb + ((tA == 0) ? PSD_LV(offH) : (PSD_LV(offF) + jbn));
-                        const int sd = (tA == 0) ? PSD_LV(strH) : PSD_LV(strF);
-                        PSD_LV(a1) = q[0];
-                        PSD_LV(a2) = q[sd];
-                        PSD_LV(a3) = q[2 * sd];
-                    }
-                }
-            }
+            // (factor 2: the next vector is column k of H_1 on rows k+1 .. k+3, for the H_1 step of position k + 1;
+            //  behind the last position of the run nobody uses it, and row k + 3 may not exist: the lane index stays
+            //  inside the wavefront, the values are not looked at)
+            PSD_PAIR_BARRIER_BARE();
+            PSD_C2_A_STEP(offF, strF, clsF, jb, 2, true, k, slot, (lkF + 1));
+            PSD_C2_FLUSH(rc0, rc1, rc2, 2, PSD_TR_R3, k, slot);
         }
-        if ((roles & 2) && s >= PSD_C2_LAG) {
-            // ------------------------------------------------------------------ B: link (kB, tB), LAG steps behind A
-            if (tB != 0) {
-                const int j = p + 1 - tB;
-                const int jb = (j - 1) * bsz;
-                double y0 = PSD_BCAST(b2, flB), y1 = PSD_BCAST(b3, flB);
-                const double tau2 = psd_refl2_lean(y0, y1);
-                const double beta2 = y0, w2 = y1;
-                const int slot = nj + 2 * (kB - ks) + 1;
-                PSD_PAR_ONCE(t, PSD_STEP_NT) {
-                    const int cls = PSD_LV(clsB);
-                    double* q = wb + (PSD_LV(offB) + jb);
-                    const int sd = PSD_LV(strB);
-                    const double xx = tau2 * (PSD_LV(b2) + w2 * PSD_LV(b3));
-                    double m2 = PSD_LV(b2) - xx, m3 = PSD_LV(b3) - xx * w2;
-                    if (cls == 1) {
-                        m2 = beta2;
-                        m3 = 0.0;
-                    }
-                    if (cls != 2) {
-                        q[0] = m2;
-                        q[sd] = m3;
-                    }
-                    if (cls == 1 && slot < PSD_TR_CAP) {
-                        psd_tr tr;
-                        tr.pos = kB + 1;
-                        tr.kind = PSD_TR_H2;
-                        tr.c0 = w2;
-                        tr.c1 = 0.0;
-                        tr.c2 = tau2;
-                        psd_tr_store_global(trb + (size_t)(j - 1) * PSD_TR_CAP + slot, tr);
-                    }
-                }
-            }
-            // next link; its operands (the lane of class 1 holds column k + 1 of H_j: the vector of the 2-reflector)
-            if (tB == p - 1) {
-                kB += 1;
-                tB = 0;
-                if (kB < ks + npos) PSD_C2_SETUP_B(kB);
-            } else {
-                tB += 1;
-            }
-            if (tB != 0 && kB < ks + npos) {
-                const int jbn = (p - tB) * bsz;
-                PSD_PAR_ONCE(t, PSD_STEP_NT) {
-                    PSD_LV(b2) = PSD_LV(b3) = 0.0;
-                    if (PSD_LV(clsB) != 2) {
-                        const double* q = wb + (PSD_LV(offB) + jbn);
-                        const int sd = PSD_LV(strB);
-                        PSD_LV(b2) = q[0];
-                        PSD_LV(b3) = q[sd];
-                    }
-                }
+        for (int e = 0; e < PSD_C2_LAG + 1; ++e) PSD_PAIR_BARRIER();
+    } else {
+        for (int e = 0; e < PSD_C2_LAG; ++e) PSD_PAIR_BARRIER_BARE();
+        for (int kk = 0; kk < npos; ++kk) {
+            const int k = ks + kk;
+            PSD_C2_SETUP_B(k);
+            PSD_PAIR_BARRIER_BARE();  // (the slot of the H_1 step: no 2-reflector)
+            int jb = (p - 1) * bsz;
+            const int slot = nj + 2 * kk + 1;
+            PSD_PAIR_BARRIER_BARE();
+            PSD_C2_B_STEP(jb, p, true, k, slot);
+            if (((p - 2) & 63) == 0) PSD_C2_FLUSH(rd0, rd1, rd2, p, PSD_TR_H2, k + 1, slot);
+            jb -= bsz;
+            for (int j = p - 1; j >= 2; --j) {
+                PSD_PAIR_BARRIER_BARE();
+                PSD_C2_B_STEP(jb, j, false, k, slot);
+                if (((j - 2) & 63) == 0) PSD_C2_FLUSH(rd0, rd1, rd2, j, PSD_TR_H2, k + 1, slot);
+                jb -= bsz;
             }
         }
         PSD_PAIR_BARRIER();
     }
+#else
+    // the simulated tier: the same steps in the order of the global step counter (A's link s, then B's link s - LAG)
+    for (int s = 0; s < L + PSD_C2_LAG; ++s) {
+        if ((roles & 1) && s < L) {
+            const int kk = s / p, tq = s - kk * p, k = ks + kk;
+            if (tq == 0) {
+                PSD_C2_SETUP_A(k);
+                PSD_C2_A_STEP(offH, strH, clsH, 0, 1, k > l, k, n1 + kk, lkH);
+            } else {
+                const int j = p + 1 - tq;
+                PSD_C2_A_STEP(offF, strF, clsF, (j - 1) * bsz, j, true, k, nj + 2 * kk, (lkF + ((j == 2) ? 1 : 0)));
+                if (((j - 2) & 63) == 0) PSD_C2_FLUSH(rc0, rc1, rc2, j, PSD_TR_R3, k, nj + 2 * kk);
+            }
+        }
+        const int q = s - PSD_C2_LAG;
+        if ((roles & 2) && q >= 0) {
+            const int kk = q / p, tq = q - kk * p, k = ks + kk;
+            if (tq == 0) {
+                PSD_C2_SETUP_B(k);
+            } else {
+                const int j = p + 1 - tq;
+                PSD_C2_B_STEP((j - 1) * bsz, j, tq == 1, k, nj + 2 * kk + 1);
+                if (((j - 2) & 63) == 0) PSD_C2_FLUSH(rd0, rd1, rd2, j, PSD_TR_H2, k + 1, nj + 2 * kk + 1);
+            }
+        }
+    }
+#endif
+    (void)L;
 #undef PSD_C2_SETUP_A
 #undef PSD_C2_SETUP_B
+#undef PSD_C2_A_STEP
+#undef PSD_C2_B_STEP
+#undef PSD_C2_FLUSH
 }
 
 // wavefront A's side of a run: publish it, run it (the helper runs B), leave the helper parked
