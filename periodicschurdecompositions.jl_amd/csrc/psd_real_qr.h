@@ -1655,6 +1655,9 @@ struct psd_c2 {
     double v0, v1, v2;        // the sweep's start vector (used when ks == l)
 };
 #define PSD_C2_MINP 8
+#ifndef PSD_C2_STAMP
+#define PSD_C2_STAMP(i) ((void)0)  // (tools/micro/c2_bench.py: in-loop cycle stamps of the timing harness)
+#endif
 #define PSD_C2_LAG 3
 #ifdef PSD_HOSTSIM
 #define PSD_C2_UNI(x) (x)
@@ -1694,14 +1697,6 @@ PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
     PSD_LANEVAR(int, strF);
     PSD_LANEVAR(int, clsF);
     int lkH = 0, lkF = 0;
-    // records of the factor steps, held by lane (j - 2) & 63 until the position (or a run of 64 factors) is through:
-    // one scattered store per 64 links instead of two global stores on every link's chain
-    PSD_LANEVAR(double, rc0);
-    PSD_LANEVAR(double, rc1);
-    PSD_LANEVAR(double, rc2);
-    PSD_LANEVAR(double, rd0);  // (B's: the simulated tier runs both strands in one function)
-    PSD_LANEVAR(double, rd1);
-    PSD_LANEVAR(double, rd2);
     // ---- B
     double y0 = 0.0, y1 = 0.0;
     PSD_LANEVAR(double, b2);
@@ -1790,7 +1785,9 @@ PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
                 PSD_LV(a3) = q[2 * sd];                                                                \
             }                                                                                          \
         }                                                                                              \
+        PSD_C2_STAMP(0);                                                                               \
         const double tau__ = psd_refl3_lean(x0, x1, x2);                                               \
+        PSD_C2_STAMP(1);                                                                               \
         const double beta__ = x0, v2__ = x1, v3__ = x2;                                                \
         PSD_PAR_ALL64(t) {                                                                 \
             const double xx = tau__ * (PSD_LV(a1) + v2__ * PSD_LV(a2) + v3__ * PSD_LV(a3));            \
@@ -1803,9 +1800,11 @@ PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
                 PSD_LV(a3) = 0.0;                                                                      \
             }                                                                                          \
         }                                                                                              \
+        PSD_C2_STAMP(2);                                                                               \
         x0 = PSD_BCAST(a1, (LK));                                                                      \
         x1 = PSD_BCAST(a1, (LK) + 1);                                                                  \
         x2 = PSD_BCAST(a1, (LK) + 2);                                                                  \
+        PSD_C2_STAMP(3);                                                                               \
         PSD_PAR_ALL64(t) {                                                                 \
             const int cls = PSD_LV(CLS);                                                               \
             double* q = wb + (PSD_LV(OFF) + (JB));                                                     \
@@ -1815,22 +1814,17 @@ PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
                 q[sd] = PSD_LV(a2);                                                                    \
                 q[2 * sd] = PSD_LV(a3);                                                                \
             }                                                                                          \
-            if ((JIDX) == 1) {                                                                         \
-                if (cls == 1 && (SLOT) < PSD_TR_CAP) {                                                 \
-                    psd_tr tr;                                                                         \
-                    tr.pos = (KPOS);                                                                   \
-                    tr.kind = PSD_TR_R3;                                                               \
-                    tr.c0 = v2__;                                                                      \
-                    tr.c1 = v3__;                                                                      \
-                    tr.c2 = tau__;                                                                     \
-                    psd_tr_store_global(trb + (SLOT), tr);                                             \
-                }                                                                                      \
-            } else if (t == (((JIDX) - 2) & 63)) {                                                     \
-                PSD_LV(rc0) = v2__;                                                                    \
-                PSD_LV(rc1) = v3__;                                                                    \
-                PSD_LV(rc2) = tau__;                                                                   \
+            if (cls == 1 && (SLOT) < PSD_TR_CAP) {                                                     \
+                psd_tr tr;                                                                             \
+                tr.pos = (KPOS);                                                                       \
+                tr.kind = PSD_TR_R3;                                                                   \
+                tr.c0 = v2__;                                                                          \
+                tr.c1 = v3__;                                                                          \
+                tr.c2 = tau__;                                                                         \
+                psd_tr_store_global(trb + (size_t)((JIDX) - 1) * PSD_TR_CAP + (SLOT), tr);             \
             }                                                                                          \
         }                                                                                              \
+        PSD_C2_STAMP(4);                                                                               \
     } while (0)
     // one link of B (factor JIDX).  FIRST: the vector comes from the class-1 lane's operands (first factor of a
     // position); otherwise (y0, y1) was handed over by the previous link.  Out: the next factor's vector, column k + 1
@@ -1871,26 +1865,14 @@ PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
                 q[0] = PSD_LV(b2);                                                                     \
                 q[sd] = PSD_LV(b3);                                                                    \
             }                                                                                          \
-            if (t == (((JIDX) - 2) & 63)) {                                                            \
-                PSD_LV(rd0) = w2__;                                                                    \
-                PSD_LV(rd1) = 0.0;                                                                     \
-                PSD_LV(rd2) = tau2__;                                                                  \
-            }                                                                                          \
-        }                                                                                              \
-    } while (0)
-    // the lane-held records of factors JLO .. min(JLO + 63, p) (JLO - 2 a multiple of 64) to their owners' lists
-#define PSD_C2_FLUSH(R0, R1, R2, JLO, KIND, POS, SLOT)                                                           \
-    do {                                                                                               \
-        PSD_PAR_ALL64(t) {                                                                             \
-            const int jj = (JLO) + t;                                                                  \
-            if (jj <= p && (SLOT) < PSD_TR_CAP) {                                                      \
+            if (cls == 1 && (SLOT) < PSD_TR_CAP) {                                                     \
                 psd_tr tr;                                                                             \
-                tr.pos = (POS);                                                                        \
-                tr.kind = (KIND);                                                                      \
-                tr.c0 = PSD_LV(R0);                                                                    \
-                tr.c1 = PSD_LV(R1);                                                                    \
-                tr.c2 = PSD_LV(R2);                                                                    \
-                psd_tr_store_global(trb + (size_t)(jj - 1) * PSD_TR_CAP + (SLOT), tr);                 \
+                tr.pos = (KPOS) + 1;                                                                   \
+                tr.kind = PSD_TR_H2;                                                                   \
+                tr.c0 = w2__;                                                                          \
+                tr.c1 = 0.0;                                                                           \
+                tr.c2 = tau2__;                                                                        \
+                psd_tr_store_global(trb + (size_t)((JIDX) - 1) * PSD_TR_CAP + (SLOT), tr);             \
             }                                                                                          \
         }                                                                                              \
     } while (0)
@@ -1917,7 +1899,6 @@ PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
             for (int j = p; j > 2; --j) {
                 PSD_PAIR_BARRIER_BARE();
                 PSD_C2_A_STEP(offF, strF, clsF, jb, j, true, k, slot, lkF);
-                if (((j - 2) & 63) == 0) PSD_C2_FLUSH(rc0, rc1, rc2, j, PSD_TR_R3, k, slot);
                 jb -= bsz;
             }
             // (factor 2: the next vector is column k of H_1 on rows k+1 .. k+3, for the H_1 step of position k + 1;
@@ -1925,7 +1906,6 @@ PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
             //  inside the wavefront, the values are not looked at)
             PSD_PAIR_BARRIER_BARE();
             PSD_C2_A_STEP(offF, strF, clsF, jb, 2, true, k, slot, (lkF + 1));
-            PSD_C2_FLUSH(rc0, rc1, rc2, 2, PSD_TR_R3, k, slot);
         }
         for (int e = 0; e < PSD_C2_LAG + 1; ++e) PSD_PAIR_BARRIER();
     } else {
@@ -1938,12 +1918,10 @@ PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
             const int slot = nj + 2 * kk + 1;
             PSD_PAIR_BARRIER_BARE();
             PSD_C2_B_STEP(jb, p, true, k, slot);
-            if (((p - 2) & 63) == 0) PSD_C2_FLUSH(rd0, rd1, rd2, p, PSD_TR_H2, k + 1, slot);
             jb -= bsz;
             for (int j = p - 1; j >= 2; --j) {
                 PSD_PAIR_BARRIER_BARE();
                 PSD_C2_B_STEP(jb, j, false, k, slot);
-                if (((j - 2) & 63) == 0) PSD_C2_FLUSH(rd0, rd1, rd2, j, PSD_TR_H2, k + 1, slot);
                 jb -= bsz;
             }
         }
@@ -1960,7 +1938,6 @@ PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
             } else {
                 const int j = p + 1 - tq;
                 PSD_C2_A_STEP(offF, strF, clsF, (j - 1) * bsz, j, true, k, nj + 2 * kk, (lkF + ((j == 2) ? 1 : 0)));
-                if (((j - 2) & 63) == 0) PSD_C2_FLUSH(rc0, rc1, rc2, j, PSD_TR_R3, k, nj + 2 * kk);
             }
         }
         const int q = s - PSD_C2_LAG;
@@ -1971,7 +1948,6 @@ PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
             } else {
                 const int j = p + 1 - tq;
                 PSD_C2_B_STEP((j - 1) * bsz, j, tq == 1, k, nj + 2 * kk + 1);
-                if (((j - 2) & 63) == 0) PSD_C2_FLUSH(rd0, rd1, rd2, j, PSD_TR_H2, k + 1, nj + 2 * kk + 1);
             }
         }
     }
@@ -1981,7 +1957,6 @@ PSD_D void psd_c2_run(const psd_c2& Cin, int roles_) {
 #undef PSD_C2_SETUP_B
 #undef PSD_C2_A_STEP
 #undef PSD_C2_B_STEP
-#undef PSD_C2_FLUSH
 }
 
 // wavefront A's side of a run: publish it, run it (the helper runs B), leave the helper parked

@@ -22,6 +22,10 @@ PSD_D void psd_tr_store_global(psd_tr* dst, const psd_tr& tr) {
     __attribute__((address_space(1))) double* q = (__attribute__((address_space(1))) double*)dst;
     q[0] = __hiloint2double(tr.kind, tr.pos); q[1] = tr.c0; q[2] = tr.c1; q[3] = tr.c2;
 }
+#ifdef STAMPS
+__device__ long long g_st[8], g_last;
+#define PSD_C2_STAMP(i) do { const long long now__ = __builtin_amdgcn_s_memtime(); if (threadIdx.y == 0) { g_st[i] += now__ - g_last; g_last = now__; } } while (0)
+#endif
 #ifdef NOBARRIER
 #undef PSD_PAIR_BARRIER
 #define PSD_PAIR_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
