@@ -898,6 +898,32 @@ class Engine:
         return wr + 1j * wi, si.value, st, log[: 3 * nl].reshape(-1, 3).copy()
 
 
+    def zpschur_dev(self, dA_ptr, n, p, lr="R", dZ_ptr=None, wantT=True, maxitfac=30):
+        """Device-resident pschur! for ComplexF64 (psd_z_pschur_dev): dA_ptr / dZ_ptr are device addresses of [p][n][n]
+        column-major blocks of interleaved (re, im) doubles.  Returns (values, schurindex, stats, sweep log)."""
+        orient = char_lr(lr)
+        wantZ = dZ_ptr is not None
+        alpha = np.zeros(n, dtype=np.complex128)
+        beta = np.zeros(n)
+        sc = np.zeros(n, dtype=np.int32)
+        si = C.c_int(0)
+        st = Stats()
+        maxlog = 2 * maxitfac * n + n + 16
+        log = np.zeros(3 * maxlog, dtype=np.int32)
+        info = C.c_int(0)
+        dp = C.POINTER(C.c_double)
+        i32p = C.POINTER(C.c_int32)
+        self.lib.psd_z_pschur_dev(self.ctx, n, p, C.c_void_p(dA_ptr), orient.encode(), int(wantT), int(wantZ),
+                                  int(maxitfac), C.c_void_p(dZ_ptr) if wantZ else None, alpha.ctypes.data_as(dp),
+                                  beta.ctypes.data_as(dp), sc.ctypes.data_as(i32p), C.byref(si), C.byref(st),
+                                  log.ctypes.data_as(i32p), maxlog, C.byref(info))
+        self._raise(info.value)
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            lam = alpha / beta * np.exp2(sc.astype(np.float64))
+        nl = min(st.nlog, maxlog)
+        return lam, si.value, st, log[: 3 * nl].reshape(-1, 3).copy()
+
+
 _default_engine = None
 
 

@@ -243,7 +243,7 @@ struct psd_ctx {
     int apply_worklist = 1;   // PSD_APPLY_WL=0: the grid-per-cursor bulk-apply kernels
     int apply_wl_grid = 2048; // workgroups of the work-list bulk apply (PSD_APPLY_WL_GRID)
     int chase2 = 1;           // two-wave chase of the real periodic QR sweep (psd_c2_run; PSD_C2=0: one wavefront per bulge)
-    int apply_wl2 = 1;        // register-line form of the work-list bulk apply (psd_apply2.h; PSD_APPLY_WL2=0: round 2's kernel)
+    int apply_wl2 = 1;        // register-line form of the work-list bulk apply (psd_apply2.h) where it is the faster one; PSD_APPLY_WL2=0: never, 2: always
     int apply_wl2_grid = 1024;  // its grid of four-wave workgroups (PSD_APPLY_WL2_GRID)
     size_t wl2_lds_set[3] = {0, 0, 0};
     int apply_wl2_wpe = 3;    // waves per SIMD its register allocation is held to at W <= 17 (3: what its LDS admits, no spills; PSD_APPLY_WL2_WPE=4)
@@ -798,7 +798,13 @@ int formq_dev(psd_ctx* c, int n, int p, const double* dH, const double* dtau, do
 int launch_apply_wl(psd_ctx* c, psd_stream_t stream, const psd_rparams& Pq, int n, int p, int pass, int NSL, int zlo1, int zhi1,
                     int mode, int W, int grid_old) {
 #ifndef PSD_HOSTSIM
-    if (c->apply_wl2) {
+    // Which form: measured per role on synthetic windows (tools/apply_bench.py, n = 1024, p = 64, W = 17, 16-60 windows):
+    // column roles 3.2-4.5 TB/s algorithmic with the register-line form against 2.2-3.4 with the LDS-streaming one; the
+    // rows role (120-byte column segments) 1.4-1.7 against 1.9-2.0; at W = 32 the register-line form needs 230 registers
+    // and loses everywhere.  So: register lines for launches without a rows role at W <= 17, LDS streaming otherwise.
+    const bool rowsrole_in_launch = pass == 0 && mode != 4;
+    const bool use2 = c->apply_wl2 == 2 || (c->apply_wl2 == 1 && W <= 17 && !rowsrole_in_launch);
+    if (use2) {
         const int g = c->apply_wl2_grid;
         void (*kern)(psd_rparams, int, int, int, int, int, int, int, int) = nullptr;
         size_t lb = 0;
@@ -1073,7 +1079,13 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
             } else if (c->apply_worklist || c->shard_world > 1 || mb) {
                 // work-list form: one grid of single-wave workgroups loops over the items of the tick
                 const int wl_grid = c->apply_wl_grid;
-                PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 0, W, wl_grid));
+                if (c->apply_wl2 == 1 && W <= 17 && wantZ) {
+                    // (rows role and Schur vectors as separate launches: each on the form that is faster for it)
+                    PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 3, W, wl_grid));
+                    PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 4, W, wl_grid));
+                } else {
+                    PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 0, W, wl_grid));
+                }
                 PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 1, NSL, zlo1, zhi1, 0, W, wl_grid));
             } else if (M == 1) {
                 PSD_LAUNCH(psd_rq_apply, psd_dim3(tiles, p, 3), PSD_APPLY_NT, lds_apply, c->stream, P, n, p);
@@ -1601,11 +1613,15 @@ int zhessenberg_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dtau) {
 }
 
 int zformq_dev(psd_ctx* c, int n, int p, const psd_z* dH, const psd_z* dtau, psd_z* dQ) {
-    PSD_LAUNCH(psd_zset_identity, psd_dim3(n, p), 64, 0, c->stream, dQ, n);
+    // a period-sharded context forms only the Q_j of its slice (psd_set_shard)
+    int jlo = 0, jhi = p;
+    c->slice(p, jlo, jhi);
+    if (jhi <= jlo) return 0;
+    PSD_LAUNCH(psd_zset_identity, psd_dim3(n, jhi - jlo), 64, 0, c->stream, dQ + (size_t)jlo * n * n, n);
     const size_t lds = PSD_HESS_NT * sizeof(psd_z);
     for (int i = n - 1; i >= 1; --i) {
         const int tiles = (n - i + 1 + 3) / 4;
-        PSD_LAUNCH(psd_zformq_step, psd_dim3(tiles, p), PSD_HESS_NT, lds, c->stream, dH, dtau, dQ, n, i);
+        PSD_LAUNCH(psd_zformq_step, psd_dim3(tiles, jhi - jlo), PSD_HESS_NT, lds, c->stream, dH, dtau, dQ, n, i, jlo);
     }
     return 0;
 }
@@ -1617,6 +1633,12 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
     if (W == 0) return PSD_INFO_NOTIMPL;
     psd_zparams P;
     P.H = dH;
+    {
+        int zl = 0, zh = p;
+        c->slice(p, zl, zh);
+        P.zlo = zl + 1;
+        P.zhi = zh;
+    }
     P.Z = wantZ ? dZ : nullptr;
     P.st = c->zst;
     P.desc = c->zdesc;
@@ -1795,6 +1817,12 @@ int zgiterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
     PSD_CHECK(psd_rt_sync(c->stream));
     psd_zgparams P;
     P.H = dH;
+    {
+        int zl = 0, zh = p;
+        c->slice(p, zl, zh);
+        P.zlo = zl + 1;
+        P.zhi = zh;
+    }
     P.Z = wantZ ? dZ : nullptr;
     P.S = c->zgS;
     P.st = c->zgst;
@@ -2270,6 +2298,8 @@ int zordschur_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
     PSD_CHECK(psd_rt_h2d(c->osel, select, (size_t)n, c->stream));
     psd_oparams O;
     O.z.H = dH;
+    O.z.zlo = 1;  // (ordschur! is not sharded: every Z_m is this context's)
+    O.z.zhi = p;
     O.z.Z = wantZ ? dZ : nullptr;
     O.z.st = c->zst;
     O.z.desc = c->zdesc;
@@ -2518,6 +2548,12 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
     PSD_CHECK(psd_rt_sync(c->stream));
     psd_gparams P;
     P.H = dH;
+    {
+        int zl = 0, zh = p;
+        c->slice(p, zl, zh);
+        P.zlo = zl + 1;
+        P.zhi = zh;
+    }
     P.Z = wantZ ? dZ : nullptr;
     P.S = c->gS;
     P.st = c->gst;
@@ -2925,6 +2961,8 @@ int zgordschur_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t
     PSD_CHECK(psd_rt_sync(c->stream));
     psd_zgoparams O;
     O.z.H = dH;
+    O.z.zlo = 1;  // (ordschur! is not sharded: every Z_m is this context's)
+    O.z.zhi = p;
     O.z.Z = wantZ ? dZ : nullptr;
     O.z.S = c->zgS;
     O.z.st = c->zgst;

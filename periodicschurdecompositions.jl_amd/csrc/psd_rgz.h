@@ -80,6 +80,9 @@ struct psd_gparams {
     int* cep;  // [PSD_TRAIN_MAX] epoch words of the cursor states (psd_pub_*), then the count of finished cursors
     double* tshift;   // [PSD_TRAIN_MAX][4] shift pairs, then a flag word
     int tick;         // launch index
+    // period sharding (psd_set_shard): the owners m (1-based, inclusive) whose Schur vectors Z_m this context holds;
+    // the updates of the others are some other rank's work (1..p without sharding)
+    int zlo, zhi;
 };
 
 PSD_HD psd_mat<double> psd_gfac(const psd_gparams& P, int n, int l) {
@@ -612,7 +615,7 @@ PSD_D void psd_gg_right(const psd_mat<double>& M, int j, double c, double s, int
     PSD_SYNC();
 }
 PSD_D void psd_gg_z(const psd_gparams& P, const psd_gstate& st, int m, int j, double c, double s) {
-    if (!st.wantZ) return;
+    if (!st.wantZ || m < P.zlo || m > P.zhi) return;
     psd_gg_right(psd_mat<double>{P.Z + (size_t)(m - 1) * st.n * st.n, st.n}, j, c, s, 1, st.n);
 }
 PSD_D void psd_gg_set2(const psd_mat<double>& M, int r1, int c1, double v1, int r2, int c2, double v2) {
@@ -1838,6 +1841,7 @@ PSD_D void psd_gq_apply_body(const psd_gparams& P, int n, int p, int role) {
         }
     } else {
         if (role == 1 && d.defer_h1 == 1 && l == 1) return;  // H_1's column updates are deferred (zero-shift pass)
+        if (role == 2 && (l < P.zlo || l > P.zhi)) return;  // (another rank's Schur vectors)
         const bool h1r = h1x && role == 1;
         const int lo = (role == 1) ? (h1r ? 1 : d.rr0) : d.zr0;
         const int hi = (role == 1) ? (h1r ? n : d.rr1) : d.zr1;

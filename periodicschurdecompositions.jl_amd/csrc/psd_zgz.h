@@ -48,6 +48,9 @@ struct psd_zgparams {
     int* cep;  // [PSD_TRAIN_MAX] epoch words of the cursor states (psd_pub_*), then the count of finished cursors
     psd_z* tshift;     // [PSD_TRAIN_MAX] shifts, then a flag word
     int tick;          // launch index
+    // period sharding (psd_set_shard): the owners m (1-based, inclusive) whose Schur vectors Z_m this context holds;
+    // the updates of the others are some other rank's work (1..p without sharding)
+    int zlo, zhi;
 };
 
 PSD_HD psd_mat<psd_z> psd_zgfac(const psd_zgparams& P, int n, int l) {
@@ -162,7 +165,7 @@ PSD_D void psd_zgg_right(const psd_mat<psd_z>& M, int j, double c, psd_z s, int 
     PSD_SYNC();
 }
 PSD_D void psd_zgg_z(const psd_zgparams& P, const psd_zgstate& st, int m, int j, double c, psd_z s) {
-    if (!st.wantZ) return;
+    if (!st.wantZ || m < P.zlo || m > P.zhi) return;
     psd_zgg_right(psd_mat<psd_z>{P.Z + (size_t)(m - 1) * st.n * st.n, st.n}, j, c, s, 1, st.n);
 }
 PSD_D void psd_zgg_set2(const psd_mat<psd_z>& M, int r1, int c1, psd_z v1, int r2, int c2, psd_z v2) {
@@ -1129,6 +1132,7 @@ PSD_D void psd_zgq_apply_body(const psd_zgparams& P, int n, int p, int role) {
         }
     } else {
         if (role == 1 && d.defer_h1 == 1 && l == 1) return;
+        if (role == 2 && (l < P.zlo || l > P.zhi)) return;  // (another rank's Schur vectors)
         const bool h1r = h1x && role == 1;
         const int lo = (role == 1) ? (h1r ? 1 : d.rr0) : d.zr0;
         const int hi = (role == 1) ? (h1r ? n : d.rr1) : d.zr1;
@@ -1270,7 +1274,7 @@ PSD_KERNEL psd_zgq_phase(psd_zgparams P, int n, int l, int wantZ) {
     } else {
         PSD_PAR_FOR(t, j - 1) { Hl(t + 1, j) = zmul(Hl(t + 1, j), z); }
     }
-    if (wantZ) {
+    if (wantZ && l >= P.zlo && l <= P.zhi) {
         const psd_mat<psd_z> Zl = psd_mat<psd_z>{P.Z + (size_t)(l - 1) * n * n, n};
         PSD_PAR_FOR(r, n) { Zl(r + 1, j) = zmul(Zl(r + 1, j), sfc); }
     }

@@ -176,11 +176,11 @@ PSD_KERNEL psd_zset_identity(psd_z* Q, int n) {
 }
 
 // backward accumulation step of Q_j = H_{j,1} ... H_{j,n-1}: lmul!(H, Q), householder.jl:190-205
-PSD_KERNEL psd_zformq_step(const psd_z* Hp, const psd_z* tau, psd_z* Q, int n, int i) {
+PSD_KERNEL psd_zformq_step(const psd_z* Hp, const psd_z* tau, psd_z* Q, int n, int i, int j0) {
     PSD_LDS_DECL;
     psd_z* red = (psd_z*)psd_lds;
     const int NT = PSD_NTHREADS;
-    const int j = PSD_BLOCK_Y + 1;
+    const int j = j0 + PSD_BLOCK_Y + 1;  // (j0: first factor of a period-sharded context's slice, 0-based)
     const int r0 = i + ((j == 1) ? 1 : 0);
     const int m = n - r0 + 1;
     if (m < 1) return;

@@ -82,6 +82,9 @@ struct psd_zparams {
     int* cep;  // [PSD_TRAIN_MAX] epoch words of the cursor states (psd_pub_*), then the count of finished cursors
     psd_z* tshift;    // [PSD_TRAIN_MAX + 1] shifts of the train, then a flag word
     int tick;         // launch index
+    // period sharding (psd_set_shard): the owners m (1-based, inclusive) whose Schur vectors Z_m this context holds;
+    // the updates of the others are some other rank's work (1..p without sharding)
+    int zlo, zhi;
 };
 
 PSD_HD psd_mat<psd_z> psd_zfac(const psd_zparams& P, int n, int j) {
@@ -1078,6 +1081,7 @@ PSD_D void psd_zq_apply_body(const psd_zparams& P, int n, int p, int role) {
     } else {
         const int jm = (role == 1) ? ((m == 1) ? p : (m - 1)) : m;
         if (role == 1 && d.defer_h1 == 1 && jm == 1) return;  // H_1's right side is deferred (downward passes)
+        if (role == 2 && (m < P.zlo || m > P.zhi)) return;  // (another rank's Schur vectors)
         const int lo = (role == 1) ? d.rr0 : d.zr0;
         const int hi = (role == 1) ? d.rr1 : d.zr1;
         const int r0 = lo + PSD_BLOCK_X * T;
@@ -1244,7 +1248,7 @@ PSD_KERNEL psd_zq_phase(psd_zparams P, int n, int l, int wantZ) {
     if (z.re == 1.0 && z.im == 0.0) return;
     const psd_z zc = zconj(z);
     PSD_PAR_FOR(t, n - j) { Hl(j, j + 1 + t) = zmul(Hl(j, j + 1 + t), z); }
-    if (wantZ) {
+    if (wantZ && l >= P.zlo && l <= P.zhi) {
         const psd_mat<psd_z> Zl = psd_mat<psd_z>{P.Z + (size_t)(l - 1) * n * n, n};
         PSD_PAR_FOR(r, n) { Zl(r + 1, j) = zmul(Zl(r + 1, j), zc); }
     }
