@@ -105,3 +105,91 @@ def test_period_sharded_pschur_gloo_world2(tmp_path):
 def test_period_sharded_pschur_gloo_world3(tmp_path):
     res = _run_sharded(tmp_path, 3, [(20, 7, "R"), (18, 2, "L"), (66, 5, "R")], 29543)
     assert res["20x7R"]["owned"] == 3 and res["18x2L"]["owned"] == 1
+
+
+_RING_WORKER = r'''
+import sys, os, json
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch, torch.distributed as dist
+import psdtest as pt, ring_rehearsal as rr
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n, p = NP
+A = pt.bench_factors(n, p, seed=31 + n + p, dtype=np.complex128)
+H0 = [np.triu(a, -1 if j == 0 else 0) for j, a in enumerate(A)]   # Hessenberg-triangular input (test/generalized.jl:67-76)
+lo, hi = rr.period_slice(p, world, rank)
+# this rank keeps ONLY its slice of the factors and of the Schur vectors
+Hloc = [H0[j].copy() for j in range(lo, hi)]
+Zloc = [np.eye(n, dtype=np.complex128) for _ in range(lo, hi)]
+resident = sum(h.nbytes for h in Hloc) + sum(z.nbytes for z in Zloc)
+ring = rr.Ring(dist)
+lam, st = rr.ring_pschur_hess(Hloc, Zloc, n, p, ring)
+# --- for the check only: everything to rank 0
+def gather(loc):
+    per = max(rr.period_slice(p, world, r)[1] - rr.period_slice(p, world, r)[0] for r in range(world))
+    send = torch.zeros((per, n, n), dtype=torch.complex128)
+    for k, m in enumerate(loc):
+        send[k] = torch.from_numpy(np.ascontiguousarray(m))
+    recv = [torch.zeros_like(send) for _ in range(world)]
+    dist.all_gather(recv, send)
+    out = []
+    for r in range(world):
+        l, h = rr.period_slice(p, world, r)
+        out += [recv[r][k].numpy() for k in range(h - l)]
+    return out
+T, Z = gather(Hloc), gather(Zloc)
+busy = torch.tensor([st["busy_beats"] / max(st["beats"], 1)], dtype=torch.float64)
+bl = [torch.zeros_like(busy) for _ in range(world)]
+dist.all_gather(bl, busy)
+if rank == 0:
+    P = pt.product(H0)
+    nP = np.linalg.norm(P, 2)
+    err = pt.match_eigs(np.linalg.eigvals(P), lam) / nP
+    res = max(np.linalg.norm(H0[l] - Z[l] @ T[l] @ Z[(l + 1) % p].conj().T) / (pt.EPS * np.linalg.norm(H0[l], 1)) for l in range(p))
+    orth = max(np.linalg.norm(Z[l] @ Z[l].conj().T - np.eye(n)) / (pt.EPS * n) for l in range(p))
+    tri = max(np.abs(np.tril(T[l], -1)).max() for l in range(p))
+    # the one-rank run of the same code on the same input: same spectrum
+    H1 = [h.copy() for h in H0]; Z1 = [np.eye(n, dtype=np.complex128) for _ in range(p)]
+    lam1, st1 = rr.ring_pschur_hess(H1, Z1, n, p, rr.Ring(None))
+    same = pt.match_eigs(lam1, lam) / nP
+    print(json.dumps({"world": world, "eig_err": err, "resid_eps": res, "orth_eps_n": orth, "tri": tri, "vs_one_rank": same,
+                      "resident_bytes_per_rank": resident, "whole_problem_bytes": 2 * p * n * n * 16,
+                      "p2p_messages": ring.p2p_messages, "p2p_bytes": ring.p2p_bytes, "collectives": ring.collectives,
+                      "sweeps": st["sweeps"], "trains": st["trains"], "busy_fraction_by_rank": [float(b.item()) for b in bl]}))
+dist.destroy_process_group()
+'''
+
+
+def _run_ring(tmp_path, world, n, p, port):
+    script = tmp_path / f"ring{world}.py"
+    script.write_text(f"ROOT = {ROOT!r}\nNP = ({n}, {p})\n" + _RING_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    import json
+
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_north_star_partition_ring_world2(tmp_path):
+    """The north_star partition (SURVEY 8e): factors AND Schur vectors sharded by period, rotation hand-off at the slice
+    boundaries point to point, a train of bulges in flight, the scalar product data by slice partials + all-gather:
+    tests/ring_rehearsal.py on 2 gloo ranks reproduces the spectrum and the reference's checkpsd invariants
+    (diagnostics.jl:190-263) with half of the problem resident per rank."""
+    r = _run_ring(tmp_path, 2, 36, 6, 29541)
+    assert r["eig_err"] <= 1e-10 and r["vs_one_rank"] <= 1e-10
+    assert r["resid_eps"] <= 100 and r["orth_eps_n"] <= 10 and r["tri"] == 0.0
+    assert r["resident_bytes_per_rank"] * 2 == r["whole_problem_bytes"]
+    assert r["p2p_messages"] > 0 and min(r["busy_fraction_by_rank"]) > 0.3
+
+
+def test_north_star_partition_ring_world3_ragged(tmp_path):
+    r = _run_ring(tmp_path, 3, 30, 7, 29543)  # (slices of 3, 2, 2 factors)
+    assert r["eig_err"] <= 1e-10 and r["vs_one_rank"] <= 1e-10
+    assert r["resid_eps"] <= 100 and r["orth_eps_n"] <= 10 and r["tri"] == 0.0
+    assert r["resident_bytes_per_rank"] * 7 == r["whole_problem_bytes"] * 3
