@@ -215,6 +215,7 @@ struct psd_ctx {
     std::vector<hipEvent_t> h2ev;
     int hess_async = -1;  // links per panel-update launch of the two-stream form (0: off, < 0: by size)
     int hess_lookahead = 1;  // PSD_HESS_LOOKAHEAD=0: the two-launch form of psd_hess.h
+    int hess_xcd = 1;        // chain strips that share a 128-byte line on one XCD (PSD_H2_XCD)
 #endif
     // period sharding (psd_set_shard): this context holds the Schur vectors Z_j of a contiguous slice of the period
     int shard_rank = 0, shard_world = 1;
@@ -588,7 +589,7 @@ void fill_bytes(psd_stats* s, int n, int p, int wantT, int wantZ, const std::vec
 // look-ahead form (psd_hess2.h): one launch per chain link, the panel updates ride one launch behind the chain
 template <int NK, int CR>
 int hessenberg2_launches(psd_ctx* c, int n, int p, const psd_hess2_args& ha) {
-    const int nC = (n + CR - 1) / CR + 1, nT = (n + PSD_H2_ROWS - 1) / PSD_H2_ROWS, nB = (n + 3) / 4;
+    const int nC = ((ha.xcd && CR < 16) ? (((n + CR - 1) / CR + 128 / CR - 1) / (128 / CR)) * (128 / CR) : (n + CR - 1) / CR) + 1, nT = (n + PSD_H2_ROWS - 1) / PSD_H2_ROWS, nB = (n + 3) / 4;
     const size_t lds = ((size_t)n + 8 + 2 * PSD_H2_NT + 64) * sizeof(double);
     int gridx = nC + nT + nB;
     if (const char* e = getenv("PSD_H2_EXPERIMENT")) {  // timing experiments only (results are wrong)
@@ -612,7 +613,7 @@ int hessenberg2_launches(psd_ctx* c, int n, int p, const psd_hess2_args& ha) {
 // matrix — its update by the previous link on it, p links earlier — is awaited by event before the launch that reads it.
 template <int NK, int CR>
 int hessenberg2_async(psd_ctx* c, int n, int p, const psd_hess2_args& ha, int K) {
-    const int nC = (n + CR - 1) / CR + 1, nT = (n + PSD_H2_ROWS - 1) / PSD_H2_ROWS, nB = (n + 3) / 4;
+    const int nC = ((ha.xcd && CR < 16) ? (((n + CR - 1) / CR + 128 / CR - 1) / (128 / CR)) * (128 / CR) : (n + CR - 1) / CR) + 1, nT = (n + PSD_H2_ROWS - 1) / PSD_H2_ROWS, nB = (n + 3) / 4;
     const size_t lds = ((size_t)n + 8 + 2 * PSD_H2_NT + 64) * sizeof(double);
     const int Q = (n - 1) * p;
     const int nbatch = Q / K + 1;  // link indices 0 .. Q (Q: the drain position)
@@ -671,6 +672,38 @@ int hessenberg2_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
     ha.ring = c->h2ring;
     ha.p = p;
     ha.ringmask = 3;
+    ha.xcd = c->hess_xcd;
+    ha.trace = nullptr;
+    ha.trace_hi = 0x7fffffff;
+    if (const char* e = getenv("PSD_H2_TRACE")) { if (atoi(e) > 1) ha.trace_hi = atoi(e); }
+    long long* h2trace = nullptr;
+    if (getenv("PSD_H2_TRACE") && psd_rt_malloc((void**)&h2trace, 1024 * 8 * sizeof(long long)) == 0) {
+        PSD_CHECK(psd_rt_memset(h2trace, 0, 1024 * 8 * sizeof(long long), c->stream));
+        ha.trace = h2trace;
+    }
+    struct H2TraceDump {
+        psd_ctx* c;
+        long long* t;
+        ~H2TraceDump() {
+            if (!t) return;
+            std::vector<long long> h(1024 * 8);
+            (void)psd_rt_sync(c->stream);
+            (void)hipMemcpy(h.data(), t, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+            double acc[8] = {0};
+            int cnt = 0;
+            double per = 0;
+            for (int q = 1; q < 1023; ++q) {
+                const long long* a = &h[(size_t)q * 8];
+                const long long* pr = &h[(size_t)(q - 1) * 8];
+                if (a[0] == 0 || a[6] == 0 || pr[0] == 0 || a[0] < pr[0]) continue;
+                for (int k = 1; k <= 6; ++k) acc[k] += (double)(a[k] - a[k - 1]);
+                per += (double)(a[0] - pr[0]);
+                ++cnt;
+            }
+            if (cnt) fprintf(stderr, "psd hess2 trace (last %d links, block 2, us): link period %.2f | ring loads %.2f | norm reduce %.2f | larfg %.2f | v to LDS + publish %.2f | gemv %.2f | finish %.2f\n", cnt, per / cnt / 100.0, acc[1] / cnt / 100.0, acc[2] / cnt / 100.0, acc[3] / cnt / 100.0, acc[4] / cnt / 100.0, acc[5] / cnt / 100.0, acc[6] / cnt / 100.0);
+            psd_rt_free(t);
+        }
+    } h2dump{c, h2trace};
     // two-stream form: K links per panel-update launch; the chain may run p - K links ahead of the updates and the ring
     // keeps every link the pending updates still read (p + K + 2 <= PSD_H2_RING)
     int K = c->hess_async;
@@ -1334,6 +1367,9 @@ int psd_create(psd_ctx** ctx, int device) {
     if (const char* e = getenv("PSD_APPLY_WL_GRID")) c->apply_wl_grid = atoi(e) > 0 ? atoi(e) : 2048;
     if (const char* e = getenv("PSD_APPLY_WL2")) c->apply_wl2 = atoi(e);
     if (const char* e = getenv("PSD_C2")) c->chase2 = atoi(e);
+#ifndef PSD_HOSTSIM
+    if (const char* e = getenv("PSD_H2_XCD")) c->hess_xcd = atoi(e);
+#endif
     if (const char* e = getenv("PSD_APPLY_WL2_GRID")) c->apply_wl2_grid = atoi(e) > 0 ? atoi(e) : 1024;
     if (const char* e = getenv("PSD_APPLY_WL2_WPE")) c->apply_wl2_wpe = atoi(e);
 #ifdef PSD_HOSTSIM

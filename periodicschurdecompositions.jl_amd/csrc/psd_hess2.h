@@ -35,6 +35,9 @@ struct psd_hess2_args {
     double* ring;  // ringmask + 1 slots of psd_h2_slot_doubles(n)
     int p;         // period
     int ringmask;  // slots - 1 (a power of two minus one: 3 when the panel updates ride one launch behind the chain)
+    int xcd;       // 1: chain blocks whose strips share a 128-byte line of the matrix run on the same XCD (see psd_hess2_link)
+    long long* trace;  // diagnostics (PSD_H2_TRACE): [1024][8] 100 MHz stamps of one chain block per link, or nullptr
+    int trace_hi;      // only links with ring position below this are recorded (PSD_H2_TRACE=<links>)
 };
 // slot layout: v[n+8] | w[n+8] | col[n+8] | hdr[8] (tau, beta) | part[2 * (n/4 + 2)]
 PSD_HD size_t psd_h2_slot_doubles(int n) { return 3 * (size_t)(n + 8) + 8 + 2 * (size_t)(n / 4 + 2); }
@@ -268,7 +271,7 @@ PSD_D void psd_h2_bulk_body(const psd_hess2_args* G, int n, const psd_h2_link Lb
 // grid = nC + nT + nB blocks with nC = ceil(n / CR), nT = ceil(n / 8), nB = ceil(n / 4);
 // LDS: (n + 8 + 2 * PSD_H2_NT + 64) doubles.
 template <int NK, int CR>
-__global__ void __launch_bounds__(PSD_H2_NT, (NK > 16 ? 2 : 4)) psd_hess2_link(const psd_hess2_args Gv, int n, int qi, int qj, int nC, int nT) {
+__global__ void __launch_bounds__(PSD_H2_NT, ((NK > 16 || NK * CR > 128) ? ((NK * CR > 256) ? 1 : 2) : 4)) psd_hess2_link(const psd_hess2_args Gv, int n, int qi, int qj, int nC, int nT) {
     extern __shared__ __attribute__((aligned(16))) char psd_lds[];
     double* vs = (double*)psd_lds;       // n + 8: the reflector (v[0] = 1) the strip kernels multiply with
     double* red = vs + (n + 8);          // 2 * NT + 64
@@ -285,6 +288,9 @@ __global__ void __launch_bounds__(PSD_H2_NT, (NK > 16 ? 2 : 4)) psd_hess2_link(c
         if (!L.valid && qi > 1) return;
         const int q = L.valid ? 0 : -1;  // (q = -1: the very first column is only staged)
         const int slot = qi * p - qj;    // ring position: any number that advances by one per link
+        long long* const trc = (G->trace != nullptr && b == 2 && tid == 0 && slot < G->trace_hi) ? (G->trace + (size_t)(slot & 1023) * 8) : nullptr;
+#define PSD_H2_STAMP(i) do { if (trc) trc[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+        PSD_H2_STAMP(0);
         const psd_h2_slot S = psd_h2_get(G, n, slot), Sn = psd_h2_get(G, n, slot + 1);
         const int r0 = L.r0 - 1;  // 0-based first row of v_q
         const int m = (q >= 0) ? (n - r0) : 0;
@@ -298,8 +304,17 @@ __global__ void __launch_bounds__(PSD_H2_NT, (NK > 16 ? 2 : 4)) psd_hess2_link(c
         const double* M = Ln.valid ? (G->H + (size_t)(Ln.j - 1) * n * n) : G->H;
         const int r0n = Ln.r0 - 1;
         const int cfirst = (q >= 0) ? r0 : (Ln.i - 1);  // column that becomes the next reflector's
-        const int t = r0n / CR + (b - 1);  // block 0 forms and publishes v_q only
-        const bool strip = Ln.valid && b > 0 && t < ntileC;
+        // block 0 forms and publishes v_q only; block b >= 1 takes strip t.  A strip of CR rows is CR * 8 = 32 or 64 bytes of
+        // every column: GS = 128 / (CR * 8) neighbouring strips share each 128-byte line, and blocks are dealt round-robin
+        // over the 8 XCDs (each with its own L2), so in strip order every line is fetched into 2 or 4 different L2s.  With
+        // G.xcd the strips of one line go to blocks b, b + 8, .. (same XCD, dispatched together).
+        int t = r0n / CR + (b - 1);
+        if (G->xcd) {
+            constexpr int GS = (CR < 16) ? 16 / CR : 1;
+            const int idx = b - 1, grp0 = (r0n / CR) / GS;
+            t = GS * (grp0 + (idx % 8) + 8 * (idx / (8 * GS))) + (idx / 8) % GS;
+        }
+        const bool strip = Ln.valid && b > 0 && t < ntileC && t >= r0n / CR;
         const int rp = tid % RP, cl = tid / RP;
         const int r = CR * t + 2 * rp;
         const bool ok0 = strip && r < n && r >= r0n, ok1 = strip && r + 1 < n && r + 1 >= r0n;
@@ -338,6 +353,7 @@ __global__ void __launch_bounds__(PSD_H2_NT, (NK > 16 ? 2 : 4)) psd_hess2_link(c
         if (q >= 0) {
             // norm of the tail from the partials of the launch that staged the column: (amax, ssq) pairs combine as
             // amax = max, ssq = sum ssq_k (amax_k / amax)^2 (dlassq); one pair per thread, one LDS exchange
+            PSD_H2_STAMP(1);
             const double amw = psd_h2_wave_max(am);
             double ssw = 0.0;
             if (amw > 0.0) {
@@ -360,7 +376,9 @@ __global__ void __launch_bounds__(PSD_H2_NT, (NK > 16 ? 2 : 4)) psd_hess2_link(c
                 }
             }
             const double xnorm = (m > 1) ? amax * sqrt(tot) : 0.0;
+            PSD_H2_STAMP(2);
             psd_h2_larfg(alpha, xnorm, tau, beta, mult);
+            PSD_H2_STAMP(3);
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const int k = tid + PSD_H2_NT * u;
@@ -387,6 +405,7 @@ __global__ void __launch_bounds__(PSD_H2_NT, (NK > 16 ? 2 : 4)) psd_hess2_link(c
         }
         if (!strip) return;
         // GEMV on the next link's matrix: rows >= r0n, columns r0.. (q = -1: plain staging of column 1 of A_p)
+        PSD_H2_STAMP(4);
         double acc0 = 0.0, acc1 = 0.0;
         if (q >= 0 && tau != 0.0) {
 #pragma unroll
@@ -410,6 +429,7 @@ __global__ void __launch_bounds__(PSD_H2_NT, (NK > 16 ? 2 : 4)) psd_hess2_link(c
             red[(wave * RP + lane) * 2 + 1] = acc1;
         }
         __syncthreads();
+        PSD_H2_STAMP(5);
         double amt = 0.0, y = 0.0;
         if (fin) {
             const double w = red[tid] + red[CR + tid] + red[2 * CR + tid] + red[3 * CR + tid];
@@ -429,10 +449,11 @@ __global__ void __launch_bounds__(PSD_H2_NT, (NK > 16 ? 2 : 4)) psd_hess2_link(c
             }
             sq = psd_h2_wave_sum(sq);
             if (lane == 0) {
-                Sn.part[2 * (b - 1)] = amax;
-                Sn.part[2 * (b - 1) + 1] = sq;
+                Sn.part[2 * (t - r0n / CR)] = amax;  // (partial norms by strip, whichever block computed them)
+                Sn.part[2 * (t - r0n / CR) + 1] = sq;
             }
         }
+        PSD_H2_STAMP(6);
         return;
     }
     // ---------------------------------------------------------------------- bulk B(q-1) on M_{q-1}
