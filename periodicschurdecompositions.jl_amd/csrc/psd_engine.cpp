@@ -224,17 +224,12 @@ struct psd_ctx {
         lo = shard_rank * base + (shard_rank < rem ? shard_rank : rem);
         hi = lo + base + (shard_rank < rem ? 1 : 0);
     }
-    // PSD_OVERLAP=1: the far part of a tick's bulk update on a second stream beside the next tick's chases
-    // (psd_rq_apply_wl modes).  Off by default: measured the far parts do run beside the chases and
-    // a train tick drops from 610 to 445 us at n = 1024, p = 64, but two more launches and two cross-stream events per tick
-    // cost 15-25 us on every tick, and most ticks are small: 811 vs 817 ms at that size, 249 vs 224 ms at n = 512, p = 16
-    int ovl_what = 3;      // far/near split (PSD_OVERLAP=1): bit 0 rows roles, bit 1 column roles (PSD_OVL_WHAT)
     int train_stop = 1;    // a long train stops admitting bulges once one of them leaves the bottom converged (PSD_TRAIN_STOP=0: never)
     int train_wdiv = 8;    // a long train has at most (range width) / train_wdiv bulges (PSD_TRAIN_WDIV; 4 is 3-15 % faster and
                            // costs 40 % more residual: every bulge of a train passes over the whole range)
     int train_long = 256;  // bulges per train of the multi-block scheduler when slots can be recycled (PSD_TRAIN_LONG; 0: one bulge per slot)
     int band_helper = 1;  // PSD_BAND_HELPER=0: a leader computes the product band of its decisions itself
-    int overlap = 3;  // 0 off, 1 far/near split of the H updates, 2 Schur-vector updates on stream2, 3 = 2 for n >= 1024
+    int overlap = 3;  // Schur-vector updates on stream2 beside the next tick's chases: 0 off, 2 on, 3 = on for n >= 1024 (PSD_OVERLAP)
     int far_grid = 0;  // grid of the far bulk-update launches (0: apply_wl_grid)
 #ifndef PSD_HOSTSIM
     hipStream_t stream2 = nullptr;  // the far parts of the bulk updates (beside the next tick's chases)
@@ -634,10 +629,11 @@ int hessenberg2_async(psd_ctx* c, int n, int p, const psd_hess2_args& ha, int K)
     if (lag < 0) lag = 0;
     if (lag > p - K - 1) lag = p - K - 1;
     int nextb = 0;  // next batch to launch
+    const bool nobulk = getenv("PSD_H2_NOBULK") != nullptr;  // (timing experiment: the chain alone; results are wrong)
     auto batch = [&](int b) -> int {
         PSD_CHECK(hipEventRecord(evA[b & 7], c->stream));
         PSD_CHECK(hipStreamWaitEvent(c->stream3, evA[b & 7], 0));
-        hipLaunchKernelGGL((psd_hess2_bulk<NK>), dim3(nT + nB, K), dim3(PSD_H2_NT), lds, c->stream3, ha, n, b * K, nT);
+        if (!nobulk) hipLaunchKernelGGL((psd_hess2_bulk<NK>), dim3(nT + nB, K), dim3(PSD_H2_NT), lds, c->stream3, ha, n, b * K, nT);
         PSD_CHECK(hipEventRecord(evB[b & 7], c->stream3));
         return 0;
     };
@@ -677,8 +673,8 @@ int hessenberg2_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
     ha.trace_hi = 0x7fffffff;
     if (const char* e = getenv("PSD_H2_TRACE")) { if (atoi(e) > 1) ha.trace_hi = atoi(e); }
     long long* h2trace = nullptr;
-    if (getenv("PSD_H2_TRACE") && psd_rt_malloc((void**)&h2trace, 1024 * 8 * sizeof(long long)) == 0) {
-        PSD_CHECK(psd_rt_memset(h2trace, 0, 1024 * 8 * sizeof(long long), c->stream));
+    if (getenv("PSD_H2_TRACE") && psd_rt_malloc((void**)&h2trace, (1024 * 8 + 1024 * 4) * sizeof(long long)) == 0) {
+        PSD_CHECK(psd_rt_memset(h2trace, 0, (1024 * 8 + 1024 * 4) * sizeof(long long), c->stream));
         ha.trace = h2trace;
     }
     struct H2TraceDump {
@@ -686,7 +682,7 @@ int hessenberg2_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
         long long* t;
         ~H2TraceDump() {
             if (!t) return;
-            std::vector<long long> h(1024 * 8);
+            std::vector<long long> h(1024 * 8 + 1024 * 4);
             (void)psd_rt_sync(c->stream);
             (void)hipMemcpy(h.data(), t, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
             double acc[8] = {0};
@@ -701,6 +697,24 @@ int hessenberg2_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
                 ++cnt;
             }
             if (cnt) fprintf(stderr, "psd hess2 trace (last %d links, block 2, us): link period %.2f | ring loads %.2f | norm reduce %.2f | larfg %.2f | v to LDS + publish %.2f | gemv %.2f | finish %.2f\n", cnt, per / cnt / 100.0, acc[1] / cnt / 100.0, acc[2] / cnt / 100.0, acc[3] / cnt / 100.0, acc[4] / cnt / 100.0, acc[5] / cnt / 100.0, acc[6] / cnt / 100.0);
+            {
+                const long long* bk = &h[1024 * 8];
+                long long t0 = 0;
+                for (int q = 0; q < 1024; ++q)
+                    if (bk[4 * q] && (!t0 || bk[4 * q] < t0)) t0 = bk[4 * q];
+                if (t0) {
+                    fprintf(stderr, "psd hess2 trace, one link, per block (start, end in us after the first start):");
+                    for (int q = 0; q < 1024; ++q)
+                        if (bk[4 * q] && (q < 12 || q % 16 == 0)) fprintf(stderr, " b%d %.2f-%.2f", q, (bk[4 * q] - t0) / 100.0, (bk[4 * q + 1] - t0) / 100.0);
+                    double lastend = 0, maxstart = 0;
+                    for (int q = 0; q < 1024; ++q)
+                        if (bk[4 * q]) {
+                            if ((bk[4 * q + 1] - t0) / 100.0 > lastend) lastend = (bk[4 * q + 1] - t0) / 100.0;
+                            if ((bk[4 * q] - t0) / 100.0 > maxstart) maxstart = (bk[4 * q] - t0) / 100.0;
+                        }
+                    fprintf(stderr, " | last start %.2f last end %.2f\n", maxstart, lastend);
+                }
+            }
             psd_rt_free(t);
         }
     } h2dump{c, h2trace};
@@ -956,7 +970,6 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     const bool mb = ((M > 1) && c->mblock) || bws != nullptr;  // (a batch always runs on the slot scheduler)
     const int NSL = mb ? PSD_SLOTS : M;
     const bool zdef = mb && wantZ && (c->overlap == 2 || (c->overlap == 3 && n >= 1024));  // Schur-vector updates on the second stream, beside the next chases
-    const bool ovl = mb && c->overlap == 1 && wantT;  // far bulk updates beside the next tick's chases (psd_rq_apply_wl modes)
     if (M > 1 || mb) {
         PSD_CHECK(c->treserve(p));
         PSD_CHECK(psd_rt_memset(c->tgl, 0, sizeof(psd_rglobal), c->stream));
@@ -1076,39 +1089,6 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
 #else
                 PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 4, W, wl_grid));
 #endif
-            } else if (ovl) {
-                // Far part of the PREVIOUS tick's bulk update: beside this tick's chases, on the second stream, behind
-                // the previous tick's near part (evE) — a rows-role far block of one window meets the column role of
-                // another, which belongs to the near part.  The serial simulation runs it right here, i.e. in the latest
-                // order the streams allow.
-                const int wl_grid = c->apply_wl_grid;
-                if (launched > 0) {
-#ifndef PSD_HOSTSIM
-                    PSD_CHECK(hipStreamWaitEvent(c->stream2, c->evE[par ^ 1], 0));
-                    PSD_CHECK(launch_apply_wl(c, c->stream2, Pprev, n, p, 0, NSL, zlo1, zhi1, 2, W, c->far_grid > 0 ? c->far_grid : wl_grid));
-                    if (c->ovl_what & 2)
-                        PSD_CHECK(launch_apply_wl(c, c->stream2, Pprev, n, p, 1, NSL, zlo1, zhi1, 2, W, c->far_grid > 0 ? c->far_grid : wl_grid));
-                    PSD_CHECK(hipEventRecord(c->evF[par ^ 1], c->stream2));
-                    PSD_CHECK(hipStreamWaitEvent(c->stream, c->evF[par ^ 1], 0));
-#else
-                    if (!getenv("PSD_OVL_DBG")) {
-                        PSD_CHECK(launch_apply_wl(c, c->stream, Pprev, n, p, 0, NSL, zlo1, zhi1, 2, W, wl_grid));
-                        PSD_CHECK(launch_apply_wl(c, c->stream, Pprev, n, p, 1, NSL, zlo1, zhi1, 2, W, wl_grid));
-                    }
-#endif
-                }
-                // near part of this tick's update, before the next tick's chases
-                PSD_LAUNCH(psd_rq_cuts, psd_dim3(1), PSD_WL_NT, 3 * PSD_SLOTS * sizeof(int), c->stream, Pq, NSL, W + 2, c->ovl_what);
-                PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 1, W, wl_grid));
-                PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 1, NSL, zlo1, zhi1, 1, W, wl_grid));
-#ifndef PSD_HOSTSIM
-                PSD_CHECK(hipEventRecord(c->evE[par], c->stream));
-#else
-                if (getenv("PSD_OVL_DBG")) {
-                    PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 2, W, wl_grid));
-                    PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 1, NSL, zlo1, zhi1, 2, W, wl_grid));
-                }
-#endif
             } else if (c->apply_worklist || c->shard_world > 1 || mb) {
                 // work-list form: one grid of single-wave workgroups loops over the items of the tick
                 const int wl_grid = c->apply_wl_grid;
@@ -1190,7 +1170,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
         }
     }
 #ifndef PSD_HOSTSIM
-    if (ovl || zdef) PSD_CHECK(hipStreamSynchronize(c->stream2));
+    if (zdef) PSD_CHECK(hipStreamSynchronize(c->stream2));
 #endif
 #ifndef PSD_HOSTSIM
     PSD_CHECK(poller.finish(pend));
@@ -1358,7 +1338,6 @@ int psd_create(psd_ctx** ctx, int device) {
     if (const char* e = getenv("PSD_BAND_HELPER")) c->band_helper = atoi(e);
     if (const char* e = getenv("PSD_TRAIN_LONG")) c->train_long = atoi(e);
     if (const char* e = getenv("PSD_TRAIN_STOP")) c->train_stop = atoi(e);
-    if (const char* e = getenv("PSD_OVL_WHAT")) c->ovl_what = atoi(e) & 3;
     if (const char* e = getenv("PSD_TRAIN_WDIV")) c->train_wdiv = atoi(e) > 0 ? atoi(e) : 8;
     if (const char* e = getenv("PSD_MB")) c->mblock = atoi(e);
     if (const char* e = getenv("PSD_TRAIN_MB")) c->train_mb_m = atoi(e);

@@ -291,6 +291,12 @@ __global__ void __launch_bounds__(PSD_H2_NT, ((NK > 16 || NK * CR > 128) ? ((NK 
         long long* const trc = (G->trace != nullptr && b == 2 && tid == 0 && slot < G->trace_hi) ? (G->trace + (size_t)(slot & 1023) * 8) : nullptr;
 #define PSD_H2_STAMP(i) do { if (trc) trc[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
         PSD_H2_STAMP(0);
+        // (one link, every block: first and last stamp, and the XCD it ran on)
+        long long* const blk = (G->trace != nullptr && tid == 0 && slot == G->trace_hi - 1 && b < 1024) ? (G->trace + 1024 * 8 + (size_t)b * 4) : nullptr;
+        if (blk) {
+            blk[0] = (long long)__builtin_amdgcn_s_memrealtime();
+            blk[2] = (long long)__builtin_amdgcn_s_getreg(63492);  // (XCC_ID: hwreg 20, offset 0, size 4... diagnostic only)
+        }
         const psd_h2_slot S = psd_h2_get(G, n, slot), Sn = psd_h2_get(G, n, slot + 1);
         const int r0 = L.r0 - 1;  // 0-based first row of v_q
         const int m = (q >= 0) ? (n - r0) : 0;
@@ -454,6 +460,7 @@ __global__ void __launch_bounds__(PSD_H2_NT, ((NK > 16 || NK * CR > 128) ? ((NK 
             }
         }
         PSD_H2_STAMP(6);
+        if (blk) blk[1] = (long long)__builtin_amdgcn_s_memrealtime();
         return;
     }
     // ---------------------------------------------------------------------- bulk B(q-1) on M_{q-1}

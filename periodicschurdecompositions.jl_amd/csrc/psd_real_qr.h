@@ -91,7 +91,7 @@ PSD_D void psd_tr_store_global(psd_tr* dst, const psd_tr& tr) {
 struct psd_apply_desc {
     int active;
     int prob;      // batch: problem the window belongs to
-    int cut;       // first far column of a split window (psd_rq_cuts)
+    int cut;       // (unused since the far / near split of round 2 went: kept for the layout of the descriptor)
     int rcut;      // first near row of its column role (rows rr0 .. rcut - 1 are far)
     int split;     // 1: a window in the middle of a sweep: the far part of its bulk update (rows role beyond `cut`, column
                    // role above `rcut`, the whole Z role) may run while the next tick chases (psd_rq_apply_wl modes)
@@ -1395,7 +1395,7 @@ PSD_D void psd_desc_write(const psd_rparams& P, psd_rstate& st, const int* lcnt,
         d.active = over ? 0 : 1;
         d.prob = st.prob;
         d.split = (split && st.wantT) ? 1 : 0;
-        d.cut = lc1 + 1;  // (nothing far until psd_rq_cuts says so)
+        d.cut = lc1 + 1;
         d.rcut = rr0;
         d.plo = plo;
         d.phi = phi;
@@ -3040,92 +3040,19 @@ PSD_D void psd_wl_compute(double* tile, int S, int nl, int t, int order, const p
 
 // zlo..zhi: the owners m (1-based) whose Z_m this context holds (period-sharded contexts: the Z role of the others is
 // some other rank's work; 1..p otherwise)
-// line ranges of a window's three roles under an apply mode (see psd_rq_apply_wl); cut: first far column
+// line ranges of a window's three roles under an apply mode (see psd_rq_apply_wl)
 PSD_HD void psd_wl_ranges(psd_apply_desc& d, int mode, int cut) {
-    if (mode == 0) return;
+    (void)cut;
     if (mode == 3) {  // everything but the Schur vectors
         d.zr1 = d.zr0 - 1;
-        return;
-    }
-    if (mode == 4) {  // the Schur vectors only (pass 0)
+    } else if (mode == 4) {  // the Schur vectors only (pass 0)
         d.lc1 = d.lc0 - 1;
         d.rr1 = d.rr0 - 1;
-        return;
-    }
-    if (mode == 1) {
-        if (d.split) {
-            if (d.lc1 > cut - 1) d.lc1 = cut - 1;
-            if (d.rr0 < d.rcut) d.rr0 = d.rcut;
-            d.zr1 = d.zr0 - 1;
-        }
-    } else {
-        if (d.split) {
-            if (d.lc0 < cut) d.lc0 = cut;
-            if (d.rr1 > d.rcut - 1) d.rr1 = d.rcut - 1;
-        } else {
-            d.lc1 = d.lc0 - 1;
-            d.zr1 = d.zr0 - 1;
-            d.rr1 = d.rr0 - 1;
-        }
-    }
-}
-// Near / far split of the bulk update of a mid-sweep window (psd_rq_apply_wl modes 1 / 2).  Near = what anything may read
-// before the far launches of this tick are done: the next windows, the trailing blocks of shift computations, RQ and
-// deflation windows are diagonal blocks of order <= W, so everything within `edge` = W + 2 of the diagonal band a window
-// sits on stays near: the rows role on the `edge` columns right of the window, the column role on the `edge` rows above it.
-// Both boundaries are moved outwards past the index range plo..phi of any other window of the tick (same problem) they
-// would cut: another window's column update R mixes its columns plo..phi, and this window's row update L commutes with
-// it only applied to ALL of those columns on the same side of R (a boundary through plo..phi would apply L twice to what
-// R carries across it); the same for a row boundary through another window's rows.  One workgroup, one lane per slot.
-// what: bit 0 = split the rows roles, bit 1 = split the column roles (a role that is not split stays near as a whole)
-PSD_KERNEL_B(PSD_WL_NT) psd_rq_cuts(psd_rparams P, int M, int edge, int what) {
-    PSD_LDS_DECL;
-    int* lplo = (int*)psd_lds;  // [M] plo, or a huge value for slots that do not count
-    int* lphi = lplo + PSD_SLOTS;
-    int* lprob = lphi + PSD_SLOTS;
-    PSD_PAR_FOR(b, M) {
-        const psd_apply_desc d = P.desc[b];
-        lplo[b] = d.active ? d.plo : 0x3fffffff;
-        lphi[b] = d.active ? d.phi : -1;
-        lprob[b] = d.prob;
-    }
-    PSD_SYNC();
-    PSD_PAR_FOR(b, M) {
-        const psd_apply_desc d = P.desc[b];
-        if (d.active && d.split) {
-            int cut = d.lc0 + edge;
-            int rcut = d.rr1 + 1 - edge;
-            for (int rep = 0; rep < M; ++rep) {
-                bool moved = false;
-                for (int o = 0; o < M; ++o) {
-                    if (o == b || lprob[o] != d.prob) continue;
-                    if (lplo[o] < cut && cut <= lphi[o]) {
-                        cut = lphi[o] + 1;
-                        moved = true;
-                    }
-                    if (lplo[o] < rcut && rcut <= lphi[o]) {
-                        rcut = lplo[o];
-                        moved = true;
-                    }
-                }
-                if (!moved) break;
-            }
-            if (rcut < d.rr0 || !(what & 2)) rcut = d.rr0;
-            if (!(what & 1)) cut = d.lc1 + 1;
-            P.desc[b].cut = cut;
-            P.desc[b].rcut = rcut;
-        }
     }
 }
 
 #define PSD_WL_GROUP 4  // 64-line tiles per item: the owner's list is staged once for all of them
-// mode 0: everything.  Modes 1 / 2 split a tick's bulk update so that most of it runs beside the NEXT tick's chases:
-//   mode 1 ("near", before the next chase): windows that end a sweep, RQ and deflation windows completely; mid-sweep
-//           windows (desc.split): the rows role up to column cut - 1 and the column role from row rcut (psd_rq_cuts);
-//   mode 2 ("far", beside the next chase: pass 0, then pass 1): mid-sweep windows: the rows role from column cut and
-//           the Z role (pass 0), the column role above row rcut (pass 1).
-// Nothing a chase, a deflation search or a shift computation reads lies in a far part: those read diagonal blocks of
-// order <= W and near-diagonal bands, a far part is at least W + 2 off the diagonal band of its window.
+// mode 0: everything.
 // Modes 3 / 4 split off the Schur vectors alone: mode 3 = the two H roles (both passes), mode 4 = the Z role (pass 0).
 // Nothing reads Z_m before the iteration ends and only owner m's lists touch it, so the Z updates of a tick only have to
 // stay in tick order among themselves: they run on a second stream beside the following ticks' chases.
