@@ -83,14 +83,16 @@ int psd_get_train_z(psd_ctx* ctx);
 int psd_set_train_g(psd_ctx* ctx, int bulges);
 int psd_get_train_g(psd_ctx* ctx);
 const char* psd_version(void);
-/* Period sharding of the real path over `world` contexts (one per GPU, one process each; DESIGN.md "Multi-GPU"): every
- * context runs the latency-bound chains (Hessenberg links, window chases) and the updates of the factors H_j they
- * read — identical on all ranks, bit for bit — while the Schur vectors, half of all bulk bytes, are split by period:
- * the context forms and updates only the Z_j of its contiguous slice of the period (Q formation and the Z role of the
- * bulk apply).  No per-tick exchange; the caller all-gathers the slices at the end if it wants every Z_j everywhere
- * (periodicschurdecompositions.jl_amd/sharded.py does, over torch.distributed: RCCL on the GPUs, gloo in the CPU test).
- * psd_shard_owned: owned[s] = 1 for the user slots s (0-based) of Z this context holds after a call with `orient`.
- * Applies to psd_d_pschur / psd_d_pschur_dev / psd_d_pschur_hess; rank 0 of world 1 (default) = everything. */
+/* Period sharding over `world` contexts (one per GPU, one process each): every context runs the
+ * latency-bound chains (Hessenberg links, window chases) and the updates of the factors H_j they read — identical on
+ * all ranks, bit for bit (the tick schedule is reproducible: tests/test_gpu_headline.py, tests/test_gpu_shard.py) — while the
+ * Schur vectors, half of all bulk bytes, are split by period: the context forms and updates only the Z_j of its
+ * contiguous slice of the period.  No per-tick exchange; the caller all-gathers the slices at the end if it wants every
+ * Z_j everywhere (periodicschurdecompositions.jl_amd/sharded.py does, over torch.distributed: RCCL on the GPUs, gloo in
+ * the CPU test).  psd_shard_owned: owned[s] = 1 for the user slots s (0-based) of Z this context holds after a call with
+ * `orient`.  Honoured by psd_d_pschur / _dev / _hess (Q formation and every Z update), by psd_z_pschur / _dev / _hess
+ * (the same: BASELINE configs[2]) and by the iterations of psd_d_gpschur / the signed psd_z_pschur (their Hessenberg
+ * stage accumulates Q on every rank); rank 0 of world 1 (default) = everything. */
 int psd_set_shard(psd_ctx* ctx, int rank, int world);
 int psd_shard_owned(psd_ctx* ctx, int p, char orient, uint8_t* owned);
 
