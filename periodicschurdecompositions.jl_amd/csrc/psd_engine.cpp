@@ -242,7 +242,6 @@ struct psd_ctx {
     int apply_wl2 = 1;        // register-line form of the work-list bulk apply (psd_apply2.h) where it is the faster one; PSD_APPLY_WL2=0: never, 2: always
     int apply_wl2_grid = 1024;  // its grid of four-wave workgroups (PSD_APPLY_WL2_GRID)
     size_t wl2_lds_set[3] = {0, 0, 0};
-    int apply_wl2_wpe = 3;    // waves per SIMD its register allocation is held to at W <= 17 (3: what its LDS admits, no spills; PSD_APPLY_WL2_WPE=4)
     psd_rostate* rost = nullptr;
     psd_tq* rotq = nullptr;
     unsigned char* rosel = nullptr;
@@ -587,12 +586,6 @@ int hessenberg2_launches(psd_ctx* c, int n, int p, const psd_hess2_args& ha) {
     const int nC = ((ha.xcd && CR < 16) ? (((n + CR - 1) / CR + 128 / CR - 1) / (128 / CR)) * (128 / CR) : (n + CR - 1) / CR) + 1, nT = (n + PSD_H2_ROWS - 1) / PSD_H2_ROWS, nB = (n + 3) / 4;
     const size_t lds = ((size_t)n + 8 + 2 * PSD_H2_NT + 64) * sizeof(double);
     int gridx = nC + nT + nB;
-    if (const char* e = getenv("PSD_H2_EXPERIMENT")) {  // timing experiments only (results are wrong)
-        const int x = atoi(e);
-        if (x == 1) gridx = nC;
-        if (x == 2) gridx = 1;
-        if (x == 3) gridx = nC + nT;
-    }
     auto link = [&](int i, int j) {
         hipLaunchKernelGGL((psd_hess2_link<NK, CR>), dim3(gridx), dim3(PSD_H2_NT), lds, c->stream, ha, n, i, j, nC, nT);
     };
@@ -623,11 +616,7 @@ int hessenberg2_async(psd_ctx* c, int n, int p, const psd_hess2_args& ha, int K)
     PSD_CHECK(hipEventRecord(evA[0], c->stream));
     PSD_CHECK(hipStreamWaitEvent(c->stream3, evA[0], 0));
     hipLaunchKernelGGL((psd_hess2_link<NK, CR>), dim3(nC), dim3(PSD_H2_NT), lds, c->stream, ha, n, 0, 1, nC, 0);  // staging
-    // (PSD_HESS_LAG: a batch is launched that many links later than it could be — tuning hook)
-    int lag = 0;
-    if (const char* e = getenv("PSD_HESS_LAG")) lag = atoi(e);
-    if (lag < 0) lag = 0;
-    if (lag > p - K - 1) lag = p - K - 1;
+    const int lag = 0;  // (launching a batch later than it could be — so that the chain finds its matrix in the Infinity Cache — was measured in rounds 2 and 3: no gain)
     int nextb = 0;  // next batch to launch
     const bool nobulk = getenv("PSD_H2_NOBULK") != nullptr;  // (timing experiment: the chain alone; results are wrong)
     auto batch = [&](int b) -> int {
@@ -727,7 +716,6 @@ int hessenberg2_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
         ha.ringmask = PSD_H2_RING - 1;
         if (n <= 256) return hessenberg2_async<4, 8>(c, n, p, ha, K);
         if (n <= 512) return hessenberg2_async<8, 8>(c, n, p, ha, K);
-        if (n <= 1024 && getenv("PSD_H2_CR8")) return hessenberg2_async<16, 8>(c, n, p, ha, K);  // (experiment)
         if (n <= 1024) return hessenberg2_async<16, 4>(c, n, p, ha, K);
         return hessenberg2_async<32, 8>(c, n, p, ha, K);
     }
@@ -858,8 +846,8 @@ int launch_apply_wl(psd_ctx* c, psd_stream_t stream, const psd_rparams& Pq, int 
         int slot = 0;
         if (W <= 17) {
             lb = psd_wl2_lds_bytes<17>();
-            if (c->apply_wl2_wpe == 4) { kern = psd_rq_apply_wl2<17, 4>; slot = 1; }
-            else { kern = psd_rq_apply_wl2<17, 3>; slot = 0; }
+            kern = psd_rq_apply_wl2<17, 3>;  // (three waves per SIMD is what its LDS admits; a 128-register build spills and measured slower)
+            slot = 0;
         } else {
             lb = psd_wl2_lds_bytes<32>();
             kern = psd_rq_apply_wl2<32, 2>;
@@ -1134,7 +1122,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                         pinfo_out[q] = (hgl.abort && hgl.pinfo[q] == 0 && hgl.pactive[q] > 0) ? hgl.info : hgl.pinfo[q];
                 break;
             }
-            if (launched > cap || (getenv("PSD_DBG_CAP") && launched > atoll(getenv("PSD_DBG_CAP")))) {
+            if (launched > cap) {
 #ifdef PSD_HOSTSIM
                 fprintf(stderr, "mb runaway: launched %lld nactive %d nspawn %d nslotmax %d nsweeps %d\n", launched, hgl.nactive,
                         hgl.nspawn, hgl.nslotmax, hgl.nsweeps);
@@ -1302,7 +1290,6 @@ int psd_create(psd_ctx** ctx, int device) {
             for (int q = keep; q < ncu; ++q) mask[q >> 5] |= (1u << (q & 31));
             rc = hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)((ncu + 31) / 32), mask);
             if (rc == hipSuccess) c->far_grid = (ncu - keep) * 8;
-            if (const char* e = getenv("PSD_FAR_GRID")) c->far_grid = atoi(e);  // (tuning hook)
         }
         if (rc != hipSuccess) rc = hipStreamCreate(&c->stream2);
         if (rc != hipSuccess) {
@@ -1350,7 +1337,6 @@ int psd_create(psd_ctx** ctx, int device) {
     if (const char* e = getenv("PSD_H2_XCD")) c->hess_xcd = atoi(e);
 #endif
     if (const char* e = getenv("PSD_APPLY_WL2_GRID")) c->apply_wl2_grid = atoi(e) > 0 ? atoi(e) : 1024;
-    if (const char* e = getenv("PSD_APPLY_WL2_WPE")) c->apply_wl2_wpe = atoi(e);
 #ifdef PSD_HOSTSIM
     c->apply_wl_grid = 3;  // (serial simulation: a few workgroups exercise the item loop)
 #endif
