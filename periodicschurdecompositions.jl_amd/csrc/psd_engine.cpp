@@ -7,6 +7,7 @@
 #include "psd_real_qr.h"
 #include "psd_apply2.h"
 #include "psd_zhess.h"
+#include "psd_zhess2.h"
 #include "psd_zqz.h"
 #include "psd_zord.h"
 #include "psd_rord.h"
@@ -212,6 +213,8 @@ struct psd_ctx {
     // look-ahead reduction (psd_hess2.h)
     double* h2ring = nullptr;
     int h2ring_n = 0;
+    double* zh2ring = nullptr;  // (the complex form's ring: psd_zhess2.h)
+    int zh2ring_n = 0;
     std::vector<hipEvent_t> h2ev;
     int hess_async = -1;  // links per panel-update launch of the two-stream form (0: off, < 0: by size)
     int hess_lookahead = 1;  // PSD_HESS_LOOKAHEAD=0: the two-launch form of psd_hess.h
@@ -391,6 +394,9 @@ struct psd_ctx {
         if (h2ring) psd_rt_free(h2ring);
         h2ring = nullptr;
         h2ring_n = 0;
+        if (zh2ring) psd_rt_free(zh2ring);
+        zh2ring = nullptr;
+        zh2ring_n = 0;
 #endif
         if (fqT) psd_rt_free(fqT);
         fqT = nullptr;
@@ -1583,9 +1589,105 @@ int psd_d_pschur_hess(psd_ctx* c, int n, int p, double* const* H, double* const*
 // complex path
 namespace {
 
+#ifndef PSD_HOSTSIM
+// look-ahead form (psd_zhess2.h), the complex counterparts of hessenberg2_launches / hessenberg2_async
+template <int NK, int CR>
+int zhessenberg2_launches(psd_ctx* c, int n, int p, const psd_zhess2_args& ha) {
+    constexpr int LG = 64 / CR;  // chain blocks per group of 8 lines (16-byte elements: 8 rows per 128-byte line)
+    const int nC = ((ha.xcd && CR < 8) ? (((n + CR - 1) / CR + LG - 1) / LG) * LG : (n + CR - 1) / CR) + 1, nT = (n + PSD_ZH2_ROWS - 1) / PSD_ZH2_ROWS, nB = (n + 3) / 4;
+    const size_t lds = ((size_t)n + 8 + 2 * PSD_ZH2_NT + 64) * sizeof(psd_z);
+    const int gridx = nC + nT + nB;
+    auto link = [&](int i, int j) {
+        hipLaunchKernelGGL((psd_zhess2_link<NK, CR>), dim3(gridx), dim3(PSD_ZH2_NT), lds, c->stream, ha, n, i, j, nC, nT);
+    };
+    link(0, 1);
+    for (int i = 1; i <= n - 1; ++i)
+        for (int j = p; j >= 1; --j) link(i, j);
+    link(n, p);
+    link(n, p - 1);
+    return 0;
+}
+template <int NK, int CR>
+int zhessenberg2_async(psd_ctx* c, int n, int p, const psd_zhess2_args& ha, int K) {
+    constexpr int LG = 64 / CR;
+    const int nC = ((ha.xcd && CR < 8) ? (((n + CR - 1) / CR + LG - 1) / LG) * LG : (n + CR - 1) / CR) + 1, nT = (n + PSD_ZH2_ROWS - 1) / PSD_ZH2_ROWS, nB = (n + 3) / 4;
+    const size_t lds = ((size_t)n + 8 + 2 * PSD_ZH2_NT + 64) * sizeof(psd_z);
+    const int Q = (n - 1) * p;
+    const int nbatch = Q / K + 1;
+    if ((int)c->h2ev.size() < 16) {
+        c->h2ev.resize(16, nullptr);
+        for (auto& e : c->h2ev) PSD_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    hipEvent_t* evA = c->h2ev.data();
+    hipEvent_t* evB = c->h2ev.data() + 8;
+    PSD_CHECK(hipEventRecord(evA[0], c->stream));
+    PSD_CHECK(hipStreamWaitEvent(c->stream3, evA[0], 0));
+    hipLaunchKernelGGL((psd_zhess2_link<NK, CR>), dim3(nC), dim3(PSD_ZH2_NT), lds, c->stream, ha, n, 0, 1, nC, 0);
+    int nextb = 0;
+    auto batch = [&](int b) -> int {
+        PSD_CHECK(hipEventRecord(evA[b & 7], c->stream));
+        PSD_CHECK(hipStreamWaitEvent(c->stream3, evA[b & 7], 0));
+        hipLaunchKernelGGL((psd_zhess2_bulk<NK>), dim3(nT + nB, K), dim3(PSD_ZH2_NT), lds, c->stream3, ha, n, b * K, nT);
+        PSD_CHECK(hipEventRecord(evB[b & 7], c->stream3));
+        return 0;
+    };
+    int idx = 0;
+    for (int i = 1; i <= n - 1; ++i)
+        for (int j = p; j >= 1; --j, ++idx) {
+            const int need = idx + 1 - p;
+            if (need >= 0 && need % K == 0) PSD_CHECK(hipStreamWaitEvent(c->stream, evB[(need / K) & 7], 0));
+            hipLaunchKernelGGL((psd_zhess2_link<NK, CR>), dim3(nC), dim3(PSD_ZH2_NT), lds, c->stream, ha, n, i, j, nC, 0);
+            if (idx >= nextb * K + K - 1) {
+                PSD_CHECK(batch(nextb));
+                ++nextb;
+            }
+        }
+    for (; nextb < nbatch; ++nextb) PSD_CHECK(batch(nextb));
+    PSD_CHECK(hipStreamWaitEvent(c->stream, evB[(nbatch - 1) & 7], 0));
+    return 0;
+}
+int zhessenberg2_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dtau) {
+    const size_t ringbytes = PSD_H2_RING * psd_zh2_slot_doubles(n) * sizeof(double);
+    if (!c->zh2ring || c->zh2ring_n < n) {
+        if (c->zh2ring) psd_rt_free(c->zh2ring);
+        c->zh2ring = nullptr;
+        PSD_CHECK(psd_rt_malloc((void**)&c->zh2ring, ringbytes));
+        c->zh2ring_n = n;
+    }
+    PSD_CHECK(psd_rt_memset(c->zh2ring, 0, ringbytes, c->stream));
+    psd_zhess2_args ha;
+    ha.H = dH;
+    ha.tau = dtau;
+    ha.ring = c->zh2ring;
+    ha.p = p;
+    ha.ringmask = 3;
+    ha.xcd = c->hess_xcd;
+    const size_t lds = ((size_t)n + 8 + 2 * PSD_ZH2_NT + 64) * sizeof(psd_z);
+    if (lds > 64 * 1024) return PSD_INFO_NOTIMPL;
+    int K = c->hess_async;
+    if (K < 0) K = (p >= 32 && n >= 512) ? 16 : 0;
+    if (K > 0 && p >= 9 * K) K = (p + 7) / 8;
+    if (K > 0 && p >= 2 * K && p + K + 2 <= PSD_H2_RING && c->stream3) {
+        ha.ringmask = PSD_H2_RING - 1;
+        if (n <= 256) return zhessenberg2_async<4, 8>(c, n, p, ha, K);
+        if (n <= 512) return zhessenberg2_async<8, 8>(c, n, p, ha, K);
+        if (n <= 1024) return zhessenberg2_async<16, 4>(c, n, p, ha, K);
+        return zhessenberg2_async<32, 4>(c, n, p, ha, K);
+    }
+    if (n <= 256) return zhessenberg2_launches<4, 8>(c, n, p, ha);
+    if (n <= 512) return zhessenberg2_launches<8, 8>(c, n, p, ha);
+    if (n <= 1024) return zhessenberg2_launches<16, 4>(c, n, p, ha);
+    return zhessenberg2_launches<32, 4>(c, n, p, ha);
+}
+#endif
+
 int zhessenberg_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dtau) {
     const size_t nn = (size_t)n * n;
     PSD_CHECK(psd_rt_memset(dtau, 0, sizeof(psd_z) * (size_t)n * p, c->stream));
+    if (n < 2) return 0;
+#ifndef PSD_HOSTSIM
+    if (p >= 3 && n <= 2048 && c->hess_lookahead) return zhessenberg2_dev(c, n, p, dH, dtau);
+#endif
     const size_t lds_refl = PSD_HESS_NT * 8;
     const size_t lds_apply = (PSD_HESS_NT + (size_t)n + 8) * sizeof(psd_z);
     for (int i = 1; i <= n - 1; ++i) {

@@ -16,6 +16,44 @@ def test_zphessenberg(gpu_engine, p):
     ec.case_zphessenberg(gpu_engine, p)
 
 
+def _zhess_vs_oracle(eng, n, p, seed):
+    A = pt.bench_factors(n, p, seed=seed, dtype=np.complex128)
+    W = [a.copy(order="F") for a in A]
+    Hs, tau, _ = eng.phessenberg_(W)
+    Ho, Qo, packed, tauo = pt.oracle_zphessenberg(A)
+    assert np.all(np.tril(Hs[0], -2) == 0)
+    for j in range(p):
+        assert np.linalg.norm(W[j] - packed[j]) < 1e-11 * max(np.linalg.norm(packed[j]), 1.0), (j,)
+        assert np.allclose(tau[j], tauo[j], rtol=0, atol=1e-11)
+        Ax = Qo[j] @ Hs[j] @ Qo[(j + 1) % p].conj().T
+        assert np.linalg.norm(A[j] - Ax) < 1e-10 * max(np.linalg.norm(A[j]), 1.0)
+    # the subdiagonal of H_1 and the diagonals of the triangular factors are real (householder.jl:113-114)
+    assert np.abs(np.diag(Hs[0], -1).imag).max() == 0.0
+    for j in range(1, p):
+        assert np.abs(np.diag(Hs[j]).imag)[:-1].max(initial=0.0) == 0.0
+
+
+@pytest.mark.parametrize("n,p", [(2, 3), (3, 4), (7, 3), (9, 5), (33, 3), (64, 7), (130, 4), (257, 5), (300, 16), (520, 3)])
+def test_zphessenberg_lookahead_vs_oracle(gpu_engine, n, p):
+    """The look-ahead reduction for ComplexF64 (csrc/psd_zhess2.h: one launch per chain link) against the oracle's
+    packed Householder storage and tau (PSD.jl:213-259 with householder.jl:110-156): odd orders, orders off the 4-row
+    strips and off the 128-column steps, the shortest period it serves (p = 3), the one-row last reflector of H_1 that
+    only turns the subdiagonal real."""
+    _zhess_vs_oracle(gpu_engine, n, p, 270 + n + p)
+
+
+@pytest.mark.parametrize("n,p,K", [(33, 8, 4), (130, 9, 4), (257, 16, 8), (300, 40, 16), (64, 70, 16), (96, 150, 16)])
+def test_zphessenberg_two_stream_vs_oracle(monkeypatch, n, p, K):
+    """two-stream form (see test_phessenberg_two_stream_vs_oracle) of the complex reduction, forced on small problems"""
+    import torch
+
+    torch.cuda.init()
+    import psd_amd
+
+    monkeypatch.setenv("PSD_HESS_ASYNC", str(K))
+    _zhess_vs_oracle(psd_amd.Engine(device=0), n, p, 370 + n + p)
+
+
 @pytest.mark.parametrize("lr", ["R", "L"])
 def test_zfull(gpu_engine, lr):
     ec.case_zfull(gpu_engine, lr)
