@@ -113,6 +113,44 @@ PSD_HD void psd_zgivens(psd_z f, psd_z g, double& cs, psd_z& sn, psd_z& r) {
     }
 }
 
+// psd_zgivens for the chase chains: the common case as straight-line code (one range test; the squares neither overflow
+// nor vanish, f not negligible against g), everything else out of line and by value (an argument passed by reference to a
+// function that is not inlined lives in scratch memory).  Same quantities as the fast path of psd_zgivens, from reciprocal roots alone.
+struct psd_zgiv_out {
+    double cs;
+    psd_z sn, r;
+};
+PSD_D_NOINLINE psd_zgiv_out psd_zgivens_slow(psd_z f, psd_z g) {
+    psd_zgiv_out o;
+    psd_zgivens(f, g, o.cs, o.sn, o.r);
+    return o;
+}
+PSD_D void psd_zgivens_lean(psd_z f, psd_z g, double& cs, psd_z& sn, psd_z& r) {
+    // cs = |f| / N, r = f N / |f|, sn = f conj(g) / (|f| N), N^2 = |f|^2 + |g|^2: with rf = 1/|f|, rn = 1/N and k = rf rn
+    // that is cs = |f|^2 k, r = f (N^2 k), sn = (f conj(g)) k — only the two reciprocal roots are on the chain, f conj(g)
+    // and the range test run beside them
+    const double f2 = zabs2(f), g2 = zabs2(g), n2 = f2 + g2;
+    double rf, rn;
+    psd_rsqrt2_fast(f2, n2, rf, rn);
+    const psd_z fg = zmul(f, zconj(g));
+    const double k = rf * rn;
+    double c0 = f2 * k;
+    psd_z r0 = zscal(n2 * k, f);
+    psd_z s0 = zscal(k, fg);
+    // (magnitudes between 1e-146 and 1e145 as in psd_zgivens: then n2 < 1e291, and f2 is normal)
+    const double scale = fmax(zabs1(f), zabs1(g));
+    const bool ok = (scale < 9.989595361011175e+145) & (scale > 1.0010415475915505e-146) & (f2 > fmax(g2, 1.0) * PSD_DBL_MIN);
+    if (!ok) {
+        const psd_zgiv_out o = psd_zgivens_slow(f, g);
+        c0 = o.cs;
+        s0 = o.sn;
+        r0 = o.r;
+    }
+    cs = c0;
+    sn = s0;
+    r = r0;
+}
+
 // stdlib lmul!(G, .): (a1, a2) <- (c a1 + s a2, -conj(s) a1 + c a2)
 PSD_HD void psd_zrot_left(double c, psd_z s, psd_z& a1, psd_z& a2) {
     const psd_z b1 = zadd(zscal(c, a1), zmul(s, a2));

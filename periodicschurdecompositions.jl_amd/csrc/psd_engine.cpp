@@ -152,9 +152,10 @@ struct psd_ctx {
         if (ztcst && p <= ztcap_p) return 0;
         ztrelease();
         PSD_CHECK(psd_rt_malloc((void**)&ztcst, sizeof(psd_zstate) * PSD_TRAIN_MAX + sizeof(int) * (PSD_TRAIN_MAX + 8)));
-        PSD_CHECK(psd_rt_malloc((void**)&ztdesc, sizeof(psd_zapply_desc) * PSD_TRAIN_MAX));
-        PSD_CHECK(psd_rt_malloc((void**)&ztcnt, sizeof(int) * PSD_TRAIN_MAX * (size_t)(p + 8)));
-        PSD_CHECK(psd_rt_malloc((void**)&zttr, sizeof(psd_ztr) * PSD_TRAIN_MAX * (size_t)p * PSD_ZTR_CAP));
+        // (two sets, by tick parity: the Schur-vector updates of a tick run on the second stream while the next tick writes its lists)
+        PSD_CHECK(psd_rt_malloc((void**)&ztdesc, 2 * sizeof(psd_zapply_desc) * PSD_TRAIN_MAX));
+        PSD_CHECK(psd_rt_malloc((void**)&ztcnt, 2 * sizeof(int) * PSD_TRAIN_MAX * (size_t)(p + 8)));
+        PSD_CHECK(psd_rt_malloc((void**)&zttr, 2 * sizeof(psd_ztr) * PSD_TRAIN_MAX * (size_t)p * PSD_ZTR_CAP));
         PSD_CHECK(psd_rt_malloc((void**)&ztshift, sizeof(psd_z) * (PSD_TRAIN_MAX + 2)));
         ztcap_p = p;
         return 0;
@@ -1769,7 +1770,7 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
     if (M > 1) {
         PSD_CHECK(c->ztreserve(p));
         PSD_CHECK(psd_rt_memset(c->ztcst, 0, sizeof(psd_zstate) * PSD_TRAIN_MAX + sizeof(int) * (PSD_TRAIN_MAX + 8), c->stream));
-        PSD_CHECK(psd_rt_memset(c->ztdesc, 0, sizeof(psd_zapply_desc) * PSD_TRAIN_MAX, c->stream));
+        PSD_CHECK(psd_rt_memset(c->ztdesc, 0, 2 * sizeof(psd_zapply_desc) * PSD_TRAIN_MAX, c->stream));
         P.cst = c->ztcst;
         P.cep = (int*)(c->ztcst + PSD_TRAIN_MAX);
         P.tshift = c->ztshift;
@@ -1784,6 +1785,11 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
     int train_oc = 100;
     if (const char* e = getenv("PSD_TRAIN_OC")) train_oc = atoi(e);  // (tuning hook)
     PSD_LAUNCH(psd_zq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, M, train_oc);
+#ifndef PSD_HOSTSIM
+    const bool zdef = M > 1 && wantZ && c->stream2 && c->evE[0] && (c->overlap == 2 || (c->overlap == 3 && n >= 1024));
+#else
+    const bool zdef = M > 1 && wantZ && c->overlap == 2;
+#endif
     const size_t lds_apply = PSD_ZTR_LDS_BYTES + (size_t)32 * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
     const int tiles = (n + PSD_ZAPPLY_NT - 1) / PSD_ZAPPLY_NT;
     const int dtiles = (n + 255) / 256;
@@ -1811,10 +1817,20 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
             }
 #endif
             P.tick = (int)launched;
+            const int par = zdef ? (int)(launched & 1) : 0;
+            psd_zparams Pq = P;
+            if (zdef) {
+#ifndef PSD_HOSTSIM
+                if (launched >= 2) PSD_CHECK(hipStreamWaitEvent(c->stream, c->evF[par], 0));  // (the Z launch that read this parity's lists)
+#endif
+                Pq.desc = P.desc + (size_t)par * PSD_TRAIN_MAX;
+                Pq.cnt = P.cnt + (size_t)par * PSD_TRAIN_MAX * (p + 8);
+                Pq.tr = P.tr + (size_t)par * PSD_TRAIN_MAX * p * PSD_ZTR_CAP;
+            }
             if (M == 1)
                 PSD_LAUNCH(psd_zq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
             else
-                PSD_LAUNCH(psd_zq_step_train, psd_dim3(M), PSD_STEP_NT, lds_step, c->stream, P, p, p + 8);
+                PSD_LAUNCH(psd_zq_step_train, psd_dim3(M), PSD_STEP_NT, lds_step, c->stream, Pq, p, p + 8);
 #ifndef PSD_HOSTSIM
             if (sample) {
                 (void)hipEventRecord(ev1, c->stream);
@@ -1823,11 +1839,25 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
 #endif
             if (M == 1) {
                 PSD_LAUNCH(psd_zq_apply, psd_dim3(tiles, p, 3), PSD_ZAPPLY_NT, lds_apply, c->stream, P, n, p);
+            } else if (zdef) {
+                // Schur-vector updates one stream over (as iterate_dev: nothing reads Z_m before the iteration ends and only
+                // owner m's lists touch it): they start when the tick's H updates are done and run beside the next tick's
+                // chases; the lists of a tick are double-buffered by parity, the chase that reuses a parity awaits evF
+                PSD_LAUNCH(psd_zq_apply_train, psd_dim3(tiles, p, M), PSD_ZAPPLY_NT, lds_apply, c->stream, Pq, n, p, p + 8, 2);
+                PSD_LAUNCH(psd_zq_apply_train, psd_dim3(tiles, p, M), PSD_ZAPPLY_NT, lds_apply, c->stream, Pq, n, p, p + 8, 1);
+#ifndef PSD_HOSTSIM
+                PSD_CHECK(hipEventRecord(c->evE[par], c->stream));
+                PSD_CHECK(hipStreamWaitEvent(c->stream2, c->evE[par], 0));
+                PSD_LAUNCH(psd_zq_apply_train, psd_dim3(tiles, p, M), PSD_ZAPPLY_NT, lds_apply, c->stream2, Pq, n, p, p + 8, 3);
+                PSD_CHECK(hipEventRecord(c->evF[par], c->stream2));
+#else
+                PSD_LAUNCH(psd_zq_apply_train, psd_dim3(tiles, p, M), PSD_ZAPPLY_NT, lds_apply, c->stream, Pq, n, p, p + 8, 3);
+#endif
             } else {
                 PSD_LAUNCH(psd_zq_apply_train, psd_dim3(tiles, p, 2 * M), PSD_ZAPPLY_NT, lds_apply, c->stream, P, n, p, p + 8, 0);
                 PSD_LAUNCH(psd_zq_apply_train, psd_dim3(tiles, p, M), PSD_ZAPPLY_NT, lds_apply, c->stream, P, n, p, p + 8, 1);
             }
-            PSD_LAUNCH(psd_zq_defer, psd_dim3(dtiles), 256, 0, c->stream, P, n);
+            PSD_LAUNCH(psd_zq_defer, psd_dim3(dtiles), 256, 0, c->stream, Pq, n);
             ++launched;
         }
 #ifdef PSD_HOSTSIM
@@ -1838,11 +1868,15 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
 #endif
         if (hst.phase == PSD_ZPH_DONE) break;
         if (launched > cap) {
+#ifndef PSD_HOSTSIM
+            if (zdef) (void)hipStreamSynchronize(c->stream2);
+#endif
             *st_out = hst;
             return PSD_INFO_RUNTIME + 0xfffe;
         }
     }
 #ifndef PSD_HOSTSIM
+    if (zdef) PSD_CHECK(hipStreamSynchronize(c->stream2));  // (the phase pass below scales columns of Z)
     PSD_CHECK(poller.finish(pend));
 #endif
     if (hst.info == 0 && wantT) {  // generalized.jl:860-908
@@ -2781,6 +2815,11 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
 #ifndef PSD_HOSTSIM
     PSD_CHECK(poller.finish(pend));
 #endif
+    if (getenv("PSD_GDBG")) {
+        fprintf(stderr, "psd signed check stages (cycles/calls: test 1, tests 2-3, start rotations, train shifts, explicit start, cursor states, 2x2 block, split):");
+        for (int q = 0; q < 8; ++q) fprintf(stderr, " %lld/%d", hst.dbg[q], hst.dbgn[q]);
+        fprintf(stderr, " | cyc decide %lld load %lld chase %lld store %lld total %lld\n", hst.cyc[0], hst.cyc[1], hst.cyc[2], hst.cyc[3], hst.cyc[4]);
+    }
     PSD_CHECK(psd_rt_last_error());
     *st_out = hst;
     if (stats) {

@@ -69,6 +69,10 @@ static inline void psd_sqrt_pair_fast(double s, double& g, double& rg) {
     g = sqrt(s);
     rg = 1.0 / g;
 }
+static inline void psd_rsqrt2_fast(double a, double b, double& ra, double& rb) {
+    ra = 1.0 / sqrt(a);
+    rb = 1.0 / sqrt(b);
+}
 static inline long long psd_clock() { return 0; }
 static inline long long psd_wallclock() { return 0; }
 // cross-workgroup words (agent-scope atomics on the GPU; the simulation runs the workgroups one after the other)
@@ -234,6 +238,20 @@ __device__ __forceinline__ void psd_sqrt_pair_fast(double s, double& g, double& 
     gg = __builtin_fma(d, h, gg);
     g = gg;
     rg = h + h;
+}
+// 1/sqrt(a) and 1/sqrt(b) together (same preconditions): seeds + two Newton steps each, the two chains written
+// interleaved (a lone wavefront issues a dependent f64 operation every 6.4 cycles: two independent chains fill the gaps)
+__device__ __forceinline__ void psd_rsqrt2_fast(double a, double b, double& ra, double& rb) {
+    double ya = __builtin_amdgcn_rsq(a), yb = __builtin_amdgcn_rsq(b);
+    double ta = a * ya, tb = b * yb, ha = 0.5 * ya, hb = 0.5 * yb;
+    double ea = __builtin_fma(-ta, ya, 1.0), eb = __builtin_fma(-tb, yb, 1.0);
+    ya = __builtin_fma(ha, ea, ya);
+    yb = __builtin_fma(hb, eb, yb);
+    ta = a * ya; tb = b * yb; ha = 0.5 * ya; hb = 0.5 * yb;
+    ea = __builtin_fma(-ta, ya, 1.0);
+    eb = __builtin_fma(-tb, yb, 1.0);
+    ra = __builtin_fma(ha, ea, ya);
+    rb = __builtin_fma(hb, eb, yb);
 }
 // Cross-workgroup words of one launch (slot roles, done flags, global counters): agent-scope atomics.  Data handed
 // from one workgroup to another INSIDE a launch goes behind a release fence on the producer and an acquire fence on

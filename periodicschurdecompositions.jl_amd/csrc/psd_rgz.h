@@ -55,6 +55,8 @@ struct psd_gstate {
     double c1, s1, c2, s2;  // starting rotations of the current sweep
     double smlnum, ulp;
     long long cyc[6];
+    long long dbg[8];  // cycles of the check's stages (PSD_GDBG: test 1, tests 2/3, start rotations, train shifts, explicit start, cursor states, 2x2 block, split)
+    int dbgn[8];
     // multishift train (as psd_rstate): bulges wanted (-2: explicit-shift start without a train, test hook) / in the
     // running train / train number / this state's cursor / tick of the leader's first window / sweeps in trains
     int train_want, train_n, train_id, cursor, train_tick0, ntrainsweeps;
@@ -1294,11 +1296,23 @@ PSD_D void psd_gq_train_shifts(const psd_gparams& P, int n, int p, int ilast, in
         T[q] = acc;
     }
     PSD_SYNC();
+#ifndef PSD_HOSTSIM
+    // (one lane alone pays an LDS round trip per operand — 1.7 ms per train at K = 16, psd_hqr.h; the workgroup is one wavefront)
+    bool finite = true;
+    for (int q = PSD_TID; q < KK; q += 64)
+        if (!(fabs(T[q]) < 1e300)) finite = false;
+    finite = __all(finite) != 0;
+    const bool okw = finite && psd_hqr_wave(T, K, K, wr, wi, PSD_TID);
+#endif
     PSD_ONE {
+#ifndef PSD_HOSTSIM
+        bool ok = okw;
+#else
         bool ok = true;
         for (int q = 0; q < KK; ++q)
             if (!(fabs(T[q]) < 1e300)) ok = false;
         ok = ok && psd_hqr(T, K, K, wr, wi);
+#endif
         int np = 0, nre = 0;
         for (int q = 0; ok && q < K; ++q) {
             if (!(wr[q] == wr[q]) || !(wi[q] == wi[q])) ok = false;
@@ -1344,6 +1358,8 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
     const int ilast = st.ilast;
     bool split = false;
     int jlo = 1;
+    long long tq = psd_clock();
+#define PSD_GDBG_STAMP(i) do { const long long tn_ = psd_clock(); st.dbg[i] += tn_ - tq; st.dbgn[i] += 1; tq = tn_; } while (0)
     if (ilast == 1) {
         split = true;
     } else {
@@ -1381,10 +1397,12 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
             if (jfound == ilast) split = true;
         }
     }
+    PSD_GDBG_STAMP(0);
     if (split) {  // :617-642
         double a, b;
         int sc;
         psd_g_safeprod(P, n, p, ilast, a, b, sc);
+        PSD_GDBG_STAMP(7);
         PSD_ONE {
             P.alpha[ilast - 1] = zmk(a, 0.0);
             P.beta[ilast - 1] = b;
@@ -1407,6 +1425,7 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
     // Tests 2 and 3 (:198-226)
     const int key2 = psd_gq_scan_diag(P, st, redi, jlo, true);
     const int key3 = (key2 == 0x7fffffff) ? psd_gq_scan_diag(P, st, redi, jlo, false) : 0x7fffffff;
+    PSD_GDBG_STAMP(1);
     // Test 4 (:229): controlled zero shift; a pending zero diagonal entry is found again afterwards (the
     // reference's fall-through into Case II/III with stale indices is a defect)
     if (st.ziter >= 7 || st.ziter < 0) {
@@ -1435,7 +1454,7 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
         const int j = ilast - 1;
         PSD_SYNC();
         PSD_ONE {
-            double* X = P.xscr;
+            double* X = ldsd;  // (in LDS: one lane walks the 2x2 blocks up to 20 + 80 times; from global scratch that was 1.4 ms per block at p = 32)
             for (int l = 1; l <= p; ++l) {  // order 2, 3, ..., p, 1 (:669-672)
                 const psd_mat<double> M = psd_gfac(P, n, (l == p) ? 1 : (l + 1));
                 X[4 * (l - 1) + 0] = M(j, j);
@@ -1444,7 +1463,37 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
                 X[4 * (l - 1) + 3] = M(j + 1, j + 1);
             }
             bool done2 = false;
-            for (int titer = 1; titer <= 2 && !done2; ++titer) {
+            // A block whose product has a clearly complex pair cannot be brought to real triangular form: the two
+            // attempts below (up to 40 single-shift passes over the p factors by one lane, 1.2 ms at p = 32) would end
+            // with done2 = false and their X discarded (:748-771 reloads the blocks).  The sign of the discriminant of
+            // the explicitly formed 2x2 product (inverses by adjugates: a scalar multiple does not change the sign;
+            // rescaled at every factor) tells; anything near zero or not finite takes the reference's route.
+            bool clearly_complex = false;
+            {
+                double m11 = X[4 * (p - 1) + 0], m12 = X[4 * (p - 1) + 1], m21 = X[4 * (p - 1) + 2], m22 = X[4 * (p - 1) + 3];
+                bool okp = true;
+                for (int l = 2; l <= p && okp; ++l) {
+                    const double* Y = X + 4 * (l - 2);
+                    double b11, b12, b21, b22;
+                    if (psd_gsig(P, l)) {
+                        b11 = Y[0]; b12 = Y[1]; b21 = Y[2]; b22 = Y[3];
+                    } else {
+                        b11 = Y[3]; b12 = -Y[1]; b21 = -Y[2]; b22 = Y[0];
+                    }
+                    const double n11 = m11 * b11 + m12 * b21, n12 = m11 * b12 + m12 * b22;
+                    const double n21 = m21 * b11 + m22 * b21, n22 = m21 * b12 + m22 * b22;
+                    const double sc = fmax(fmax(fabs(n11), fabs(n12)), fmax(fabs(n21), fabs(n22)));
+                    if (!(sc > 0.0) || !(sc < 1e300)) okp = false;
+                    const double rs = 1.0 / sc;
+                    m11 = n11 * rs; m12 = n12 * rs; m21 = n21 * rs; m22 = n22 * rs;
+                }
+                if (okp) {
+                    const double hd = 0.5 * (m11 - m22), od = m12 * m21;
+                    const double disc = hd * hd + od;
+                    clearly_complex = disc < -1e-6 * fmax(hd * hd, fabs(od));
+                }
+            }
+            for (int titer = 1; titer <= 2 && !done2 && !clearly_complex; ++titer) {
                 psd_g_rp2x2ssr(p, X, P);
                 const double* Xp = X + 4 * (p - 1);
                 done2 = fabs(Xp[2]) < PSD_DBL_EPS * fmax(fabs(Xp[0]), fmax(fabs(Xp[1]), fabs(Xp[3])));
@@ -1463,7 +1512,7 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
                 red[1] = c1;
                 red[2] = s1;
             } else {  // conjugate pair (:748-771)
-                psd_z* Xc = (psd_z*)(P.xscr + 4 * p);
+                psd_z* Xc = (psd_z*)(ldsd + 4 * p);
                 for (int l = 1; l <= p; ++l) {
                     const psd_mat<double> M = psd_gfac(P, n, l);
                     Xc[4 * (l - 1) + 0] = zmk(M(j, j), 0.0);
@@ -1488,6 +1537,7 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
         const bool done2 = red[0] != 0.0;
         const double r1 = red[1], r2 = red[2];
         PSD_SYNC();
+        PSD_GDBG_STAMP(6);
         if (done2) {
             st.n2real += 1;
             psd_glog(P, st, 5, j, ilast);
@@ -1526,6 +1576,7 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
     }
     PSD_SYNC();
     psd_g_qzrots(P, n, p, ifirst, ilast - ifirst + 1, st.c1, st.s1, st.c2, st.s2);
+    PSD_GDBG_STAMP(2);
     st.train_n = 1;
     if ((st.train_want >= 2 || st.train_want == -2) && P.tshift != nullptr && ilast - ifirst + 1 >= 4) {
         // window width of the train by the cost model of psd_rq_shift
@@ -1552,6 +1603,7 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
         if ((m >= 2 || st.train_want == -2) && m >= 1 && 2 * m + 2 <= w) {
             int* okf = (int*)P.tshift + 8 * PSD_TRAIN_MAX;
             psd_gq_train_shifts(P, n, p, ilast, ms, ldsd, okf);
+            PSD_GDBG_STAMP(3);
             if (*okf && m > ms) {
                 PSD_ONE {
                     for (int b = ms; b < m; ++b)
@@ -1571,6 +1623,7 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
                 }
             }
             PSD_SYNC();
+            PSD_GDBG_STAMP(4);
         }
     }
     st.phase = PSD_GPH_SWEEP;
@@ -1597,6 +1650,7 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
             }
         }
         PSD_SYNC();
+        PSD_GDBG_STAMP(5);
     }
     return false;
 }
@@ -1958,6 +2012,7 @@ PSD_KERNEL psd_gq_init(psd_gparams P, int n, int p, int wantT, int wantZ, int W,
         st.ulp = PSD_DBL_EPS;
         st.smlnum = PSD_DBL_MIN * ((double)n / PSD_DBL_EPS);
         for (int q = 0; q < 6; ++q) st.cyc[q] = 0;
+        for (int q = 0; q < 8; ++q) { st.dbg[q] = 0; st.dbgn[q] = 0; }
         if (n == 0) st.phase = PSD_GPH_DONE;
         if (hessmode) {  // stage 2 of _phessenberg!(A, S): columns 1..n-2, positions n-1 down to hj+1
             st.phase = (n >= 3) ? PSD_GPH_HESS : PSD_GPH_DONE;

@@ -559,55 +559,73 @@ PSD_D void psd_zq_check(const psd_zparams& P, psd_zstate& st, double* red, int* 
     }
 }
 
-// Hot micro-step of the complex sweep (generalized.jl:823-845, S[l] true), factor l >= 2 at position j:
+// Hot chain of the complex sweep (generalized.jl:823-845, S[l] true) at position j, factors l = p..2.  Per factor:
 // incoming rotation G' from the right on columns (j, j+1) of H_l (lanes = rows r0..j+1), new rotation
 // from (H_l[j,j], H_l[j+1,j]), applied from the left to rows (j, j+1) (lanes = columns j+1..c1max).
-// One pass: operands loaded once, the chain values (f, g and the 2 corner entries of column j+1)
-// travel by v_readlane, one wave-level sync.  (c, s) in: incoming rotation; out: the new one.
-PSD_D void psd_zq_micro(const psd_zparams& P, const psd_zwin& w, int l, int j, int nr, int nl,
+// One pass per factor: operands loaded once, the chain values (f, g and the 2 corner entries of column j+1)
+// travel by v_readlane.  A step touches H_l only, so the operands of factor l - 1 are requested BEFORE the step of
+// factor l runs (their LDS round trip, 120-130 cycles, is off the chain), and nothing waits for a step's stores: one
+// wavefront's DS operations complete in order, and what a step wrote is read again a whole lap later.
+// (c, s) in: rotation from H_1's rows; out: the one that goes to H_1's columns.
+PSD_D void psd_zq_chain(const psd_zparams& P, const psd_zwin& w, int p, int j, int nr, int nl,
                         PSD_LANEVAR_REF(int, lane_off), PSD_LANEVAR_REF(int, lane_str), double& c, psd_z& s,
                         int slot) {
     const int cnt = nr + nl;
-    const int boff = (l - 1) * w.bsz;
     PSD_LANEVAR(psd_z, x1);
     PSD_LANEVAR(psd_z, x2);
+    PSD_LANEVAR(psd_z, y1);
+    PSD_LANEVAR(psd_z, y2);
     PSD_PAR_ONCE(t, cnt) {
-        const psd_z* q = w.b + (boff + PSD_LV(lane_off));
+        const psd_z* q = w.b + ((p - 1) * w.bsz + PSD_LV(lane_off));
         PSD_LV(x1) = q[0];
         PSD_LV(x2) = q[PSD_LV(lane_str)];
-        if (t < nr) psd_zrot_right_adj(c, s, PSD_LV(x1), PSD_LV(x2));
     }
-    // rows j and j+1 are the last two row-lanes
-    const psd_z f = PSD_BCASTZ(x1, nr - 2), g = PSD_BCASTZ(x1, nr - 1);
-    const psd_z top = PSD_BCASTZ(x2, nr - 2), bot = PSD_BCASTZ(x2, nr - 1);
-    psd_z r;
-    psd_zgivens(f, g, c, s, r);
-    PSD_PAR_ONCE(t, cnt) {
-        psd_z* q = w.b + (boff + PSD_LV(lane_off));
-        if (t < nr) {
-            if (t >= nr - 2) {  // rows j, j+1: column j becomes (r, 0); their column j+1 belongs to the left pass
-                q[0] = (t == nr - 2) ? r : zmk(0.0, 0.0);
-            } else {
-                q[0] = PSD_LV(x1);
-                q[PSD_LV(lane_str)] = PSD_LV(x2);
-            }
-        } else {
-            psd_z a1 = PSD_LV(x1), a2 = PSD_LV(x2);
-            if (t == nr) {  // column j+1: entries already touched by the right pass
-                a1 = top;
-                a2 = bot;
-            }
-            psd_zrot_left(c, s, a1, a2);
-            q[0] = a1;
-            q[PSD_LV(lane_str)] = a2;
+    for (int l = p; l >= 2; --l) {
+        const int boff = (l - 1) * w.bsz;
+        PSD_PAR_ONCE(t, cnt) {
+            if (t < nr) psd_zrot_right_adj(c, s, PSD_LV(x1), PSD_LV(x2));
         }
-        if (t == 0) {
-            psd_ztr tr;
-            tr.pos = j;
-            tr.pad = 0;
-            tr.c = c;
-            tr.s = s;
-            if (slot < PSD_ZTR_CAP) P.tr[(size_t)(l - 1) * PSD_ZTR_CAP + slot] = tr;
+        // rows j and j+1 are the last two row-lanes
+        const psd_z f = PSD_BCASTZ(x1, nr - 2), g = PSD_BCASTZ(x1, nr - 1);
+        const psd_z top = PSD_BCASTZ(x2, nr - 2), bot = PSD_BCASTZ(x2, nr - 1);
+        if (l > 2) {  // (requested here, behind the first use of this step's operands: the wait in front of that use then covers the previous step's stores only, and the round trip runs beside the rotation's arithmetic)
+            PSD_PAR_ONCE(t, cnt) {
+                const psd_z* q = w.b + (boff - w.bsz + PSD_LV(lane_off));
+                PSD_LV(y1) = q[0];
+                PSD_LV(y2) = q[PSD_LV(lane_str)];
+            }
+        }
+        psd_z r;
+        psd_zgivens_lean(f, g, c, s, r);
+        PSD_PAR_ONCE(t, cnt) {
+            psd_z* q = w.b + (boff + PSD_LV(lane_off));
+            if (t < nr) {
+                if (t >= nr - 2) {  // rows j, j+1: column j becomes (r, 0); their column j+1 belongs to the left pass
+                    q[0] = (t == nr - 2) ? r : zmk(0.0, 0.0);
+                } else {
+                    q[0] = PSD_LV(x1);
+                    q[PSD_LV(lane_str)] = PSD_LV(x2);
+                }
+            } else {
+                psd_z a1 = PSD_LV(x1), a2 = PSD_LV(x2);
+                if (t == nr) {  // column j+1: entries already touched by the right pass
+                    a1 = top;
+                    a2 = bot;
+                }
+                psd_zrot_left(c, s, a1, a2);
+                q[0] = a1;
+                q[PSD_LV(lane_str)] = a2;
+            }
+            if (t == 0) {
+                psd_ztr tr;
+                tr.pos = j;
+                tr.pad = 0;
+                tr.c = c;
+                tr.s = s;
+                if (slot < PSD_ZTR_CAP) P.tr[(size_t)(l - 1) * PSD_ZTR_CAP + slot] = tr;
+            }
+            PSD_LV(x1) = PSD_LV(y1);
+            PSD_LV(x2) = PSD_LV(y2);
         }
     }
     PSD_WAVE_SYNC();
@@ -665,7 +683,7 @@ PSD_D void psd_zq_sweep_window(const psd_zparams& P, psd_zstate& st, psd_z* ldsz
                 }
             }
             const int slot = j - ks;
-            for (int l = p; l >= 2; --l) psd_zq_micro(P, w, l, j, nr, nl, lane_off, lane_str, c, s, slot);
+            psd_zq_chain(P, w, p, j, nr, nl, lane_off, lane_str, c, s, slot);
         }
         const int itmp = (j + 2 < ilastm) ? (j + 2) : ilastm;
         psd_zwin_right(w, 1, j, c, s, ifirstm, itmp);
@@ -893,6 +911,9 @@ PSD_D void psd_zq_step_body(const psd_zparams& P) {
                     st.nsweeps += 1;
                     st.iiter += 1;
                     st.jiter += 1;
+                    // (cycle counters: the cursors' windows count like the leader's; [5] = what a cursor spends outside its windows)
+                    for (int q = 1; q <= 3; ++q) st.cyc[q] += P.cst[b].cyc[q];
+                    st.cyc[5] += P.cst[b].cyc[4] - (P.cst[b].cyc[1] + P.cst[b].cyc[2] + P.cst[b].cyc[3]);
                 }
                 st.train_n = 1;
                 st.W = st.Wmax;
@@ -904,7 +925,7 @@ PSD_D void psd_zq_step_body(const psd_zparams& P) {
         }
     }
     st.cyc[4] += psd_clock() - tk0;
-    st.cyc[5] += psd_wallclock() - tw0;
+    (void)tw0;
     if (st.info == PSD_LIST_OVERFLOW) st.phase = PSD_ZPH_DONE;  // (a window that overran a list ends the call)
     PSD_SYNC();
     PSD_ONE { *P.st = st; }
@@ -915,6 +936,7 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_zq_step(psd_zparams P) { psd_zq_step_body(P); }
 PSD_D void psd_zq_cursor_body(const psd_zparams& P, int b) {
     PSD_LDS_DECL;
     PSD_ONE { P.desc->active = 0; P.desc->defer_run = 0; }
+    const long long tb0 = psd_clock();
     psd_zstate st;
     if (!psd_pub_read(P.cep + b, P.tick, P.st, st)) return;  // (published in an earlier launch, not being rewritten)
     if (st.cursor != b) return;
@@ -930,6 +952,7 @@ PSD_D void psd_zq_cursor_body(const psd_zparams& P, int b) {
         st.phase = PSD_ZPH_SWEEP;
     }
     psd_zq_sweep_window(P, st, ldsz, lcnt);
+    st.cyc[4] += psd_clock() - tb0;
     PSD_SYNC();
     PSD_ONE {
         *P.st = st;
@@ -1136,9 +1159,11 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply(psd_zparams P, int n, int p) { psd_zq_a
 
 // bulk updates of all cursors of a tick in two launches (see psd_rq_apply_train)
 PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply_train(psd_zparams P, int n, int p, int cstride, int pass) {
+    // pass 0: rows of H_m and Schur vectors (grid.z = 2 M), 1: columns of H_{m-1}, 2: rows alone, 3: Schur vectors alone
+    // (grid.z = M; the Z updates of a tick as their own launch on the second stream, see ziterate_dev)
     const int z = PSD_BLOCK_Z;
     const int b = (pass == 0) ? (z >> 1) : z;
-    const int role = (pass == 0) ? ((z & 1) ? 2 : 0) : 1;
+    const int role = (pass == 0) ? ((z & 1) ? 2 : 0) : ((pass == 1) ? 1 : ((pass == 2) ? 0 : 2));
     psd_zparams Q = P;
     Q.desc = P.desc + b;
     Q.cnt = P.cnt + (size_t)b * cstride;

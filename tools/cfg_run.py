@@ -26,4 +26,4 @@ for _ in range(rep):
         ps = eng.pschur_([a.copy(order="F") for a in A], "R", S=S)
     st = ps.stats
     print(which, "ms", st.ms_total - st.ms_copy, "hess", st.ms_hess, "formq/stage1", st.ms_formq, "iter", st.ms_iter, "sweeps", st.nsweeps,
-          "launches", st.nlaunch_step, "windows", st.nwindows, flush=True)
+          "launches", st.nlaunch_step, "windows", st.nwindows, "cycles(decide,load,chase,store,total,wall)", list(st.step_cycles), flush=True)

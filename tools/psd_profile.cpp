@@ -1,5 +1,6 @@
 // Standalone driver for profiler runs (rocprofv3 --pmc crashes under the python/torch harness on this image).
-// Usage: psd_profile [n] [p] [repeat]  — solves pschur!(A,:R) on A_j = I + 0.5 G_j/sqrt(n) through the C ABI.
+// Usage: psd_profile [n] [p] [repeat] [d|z]  — solves pschur!(A,:R) on A_j = I + 0.5 G_j/sqrt(n) through the C ABI
+// (z: ComplexF64, re and im of G_j ~ N(0, 1/2)).
 // Linked DIRECTLY against libpsd_mi355x.so (round 1 dlopen()ed it after the profiler had initialised the GPU; the
 // unfiltered --pmc run of that build died with a SIGSEGV on a profiler thread, gpurun_out/pmc_fetch.log).  With
 // PSD_PROFILE_MAPS=<file> the process writes /proc/self/maps there once the library and the HIP runtime are up, so
@@ -41,6 +42,28 @@ int main(int argc, char** argv) {
         if (out) fclose(out);
     }
     const size_t nn = (size_t)n * n;
+    if (argc > 4 && argv[4][0] == 'z') {
+        std::vector<std::vector<double>> A0(p, std::vector<double>(2 * nn)), A(p), Z(p, std::vector<double>(2 * nn));
+        uint64_t s = 1237;
+        for (int j = 0; j < p; ++j)
+            for (size_t q = 0; q < nn; ++q) {
+                A0[j][2 * q] = 0.5 * gauss(s) / std::sqrt(2.0 * n) + ((q % (n + 1)) == 0 ? 1.0 : 0.0);
+                A0[j][2 * q + 1] = 0.5 * gauss(s) / std::sqrt(2.0 * n);
+            }
+        std::vector<double> alpha(2 * n), beta(n);
+        std::vector<int32_t> asc(n);
+        for (int r = 0; r < rep; ++r) {
+            std::vector<double*> Ap(p), Zp(p);
+            for (int j = 0; j < p; ++j) { A[j] = A0[j]; Ap[j] = A[j].data(); Zp[j] = Z[j].data(); }
+            psd_stats st; int si = 0, info = 0;
+            psd_z_pschur(ctx, n, p, Ap.data(), nullptr, 'R', 1, 1, 30, Zp.data(), alpha.data(), beta.data(), asc.data(), &si, &st, nullptr, 0, &info);
+            printf("{\"n\": %d, \"p\": %d, \"dtype\": \"c128\", \"info\": %d, \"sweeps\": %d, \"windows\": %d, \"launches\": %d, \"ms_total\": %.3f, "
+                   "\"ms_iter\": %.3f, \"ms_hess\": %.3f, \"bytes_sweeps\": %.0f}\n",
+                   n, p, info, st.nsweeps, st.nwindows, st.nlaunch_step, st.ms_total, st.ms_iter, st.ms_hess, st.bytes_sweeps);
+        }
+        destroy(ctx);
+        return 0;
+    }
     std::vector<std::vector<double>> A0(p, std::vector<double>(nn)), A(p), Z(p, std::vector<double>(nn));
     uint64_t s = 1236;
     for (int j = 0; j < p; ++j)
