@@ -238,6 +238,8 @@ struct psd_ctx {
 #ifndef PSD_HOSTSIM
     hipStream_t stream2 = nullptr;  // the far parts of the bulk updates (beside the next tick's chases)
     hipStream_t stream3 = nullptr;  // the panel updates of the Hessenberg reduction (beside its chain)
+    hipStream_t stream4 = nullptr;  // every other chain launch of the Hessenberg reduction in pipe mode (hessenberg2_pipe)
+    int hess_pipe = 1;              // PSD_H2_PIPE=0: chain launches back to back on one stream
     hipEvent_t evE[2] = {nullptr, nullptr}, evF[2] = {nullptr, nullptr};
 #endif
     int apply_worklist = 1;   // PSD_APPLY_WL=0: the grid-per-cursor bulk-apply kernels
@@ -650,14 +652,72 @@ int hessenberg2_async(psd_ctx* c, int n, int p, const psd_hess2_args& ha, int K)
     PSD_CHECK(hipStreamWaitEvent(c->stream, evB[(nbatch - 1) & 7], 0));
     return 0;
 }
+// Pipe form of the two-stream reduction: the chain launches alternate between two streams, so that the launch of link
+// q + 1 is resident and has requested its strip of the next matrix while the launch of link q still runs; it then polls the
+// staged column, which travels as self-validating records (psd_h2_tag).  At most two chain launches are in flight (a
+// stream runs its own launches in order), a waiting launch holds one workgroup slot of four per CU, and every wait is
+// bounded.  A batch of panel updates waits for BOTH chain streams (a launch can end before its predecessor's block 0 has
+// stored v and tau), and what the chain needs of a batch is awaited on both streams.
+template <int NK, int CR>
+int hessenberg2_pipe(psd_ctx* c, int n, int p, const psd_hess2_args& ha, int K) {
+    const int nC = ((ha.xcd && CR < 16) ? (((n + CR - 1) / CR + 128 / CR - 1) / (128 / CR)) * (128 / CR) : (n + CR - 1) / CR) + 1, nT = (n + PSD_H2_ROWS - 1) / PSD_H2_ROWS, nB = (n + 3) / 4;
+    const size_t lds = ((size_t)n + 8 + 2 * PSD_H2_NT + 64) * sizeof(double);
+    const int Q = (n - 1) * p;
+    const int nbatch = Q / K + 1;
+    if ((int)c->h2ev.size() < 26) {
+        const size_t old = c->h2ev.size();
+        c->h2ev.resize(26, nullptr);
+        for (size_t q = old; q < c->h2ev.size(); ++q) PSD_CHECK(hipEventCreateWithFlags(&c->h2ev[q], hipEventDisableTiming));
+    }
+    hipEvent_t* evA = c->h2ev.data();       // [8]: chain stream 0 reached the end of a batch
+    hipEvent_t* evB = c->h2ev.data() + 8;   // [8]: a batch of panel updates is done
+    hipEvent_t* evC = c->h2ev.data() + 16;  // [8]: chain stream 1 reached the end of a batch
+    hipEvent_t evJ = c->h2ev[24], evK = c->h2ev[25];
+    hipStream_t S[2] = {c->stream, c->stream4};
+    PSD_CHECK(hipEventRecord(evJ, c->stream));  // (whatever ran on the main stream before: the memsets, the caller's work)
+    PSD_CHECK(hipStreamWaitEvent(c->stream3, evJ, 0));
+    PSD_CHECK(hipStreamWaitEvent(c->stream4, evJ, 0));
+    hipLaunchKernelGGL((psd_hess2_link<NK, CR>), dim3(nC), dim3(PSD_H2_NT), lds, S[0], ha, n, 0, 1, nC, 0);  // staging
+    int nextb = 0;
+    const bool nobulk = getenv("PSD_H2_NOBULK") != nullptr;  // (timing experiment: the chain alone; results are wrong)
+    auto batch = [&](int b) -> int {
+        PSD_CHECK(hipEventRecord(evA[b & 7], S[0]));
+        PSD_CHECK(hipEventRecord(evC[b & 7], S[1]));
+        PSD_CHECK(hipStreamWaitEvent(c->stream3, evA[b & 7], 0));
+        PSD_CHECK(hipStreamWaitEvent(c->stream3, evC[b & 7], 0));
+        if (!nobulk) hipLaunchKernelGGL((psd_hess2_bulk<NK>), dim3(nT + nB, K), dim3(PSD_H2_NT), lds, c->stream3, ha, n, b * K, nT);
+        PSD_CHECK(hipEventRecord(evB[b & 7], c->stream3));
+        return 0;
+    };
+    int idx = 0;
+    for (int i = 1; i <= n - 1; ++i)
+        for (int j = p; j >= 1; --j, ++idx) {
+            hipStream_t s = S[(idx + 1) & 1];
+            // chain#idx reads the matrix of link idx + 1, last updated by B(idx + 1 - p): batch (idx + 1 - p) / K; the launch
+            // behind it, on the other stream, reads a matrix of the same batch
+            const int need = idx + 1 - p;
+            if (need >= 0 && need % K == 0) PSD_CHECK(hipStreamWaitEvent(s, evB[(need / K) & 7], 0));
+            if (need >= 1 && (need - 1) % K == 0) PSD_CHECK(hipStreamWaitEvent(s, evB[((need - 1) / K) & 7], 0));
+            hipLaunchKernelGGL((psd_hess2_link<NK, CR>), dim3(nC), dim3(PSD_H2_NT), lds, s, ha, n, i, j, nC, 0);
+            if (idx >= nextb * K + K - 1) {
+                PSD_CHECK(batch(nextb));
+                ++nextb;
+            }
+        }
+    for (; nextb < nbatch; ++nextb) PSD_CHECK(batch(nextb));
+    PSD_CHECK(hipEventRecord(evK, S[1]));
+    PSD_CHECK(hipStreamWaitEvent(c->stream, evK, 0));
+    PSD_CHECK(hipStreamWaitEvent(c->stream, evB[(nbatch - 1) & 7], 0));
+    return 0;
+}
 int hessenberg2_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
     if (!c->h2ring || c->h2ring_n < n) {
         if (c->h2ring) psd_rt_free(c->h2ring);
         c->h2ring = nullptr;
-        PSD_CHECK(psd_rt_malloc((void**)&c->h2ring, PSD_H2_RING * psd_h2_slot_doubles(n) * sizeof(double)));
+        PSD_CHECK(psd_rt_malloc((void**)&c->h2ring, PSD_H2_RING * psd_h2_slot_doubles(n) * sizeof(double) + 64));
         c->h2ring_n = n;
     }
-    PSD_CHECK(psd_rt_memset(c->h2ring, 0, PSD_H2_RING * psd_h2_slot_doubles(c->h2ring_n) * sizeof(double), c->stream));
+    PSD_CHECK(psd_rt_memset(c->h2ring, 0, PSD_H2_RING * psd_h2_slot_doubles(c->h2ring_n) * sizeof(double) + 64, c->stream));
     psd_hess2_args ha;
     ha.H = dH;
     ha.tau = dtau;
@@ -667,6 +727,8 @@ int hessenberg2_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
     ha.xcd = c->hess_xcd;
     ha.trace = nullptr;
     ha.trace_hi = 0x7fffffff;
+    ha.pipe = 0;
+    ha.err = (int*)(c->h2ring + PSD_H2_RING * psd_h2_slot_doubles(c->h2ring_n));
     if (const char* e = getenv("PSD_H2_TRACE")) { if (atoi(e) > 1) ha.trace_hi = atoi(e); }
     long long* h2trace = nullptr;
     if (getenv("PSD_H2_TRACE") && psd_rt_malloc((void**)&h2trace, (1024 * 8 + 1024 * 4) * sizeof(long long)) == 0) {
@@ -717,10 +779,24 @@ int hessenberg2_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
     // two-stream form: K links per panel-update launch; the chain may run p - K links ahead of the updates and the ring
     // keeps every link the pending updates still read (p + K + 2 <= PSD_H2_RING)
     int K = c->hess_async;
-    if (K < 0) K = (p >= 32 && n >= 512) ? 16 : 0;
+    if (K < 0) K = (p >= 32 && n >= 512) ? ((p >= 48 && c->hess_pipe && c->stream4) ? 24 : 16) : 0;  // (measured at p = 64: 16 / 24 / 32 links per batch 548 / 529 / 540 ms)
     if (K > 0 && p >= 9 * K) K = (p + 7) / 8;
     if (K > 0 && p >= 2 * K && p + K + 2 <= PSD_H2_RING && c->stream3) {
         ha.ringmask = PSD_H2_RING - 1;
+        if (c->hess_pipe && c->stream4) {
+            ha.pipe = 1;
+            int rc;
+            if (n <= 256) rc = hessenberg2_pipe<4, 8>(c, n, p, ha, K);
+            else if (n <= 512) rc = hessenberg2_pipe<8, 8>(c, n, p, ha, K);
+            else if (n <= 1024) rc = hessenberg2_pipe<16, 4>(c, n, p, ha, K);
+            else rc = hessenberg2_pipe<32, 8>(c, n, p, ha, K);
+            if (rc != 0) return rc;
+            // (a launch that gave up waiting left void results: say so.  One word, read when the reduction is done)
+            int herr = 0;
+            PSD_CHECK(psd_rt_d2h(&herr, ha.err, sizeof(int), c->stream));
+            PSD_CHECK(psd_rt_sync(c->stream));
+            return herr ? PSD_INFO_RUNTIME + 0xfffb : 0;
+        }
         if (n <= 256) return hessenberg2_async<4, 8>(c, n, p, ha, K);
         if (n <= 512) return hessenberg2_async<8, 8>(c, n, p, ha, K);
         if (n <= 1024) return hessenberg2_async<16, 4>(c, n, p, ha, K);
@@ -1305,7 +1381,7 @@ int psd_create(psd_ctx** ctx, int device) {
         }
         // the same for the panel updates of the Hessenberg reduction: its chain launches are HBM-latency chains that
         // slow down under the panel traffic; half of the chip for the panels measured best (PSD_HESS_CUS)
-        int keeph = 128;
+        int keeph = 64;  // (128 until the chain launches overlapped: hessenberg2_pipe)
         if (const char* e = getenv("PSD_HESS_CUS")) keeph = atoi(e);
         rc = hipErrorInvalidValue;
         if (ncu > keeph + 32 && keeph > 0 && ncu <= 1024) {
@@ -1319,6 +1395,8 @@ int psd_create(psd_ctx** ctx, int device) {
             psd_destroy(c);
             return PSD_INFO_RUNTIME + 4;
         }
+        if (hipStreamCreate(&c->stream4) != hipSuccess) c->stream4 = nullptr;
+        if (const char* e = getenv("PSD_H2_PIPE")) c->hess_pipe = atoi(e);
     }
 #endif
 #ifndef PSD_HOSTSIM
@@ -1397,6 +1475,7 @@ int psd_destroy(psd_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
+    if (c->stream4) (void)hipStreamDestroy(c->stream4);
     if (c->stream) (void)hipStreamDestroy(c->stream);
 #endif
     delete c;

@@ -38,12 +38,22 @@ struct psd_hess2_args {
     int xcd;       // 1: chain blocks whose strips share a 128-byte line of the matrix run on the same XCD (see psd_hess2_link)
     long long* trace;  // diagnostics (PSD_H2_TRACE): [1024][8] 100 MHz stamps of one chain block per link, or nullptr
     int trace_hi;      // only links with ring position below this are recorded (PSD_H2_TRACE=<links>)
+    int pipe;          // 1: consecutive chain launches overlap (two streams); the staged column travels as self-validating records (see psd_h2_tag)
+    int* err;          // pipe: set when a launch gave up waiting for its predecessor's records (the host reports a runtime error)
 };
-// slot layout: v[n+8] | w[n+8] | col[n+8] | hdr[8] (tau, beta) | part[2 * (n/4 + 2)]
-PSD_HD size_t psd_h2_slot_doubles(int n) { return 3 * (size_t)(n + 8) + 8 + 2 * (size_t)(n / 4 + 2); }
+// slot layout: v[n+8] | w[n+8] | col[n+8] | hdr[8] (tau, beta) | part[2 * (n/4 + 2)] | rec[2 (n+8)]
+PSD_HD size_t psd_h2_slot_doubles(int n) { return 5 * (size_t)(n + 8) + 8 + 2 * (size_t)(n / 4 + 2); }
 struct psd_h2_slot {
     double *v, *w, *col, *hdr, *part;
+    unsigned long long* rec;  // pipe mode: the staged column as (bits(x), bits(x) ^ tag) pairs
 };
+// Pipe mode.  A chain launch needs of its predecessor only the staged column.  With the launches of consecutive links on two
+// streams the next launch is resident and has its strip of the matrix in registers while the previous one still runs; it
+// then polls the column.  Every entry is a record (bits(x), bits(x) ^ tag(link)) written and read with 8-byte agent-scope
+// accesses (no fences, no read-modify-write; measured 3.7 us per hand-over against 10 us for a counter barrier,
+// tools/micro/grid_barrier.cpp): whatever mixture of old and new halves a reader sees fails the check unless the value
+// is the one the producer wrote (a slot is reused 256 links later, its old records carry another tag).
+PSD_HD unsigned long long psd_h2_tag(int slot) { return ((unsigned long long)(unsigned)(slot + 3)) * 0x9E3779B97F4A7C15ull | 1ull; }
 PSD_D psd_h2_slot psd_h2_get(const psd_hess2_args* G, int n, int q) {
     double* b = G->ring + (size_t)(q & G->ringmask) * psd_h2_slot_doubles(n);
     psd_h2_slot s;
@@ -52,6 +62,7 @@ PSD_D psd_h2_slot psd_h2_get(const psd_hess2_args* G, int n, int q) {
     s.col = b + 2 * (size_t)(n + 8);
     s.hdr = b + 3 * (size_t)(n + 8);
     s.part = s.hdr + 8;
+    s.rec = (unsigned long long*)(s.part + 2 * (size_t)(n / 4 + 2));
     return s;
 }
 struct psd_h2_link {
@@ -347,7 +358,8 @@ __global__ void __launch_bounds__(PSD_H2_NT, ((NK > 16 || NK * CR > 128) ? ((NK 
         double am = 0.0, sq = 0.0, alpha = 0.0;
         // (vector memory operations return in issue order: the small ring reads go first, so that forming the reflector
         //  does not wait for the strip)
-        if (q >= 0) {
+        const bool pipe = G->pipe != 0;
+        if (q >= 0 && !pipe) {
             const int np_ = ntileC - r0 / CR;
             if (tid < np_) {
                 am = S.part[2 * tid];
@@ -367,6 +379,81 @@ __global__ void __launch_bounds__(PSD_H2_NT, ((NK > 16 || NK * CR > 128) ? ((NK 
                 const int cc = cl + CL * k;
                 a0[k] = a1[k] = 0.0;
                 if (cc < m) psd_h2_ld2(M, n, r, r0 + cc, ok0, ok1, a0[k], a1[k]);
+            }
+        }
+        if (q >= 0 && pipe) {
+            // the strip is on its way; now the column of the previous launch (which may still be running)
+            const unsigned long long tag = psd_h2_tag(slot);
+            const unsigned long long* rec = S.rec + 2 * (size_t)r0;
+            unsigned long long xb[NV], ab = 0;
+            int spins = 0;
+            // first the cheap watch: one record per strip of the previous launch (thread t: the first row of strip t at or
+            // below r0) — 257 workgroups that each poll the whole column would take several TB/s from the panel updates
+            {
+                const int rw = CR * (r0 / CR + tid);
+                const int kw = (rw > r0) ? (rw - r0) : 0;
+                const bool watch = kw < m && (tid == 0 || rw > r0);
+                for (;;) {
+                    bool okr = true;
+                    if (watch) {
+                        const unsigned long long x = __hip_atomic_load(rec + 2 * kw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long cx = __hip_atomic_load(rec + 2 * kw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        okr = (x ^ cx) == tag;
+                    }
+                    const bool giveup = __hip_atomic_load(G->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                    if (__syncthreads_and((okr || giveup) ? 1 : 0)) break;
+                    if (++spins > (1 << 17)) {
+                        if (tid == 0) __hip_atomic_store(G->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            for (;;) {
+                bool okr = true;
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int k = tid + PSD_H2_NT * u;
+                    xb[u] = 0;
+                    if (k < m) {
+                        const unsigned long long x = __hip_atomic_load(rec + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long cx = __hip_atomic_load(rec + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        okr = okr && ((x ^ cx) == tag);
+                        xb[u] = x;
+                    }
+                }
+                {
+                    const unsigned long long x = __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long cx = __hip_atomic_load(rec + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    okr = okr && ((x ^ cx) == tag);
+                    ab = x;
+                }
+                const bool giveup = __hip_atomic_load(G->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                if (__syncthreads_and((okr || giveup) ? 1 : 0)) break;
+                if (++spins > (1 << 17)) {  // (every wave reaches an exit: about a second; the results are then void and the host says so)
+                    if (tid == 0) __hip_atomic_store(G->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            alpha = __longlong_as_double((long long)ab);
+            // this thread's share of the tail's scaled sum of squares (dlassq pair), entries k >= 1
+            am = 0.0;
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int k = tid + PSD_H2_NT * u;
+                xcol[u] = (k < m) ? __longlong_as_double((long long)xb[u]) : 0.0;
+                if (k >= 1 && k < m) am = fmax(am, fabs(xcol[u]));
+            }
+            sq = 0.0;
+            if (am > 0.0) {
+                const double ra = 1.0 / am;
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int k = tid + PSD_H2_NT * u;
+                    if (k >= 1 && k < m) {
+                        const double z = xcol[u] * ra;
+                        sq += z * z;
+                    }
+                }
             }
         }
         if (q >= 0) {
@@ -453,12 +540,18 @@ __global__ void __launch_bounds__(PSD_H2_NT, ((NK > 16 || NK * CR > 128) ? ((NK 
         if (fin) {
             const double w = red[tid] + red[CR + tid] + red[2 * CR + tid] + red[3 * CR + tid];
             y = mfirst - tau * w;
-            Sn.col[rfin] = y;
+            if (pipe) {
+                const unsigned long long yb = (unsigned long long)__double_as_longlong(y);
+                __hip_atomic_store(Sn.rec + 2 * (size_t)rfin, yb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(Sn.rec + 2 * (size_t)rfin + 1, yb ^ psd_h2_tag(slot + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                Sn.col[rfin] = y;
+            }
             S.w[rfin] = w;
             if (rfin > r0n) amt = fabs(y);
             else y = 0.0;  // the reflector's first entry is not part of the tail
         }
-        if (wave == 0) {
+        if (wave == 0 && !pipe) {
             // partial scaled sum of squares of this strip's tail entries (lanes 0..CR-1 carry them)
             const double amax = psd_h2_wave_max(amt);
             double sq = 0.0;

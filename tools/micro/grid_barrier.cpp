@@ -35,6 +35,37 @@ __global__ void __launch_bounds__(256) k_barrier(int* counter, int* abortf, doub
     if (tid == 0) data[2 * nblocks + b] = acc;
 }
 
+// Dataflow variant (no fences, no read-modify-write atomics): block b writes its value and then a tag (= iteration) with
+// agent-scope stores; thread t of every block polls tag[t] with agent-scope loads until all nblocks tags carry the
+// iteration, then reads a neighbour's value (agent-scope load).  This is what a chain launch that waits for its
+// predecessor's partial norms would do.  tags: [2][nblocks] by iteration parity, vals likewise.
+__global__ void __launch_bounds__(256) k_flow(unsigned long long* tags, double* vals, int* abortf, double* out, int iters, int nblocks) {
+    const int tid = threadIdx.x, b = blockIdx.x;
+    double acc = 0.0;
+    for (int it = 1; it <= iters; ++it) {
+        unsigned long long* tg = tags + (size_t)(it & 1) * 512;
+        double* vl = vals + (size_t)(it & 1) * 512;
+        if (tid == 0) {
+            __hip_atomic_store(vl + b, acc + 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(tg + b, (unsigned long long)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        int spins = 0;
+        for (;;) {
+            bool ok = true;
+            for (int q = tid; q < nblocks; q += 256)
+                ok = ok && (__hip_atomic_load(tg + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)it);
+            if (__syncthreads_and(ok ? 1 : 0)) break;
+            if (++spins > (1 << 20)) {
+                if (tid == 0) __hip_atomic_store(abortf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+        if (tid == 0) acc = __hip_atomic_load(vl + (b + 1) % nblocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) out[b] = acc;
+}
+
 __global__ void __launch_bounds__(256) k_step(double* data, int it, int nblocks) {
     const int tid = threadIdx.x, b = blockIdx.x;
     if (tid == 0) {
@@ -71,6 +102,30 @@ int main(int argc, char** argv) {
         hipMemcpy(&last, data + 2 * nblocks, 8, hipMemcpyDeviceToHost);
         printf("grid barrier: %d blocks, %d iterations: %.3f ms = %.3f us per barrier (abort %d, chain value %.0f of %d)\n", nblocks, iters,
                ms, 1e3 * ms / iters, ab, last, iters);
+    }
+    if (nblocks <= 512) {
+        unsigned long long* tags;
+        double *vals, *out;
+        hipMalloc(&tags, 8 * 1024);
+        hipMalloc(&vals, 8 * 1024);
+        hipMalloc(&out, 8 * 512);
+        for (int rep = 0; rep < 3; ++rep) {
+            hipMemsetAsync(tags, 0, 8 * 1024, s);
+            hipMemsetAsync(vals, 0, 8 * 1024, s);
+            hipMemsetAsync(abortf, 0, 4, s);
+            hipEventRecord(e0, s);
+            hipLaunchKernelGGL(k_flow, dim3(nblocks), dim3(256), 0, s, tags, vals, abortf, out, iters, nblocks);
+            hipEventRecord(e1, s);
+            hipStreamSynchronize(s);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            int ab = 0;
+            double last = 0;
+            hipMemcpy(&ab, abortf, 4, hipMemcpyDeviceToHost);
+            hipMemcpy(&last, out, 8, hipMemcpyDeviceToHost);
+            printf("dataflow tags: %d blocks, %d iterations: %.3f ms = %.3f us per step (abort %d, chain value %.0f of %d)\n", nblocks, iters, ms,
+                   1e3 * ms / iters, ab, last, iters);
+        }
     }
     for (int rep = 0; rep < 3; ++rep) {
         hipMemsetAsync(data, 0, sizeof(double) * 3 * nblocks, s);
