@@ -784,11 +784,15 @@ int hessenberg2_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
     if (K > 0 && p >= 2 * K && p + K + 2 <= PSD_H2_RING && c->stream3) {
         ha.ringmask = PSD_H2_RING - 1;
         if (c->hess_pipe && c->stream4) {
-            ha.pipe = 1;
+            ha.pipe = 2;  // (every poll round reads the whole column; 1: a watch round on one record per strip first — one more round trip per link, 477 against 442 ms)
+            if (const char* e = getenv("PSD_H2_POLL")) ha.pipe = (atoi(e) == 1) ? 1 : 2;
+            if (const char* e = getenv("PSD_H2_XCD")) ha.xcd = atoi(e); else if (n > 512 && n <= 1024) ha.xcd = 0;  // (8-row strips: two per line, the mapping no longer pays: 482 -> 474 ms)
             int rc;
             if (n <= 256) rc = hessenberg2_pipe<4, 8>(c, n, p, ha, K);
             else if (n <= 512) rc = hessenberg2_pipe<8, 8>(c, n, p, ha, K);
-            else if (n <= 1024) rc = hessenberg2_pipe<16, 4>(c, n, p, ha, K);
+            // (strips of 8 rows here, 4 in the one-stream forms: with the strip requested before the wait the GEMV no longer
+            //  needs every CU's memory pipeline, and half as many workgroups poll; measured 4 / 8 / 16 / 32 rows: 519 / 483 / 542 / 570 ms)
+            else if (n <= 1024) rc = hessenberg2_pipe<16, 8>(c, n, p, ha, K);
             else rc = hessenberg2_pipe<32, 8>(c, n, p, ha, K);
             if (rc != 0) return rc;
             // (a launch that gave up waiting left void results: say so.  One word, read when the reduction is done)

@@ -387,9 +387,10 @@ __global__ void __launch_bounds__(PSD_H2_NT, ((NK > 16 || NK * CR > 128) ? ((NK 
             const unsigned long long* rec = S.rec + 2 * (size_t)r0;
             unsigned long long xb[NV], ab = 0;
             int spins = 0;
-            // first the cheap watch: one record per strip of the previous launch (thread t: the first row of strip t at or
-            // below r0) — 257 workgroups that each poll the whole column would take several TB/s from the panel updates
-            {
+            // pipe == 1: first a cheap watch on one record per strip of the previous launch (thread t: the first row of
+            // strip t at or below r0), then the column.  With 129 workgroups of 8-row strips polling the whole column costs
+            // less than the extra round trip, so this is off by default (PSD_H2_POLL=1 turns it on)
+            if (G->pipe == 1) {
                 const int rw = CR * (r0 / CR + tid);
                 const int kw = (rw > r0) ? (rw - r0) : 0;
                 const bool watch = kw < m && (tid == 0 || rw > r0);
