@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(PSD_H2_NT, ((NK > 16 || NK * CR > 128) ? ((NK 
         const bool fin = strip && tid < CR && rfin < n && rfin >= r0n;
         constexpr int NV = (64 * NK + PSD_H2_NT - 1) / PSD_H2_NT;  // entries of v per thread
         double xcol[NV];
-        double tau = 0.0, beta = 0.0, mult = 0.0;
+        double tau = 0.0, beta = 0.0, mult = 0.0, xnorm = 0.0;
         double am = 0.0, sq = 0.0, alpha = 0.0;
         // (vector memory operations return in issue order: the small ring reads go first, so that forming the reflector
         //  does not wait for the strip)
@@ -422,12 +422,6 @@ __global__ void __launch_bounds__(PSD_H2_NT, ((NK > 16 || NK * CR > 128) ? ((NK 
                         xb[u] = x;
                     }
                 }
-                {
-                    const unsigned long long x = __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long cx = __hip_atomic_load(rec + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    okr = okr && ((x ^ cx) == tag);
-                    ab = x;
-                }
                 const bool giveup = __hip_atomic_load(G->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
                 if (__syncthreads_and((okr || giveup) ? 1 : 0)) break;
                 if (++spins > (1 << 17)) {  // (every wave reaches an exit: about a second; the results are then void and the host says so)
@@ -435,63 +429,99 @@ __global__ void __launch_bounds__(PSD_H2_NT, ((NK > 16 || NK * CR > 128) ? ((NK 
                 }
                 __builtin_amdgcn_s_sleep(2);
             }
-            alpha = __longlong_as_double((long long)ab);
-            // this thread's share of the tail's scaled sum of squares (dlassq pair), entries k >= 1
+            // this thread's share of the tail (entries k >= 1): largest magnitude and PLAIN sum of squares — the scaled form
+            // (dlassq) is only run when the magnitudes call for it, see below; alpha is thread 0's first entry
             am = 0.0;
+            sq = 0.0;
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const int k = tid + PSD_H2_NT * u;
                 xcol[u] = (k < m) ? __longlong_as_double((long long)xb[u]) : 0.0;
-                if (k >= 1 && k < m) am = fmax(am, fabs(xcol[u]));
-            }
-            sq = 0.0;
-            if (am > 0.0) {
-                const double ra = 1.0 / am;
-#pragma unroll
-                for (int u = 0; u < NV; ++u) {
-                    const int k = tid + PSD_H2_NT * u;
-                    if (k >= 1 && k < m) {
-                        const double z = xcol[u] * ra;
-                        sq += z * z;
-                    }
+                if (k >= 1 && k < m) {
+                    am = fmax(am, fabs(xcol[u]));
+                    sq = __builtin_fma(xcol[u], xcol[u], sq);
                 }
+                // the RAW column goes to LDS (its first entry as zero): w = M v = M[:, 0] + mult (M[:, 1:] x[1:]), so the
+                // strip can be multiplied while the norm is reduced and the reflector's scalars are formed
+                if (k < m) vs[k] = (k == 0) ? 0.0 : xcol[u];
             }
+            (void)ab;
         }
         if (q >= 0) {
             // norm of the tail from the partials of the launch that staged the column: (amax, ssq) pairs combine as
             // amax = max, ssq = sum ssq_k (amax_k / amax)^2 (dlassq); one pair per thread, one LDS exchange
             PSD_H2_STAMP(1);
-            const double amw = psd_h2_wave_max(am);
-            double ssw = 0.0;
-            if (amw > 0.0) {
-                const double f = am / amw;
-                ssw = sq * (f * f);
-            }
-            ssw = psd_h2_wave_sum(ssw);
-            if (lane == 0) {
-                red[2 * wave] = amw;
-                red[2 * wave + 1] = ssw;
-            }
-            __syncthreads();
-            const double amax = fmax(fmax(red[0], red[2]), fmax(red[4], red[6]));
-            double tot = 0.0;
-            if (amax > 0.0) {
-#pragma unroll
-                for (int wv = 0; wv < 4; ++wv) {
-                    const double f = red[2 * wv] / amax;
-                    tot += red[2 * wv + 1] * (f * f);
+            if (pipe) {
+                // two independent wave reductions (largest magnitude, plain sum of squares), one LDS exchange; the root
+                // without the IEEE wrapper when every square is far from the range limits, the scaled sum otherwise
+                const double amw = psd_h2_wave_max(am);
+                const double s2w = psd_h2_wave_sum(sq);
+                if (lane == 0) {
+                    red[2 * wave] = amw;
+                    red[2 * wave + 1] = s2w;
                 }
-            }
-            const double xnorm = (m > 1) ? amax * sqrt(tot) : 0.0;
-            PSD_H2_STAMP(2);
-            psd_h2_larfg(alpha, xnorm, tau, beta, mult);
-            PSD_H2_STAMP(3);
+                if (tid == 0) red[8] = xcol[0];
+                __syncthreads();
+                alpha = red[8];
+                const double amax = fmax(fmax(red[0], red[2]), fmax(red[4], red[6]));
+                const double s2 = (red[1] + red[3]) + (red[5] + red[7]);
+                if (m > 1 && amax > 0.0) {
+                    if (amax < 1e140 && amax > 1e-140) {
+                        double g, rg;
+                        psd_sqrt_pair_fast(s2, g, rg);
+                        xnorm = g;
+                    } else {
+                        __syncthreads();
+                        double ss = 0.0;
 #pragma unroll
-            for (int u = 0; u < NV; ++u) {
-                const int k = tid + PSD_H2_NT * u;
-                if (k < m) vs[k] = (k == 0) ? 1.0 : xcol[u] * mult;
+                        for (int u = 0; u < NV; ++u) {
+                            const int k = tid + PSD_H2_NT * u;
+                            if (k >= 1 && k < m) {
+                                const double z = xcol[u] / amax;
+                                ss += z * z;
+                            }
+                        }
+                        ss = psd_h2_wave_sum(ss);
+                        if (lane == 0) red[16 + wave] = ss;
+                        __syncthreads();
+                        xnorm = amax * sqrt((red[16] + red[17]) + (red[18] + red[19]));
+                    }
+                }
+            } else {
+                const double amw = psd_h2_wave_max(am);
+                double ssw = 0.0;
+                if (amw > 0.0) {
+                    const double f = am / amw;
+                    ssw = sq * (f * f);
+                }
+                ssw = psd_h2_wave_sum(ssw);
+                if (lane == 0) {
+                    red[2 * wave] = amw;
+                    red[2 * wave + 1] = ssw;
+                }
+                __syncthreads();
+                const double amax = fmax(fmax(red[0], red[2]), fmax(red[4], red[6]));
+                double tot = 0.0;
+                if (amax > 0.0) {
+#pragma unroll
+                    for (int wv = 0; wv < 4; ++wv) {
+                        const double f = red[2 * wv] / amax;
+                        tot += red[2 * wv + 1] * (f * f);
+                    }
+                }
+                xnorm = (m > 1) ? amax * sqrt(tot) : 0.0;
             }
-            __syncthreads();
+            PSD_H2_STAMP(2);
+            if (!pipe || b == 0) psd_h2_larfg(alpha, xnorm, tau, beta, mult);  // (pipe: the strip workgroups form the scalars behind their GEMV, below)
+            PSD_H2_STAMP(3);
+            if (!pipe) {
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int k = tid + PSD_H2_NT * u;
+                    if (k < m) vs[k] = (k == 0) ? 1.0 : xcol[u] * mult;
+                }
+                __syncthreads();
+            }
             if (b == 0) {  // publish v_q, store it LAPACK-style (PSD.jl:232-236,241-244)
                 double* Mq = G->H + (size_t)(L.j - 1) * n * n;
                 const int c = L.i - 1;
@@ -499,8 +529,9 @@ __global__ void __launch_bounds__(PSD_H2_NT, ((NK > 16 || NK * CR > 128) ? ((NK 
                 for (int u = 0; u < NV; ++u) {
                     const int k = tid + PSD_H2_NT * u;
                     if (k < m) {
-                        S.v[k] = vs[k];
-                        Mq[(size_t)c * n + r0 + k] = (tau != 0.0) ? ((k == 0) ? beta : vs[k]) : xcol[u];
+                        const double vk = (k == 0) ? 1.0 : xcol[u] * mult;
+                        S.v[k] = vk;
+                        Mq[(size_t)c * n + r0 + k] = (tau != 0.0) ? ((k == 0) ? beta : vk) : xcol[u];
                     }
                 }
                 if (tid == 0) {
@@ -514,7 +545,7 @@ __global__ void __launch_bounds__(PSD_H2_NT, ((NK > 16 || NK * CR > 128) ? ((NK 
         // GEMV on the next link's matrix: rows >= r0n, columns r0.. (q = -1: plain staging of column 1 of A_p)
         PSD_H2_STAMP(4);
         double acc0 = 0.0, acc1 = 0.0;
-        if (q >= 0 && tau != 0.0) {
+        if (q >= 0 && (pipe || tau != 0.0)) {
 #pragma unroll
             for (int k = 0; k < NKS; ++k) {
                 const int cc = cl + CL * k;
@@ -526,20 +557,24 @@ __global__ void __launch_bounds__(PSD_H2_NT, ((NK > 16 || NK * CR > 128) ? ((NK 
             }
         }
         // reduce over the column lanes of a row pair: inside a wave (lanes with equal lane % RP), then the 4 waves
+        // (pipe: its own part of the exchange area — workgroup mates may still be reading the norm's)
+        double* const redg = pipe ? (red + 64) : red;
 #pragma unroll
         for (int sft = RP; sft < 64; sft <<= 1) {
             acc0 += __shfl_xor(acc0, sft, 64);
             acc1 += __shfl_xor(acc1, sft, 64);
         }
         if (lane < RP) {
-            red[(wave * RP + lane) * 2] = acc0;
-            red[(wave * RP + lane) * 2 + 1] = acc1;
+            redg[(wave * RP + lane) * 2] = acc0;
+            redg[(wave * RP + lane) * 2 + 1] = acc1;
         }
+        if (pipe && q >= 0) psd_h2_larfg(alpha, xnorm, tau, beta, mult);
         __syncthreads();
         PSD_H2_STAMP(5);
         double amt = 0.0, y = 0.0;
         if (fin) {
-            const double w = red[tid] + red[CR + tid] + red[2 * CR + tid] + red[3 * CR + tid];
+            double w = redg[tid] + redg[CR + tid] + redg[2 * CR + tid] + redg[3 * CR + tid];
+            if (pipe && q >= 0) w = (tau != 0.0) ? __builtin_fma(mult, w, mfirst) : 0.0;  // (the unit entry of v times column r0)
             y = mfirst - tau * w;
             if (pipe) {
                 const unsigned long long yb = (unsigned long long)__double_as_longlong(y);
