@@ -88,6 +88,7 @@ PSD_D psd_h2_link psd_h2_linkat(int i, int j, int d, int n, int p) {
 }
 
 typedef double psd_h2_v2 __attribute__((ext_vector_type(2), aligned(8)));
+typedef unsigned psd_h2_u4 __attribute__((ext_vector_type(4)));
 
 // two consecutive rows (r, r+1) of column c (0-based); the second is masked at the bottom edge
 PSD_D void psd_h2_ld2(const double* M, int n, int r, int c, bool ok0, bool ok1, double& x0, double& x1) {
@@ -409,19 +410,24 @@ __global__ void __launch_bounds__(PSD_H2_NT, ((NK > 16 || NK * CR > 128) ? ((NK 
                     __builtin_amdgcn_s_sleep(2);
                 }
             }
+            // (a record per 16-byte load, sc1 = coherent at agent scope like the atomic loads: a wavefront's 64 records are
+            //  one contiguous KiB instead of 128 separate 8-byte requests; a torn 16-byte read fails the check like any other
+            //  mixture of old and new halves)
+            const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, m * 16, 0x00020000);
             for (;;) {
                 bool okr = true;
 #pragma unroll
                 for (int u = 0; u < NV; ++u) {
                     const int k = tid + PSD_H2_NT * u;
                     xb[u] = 0;
-                    if (k < m) {
-                        const unsigned long long x = __hip_atomic_load(rec + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned long long cx = __hip_atomic_load(rec + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        okr = okr && ((x ^ cx) == tag);
+                    if (PSD_H2_NT * u < m) {
+                        const psd_h2_u4 t4 = __builtin_amdgcn_raw_buffer_load_b128(rsr, (k < m) ? (unsigned)k * 16u : 0xfffffff0u, 0, 16);
+                        const unsigned long long x = ((unsigned long long)t4.y << 32) | t4.x, cx = ((unsigned long long)t4.w << 32) | t4.z;
+                        okr = okr && (k >= m || (x ^ cx) == tag);
                         xb[u] = x;
                     }
                 }
+                asm volatile("" ::: "memory");
                 const bool giveup = __hip_atomic_load(G->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
                 if (__syncthreads_and((okr || giveup) ? 1 : 0)) break;
                 if (++spins > (1 << 17)) {  // (every wave reaches an exit: about a second; the results are then void and the host says so)
