@@ -465,9 +465,9 @@ def main():
                                         "frac": hess_gbs / HBM_PEAK_GBS if hess_gbs else None,
                                         "alg_bytes_per_launch": st.bytes_hess / links if links else None,
                                         "avg_launch_ms": st.ms_hess / links if links else None,
-                                        "note": "one chain launch per link on the main stream (the panel updates of 16 links per launch run on a "
-                                                "second, CU-masked stream beside it); algorithmic bytes 16*(m*(m+1) + n*m) per link / "
-                                                "HIP-event duration of the reduction per link"},
+                                        "note": "one chain launch per link, consecutive launches overlapping on two streams (DESIGN section 0e; the panel "
+                                                "updates of 24 links per launch run on a third, CU-masked stream beside them); algorithmic bytes "
+                                                "16*(m*(m+1) + n*m) per link / HIP-event duration of the whole reduction per link"},
                     "reference_equivalent": None if refeq is None else {
                         "sweeps": refeq["sweeps"], "bytes": refeq["bytes_sweeps"], "sweeps_per_eigenvalue": refeq["sweeps"] / n,
                         "achieved": refeq["bytes_sweeps"] / (ms_iter / args.steps * 1e-3) / 1e9,
