@@ -708,6 +708,31 @@ int hessenberg2_pipe(psd_ctx* c, int n, int p, const psd_hess2_args& ha, int K) 
     PSD_CHECK(hipEventRecord(evK, S[1]));
     PSD_CHECK(hipStreamWaitEvent(c->stream, evK, 0));
     PSD_CHECK(hipStreamWaitEvent(c->stream, evB[(nbatch - 1) & 7], 0));
+    if (getenv("PSD_H2_BULKBENCH")) {
+        // diagnostics: the panel kernel ALONE on the finished matrices (the transformations it applies are the ring's
+        // leftovers: results void), the first 100 batches back to back on the panel stream
+        PSD_CHECK(hipDeviceSynchronize());
+        hipEvent_t e0, e1;
+        PSD_CHECK(hipEventCreate(&e0));
+        PSD_CHECK(hipEventCreate(&e1));
+        const int nb = nbatch < 100 ? nbatch : 100;
+        for (int which = 0; which < 2; ++which) {
+            hipStream_t st = which ? c->stream : c->stream3;
+            PSD_CHECK(hipEventRecord(e0, st));
+            for (int b = 0; b < nb; ++b)
+                hipLaunchKernelGGL((psd_hess2_bulk<NK>), dim3(nT + nB, K), dim3(PSD_H2_NT), lds, st, ha, n, b * K, nT);
+            PSD_CHECK(hipEventRecord(e1, st));
+            PSD_CHECK(hipStreamSynchronize(st));
+            float ms = 0;
+            PSD_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            double by = 0;
+            for (int idx2 = 0; idx2 < nb * K; ++idx2) by += 16.0 * n * (n - (idx2 / p + 1));
+            fprintf(stderr, "psd hess2 bulk alone (%s stream): %d batches of %d links in %.3f ms = %.1f us per batch, %.0f GB/s algorithmic (read + write)\n",
+                    which ? "unmasked" : "panel", nb, K, ms, 1e3 * ms / nb, by / ms / 1e6);
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
     return 0;
 }
 int hessenberg2_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {

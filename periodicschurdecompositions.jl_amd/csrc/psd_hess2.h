@@ -179,10 +179,80 @@ PSD_D void psd_h2_larfg(double alpha, double xnorm, double& tau, double& beta, d
     for (int q = 0; q < kount; ++q) beta *= sfmin;
 }
 
+// Bottom part of a panel update with CPW columns per wavefront (two-stream forms, NK <= 16): the two vectors of the link
+// (w of the right reflector, v of the left one: 16 + 16 doubles per lane) stay in registers for all of the wave's columns,
+// and the next column is requested before the current one is reduced.  One column per wave read both vectors again for
+// every column (two thirds of its load instructions, all L2 traffic) and had one column's loads in flight per wave:
+// the panel kernel alone ran at 2.3 TB/s on its 192 CUs (PSD_H2_BULKBENCH).
+template <int NKC>
+PSD_D void psd_h2_col_load(const double* M, int n, int R0, int mL, int c, int lane, double (&a0)[NKC], double (&a1)[NKC]) {
+#pragma unroll
+    for (int k = 0; k < NKC; ++k) {
+        const int rr = 2 * lane + 128 * k;
+        a0[k] = a1[k] = 0.0;
+        if (rr < mL) psd_h2_ld2(M, n, R0 + rr, c, true, rr + 1 < mL, a0[k], a1[k]);
+    }
+}
+template <int NKC>
+PSD_D void psd_h2_col_update(double* M, int n, int R0, int mL, int c, int lane, double vc, double tauL, const double (&w0)[NKC],
+                             const double (&w1)[NKC], const double (&v0)[NKC], const double (&v1)[NKC], double (&a0)[NKC], double (&a1)[NKC]) {
+    double z = 0.0;
+#pragma unroll
+    for (int k = 0; k < NKC; ++k) {  // (entries outside the reflector are zero in a, w and v alike)
+        a0[k] = __builtin_fma(-vc, w0[k], a0[k]);
+        a1[k] = __builtin_fma(-vc, w1[k], a1[k]);
+        z = __builtin_fma(a0[k], v0[k], z);
+        z = __builtin_fma(a1[k], v1[k], z);
+    }
+    z = tauL * psd_h2_wave_sum(z);
+#pragma unroll
+    for (int k = 0; k < NKC; ++k) {
+        const int rr = 2 * lane + 128 * k;
+        if (rr < mL) psd_h2_st2(M, n, R0 + rr, c, true, rr + 1 < mL, __builtin_fma(-z, v0[k], a0[k]), __builtin_fma(-z, v1[k], a1[k]));
+    }
+}
+template <int NK, int CPW>
+PSD_D void psd_h2_bulk_bottom_multi(double* M, int n, const psd_h2_slot& SR, const psd_h2_slot& SL, double tauR, double tauL, int rR, int R0,
+                                    int ci, int B, int lane, int wave) {
+    constexpr int NKC = (NK + 1) / 2;
+    const int mL = n - R0;
+    const int c0 = ci + (B * 4 + wave) * CPW;
+    if (c0 >= n) return;
+    double a0[NKC], a1[NKC], b0[NKC], b1[NKC];
+    psd_h2_col_load<NKC>(M, n, R0, mL, c0, lane, a0, a1);
+    double w0[NKC], w1[NKC], v0[NKC], v1[NKC], vcs[CPW];
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) {
+        const int c = c0 + j;
+        vcs[j] = (tauR != 0.0 && c < n && c >= rR) ? tauR * SR.v[c - rR] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < NKC; ++k) {
+        const int rr = 2 * lane + 128 * k;
+        w0[k] = (tauR != 0.0 && rr < mL) ? SR.w[R0 + rr] : 0.0;
+        w1[k] = (tauR != 0.0 && rr + 1 < mL) ? SR.w[R0 + rr + 1] : 0.0;
+        v0[k] = (tauL != 0.0 && rr < mL) ? SL.v[rr] : 0.0;
+        v1[k] = (tauL != 0.0 && rr + 1 < mL) ? SL.v[rr + 1] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < CPW; j += 2) {  // (column c0 + j is in a0/a1 here; no early exit, so that the loop unrolls)
+        const int c = c0 + j;
+        if (c < n) {
+            const bool more1 = j + 1 < CPW && c + 1 < n;
+            if (more1) psd_h2_col_load<NKC>(M, n, R0, mL, c + 1, lane, b0, b1);
+            psd_h2_col_update<NKC>(M, n, R0, mL, c, lane, vcs[j], tauL, w0, w1, v0, v1, a0, a1);
+            if (more1) {
+                if (j + 2 < CPW && c + 2 < n) psd_h2_col_load<NKC>(M, n, R0, mL, c + 2, lane, a0, a1);
+                psd_h2_col_update<NKC>(M, n, R0, mL, c + 1, lane, vcs[(j + 1 < CPW) ? j + 1 : j], tauL, w0, w1, v0, v1, b0, b1);
+            }
+        }
+    }
+}
+
 // The deferred update of the matrix of link Lb: M <- H(v_Lb)' (M H(v_La)), La the link before Lb (either may lie outside
 // the chain: first link / drain).  bb: block index inside the update (nT row strips above the reflector, then the
 // 4-column groups of the bottom part); slotb: ring position of Lb.
-template <int NK>
+template <int NK, int CPW = 1>
 PSD_D void psd_h2_bulk_body(const psd_hess2_args* G, int n, const psd_h2_link Lb, const psd_h2_link La, int slotb, int bb, int nT,
                             double* vs, double* red) {
     const int p = G->p;
@@ -250,6 +320,10 @@ PSD_D void psd_h2_bulk_body(const psd_hess2_args* G, int n, const psd_h2_link Lb
     // rows R0..n-1: one wavefront per column, the column in registers: a <- a - tauR w v_c, then the left reflector
     if (!Lb.valid) return;
     if (tauR == 0.0 && tauL == 0.0) return;
+    if constexpr (CPW > 1) {
+        psd_h2_bulk_bottom_multi<NK, CPW>(M, n, SR, SL, tauR, tauL, rR, R0, Lb.i, bb - nT, lane, wave);
+        return;
+    }
     const int c = Lb.i + 4 * (bb - nT) + wave;  // 0-based column: the columns right of the reflector's (Lb.i - 1)
     if (c >= n) return;
     const int mL = n - R0;
@@ -618,8 +692,8 @@ __global__ void __launch_bounds__(PSD_H2_NT, ((NK > 16 || NK * CR > 128) ? ((NK 
 // The updates of K consecutive links in one launch (K distinct matrices: K <= p), for the two-stream form in which the
 // chain launches carry no bulk part.  idx0: chain index of the first link ((i - 1) p + (p - j)); Q = (n - 1) p itself is
 // the drain position (the last right reflector on A_p).  grid = (nT + nB, K).
-template <int NK>
-__global__ void __launch_bounds__(PSD_H2_NT, (NK > 16 ? 2 : 4)) psd_hess2_bulk(const psd_hess2_args Gv, int n, int idx0, int nT) {
+template <int NK, int CPW = (NK <= 16 ? 4 : 1)>
+__global__ void __launch_bounds__(PSD_H2_NT, (NK > 16 ? 2 : (CPW > 1 ? 3 : 4))) psd_hess2_bulk(const psd_hess2_args Gv, int n, int idx0, int nT) {
     extern __shared__ __attribute__((aligned(16))) char psd_lds[];
     double* vs = (double*)psd_lds;
     double* red = vs + (n + 8);
@@ -633,7 +707,7 @@ __global__ void __launch_bounds__(PSD_H2_NT, (NK > 16 ? 2 : 4)) psd_hess2_bulk(c
     Lb.valid = (idx < Q) ? 1 : 0;
     Lb.r0 = (Lb.j == 1) ? (Lb.i + 1) : Lb.i;
     La = psd_h2_linkat(Lb.i, Lb.j, -1, n, p);
-    psd_h2_bulk_body<NK>(&Gv, n, Lb, La, idx, (int)blockIdx.x, nT, vs, red);
+    psd_h2_bulk_body<NK, CPW>(&Gv, n, Lb, La, idx, (int)blockIdx.x, nT, vs, red);
 }
 
 #endif
