@@ -1,6 +1,7 @@
 // Host side of libpsd_mi355x: launch sequencing and the C ABI (include/psd_mi355x.h).
 // Built by hipcc (-x hip, gfx950).  tests/hostsim builds the same file with g++ -DPSD_HOSTSIM as a
 // serial simulation for the CPU-only test tier; the package never loads that build.
+#include <atomic>
 #include "psd_hess.h"
 #include "psd_hess2.h"
 #include "psd_formq2.h"
@@ -107,6 +108,13 @@ bool ord_slots(char orient, int schurindex, int p, std::vector<int>& slotA, std:
 size_t apply_lds_bytes() { return PSD_TR_LDS_BYTES + (size_t)32 * (PSD_APPLY_NT + 1) * 8; }
 
 }  // namespace
+
+// Contexts alive in this process.  The pipe form of the Hessenberg reduction parks a launch of 129 workgroups on the chip
+// while it waits for its predecessor; one context never holds more than two such launches (258 of the chip's 1024 workgroup
+// slots), but several contexts reducing at once could fill the slots with waiting workgroups whose predecessors then cannot
+// become resident (every wait is bounded, so that would end in a runtime error, not in a hang).  With more than one context
+// alive the reduction therefore takes the back-to-back form.  Other PROCESSES on the same GPU are not seen: PSD_H2_PIPE=0.
+static std::atomic<int> g_live_contexts{0};
 
 struct psd_ctx {
     int device = 0;
@@ -235,11 +243,12 @@ struct psd_ctx {
     int band_helper = 1;  // PSD_BAND_HELPER=0: a leader computes the product band of its decisions itself
     int overlap = 3;  // Schur-vector updates on stream2 beside the next tick's chases: 0 off, 2 on, 3 = on for n >= 1024 (PSD_OVERLAP)
     int far_grid = 0;  // grid of the far bulk-update launches (0: apply_wl_grid)
+    bool counted = false;  // (this context is in g_live_contexts)
 #ifndef PSD_HOSTSIM
     hipStream_t stream2 = nullptr;  // the far parts of the bulk updates (beside the next tick's chases)
     hipStream_t stream3 = nullptr;  // the panel updates of the Hessenberg reduction (beside its chain)
     hipStream_t stream4 = nullptr;  // every other chain launch of the Hessenberg reduction in pipe mode (hessenberg2_pipe)
-    int hess_pipe = 1;              // PSD_H2_PIPE=0: chain launches back to back on one stream
+    int hess_pipe = 1;              // PSD_H2_PIPE=0: chain launches back to back on one stream; 2: pipe form also beside other contexts
     hipEvent_t evE[2] = {nullptr, nullptr}, evF[2] = {nullptr, nullptr};
 #endif
     int apply_worklist = 1;   // PSD_APPLY_WL=0: the grid-per-cursor bulk-apply kernels
@@ -808,7 +817,7 @@ int hessenberg2_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
     if (K > 0 && p >= 9 * K) K = (p + 7) / 8;
     if (K > 0 && p >= 2 * K && p + K + 2 <= PSD_H2_RING && c->stream3) {
         ha.ringmask = PSD_H2_RING - 1;
-        if (c->hess_pipe && c->stream4) {
+        if (c->stream4 && (c->hess_pipe == 2 || (c->hess_pipe && g_live_contexts.load() <= 1))) {  // (PSD_H2_PIPE=2: also beside other contexts)
             ha.pipe = 2;  // (every poll round reads the whole column; 1: a watch round on one record per strip first — one more round trip per link, 477 against 442 ms)
             if (const char* e = getenv("PSD_H2_POLL")) ha.pipe = (atoi(e) == 1) ? 1 : 2;
             if (const char* e = getenv("PSD_H2_XCD")) ha.xcd = atoi(e); else if (n > 512 && n <= 1024) ha.xcd = 0;  // (8-row strips: two per line, the mapping no longer pays: 482 -> 474 ms)
@@ -1457,6 +1466,8 @@ int psd_create(psd_ctx** ctx, int device) {
     if (const char* e = getenv("PSD_TRAIN")) c->train_m = c->ztrain_m = c->gtrain_m = atoi(e);
     if (const char* e = getenv("PSD_TRAIN_Z")) c->ztrain_m = atoi(e);
     if (const char* e = getenv("PSD_TRAIN_G")) c->gtrain_m = atoi(e);
+    c->counted = true;
+    g_live_contexts.fetch_add(1);
     *ctx = c;
     return 0;
 }
@@ -1484,6 +1495,8 @@ int psd_get_train_g(psd_ctx* c) { return c ? c->gtrain_m : -1; }
 
 int psd_destroy(psd_ctx* c) {
     if (!c) return 0;
+    if (c->counted) g_live_contexts.fetch_sub(1);
+    c->counted = false;
     c->grelease();
     c->gtrelease();
     c->zgrelease();

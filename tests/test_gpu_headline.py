@@ -81,3 +81,12 @@ def test_trains_off_sweep_parity_512(gpu_engine):
 def test_checkpsd_pinned_near_full_size(gpu_engine):
     """the verifier the full-size tests rely on, against the numpy restatement at an order off the tile grid"""
     ec.case_checkpsd(gpu_engine, [(520, 3, "R", "d")])
+
+
+def test_pipe_form_above_1024(gpu_engine):
+    """n > 1024 takes the 32-column-step instantiation of the chain kernel (`psd_hess2_link<32, 8>`), p >= 32 the
+    overlapping launches: accuracy of the whole call at n = 1100, p = 32"""
+    n, p = 1100, 32
+    As = pt.bench_factors(n, p, seed=91)
+    ps = gpu_engine.pschur(As, "R")
+    _accuracy(gpu_engine, ps, As)

@@ -235,9 +235,12 @@ def test_formq_blocked(monkeypatch):
     ec.case_formq_blocked(make, [(64, 3, "R"), (97, 2, "L"), (130, 1, "R"), (257, 5, "R"), (512, 4, "L")])
 
 
+@pytest.mark.parametrize("pipe", ["2", "0"])
 @pytest.mark.parametrize("n,p,K", [(33, 8, 4), (130, 9, 4), (257, 16, 8), (300, 40, 16), (64, 70, 16), (96, 150, 16)])
-def test_phessenberg_two_stream_vs_oracle(monkeypatch, n, p, K):
-    """The two-stream form of the look-ahead reduction (chain launches alone on the main stream, the panel updates of K
+def test_phessenberg_two_stream_vs_oracle(monkeypatch, n, p, K, pipe):
+    """The multi-stream forms of the look-ahead reduction — pipe "2": consecutive chain launches overlap on two streams
+    and hand the staged column over as self-validating records; "0": back to back on one stream.
+    The two-stream form of the look-ahead reduction (chain launches alone on the main stream, the panel updates of K
     consecutive links as one launch on the second stream, awaited by event p - 1 links later; by itself only for
     p >= 32, n >= 512) forced on small problems: periods that are not multiples of K, a last batch that is only the
     drain position, p >= 9 K (K is raised), against the oracle's packed storage and tau."""
@@ -247,6 +250,7 @@ def test_phessenberg_two_stream_vs_oracle(monkeypatch, n, p, K):
     import psd_amd
 
     monkeypatch.setenv("PSD_HESS_ASYNC", str(K))
+    monkeypatch.setenv("PSD_H2_PIPE", pipe)  # ("2": overlapping chain launches although the session's engine is alive too)
     eng = psd_amd.Engine(device=0)
     A = pt.bench_factors(n, p, seed=170 + n + p)
     W = [a.copy(order="F") for a in A]
