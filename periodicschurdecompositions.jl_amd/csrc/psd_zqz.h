@@ -911,9 +911,10 @@ PSD_D void psd_zq_step_body(const psd_zparams& P) {
                     st.nsweeps += 1;
                     st.iiter += 1;
                     st.jiter += 1;
-                    // (cycle counters: the cursors' windows count like the leader's; [5] = what a cursor spends outside its windows)
+                    // (cycle counters: the cursors' windows count like the leader's; what a cursor spends outside its windows — state
+                    //  read, start rotation — goes with the decisions)
                     for (int q = 1; q <= 3; ++q) st.cyc[q] += P.cst[b].cyc[q];
-                    st.cyc[5] += P.cst[b].cyc[4] - (P.cst[b].cyc[1] + P.cst[b].cyc[2] + P.cst[b].cyc[3]);
+                    st.cyc[0] += P.cst[b].cyc[4] - (P.cst[b].cyc[1] + P.cst[b].cyc[2] + P.cst[b].cyc[3]);
                 }
                 st.train_n = 1;
                 st.W = st.Wmax;
@@ -925,7 +926,7 @@ PSD_D void psd_zq_step_body(const psd_zparams& P) {
         }
     }
     st.cyc[4] += psd_clock() - tk0;
-    (void)tw0;
+    st.cyc[5] += psd_wallclock() - tw0;
     if (st.info == PSD_LIST_OVERFLOW) st.phase = PSD_ZPH_DONE;  // (a window that overran a list ends the call)
     PSD_SYNC();
     PSD_ONE { *P.st = st; }
