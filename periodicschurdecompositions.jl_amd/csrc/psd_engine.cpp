@@ -762,6 +762,8 @@ int hessenberg2_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
     ha.trace = nullptr;
     ha.trace_hi = 0x7fffffff;
     ha.pipe = 0;
+    ha.fault = -1;
+    if (const char* e = getenv("PSD_H2_FAULT")) ha.fault = atoi(e);  // (test hook: the hand-over to this link never validates)
     ha.err = (int*)(c->h2ring + PSD_H2_RING * psd_h2_slot_doubles(c->h2ring_n));
     if (const char* e = getenv("PSD_H2_TRACE")) { if (atoi(e) > 1) ha.trace_hi = atoi(e); }
     long long* h2trace = nullptr;

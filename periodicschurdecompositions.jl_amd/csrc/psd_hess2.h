@@ -40,6 +40,7 @@ struct psd_hess2_args {
     int trace_hi;      // only links with ring position below this are recorded (PSD_H2_TRACE=<links>)
     int pipe;          // 1: consecutive chain launches overlap (two streams); the staged column travels as self-validating records (see psd_h2_tag)
     int* err;          // pipe: set when a launch gave up waiting for its predecessor's records (the host reports a runtime error)
+    int fault;         // test hook (PSD_H2_FAULT=<link>): the records for this link are written with a wrong tag; -1: off
 };
 // slot layout: v[n+8] | w[n+8] | col[n+8] | hdr[8] (tau, beta) | part[2 * (n/4 + 2)] | rec[2 (n+8)]
 PSD_HD size_t psd_h2_slot_doubles(int n) { return 5 * (size_t)(n + 8) + 8 + 2 * (size_t)(n / 4 + 2); }
@@ -659,7 +660,8 @@ __global__ void __launch_bounds__(PSD_H2_NT, ((NK > 16 || NK * CR > 128) ? ((NK 
             if (pipe) {
                 const unsigned long long yb = (unsigned long long)__double_as_longlong(y);
                 __hip_atomic_store(Sn.rec + 2 * (size_t)rfin, yb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(Sn.rec + 2 * (size_t)rfin + 1, yb ^ psd_h2_tag(slot + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(Sn.rec + 2 * (size_t)rfin + 1, yb ^ psd_h2_tag(slot + 1) ^ ((G->fault == slot + 1) ? 0x10ull : 0ull), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 Sn.col[rfin] = y;
             }

@@ -291,3 +291,31 @@ def test_pschur_switches(monkeypatch, env):
         assert ok, (env, n, p, err.max())
         P = pt.product(A, left=(lr == "L"))
         assert pt.match_eigs(np.linalg.eigvals(P), ps.values) <= 1e-10 * np.linalg.norm(P, 2)
+
+
+def test_pipe_form_gives_up_loudly(monkeypatch):
+    """A hand-over that never validates (test hook: the records of one link carry a wrong tag) must end in a runtime error
+    within the bounded wait, not in a hang and not in silently wrong factors; the engine works again afterwards."""
+    import time
+
+    import torch
+
+    torch.cuda.init()
+    import psd_amd
+
+    monkeypatch.setenv("PSD_HESS_ASYNC", "4")
+    monkeypatch.setenv("PSD_H2_PIPE", "2")
+    monkeypatch.setenv("PSD_H2_FAULT", "200")
+    bad = psd_amd.Engine(device=0)
+    A = pt.bench_factors(96, 12, seed=5)
+    t0 = time.time()
+    with pytest.raises(RuntimeError):
+        bad.phessenberg_([a.copy(order="F") for a in A])
+    assert time.time() - t0 < 20.0
+    monkeypatch.delenv("PSD_H2_FAULT")
+    good = psd_amd.Engine(device=0)
+    W = [a.copy(order="F") for a in A]
+    Hs, tau, _ = good.phessenberg_(W)
+    Ho, Qo, packed, tauo = pt.oracle_phessenberg(A)
+    for j in range(len(A)):
+        assert np.linalg.norm(W[j] - packed[j]) < 1e-11 * max(np.linalg.norm(packed[j]), 1.0)
