@@ -1770,8 +1770,59 @@ int zhessenberg2_async(psd_ctx* c, int n, int p, const psd_zhess2_args& ha, int 
     PSD_CHECK(hipStreamWaitEvent(c->stream, evB[(nbatch - 1) & 7], 0));
     return 0;
 }
+// pipe form for ComplexF64 (see hessenberg2_pipe)
+template <int NK, int CR>
+int zhessenberg2_pipe(psd_ctx* c, int n, int p, const psd_zhess2_args& ha, int K) {
+    constexpr int LG = 64 / CR;
+    const int nC = ((ha.xcd && CR < 8) ? (((n + CR - 1) / CR + LG - 1) / LG) * LG : (n + CR - 1) / CR) + 1, nT = (n + PSD_ZH2_ROWS - 1) / PSD_ZH2_ROWS, nB = (n + 3) / 4;
+    const size_t lds = ((size_t)n + 8 + 2 * PSD_ZH2_NT + 64) * sizeof(psd_z);
+    const int Q = (n - 1) * p;
+    const int nbatch = Q / K + 1;
+    if ((int)c->h2ev.size() < 26) {
+        const size_t old = c->h2ev.size();
+        c->h2ev.resize(26, nullptr);
+        for (size_t q = old; q < c->h2ev.size(); ++q) PSD_CHECK(hipEventCreateWithFlags(&c->h2ev[q], hipEventDisableTiming));
+    }
+    hipEvent_t* evA = c->h2ev.data();
+    hipEvent_t* evB = c->h2ev.data() + 8;
+    hipEvent_t* evC = c->h2ev.data() + 16;
+    hipEvent_t evJ = c->h2ev[24], evK = c->h2ev[25];
+    hipStream_t S[2] = {c->stream, c->stream4};
+    PSD_CHECK(hipEventRecord(evJ, c->stream));
+    PSD_CHECK(hipStreamWaitEvent(c->stream3, evJ, 0));
+    PSD_CHECK(hipStreamWaitEvent(c->stream4, evJ, 0));
+    hipLaunchKernelGGL((psd_zhess2_link<NK, CR>), dim3(nC), dim3(PSD_ZH2_NT), lds, S[0], ha, n, 0, 1, nC, 0);
+    int nextb = 0;
+    auto batch = [&](int b) -> int {
+        PSD_CHECK(hipEventRecord(evA[b & 7], S[0]));
+        PSD_CHECK(hipEventRecord(evC[b & 7], S[1]));
+        PSD_CHECK(hipStreamWaitEvent(c->stream3, evA[b & 7], 0));
+        PSD_CHECK(hipStreamWaitEvent(c->stream3, evC[b & 7], 0));
+        hipLaunchKernelGGL((psd_zhess2_bulk<NK>), dim3(nT + nB, K), dim3(PSD_ZH2_NT), lds, c->stream3, ha, n, b * K, nT);
+        PSD_CHECK(hipEventRecord(evB[b & 7], c->stream3));
+        return 0;
+    };
+    int idx = 0;
+    for (int i = 1; i <= n - 1; ++i)
+        for (int j = p; j >= 1; --j, ++idx) {
+            hipStream_t s = S[(idx + 1) & 1];
+            const int need = idx + 1 - p;
+            if (need >= 0 && need % K == 0) PSD_CHECK(hipStreamWaitEvent(s, evB[(need / K) & 7], 0));
+            if (need >= 1 && (need - 1) % K == 0) PSD_CHECK(hipStreamWaitEvent(s, evB[((need - 1) / K) & 7], 0));
+            hipLaunchKernelGGL((psd_zhess2_link<NK, CR>), dim3(nC), dim3(PSD_ZH2_NT), lds, s, ha, n, i, j, nC, 0);
+            if (idx >= nextb * K + K - 1) {
+                PSD_CHECK(batch(nextb));
+                ++nextb;
+            }
+        }
+    for (; nextb < nbatch; ++nextb) PSD_CHECK(batch(nextb));
+    PSD_CHECK(hipEventRecord(evK, S[1]));
+    PSD_CHECK(hipStreamWaitEvent(c->stream, evK, 0));
+    PSD_CHECK(hipStreamWaitEvent(c->stream, evB[(nbatch - 1) & 7], 0));
+    return 0;
+}
 int zhessenberg2_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dtau) {
-    const size_t ringbytes = PSD_H2_RING * psd_zh2_slot_doubles(n) * sizeof(double);
+    const size_t ringbytes = PSD_H2_RING * psd_zh2_slot_doubles(n) * sizeof(double) + 64;  // (+ the pipe form's error word)
     if (!c->zh2ring || c->zh2ring_n < n) {
         if (c->zh2ring) psd_rt_free(c->zh2ring);
         c->zh2ring = nullptr;
@@ -1786,6 +1837,8 @@ int zhessenberg2_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dtau) {
     ha.p = p;
     ha.ringmask = 3;
     ha.xcd = c->hess_xcd;
+    ha.pipe = 0;
+    ha.err = (int*)(c->zh2ring + PSD_H2_RING * psd_zh2_slot_doubles(n));
     const size_t lds = ((size_t)n + 8 + 2 * PSD_ZH2_NT + 64) * sizeof(psd_z);
     if (lds > 64 * 1024) return PSD_INFO_NOTIMPL;
     int K = c->hess_async;
@@ -1793,6 +1846,18 @@ int zhessenberg2_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dtau) {
     if (K > 0 && p >= 9 * K) K = (p + 7) / 8;
     if (K > 0 && p >= 2 * K && p + K + 2 <= PSD_H2_RING && c->stream3) {
         ha.ringmask = PSD_H2_RING - 1;
+        if (c->stream4 && n <= 1024 && (c->hess_pipe == 2 || (c->hess_pipe && g_live_contexts.load() <= 1))) {
+            ha.pipe = 1;
+            int rc;
+            if (n <= 256) rc = zhessenberg2_pipe<4, 8>(c, n, p, ha, K);
+            else if (n <= 512) rc = zhessenberg2_pipe<8, 8>(c, n, p, ha, K);
+            else rc = zhessenberg2_pipe<16, 8>(c, n, p, ha, K);
+            if (rc != 0) return rc;
+            int herr = 0;
+            PSD_CHECK(psd_rt_d2h(&herr, ha.err, sizeof(int), c->stream));
+            PSD_CHECK(psd_rt_sync(c->stream));
+            return herr ? PSD_INFO_RUNTIME + 0xfffb : 0;
+        }
         if (n <= 256) return zhessenberg2_async<4, 8>(c, n, p, ha, K);
         if (n <= 512) return zhessenberg2_async<8, 8>(c, n, p, ha, K);
         if (n <= 1024) return zhessenberg2_async<16, 4>(c, n, p, ha, K);

@@ -27,12 +27,15 @@ struct psd_zhess2_args {
     int p;
     int ringmask;
     int xcd;       // chain strips that share a 128-byte line on one XCD (CR = 4: two strips per line)
+    int pipe;      // 1: consecutive chain launches overlap on two streams, the staged column travels as self-validating records (psd_hess2.h)
+    int* err;      // pipe: set when a launch gave up waiting
 };
-// slot layout (doubles): v[2 (n+8)] | w[2 (n+8)] | col[2 (n+8)] | hdr[8] (tau.re, tau.im, beta) | part[2 (n/4 + 2)]
-PSD_HD size_t psd_zh2_slot_doubles(int n) { return 6 * (size_t)(n + 8) + 8 + 2 * (size_t)(n / 4 + 2); }
+// slot layout (doubles): v[2 (n+8)] | w[2 (n+8)] | col[2 (n+8)] | hdr[8] (tau.re, tau.im, beta) | part[2 (n/4 + 2)] | rec[4 (n+8)]
+PSD_HD size_t psd_zh2_slot_doubles(int n) { return 10 * (size_t)(n + 8) + 8 + 2 * (size_t)(n / 4 + 2); }
 struct psd_zh2_slot {
     psd_z *v, *w, *col;
     double *hdr, *part;
+    unsigned long long* rec;  // pipe mode: entry k as (bits(re), bits(re) ^ tag, bits(im), bits(im) ^ tag)
 };
 PSD_D psd_zh2_slot psd_zh2_get(const psd_zhess2_args* G, int n, int q) {
     double* b = G->ring + (size_t)(q & G->ringmask) * psd_zh2_slot_doubles(n);
@@ -42,6 +45,7 @@ PSD_D psd_zh2_slot psd_zh2_get(const psd_zhess2_args* G, int n, int q) {
     s.col = (psd_z*)(b + 4 * (size_t)(n + 8));
     s.hdr = b + 6 * (size_t)(n + 8);
     s.part = s.hdr + 8;
+    s.rec = (unsigned long long*)(s.part + 2 * (size_t)(n / 4 + 2));
     return s;
 }
 
@@ -261,7 +265,8 @@ __global__ void __launch_bounds__(PSD_ZH2_NT, (NK > 8 ? 2 : 4)) psd_zhess2_link(
         psd_z xcol[NV];
         psd_z tau = zmk(0.0, 0.0), mult = zmk(0.0, 0.0), alpha = zmk(0.0, 0.0);
         double beta = 0.0, am = 0.0, sq = 0.0;
-        if (q >= 0) {
+        const bool pipe = G->pipe != 0;
+        if (q >= 0 && !pipe) {
             const int np_ = ntileC - r0 / CR;
             constexpr int NPP = (64 * NK / CR + PSD_ZH2_NT - 1) / PSD_ZH2_NT;  // (amax, ssq) pairs per thread
 #pragma unroll
@@ -293,36 +298,127 @@ __global__ void __launch_bounds__(PSD_ZH2_NT, (NK > 8 ? 2 : 4)) psd_zhess2_link(
                 if (cc < m) psd_zh2_ld2(M, n, r, r0 + cc, ok0, ok1, a0[k], a1[k]);
             }
         }
-        if (q >= 0) {
-            const double amw = psd_h2_wave_max(am);
-            double ssw = 0.0;
-            if (amw > 0.0) {
-                const double f = am / amw;
-                ssw = sq * (f * f);
-            }
-            ssw = psd_h2_wave_sum(ssw);
-            if (lane == 0) {
-                redd[2 * wave] = amw;
-                redd[2 * wave + 1] = ssw;
-            }
-            __syncthreads();
-            const double amax = fmax(fmax(redd[0], redd[2]), fmax(redd[4], redd[6]));
-            double tot = 0.0;
-            if (amax > 0.0) {
+        if (q >= 0 && pipe) {
+            // the strip is on its way; now the column of the previous launch, which may still be running (psd_hess2.h:
+            // every double as a record (bits, bits ^ tag), polled with 16-byte coherent loads until all of them validate)
+            const unsigned long long tag = psd_h2_tag(slot);
+            const unsigned long long* rec = S.rec + 4 * (size_t)r0;
+            const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, m * 32, 0x00020000);
+            unsigned long long xr[NV], xi[NV];
+            int spins = 0;
+            for (;;) {
+                bool okr = true;
 #pragma unroll
-                for (int wv = 0; wv < 4; ++wv) {
-                    const double f = redd[2 * wv] / amax;
-                    tot += redd[2 * wv + 1] * (f * f);
+                for (int u = 0; u < NV; ++u) {
+                    const int k = tid + PSD_ZH2_NT * u;
+                    xr[u] = xi[u] = 0;
+                    if (PSD_ZH2_NT * u < m) {
+                        const unsigned off = (k < m) ? (unsigned)k * 32u : 0xffffffe0u;
+                        const psd_h2_u4 t4 = __builtin_amdgcn_raw_buffer_load_b128(rsr, off, 0, 16);
+                        const psd_h2_u4 s4 = __builtin_amdgcn_raw_buffer_load_b128(rsr, off, 16, 16);
+                        const unsigned long long x = ((unsigned long long)t4.y << 32) | t4.x, cx = ((unsigned long long)t4.w << 32) | t4.z;
+                        const unsigned long long y = ((unsigned long long)s4.y << 32) | s4.x, cy = ((unsigned long long)s4.w << 32) | s4.z;
+                        okr = okr && (k >= m || ((x ^ cx) == tag && (y ^ cy) == tag));
+                        xr[u] = x;
+                        xi[u] = y;
+                    }
                 }
+                asm volatile("" ::: "memory");
+                const bool giveup = __hip_atomic_load(G->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                if (__syncthreads_and((okr || giveup) ? 1 : 0)) break;
+                if (++spins > (1 << 17)) {  // (every wave reaches an exit; the results are then void and the host says so)
+                    if (tid == 0) __hip_atomic_store(G->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __builtin_amdgcn_s_sleep(2);
             }
-            const double xnorm = (m > 1) ? amax * sqrt(tot) : 0.0;
-            psd_zh2_larfg(alpha, xnorm, tau, beta, mult);
+            // this thread's share of the tail (entries k >= 1): largest |re|, |im| and PLAIN sum of squares; the raw column
+            // goes to LDS with its first entry as zero (w = M v = M[:, 0] + mult (M[:, 1:] x[1:]))
+            am = 0.0;
+            sq = 0.0;
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const int k = tid + PSD_ZH2_NT * u;
-                if (k < m) vs[k] = (k == 0) ? zmk(1.0, 0.0) : zmul(xcol[u], mult);
+                xcol[u] = (k < m) ? zmk(__longlong_as_double((long long)xr[u]), __longlong_as_double((long long)xi[u])) : zmk(0.0, 0.0);
+                if (k >= 1 && k < m) {
+                    am = fmax(am, zabs1(xcol[u]));
+                    sq = __builtin_fma(xcol[u].re, xcol[u].re, sq);
+                    sq = __builtin_fma(xcol[u].im, xcol[u].im, sq);
+                }
+                if (k < m) vs[k] = (k == 0) ? zmk(0.0, 0.0) : xcol[u];
             }
-            __syncthreads();
+        }
+        double xnorm = 0.0;
+        if (q >= 0) {
+            if (pipe) {
+                const double amw = psd_h2_wave_max(am);
+                const double s2w = psd_h2_wave_sum(sq);
+                if (lane == 0) {
+                    redd[2 * wave] = amw;
+                    redd[2 * wave + 1] = s2w;
+                }
+                if (tid == 0) {
+                    redd[8] = xcol[0].re;
+                    redd[9] = xcol[0].im;
+                }
+                __syncthreads();
+                alpha = zmk(redd[8], redd[9]);
+                const double amax = fmax(fmax(redd[0], redd[2]), fmax(redd[4], redd[6]));
+                const double s2 = (redd[1] + redd[3]) + (redd[5] + redd[7]);
+                if (m > 1 && amax > 0.0) {
+                    if (amax < 1e140 && amax > 1e-140) {
+                        double g, rg;
+                        psd_sqrt_pair_fast(s2, g, rg);
+                        xnorm = g;
+                    } else {
+                        __syncthreads();
+                        double ss = 0.0;
+#pragma unroll
+                        for (int u = 0; u < NV; ++u) {
+                            const int k = tid + PSD_ZH2_NT * u;
+                            if (k >= 1 && k < m) {
+                                const double zr = xcol[u].re / amax, zi = xcol[u].im / amax;
+                                ss += zr * zr + zi * zi;
+                            }
+                        }
+                        ss = psd_h2_wave_sum(ss);
+                        if (lane == 0) redd[16 + wave] = ss;
+                        __syncthreads();
+                        xnorm = amax * sqrt((redd[16] + redd[17]) + (redd[18] + redd[19]));
+                    }
+                }
+            } else {
+                const double amw = psd_h2_wave_max(am);
+                double ssw = 0.0;
+                if (amw > 0.0) {
+                    const double f = am / amw;
+                    ssw = sq * (f * f);
+                }
+                ssw = psd_h2_wave_sum(ssw);
+                if (lane == 0) {
+                    redd[2 * wave] = amw;
+                    redd[2 * wave + 1] = ssw;
+                }
+                __syncthreads();
+                const double amax = fmax(fmax(redd[0], redd[2]), fmax(redd[4], redd[6]));
+                double tot = 0.0;
+                if (amax > 0.0) {
+#pragma unroll
+                    for (int wv = 0; wv < 4; ++wv) {
+                        const double f = redd[2 * wv] / amax;
+                        tot += redd[2 * wv + 1] * (f * f);
+                    }
+                }
+                xnorm = (m > 1) ? amax * sqrt(tot) : 0.0;
+            }
+            if (!pipe || b == 0) psd_zh2_larfg(alpha, xnorm, tau, beta, mult);  // (pipe: the strip workgroups form the scalars behind their GEMV)
+            if (!pipe) {
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int k = tid + PSD_ZH2_NT * u;
+                    if (k < m) vs[k] = (k == 0) ? zmk(1.0, 0.0) : zmul(xcol[u], mult);
+                }
+                __syncthreads();
+            }
             if (b == 0) {  // publish v_q, store it LAPACK-style (PSD.jl:232-236,241-244)
                 psd_z* Mq = G->H + (size_t)(L.j - 1) * n * n;
                 const int c = L.i - 1;
@@ -331,8 +427,9 @@ __global__ void __launch_bounds__(PSD_ZH2_NT, (NK > 8 ? 2 : 4)) psd_zhess2_link(
                 for (int u = 0; u < NV; ++u) {
                     const int k = tid + PSD_ZH2_NT * u;
                     if (k < m) {
-                        S.v[k] = vs[k];
-                        Mq[(size_t)c * n + r0 + k] = nz ? ((k == 0) ? zmk(beta, 0.0) : vs[k]) : xcol[u];
+                        const psd_z vk = (k == 0) ? zmk(1.0, 0.0) : zmul(xcol[u], mult);
+                        S.v[k] = vk;
+                        Mq[(size_t)c * n + r0 + k] = nz ? ((k == 0) ? zmk(beta, 0.0) : vk) : xcol[u];
                     }
                 }
                 if (tid == 0) {
@@ -345,7 +442,7 @@ __global__ void __launch_bounds__(PSD_ZH2_NT, (NK > 8 ? 2 : 4)) psd_zhess2_link(
         }
         if (!strip) return;
         psd_z acc0 = zmk(0.0, 0.0), acc1 = zmk(0.0, 0.0);
-        if (q >= 0 && !ziszero(tau)) {
+        if (q >= 0 && (pipe || !ziszero(tau))) {
 #pragma unroll
             for (int k = 0; k < NKS; ++k) {
                 const int cc = cl + CL * k;
@@ -356,27 +453,40 @@ __global__ void __launch_bounds__(PSD_ZH2_NT, (NK > 8 ? 2 : 4)) psd_zhess2_link(
                 }
             }
         }
+        psd_z* const redg = pipe ? (red + 64) : red;  // (pipe: workgroup mates may still be reading the norm's exchange area)
 #pragma unroll
         for (int sft = RP; sft < 64; sft <<= 1) {
             acc0 = zadd(acc0, psd_zh2_shfl_xor(acc0, sft));
             acc1 = zadd(acc1, psd_zh2_shfl_xor(acc1, sft));
         }
         if (lane < RP) {
-            red[(wave * RP + lane) * 2] = acc0;
-            red[(wave * RP + lane) * 2 + 1] = acc1;
+            redg[(wave * RP + lane) * 2] = acc0;
+            redg[(wave * RP + lane) * 2 + 1] = acc1;
         }
+        if (pipe && q >= 0) psd_zh2_larfg(alpha, xnorm, tau, beta, mult);
         __syncthreads();
         double amt = 0.0;
         psd_z y = zmk(0.0, 0.0);
         if (fin) {
-            const psd_z w = zadd(zadd(red[tid], red[CR + tid]), zadd(red[2 * CR + tid], red[3 * CR + tid]));
+            psd_z w = zadd(zadd(redg[tid], redg[CR + tid]), zadd(redg[2 * CR + tid], redg[3 * CR + tid]));
+            if (pipe && q >= 0) w = ziszero(tau) ? zmk(0.0, 0.0) : zadd(mfirst, zmul(mult, w));  // (the unit entry of v times column r0)
             y = zsub(mfirst, zmul(tau, w));
-            Sn.col[rfin] = y;
+            if (pipe) {
+                const unsigned long long tg = psd_h2_tag(slot + 1);
+                const unsigned long long br = (unsigned long long)__double_as_longlong(y.re), bi = (unsigned long long)__double_as_longlong(y.im);
+                unsigned long long* q4 = Sn.rec + 4 * (size_t)rfin;
+                __hip_atomic_store(q4, br, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(q4 + 1, br ^ tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(q4 + 2, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(q4 + 3, bi ^ tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                Sn.col[rfin] = y;
+            }
             S.w[rfin] = w;
             if (rfin > r0n) amt = zabs1(y);
             else y = zmk(0.0, 0.0);
         }
-        if (wave == 0) {
+        if (wave == 0 && !pipe) {
             const double amax = psd_h2_wave_max(amt);
             double s2 = 0.0;
             if (amax > 0.0 && amt > 0.0) {

@@ -42,15 +42,18 @@ def test_zphessenberg_lookahead_vs_oracle(gpu_engine, n, p):
     _zhess_vs_oracle(gpu_engine, n, p, 270 + n + p)
 
 
-@pytest.mark.parametrize("n,p,K", [(33, 8, 4), (130, 9, 4), (257, 16, 8), (300, 40, 16), (64, 70, 16), (96, 150, 16)])
-def test_zphessenberg_two_stream_vs_oracle(monkeypatch, n, p, K):
-    """two-stream form (see test_phessenberg_two_stream_vs_oracle) of the complex reduction, forced on small problems"""
+@pytest.mark.parametrize("pipe", ["2", "0"])
+@pytest.mark.parametrize("n,p,K", [(33, 8, 4), (130, 9, 4), (257, 16, 8), (300, 40, 16), (64, 70, 16), (96, 150, 16), (520, 8, 4)])
+def test_zphessenberg_two_stream_vs_oracle(monkeypatch, n, p, K, pipe):
+    """multi-stream forms (see test_phessenberg_two_stream_vs_oracle) of the complex reduction, forced on small problems:
+    pipe "2" = overlapping chain launches with the column as self-validating records, "0" = back to back"""
     import torch
 
     torch.cuda.init()
     import psd_amd
 
     monkeypatch.setenv("PSD_HESS_ASYNC", str(K))
+    monkeypatch.setenv("PSD_H2_PIPE", pipe)
     _zhess_vs_oracle(psd_amd.Engine(device=0), n, p, 370 + n + p)
 
 
