@@ -1842,7 +1842,7 @@ int zhessenberg2_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dtau) {
     const size_t lds = ((size_t)n + 8 + 2 * PSD_ZH2_NT + 64) * sizeof(psd_z);
     if (lds > 64 * 1024) return PSD_INFO_NOTIMPL;
     int K = c->hess_async;
-    if (K < 0) K = (p >= 32 && n >= 512) ? 16 : 0;
+    if (K < 0) K = (p >= 32 && n >= 512) ? ((p >= 48 && c->hess_pipe && c->stream4 && n <= 1024) ? 24 : 16) : 0;  // (as hessenberg2_dev: 16 / 24 / 32 links per batch 633 / 604 / 621 ms at p = 64)
     if (K > 0 && p >= 9 * K) K = (p + 7) / 8;
     if (K > 0 && p >= 2 * K && p + K + 2 <= PSD_H2_RING && c->stream3) {
         ha.ringmask = PSD_H2_RING - 1;

@@ -63,6 +63,7 @@ struct psd_zstate {
     // multishift train: bulges wanted / in the running train / train number / this state's cursor / tick of the leader's
     // first window / row whose diagonal entries are this bulge's shift / exceptional-shift bookkeeping / sweeps in trains
     int train_want, train_n, train_id, cursor, train_tick0, shidx, exc_dec, ntrainsweeps;
+    int cstart, cfirst;  // cursor: the tick of its first window and that window's number of positions (cursors W positions apart)
     psd_z shift;  // this bulge's shift (an eigenvalue of the trailing block of the product)
 };
 
@@ -491,10 +492,12 @@ PSD_D void psd_zq_check(const psd_zparams& P, psd_zstate& st, double* red, int* 
             int nb = st.Wmax - 3, m = 1;
             double best = 1e300;
             for (int nbc = (st.Wmax - 3 < 8) ? ((st.Wmax > 4) ? st.Wmax - 3 : 1) : 8; nbc <= st.Wmax - 3; ++nbc) {
-                int mc = 1 + (w - nbc) / (2 * nbc);
+                // (cursors nbc + 3 positions apart — their windows only have to be disjoint — as in the real engine since round 2;
+                //  two whole windows apart before: a train of m bulges fills and drains in ceil((m-1)(nbc+3)/nbc) ticks, not 2(m-1))
+                int mc = 1 + (w - nbc) / (nbc + 3);
                 if (mc > mt) mc = mt;
                 if (mc < 2) break;
-                const double cost = (double)((w + nbc - 1) / nbc + 2 * (mc - 1)) * (double)(nbc * p + st.train_oc) / mc;
+                const double cost = (double)((w + nbc - 1) / nbc + ((mc - 1) * (nbc + 3) + nbc - 1) / nbc) * (double)(nbc * p + st.train_oc) / mc;
                 if (cost < best) {
                     best = cost;
                     nb = nbc;
@@ -543,6 +546,12 @@ PSD_D void psd_zq_check(const psd_zparams& P, psd_zstate& st, double* red, int* 
             for (int b = 1; b < st.train_n; ++b) {
                 psd_zstate cs = st;
                 cs.cursor = b;
+                {  // bulge b runs b W positions behind the leader: first tick in which its window reaches into the block, and the part inside
+                    const int nbw = st.W - 3, spc = st.W;
+                    const int d = (b * spc - nbw + 1 + nbw - 1) / nbw;  // ceil((b W - nb + 1) / nb) >= 1
+                    cs.cstart = st.train_tick0 + d;
+                    cs.cfirst = d * nbw - b * spc + nbw;                 // 1 .. nb positions
+                }
                 cs.phase = PSD_ZPH_CWAIT;
                 cs.shidx = ilast;
                 cs.shift = P.tshift[b];
@@ -634,7 +643,7 @@ PSD_D void psd_zq_chain(const psd_zparams& P, const psd_zwin& w, int p, int j, i
 // generalized.jl:808-852: one window of the single-shift sweep (positions kcur..kcur+nb-1)
 PSD_D void psd_zq_sweep_window(const psd_zparams& P, psd_zstate& st, psd_z* ldsz, int* lcnt) {
     const int n = st.n, p = st.p, ifirst = st.ifirst, ilast = st.ilast, ifirstm = st.ifirstm, ilastm = st.ilastm;
-    const int nb = st.W - 3;
+    const int nb = (st.cursor > 0 && st.cfirst > 0 && st.kcur == st.ifirst) ? st.cfirst : (st.W - 3);  // (a cursor's first window: the part inside the block)
     const int ks = st.kcur;
     const int ke = (ks + nb - 1 < ilast - 1) ? (ks + nb - 1) : (ilast - 1);
     psd_zwin w;
@@ -946,7 +955,7 @@ PSD_D void psd_zq_cursor_body(const psd_zparams& P, int b) {
     const size_t winb = (size_t)st.p * st.Wmax * (st.Wmax + 1);
     int* lcnt = (int*)((double*)(ldsz + winb) + PSD_STEP_NT) + 2 * PSD_STEP_NT;
     if (st.phase == PSD_ZPH_CWAIT) {
-        if (P.tick < st.train_tick0 + 2 * b) return;
+        if (P.tick < st.cstart) return;
         if (!psd_zq_start_rot_mu(P, st.n, st.p, st.ifirst, st.shift, st.c0, st.s0))
             psd_zq_start_rot(P, st.n, st.p, st.ifirst, st.shidx, st.c0, st.s0);
         st.kcur = st.ifirst;
@@ -1243,7 +1252,7 @@ PSD_KERNEL psd_zq_init(psd_zparams P, int n, int p, int wantT, int wantZ, int W,
         st.safmin = PSD_DBL_MIN;
         st.smlnum = PSD_DBL_MIN * ((double)n / PSD_DBL_EPS);
         for (int q = 0; q < 6; ++q) st.cyc[q] = 0;
-        st.train_want = train_want; st.train_n = 1; st.train_id = 0; st.cursor = 0; st.train_tick0 = 0;
+        st.train_want = train_want; st.train_n = 1; st.train_id = 0; st.cursor = 0; st.train_tick0 = 0; st.cstart = 0; st.cfirst = 0;
         st.shidx = n; st.exc_dec = 0; st.ntrainsweeps = 0; st.shift = zmk(0.0, 0.0);
         *P.st = st;
         P.desc->active = 0;
