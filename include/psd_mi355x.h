@@ -71,8 +71,9 @@ int psd_set_profile(psd_ctx* ctx, int profile);
  * decomposition up to rounding and iteration path; psd_stats.reserved counts the sweeps that ran inside trains. */
 int psd_set_train(psd_ctx* ctx, int bulges);
 int psd_get_train(psd_ctx* ctx);
-/* psd_set_train sets every path; these two address the complex single-shift path alone (its bulges
- * take the eigenvalues of the trailing m x m block of the product as shifts) */
+/* psd_set_train sets every path (32 or more = every engine's own default); these two address the complex single-shift
+ * path alone (its bulges take the eigenvalues of the trailing m x m block of the product as shifts, m <= 16, reused by
+ * longer trains; default 48 bulges W positions apart, at most 64) */
 int psd_set_train_z(psd_ctx* ctx, int bulges);
 int psd_get_train_z(psd_ctx* ctx);
 /* the signed paths psd_d_pschur(A, S) / psd_z_pschur(A, S) (double-shift sweeps of rgeneralized.jl:806-1054, single-shift

@@ -141,7 +141,7 @@ struct psd_ctx {
     size_t step_lds_set = 0, zstep_lds_set = 0, rostep_lds_set = 0;
     psd_hess_args* hargs = nullptr;  // device argument block of the graph-replayed Hessenberg reduction
     // multishift trains: bulges per train (0/1 = off), per-cursor state / descriptor / lists
-    int ztrain_m = 32;  // complex single-shift engine (shifts from a block of order <= PSD_ZHQR_MAX, reused by longer trains) (psd_set_train sets both; psd_set_train_z / PSD_TRAIN_Z this one)
+    int ztrain_m = 48;  // complex single-shift engine (shifts from a block of order <= PSD_ZHQR_MAX, reused by longer trains) (psd_set_train sets both; psd_set_train_z / PSD_TRAIN_Z this one)
     int train_m = 32;  // default: trains of up to 32 bulges (psd_set_train / PSD_TRAIN; 0 or 1 = the reference's iteration)
     int tcap_p = 0;
     psd_rstate* tcst = nullptr;
@@ -1478,13 +1478,14 @@ int psd_set_train(psd_ctx* c, int bulges) {
     if (!c) return -1;
     c->train_m = (bulges < 0) ? 0 : ((bulges > 32) ? 32 : bulges);
     c->ztrain_m = c->gtrain_m = c->train_m;
+    if (c->train_m >= 32) c->ztrain_m = 48;  // (the maximum = every engine's own default)
     return 0;
 }
 
 int psd_get_train(psd_ctx* c) { return c ? c->train_m : -1; }
 int psd_set_train_z(psd_ctx* c, int bulges) {
     if (!c) return -1;
-    c->ztrain_m = (bulges < 0) ? 0 : ((bulges > 32) ? 32 : bulges);
+    c->ztrain_m = (bulges < 0) ? 0 : ((bulges > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : bulges);
     return 0;
 }
 int psd_get_train_z(psd_ctx* c) { return c ? c->ztrain_m : -1; }
@@ -1970,7 +1971,7 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
 #endif
     }
-    int train_oc = 100;
+    int train_oc = 200;  // (100 until the cursors moved to W positions apart; 200-400 measured alike)
     if (const char* e = getenv("PSD_TRAIN_OC")) train_oc = atoi(e);  // (tuning hook)
     PSD_LAUNCH(psd_zq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, M, train_oc);
 #ifndef PSD_HOSTSIM
