@@ -1979,7 +1979,9 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
 #else
     const bool zdef = M > 1 && wantZ && c->overlap == 2;
 #endif
-    const size_t lds_apply = PSD_ZTR_LDS_BYTES + (size_t)32 * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
+    // (the tile holds the rows a window's lists span: at most W + 1, not the 32 the kernel could serve — at p = 64 (W = 12) that is
+    //  13.5 KiB instead of 33 KiB per single-wave workgroup, twelve of them per CU instead of four)
+    const size_t lds_apply = PSD_ZTR_LDS_BYTES + (size_t)((W + 2 < 32) ? (W + 2) : 32) * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
     const int tiles = (n + PSD_ZAPPLY_NT - 1) / PSD_ZAPPLY_NT;
     const int dtiles = (n + 255) / 256;
     const int batch = 32;

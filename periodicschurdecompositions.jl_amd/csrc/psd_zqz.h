@@ -1056,19 +1056,22 @@ PSD_D void psd_zq_apply_body(const psd_zparams& P, int n, int p, int role) {
         const psd_mat<psd_z> M = psd_mat<psd_z>{P.H + (size_t)(m - 1) * n * n, n};
         const int ldt = T + 1;
         // rows panel -> LDS (a thread owns a column); eight loads in flight per thread
-        PSD_PAR_FOR(t0, 32 * 2) {  // (S <= 32; thread t0 covers row t0 & 31 of the columns (t0 >> 5) + 2 k)
-            const int r = t0 & 31, cb = t0 >> 5;
+        // (S <= 32 rows; RW = 16 or 32 row lanes, ncb = 64 / RW column phases: thread t0 covers row t0 % RW of the columns
+        //  t0 / RW + ncb k — at p = 64 a window has 11 rows: with 32 row lanes two thirds of the wavefront sat idle here)
+        const int RW = (S > 16) ? 32 : 16, ncb = PSD_ZAPPLY_NT / RW;
+        PSD_PAR_FOR(t0, PSD_ZAPPLY_NT) {
+            const int r = t0 & (RW - 1), cb = t0 / RW;
             if (r >= S) continue;
-            for (int k0 = 0; k0 < T / 2; k0 += 8) {
+            for (int k0 = 0; k0 < T / ncb; k0 += 8) {
                 psd_z v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int c = cb + 2 * (k0 + u);
+                    const int c = cb + ncb * (k0 + u);
                     v[u] = z0;
                     if (c < nc) v[u] = M(d.plo + r, c0 + c);
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) tile[r * ldt + cb + 2 * (k0 + u)] = v[u];
+                for (int u = 0; u < 8; ++u) tile[r * ldt + cb + ncb * (k0 + u)] = v[u];
             }
         }
         const int order = psd_ztr_stage(gtr, cnt, ltr, flags);
@@ -1097,16 +1100,16 @@ PSD_D void psd_zq_apply_body(const psd_zparams& P, int n, int p, int role) {
             }
         }
         PSD_SYNC();
-        PSD_PAR_FOR(t0, 32 * 2) {
-            const int r = t0 & 31, cb = t0 >> 5;
+        PSD_PAR_FOR(t0, PSD_ZAPPLY_NT) {
+            const int r = t0 & (RW - 1), cb = t0 / RW;
             if (r >= S) continue;
-            for (int k0 = 0; k0 < T / 2; k0 += 8) {
+            for (int k0 = 0; k0 < T / ncb; k0 += 8) {
                 psd_z v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = tile[r * ldt + cb + 2 * (k0 + u)];
+                for (int u = 0; u < 8; ++u) v[u] = tile[r * ldt + cb + ncb * (k0 + u)];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int c = cb + 2 * (k0 + u);
+                    const int c = cb + ncb * (k0 + u);
                     if (c < nc) M(d.plo + r, c0 + c) = v[u];
                 }
             }
