@@ -1982,7 +1982,22 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
     // (the tile holds the rows a window's lists span: at most W + 1, not the 32 the kernel could serve — at p = 64 (W = 12) that is
     //  13.5 KiB instead of 33 KiB per single-wave workgroup, twelve of them per CU instead of four)
     const size_t lds_apply = PSD_ZTR_LDS_BYTES + (size_t)((W + 2 < 32) ? (W + 2) : 32) * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
+    const size_t lds_wl = lds_apply + sizeof(int) * 2 * (PSD_TRAIN_MAX + 2);  // (+ the work list's item table)
+#ifndef PSD_HOSTSIM
+    int wl_grid = 3072;  // (single-wave workgroups, 12 per CU)
+    if (const char* e = getenv("PSD_ZWL_GRID")) wl_grid = atoi(e);
+#else
+    const int wl_grid = 6;
+#endif
     const int tiles = (n + PSD_ZAPPLY_NT - 1) / PSD_ZAPPLY_NT;
+    // one role of the tick's bulk updates (pass: 1 columns, 2 rows, 3 Schur vectors): work list, or the grid-per-cursor form (PSD_APPLY_WL=0)
+    auto zapply = [&](psd_stream_t st_, const psd_zparams& Pz, int pass) -> int {
+        if (c->apply_worklist)
+            PSD_LAUNCH(psd_zq_apply_wl, psd_dim3(wl_grid), PSD_ZAPPLY_NT, lds_wl, st_, Pz, n, p, p + 8, pass, M, (int)lds_apply);
+        else
+            PSD_LAUNCH(psd_zq_apply_train, psd_dim3(tiles, p, M), PSD_ZAPPLY_NT, lds_apply, st_, Pz, n, p, p + 8, pass);
+        return 0;
+    };
     const int dtiles = (n + 255) / 256;
     const int batch = 32;
     psd_zstate hst;
@@ -2034,16 +2049,20 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
                 // Schur-vector updates one stream over (as iterate_dev: nothing reads Z_m before the iteration ends and only
                 // owner m's lists touch it): they start when the tick's H updates are done and run beside the next tick's
                 // chases; the lists of a tick are double-buffered by parity, the chase that reuses a parity awaits evF
-                PSD_LAUNCH(psd_zq_apply_train, psd_dim3(tiles, p, M), PSD_ZAPPLY_NT, lds_apply, c->stream, Pq, n, p, p + 8, 2);
-                PSD_LAUNCH(psd_zq_apply_train, psd_dim3(tiles, p, M), PSD_ZAPPLY_NT, lds_apply, c->stream, Pq, n, p, p + 8, 1);
+                PSD_CHECK(zapply(c->stream, Pq, 2));
+                PSD_CHECK(zapply(c->stream, Pq, 1));
 #ifndef PSD_HOSTSIM
                 PSD_CHECK(hipEventRecord(c->evE[par], c->stream));
                 PSD_CHECK(hipStreamWaitEvent(c->stream2, c->evE[par], 0));
-                PSD_LAUNCH(psd_zq_apply_train, psd_dim3(tiles, p, M), PSD_ZAPPLY_NT, lds_apply, c->stream2, Pq, n, p, p + 8, 3);
+                PSD_CHECK(zapply(c->stream2, Pq, 3));
                 PSD_CHECK(hipEventRecord(c->evF[par], c->stream2));
 #else
-                PSD_LAUNCH(psd_zq_apply_train, psd_dim3(tiles, p, M), PSD_ZAPPLY_NT, lds_apply, c->stream, Pq, n, p, p + 8, 3);
+                PSD_CHECK(zapply(c->stream, Pq, 3));
 #endif
+            } else if (c->apply_worklist) {
+                PSD_CHECK(zapply(c->stream, P, 2));
+                if (wantZ) PSD_CHECK(zapply(c->stream, P, 3));
+                PSD_CHECK(zapply(c->stream, P, 1));
             } else {
                 PSD_LAUNCH(psd_zq_apply_train, psd_dim3(tiles, p, 2 * M), PSD_ZAPPLY_NT, lds_apply, c->stream, P, n, p, p + 8, 0);
                 PSD_LAUNCH(psd_zq_apply_train, psd_dim3(tiles, p, M), PSD_ZAPPLY_NT, lds_apply, c->stream, P, n, p, p + 8, 1);

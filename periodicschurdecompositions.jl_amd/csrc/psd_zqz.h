@@ -1034,11 +1034,10 @@ PSD_D int psd_ztr_stage(const psd_ztr* gtr, int cnt, psd_ztr* ltr, int* flags) {
     return !flags[0] ? 1 : (!flags[1] ? -1 : 0);
 }
 
-PSD_D void psd_zq_apply_body(const psd_zparams& P, int n, int p, int role) {
+PSD_D void psd_zq_apply_item(const psd_zparams& P, int n, int p, int role, int bx, int m) {
     PSD_LDS_DECL;
     const psd_zapply_desc d = *P.desc;
     if (!d.active) return;
-    const int m = PSD_BLOCK_Y + 1;
     const int cnt = P.cnt[m - 1] < PSD_ZTR_CAP ? P.cnt[m - 1] : PSD_ZTR_CAP;
     if (cnt <= 0) return;
     const int T = PSD_ZAPPLY_NT;
@@ -1050,7 +1049,7 @@ PSD_D void psd_zq_apply_body(const psd_zparams& P, int n, int p, int role) {
     const psd_z z0 = zmk(0.0, 0.0);
     if (role == 0) {
         if (d.defer_h1 == 2 && m == 1) return;  // H_1's left side is deferred (upward pass of Case II)
-        const int c0 = d.lc0 + PSD_BLOCK_X * T;
+        const int c0 = d.lc0 + bx * T;
         if (c0 > d.lc1) return;
         const int nc = (d.lc1 - c0 + 1 < T) ? (d.lc1 - c0 + 1) : T;
         const psd_mat<psd_z> M = psd_mat<psd_z>{P.H + (size_t)(m - 1) * n * n, n};
@@ -1120,7 +1119,7 @@ PSD_D void psd_zq_apply_body(const psd_zparams& P, int n, int p, int role) {
         if (role == 2 && (m < P.zlo || m > P.zhi)) return;  // (another rank's Schur vectors)
         const int lo = (role == 1) ? d.rr0 : d.zr0;
         const int hi = (role == 1) ? d.rr1 : d.zr1;
-        const int r0 = lo + PSD_BLOCK_X * T;
+        const int r0 = lo + bx * T;
         if (r0 > hi) return;
         const int nr = (hi - r0 + 1 < T) ? (hi - r0 + 1) : T;
         psd_z* base = (role == 1) ? P.H : P.Z;
@@ -1168,6 +1167,8 @@ PSD_D void psd_zq_apply_body(const psd_zparams& P, int n, int p, int role) {
     }
 }
 
+PSD_D void psd_zq_apply_body(const psd_zparams& P, int n, int p, int role) { psd_zq_apply_item(P, n, p, role, PSD_BLOCK_X, PSD_BLOCK_Y + 1); }
+
 PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply(psd_zparams P, int n, int p) { psd_zq_apply_body(P, n, p, PSD_BLOCK_Z); }
 
 // bulk updates of all cursors of a tick in two launches (see psd_rq_apply_train)
@@ -1182,6 +1183,60 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply_train(psd_zparams P, int n, int p, int 
     Q.cnt = P.cnt + (size_t)b * cstride;
     Q.tr = P.tr + (size_t)b * p * PSD_ZTR_CAP;
     psd_zq_apply_body(Q, n, p, role);
+}
+
+// The same updates as a work list (as psd_rq_apply_wl of the real engine): a fixed grid of single-wave workgroups loops over
+// the items (cursor, owner, 64-line tile) of the tick's ACTIVE cursors.  The grid-per-cursor launches start tiles x p x M
+// workgroups of which most find their cursor idle (8 of 48 cursors have a window in an average tick at n = 1024) and all pay
+// the descriptor and list staging before their one tile.  pass: 1 columns of H_{m-1}, 2 rows of H_m, 3 Schur vectors.
+// tbl: byte offset of the item table behind the tile in LDS (2 (M + 1) ints).
+PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply_wl(psd_zparams P, int n, int p, int cstride, int pass, int M, int tbl) {
+    PSD_LDS_DECL;
+    int* ioff = (int*)(psd_lds + tbl);  // [M + 1]
+    int* nt = ioff + (M + 1);           // [M]
+    const int T = PSD_ZAPPLY_NT;
+    const int role = (pass == 1) ? 1 : ((pass == 2) ? 0 : 2);
+    PSD_PAR_FOR(b, M) {
+        const psd_zapply_desc d = P.desc[b];
+        int q = 0;
+        if (d.active) {
+            const int lo = (role == 0) ? d.lc0 : ((role == 1) ? d.rr0 : d.zr0);
+            const int hi = (role == 0) ? d.lc1 : ((role == 1) ? d.rr1 : d.zr1);
+            if (hi >= lo) q = (hi - lo + T) / T;
+        }
+        nt[b] = q;
+    }
+    PSD_SYNC();
+    PSD_ONE {
+        int acc = 0;
+        for (int b = 0; b < M; ++b) {
+            ioff[b] = acc;
+            acc += p * nt[b];
+        }
+        ioff[M] = acc;
+    }
+    PSD_SYNC();
+    const int total = ioff[M];
+    for (int item = PSD_BLOCK_X; item < total; item += PSD_GRID_X) {
+        int b = 0;
+        {  // last b with ioff[b] <= item (idle cursors repeat an offset)
+            int lo_ = 0, hi_ = M - 1;
+            while (lo_ < hi_) {
+                const int mid = (lo_ + hi_ + 1) >> 1;
+                if (ioff[mid] <= item) lo_ = mid;
+                else hi_ = mid - 1;
+            }
+            b = lo_;
+        }
+        const int q = item - ioff[b];
+        const int m = q / nt[b] + 1, bx = q - (m - 1) * nt[b];
+        psd_zparams Q = P;
+        Q.desc = P.desc + b;
+        Q.cnt = P.cnt + (size_t)b * cstride;
+        Q.tr = P.tr + (size_t)b * p * PSD_ZTR_CAP;
+        psd_zq_apply_item(Q, n, p, role, bx, m);
+        PSD_SYNC();  // (the list and the tile in LDS are reused by the next item)
+    }
 }
 
 // Deferred right side of H_1 after a zero-shift pass (generalized.jl:436-444):
