@@ -1984,7 +1984,7 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
     const size_t lds_apply = PSD_ZTR_LDS_BYTES + (size_t)((W + 2 < 32) ? (W + 2) : 32) * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
     const size_t lds_wl = lds_apply + sizeof(int) * 2 * (PSD_TRAIN_MAX + 2);  // (+ the work list's item table)
 #ifndef PSD_HOSTSIM
-    int wl_grid = 3072;  // (single-wave workgroups, 12 per CU)
+    int wl_grid = 2048;  // (single-wave workgroups; 1024 .. 2560 measured alike, 3072 and more slower)
     if (const char* e = getenv("PSD_ZWL_GRID")) wl_grid = atoi(e);
 #else
     const int wl_grid = 6;
