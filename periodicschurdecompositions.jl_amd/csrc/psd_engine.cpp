@@ -1912,6 +1912,19 @@ int zformq_dev(psd_ctx* c, int n, int p, const psd_z* dH, const psd_z* dtau, psd
     if (jhi <= jlo) return 0;
     PSD_LAUNCH(psd_zset_identity, psd_dim3(n, jhi - jlo), 64, 0, c->stream, dQ + (size_t)jlo * n * n, n);
     const size_t lds = PSD_HESS_NT * sizeof(psd_z);
+#ifndef PSD_HOSTSIM
+    if (n >= 64 && n <= 1024 && c->formq_blocked) {
+        // B reflectors per pass over the Q_j (psd_zformq_blk); PSD_FORMQ_BLOCKED=0: one launch per reflector
+        const int B = 8;
+        for (int i = n - 1; i >= 1; i -= B) {
+            const int ilow = (i - B + 1 >= 1) ? (i - B + 1) : 1;
+            const int tiles = (n - ilow + 1 + 3) / 4;
+            if (n <= 512) hipLaunchKernelGGL((psd_zformq_blk<8>), dim3(tiles, jhi - jlo), dim3(256), 0, c->stream, dH, dtau, dQ, n, i, B, jlo);
+            else hipLaunchKernelGGL((psd_zformq_blk<16>), dim3(tiles, jhi - jlo), dim3(256), 0, c->stream, dH, dtau, dQ, n, i, B, jlo);
+        }
+        return 0;
+    }
+#endif
     for (int i = n - 1; i >= 1; --i) {
         const int tiles = (n - i + 1 + 3) / 4;
         PSD_LAUNCH(psd_zformq_step, psd_dim3(tiles, jhi - jlo), PSD_HESS_NT, lds, c->stream, dH, dtau, dQ, n, i, jlo);

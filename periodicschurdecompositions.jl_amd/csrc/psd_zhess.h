@@ -221,6 +221,63 @@ PSD_KERNEL psd_zformq_step(const psd_z* Hp, const psd_z* tau, psd_z* Q, int n, i
     }
 }
 
+#ifndef PSD_HOSTSIM
+// B consecutive steps of that accumulation in one pass over Q_j (n <= 64 NR): one wavefront per column, the column (rows
+// cmin..n) in registers, reflectors i, i-1, .., i-B+1 applied to it one after the other (each read once).  The one-reflector
+// launches read every column twice and wrote it once per reflector (3 x 16 bytes per element and reflector: 192 ms for
+// Q_1..Q_64 at n = 1024, 3.8 TB/s); here the column moves once per B reflectors.  Rows of the column above a reflector's
+// first row are left alone; a column left of it holds zeros there, so applying the reflector to it changes nothing.
+template <int NR>
+__global__ void __launch_bounds__(256) psd_zformq_blk(const psd_z* Hp, const psd_z* tau, psd_z* Q, int n, int i, int B, int j0) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = j0 + (int)blockIdx.y + 1;
+    const int off1 = (j == 1) ? 1 : 0;
+    const int ilow = (i - B + 1 >= 1) ? (i - B + 1) : 1;
+    const int cmin = ilow + off1;  // first row (and column) any reflector of the block touches
+    const int c = cmin + 4 * (int)blockIdx.x + wave;
+    if (c > n) return;
+    const psd_z* V = Hp + (size_t)(j - 1) * n * n;
+    psd_z* M = Q + (size_t)(j - 1) * n * n;
+    psd_z a[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        const int r = cmin + lane + 64 * u;
+        a[u] = (r <= n) ? M[(size_t)(c - 1) * n + (r - 1)] : zmk(0.0, 0.0);
+    }
+    for (int ik = i; ik >= ilow; --ik) {
+        const int r0 = ik + off1;
+        if (r0 > n) continue;
+        const psd_z tj = tau[(size_t)(j - 1) * n + (ik - 1)];
+        if (ziszero(tj)) continue;
+        psd_z v[NR];
+        psd_z dot = zmk(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int r = cmin + lane + 64 * u;
+            v[u] = zmk(0.0, 0.0);
+            if (r == r0) v[u] = zmk(1.0, 0.0);
+            else if (r > r0 && r <= n) v[u] = V[(size_t)(ik - 1) * n + (r - 1)];
+            // (conj(v) a)
+            dot.re += v[u].re * a[u].re + v[u].im * a[u].im;
+            dot.im += v[u].re * a[u].im - v[u].im * a[u].re;
+        }
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            dot.re += __shfl_xor(dot.re, sft, 64);
+            dot.im += __shfl_xor(dot.im, sft, 64);
+        }
+        const psd_z va = zmul(tj, dot);
+#pragma unroll
+        for (int u = 0; u < NR; ++u) a[u] = zsub(a[u], zmul(va, v[u]));
+    }
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        const int r = cmin + lane + 64 * u;
+        if (r <= n) M[(size_t)(c - 1) * n + (r - 1)] = a[u];
+    }
+}
+#endif
+
 PSD_KERNEL psd_ztriu(psd_z* H, int n) {
     const int c = PSD_BLOCK_X + 1, j = PSD_BLOCK_Y + 1;
     const psd_mat<psd_z> M = psd_mat<psd_z>{H + (size_t)(j - 1) * n * n, n};

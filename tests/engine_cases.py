@@ -1397,6 +1397,24 @@ def case_pschur_hess_batch_one_fails(eng, n=24, p=3):
         eng.pschur_hess_batch_([(W[0], W[1:]) for W in Ws], maxitfac=2)
 
 
+def case_zformq_blocked(make_engine, sizes):
+    """ComplexF64: B reflectors per pass over the Q_j (csrc/psd_zhess.h, psd_zformq_blk) against one launch per reflector:
+    same T and eigenvalues, Z equal to rounding, unitary."""
+    blocked = make_engine({"PSD_FORMQ_BLOCKED": "1"})
+    plain = make_engine({"PSD_FORMQ_BLOCKED": "0"})
+    for (n, p, lr) in sizes:
+        A = pt.bench_factors(n, p, seed=300 + n + p, dtype=np.complex128)
+        pb = blocked.pschur(A, lr)
+        pp = plain.pschur(A, lr)
+        assert np.array_equal(pb.values, pp.values)
+        for j in range(p):
+            assert np.array_equal(pb.Ts[j], pp.Ts[j])
+            d = np.abs(pb.Z[j] - pp.Z[j]).max()
+            assert d < 50 * pt.EPS * np.sqrt(n), (n, p, j, d)
+            orth = np.linalg.norm(pb.Z[j].conj().T @ pb.Z[j] - np.eye(n))
+            assert orth < 10 * pt.EPS * n, (n, p, j, orth)
+
+
 def case_formq_blocked(make_engine, sizes):
     """Blocked (compact-WY, csrc/psd_formq2.h) against reflector-by-reflector (csrc/psd_hess.h) materialisation of the
     Q_j (PSD.jl:136-143): both engines reduce and iterate the same H, so their Z_j differ by the rounding of Q_j only.

@@ -156,3 +156,19 @@ def test_ordschur_supplementary_z(gpu_engine):
 
 def test_ztrains(gpu_engine):
     ec.case_ztrains(gpu_engine, [(150, 3, "R"), (120, 12, "L"), (256, 40, "R")])
+
+
+def test_zformq_blocked(monkeypatch):
+    """eight reflectors per pass over the Q_j against one launch per reflector; orders off the 64-row lanes and the
+    8-reflector blocks, both factor-1 and factor-j row offsets, both kernel instantiations (n <= 512, n <= 1024)"""
+    import torch
+
+    torch.cuda.init()
+    import psd_amd
+
+    def make(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        return psd_amd.Engine(device=0)
+
+    ec.case_zformq_blocked(make, [(64, 3, "R"), (97, 2, "L"), (130, 1, "R"), (257, 5, "R"), (520, 3, "L")])
