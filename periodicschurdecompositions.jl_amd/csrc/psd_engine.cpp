@@ -1915,7 +1915,7 @@ int zformq_dev(psd_ctx* c, int n, int p, const psd_z* dH, const psd_z* dtau, psd
 #ifndef PSD_HOSTSIM
     if (n >= 64 && n <= 1024 && c->formq_blocked) {
         // B reflectors per pass over the Q_j (psd_zformq_blk); PSD_FORMQ_BLOCKED=0: one launch per reflector
-        const int B = 8;
+        const int B = 16;
         for (int i = n - 1; i >= 1; i -= B) {
             const int ilow = (i - B + 1 >= 1) ? (i - B + 1) : 1;
             const int tiles = (n - ilow + 1 + 3) / 4;
