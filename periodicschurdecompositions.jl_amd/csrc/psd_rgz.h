@@ -60,6 +60,7 @@ struct psd_gstate {
     // multishift train (as psd_rstate): bulges wanted (-2: explicit-shift start without a train, test hook) / in the
     // running train / train number / this state's cursor / tick of the leader's first window / sweeps in trains
     int train_want, train_n, train_id, cursor, train_tick0, ntrainsweeps;
+    int cstart, cfirst;  // cursor: the tick of its first window and that window's number of positions (cursors W positions apart)
     int Wmax, train_oc;  // LDS layout width (W is the running sweep's, <= Wmax); o / c of the width rule (psd_rq_shift)
     double sh[4];  // this bulge's shift pair: rt1r, rt1i, rt2r, rt2i
 };
@@ -1006,7 +1007,7 @@ PSD_D void psd_gq_sweep_window(const psd_gparams& P, psd_gstate& st, double* lds
     const int n = st.n, p = st.p, ifirst = st.ifirst, ilast = st.ilast, ifirstm = st.ifirstm, ilastm = st.ilastm;
     const int ks = st.kcur;
     const bool first = (ks == ifirst);
-    int ke = first ? (ifirst + st.W - 4) : (ks + st.W - 5);
+    int ke = first ? (ifirst + ((st.cursor > 0 && st.cfirst > 0) ? st.cfirst : (st.W - 3)) - 1) : (ks + st.W - 5);  // (a cursor's first window: its part of the schedule)
     if (ke > ilast - 2) ke = ilast - 2;
     psd_gwin w;
     w.b = ldsd;
@@ -1586,10 +1587,11 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
         int nb = st.Wmax - 4, m = 1;
         double best = 1e300;
         for (int nbc = (st.Wmax - 4 < 8) ? ((st.Wmax > 5) ? st.Wmax - 4 : 1) : 8; nbc <= st.Wmax - 4 && mt >= 2; ++nbc) {
-            int mc = 1 + (w - nbc) / (2 * nbc);
+            // (cursors nbc + 4 = W positions apart — their windows only have to be disjoint; two windows apart before)
+            int mc = 1 + (w - nbc) / (nbc + 4);
             if (mc > mt) mc = mt;
             if (mc < 2) break;
-            const double cost = (double)((w + nbc - 1) / nbc + 2 * (mc - 1)) * (double)(nbc * p + st.train_oc) / mc;
+            const double cost = (double)((w + nbc - 1) / nbc + ((mc - 1) * (nbc + 4) + nbc - 1) / nbc) * (double)(nbc * p + st.train_oc) / mc;
             if (cost < best) {
                 best = cost;
                 nb = nbc;
@@ -1638,6 +1640,13 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
             for (int b = 1; b < st.train_n; ++b) {
                 psd_gstate cs = st;
                 cs.cursor = b;
+                {   // bulge b follows b W positions behind the leader, whose window starts at ifirst + 1 + d nb in tick tick0 + d (its
+                    // first window has nb + 1 positions): b's first window, D ticks after the leader's, has f positions
+                    const int nbw = st.W - 4, spc = st.W;
+                    const int D = (b * spc + nbw - 1) / nbw - 1;  // ceil(b W / nb) - 1
+                    cs.cstart = st.train_tick0 + D;
+                    cs.cfirst = 1 + (D + 1) * nbw - b * spc;      // 1 .. nb
+                }
                 cs.phase = PSD_GPH_CWAIT;
                 for (int q = 0; q < 4; ++q) cs.sh[q] = P.tshift[4 * b + q];
                 cs.kcur = 0;
@@ -1729,7 +1738,7 @@ PSD_D void psd_gq_cursor_body(const psd_gparams& P, int b) {
     const size_t winb = (size_t)st.p * st.Wmax * (st.Wmax + 1);
     int* lcnt = (int*)(ldsd + winb + PSD_NTHREADS) + 2 * PSD_NTHREADS;
     if (st.phase == PSD_GPH_CWAIT) {
-        if (P.tick < st.train_tick0 + 2 * b) return;
+        if (P.tick < st.cstart) return;
         double c1, s1, c2, s2;
         if (!psd_gq_start_explicit(P, st.n, st.p, st.ifirst, st.sh, ldsd, c1, s1, c2, s2)) {
             st.phase = PSD_GPH_CDONE;  // (not finite: this bulge is dropped)
@@ -2013,6 +2022,7 @@ PSD_KERNEL psd_gq_init(psd_gparams P, int n, int p, int wantT, int wantZ, int W,
         st.smlnum = PSD_DBL_MIN * ((double)n / PSD_DBL_EPS);
         for (int q = 0; q < 6; ++q) st.cyc[q] = 0;
         for (int q = 0; q < 8; ++q) { st.dbg[q] = 0; st.dbgn[q] = 0; }
+        st.cstart = 0; st.cfirst = 0;
         if (n == 0) st.phase = PSD_GPH_DONE;
         if (hessmode) {  // stage 2 of _phessenberg!(A, S): columns 1..n-2, positions n-1 down to hj+1
             st.phase = (n >= 3) ? PSD_GPH_HESS : PSD_GPH_DONE;
