@@ -64,7 +64,7 @@ int psd_create(psd_ctx** ctx, int device);
 int psd_destroy(psd_ctx* ctx);
 /* profile != 0: sample the chase kernel's duration with HIP events (every 16th launch) */
 int psd_set_profile(psd_ctx* ctx, int profile);
-/* Multishift trains in the real and the complex periodic QR / QZ iteration.  bulges >= 2 (default and maximum 32, 16 in the complex signed engine; PSD_TRAIN in the
+/* Multishift trains in the real and the complex periodic QR / QZ iteration.  bulges >= 2 (default and maximum 32 — the engines' own defaults: 32 real, 48 complex and real signed, 16 complex signed; PSD_TRAIN in the
  * environment presets it): a sweep of a large active block becomes a train of up to `bulges` double-shift sweeps whose
  * shifts are the eigenvalues of the trailing 2m x 2m block of the product (m <= 8; a longer train runs through the pairs
  * twice), chased as cursors two windows apart by one workgroup each, in windows whose width a cost model picks per train.  0 or 1: the reference's one-shift-one-sweep iteration (PSD.jl:729-763), sweep for sweep.  Same

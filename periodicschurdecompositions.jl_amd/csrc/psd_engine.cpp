@@ -285,7 +285,7 @@ struct psd_ctx {
     int *gascale = nullptr, *gcnt = nullptr, *glog = nullptr;
     size_t gstep_lds_set = 0, ghess_lds_set = 0;
     // multishift trains of the real signed engine (psd_set_train sets all engines; psd_set_train_g / PSD_TRAIN_G this one)
-    int gtrain_m = 32, gtcap_p = 0;
+    int gtrain_m = 48, gtcap_p = 0;  // (real signed engine: 48 bulges W positions apart; the complex signed one caps at 16)
     psd_gstate* gtcst = nullptr;
     double* gtshift = nullptr;
     psd_gapply_desc* gtdesc = nullptr;
@@ -1478,7 +1478,7 @@ int psd_set_train(psd_ctx* c, int bulges) {
     if (!c) return -1;
     c->train_m = (bulges < 0) ? 0 : ((bulges > 32) ? 32 : bulges);
     c->ztrain_m = c->gtrain_m = c->train_m;
-    if (c->train_m >= 32) c->ztrain_m = 48;  // (the maximum = every engine's own default)
+    if (c->train_m >= 32) c->ztrain_m = c->gtrain_m = 48;  // (the maximum = every engine's own default)
     return 0;
 }
 
@@ -1491,7 +1491,7 @@ int psd_set_train_z(psd_ctx* c, int bulges) {
 int psd_get_train_z(psd_ctx* c) { return c ? c->ztrain_m : -1; }
 int psd_set_train_g(psd_ctx* c, int bulges) {
     if (!c) return -1;
-    c->gtrain_m = (bulges == -2) ? -2 : ((bulges < 0) ? 0 : ((bulges > 32) ? 32 : bulges));
+    c->gtrain_m = (bulges == -2) ? -2 : ((bulges < 0) ? 0 : ((bulges > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : bulges));
     return 0;
 }
 int psd_get_train_g(psd_ctx* c) { return c ? c->gtrain_m : -1; }
