@@ -237,8 +237,10 @@ struct psd_ctx {
         hi = lo + base + (shard_rank < rem ? 1 : 0);
     }
     int train_stop = 1;    // a long train stops admitting bulges once one of them leaves the bottom converged (PSD_TRAIN_STOP=0: never)
-    int train_wdiv = 8;    // a long train has at most (range width) / train_wdiv bulges (PSD_TRAIN_WDIV; 4 is 3-15 % faster and
-                           // costs 40 % more residual: every bulge of a train passes over the whole range)
+    int train_wdiv = 8;    // a long train has at most (range width) / train_wdiv bulges (PSD_TRAIN_WDIV).  4 is 2.5 % (n = 1024, p = 64) to
+                           // 16 % (n = 512, p = 16) faster on the iteration and was tried as the default at the end of round 3: the
+                           // residual grows by 8-9 % on the bench inputs, and 1 of 485 random cases (n = 371, p = 8) left the residual
+                           // gate by 3.6 % (tests/gpu_fuzz_real.py; worst case 0.80 of the gate with 8) - not kept
     int train_long = 256;  // bulges per train of the multi-block scheduler when slots can be recycled (PSD_TRAIN_LONG; 0: one bulge per slot)
     int band_helper = 1;  // PSD_BAND_HELPER=0: a leader computes the product band of its decisions itself
     int overlap = 3;  // Schur-vector updates on stream2 beside the next tick's chases: 0 off, 2 on, 3 = on for n >= 1024 (PSD_OVERLAP)
