@@ -986,8 +986,8 @@ int launch_apply_wl(psd_ctx* c, psd_stream_t stream, const psd_rparams& Pq, int 
         return 0;
     }
 #endif
-    (void)W;
-    PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(grid_old), PSD_WL_NT, psd_wl_lds_bytes(), stream, Pq, n, p, p + 8, pass, NSL, zlo1, zhi1, mode);
+    const int ld = psd_wl_pitch(W);
+    PSD_LAUNCH(psd_rq_apply_wl, psd_dim3(grid_old), PSD_WL_NT, psd_wl_lds_bytes(ld), stream, Pq, n, p, p + 8, pass, NSL, zlo1, zhi1, mode, ld);
     return 0;
 }
 

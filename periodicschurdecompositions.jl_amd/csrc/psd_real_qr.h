@@ -2896,8 +2896,11 @@ PSD_KERNEL_B(PSD_APPLY_NT) psd_rq_apply_train(psd_rparams P, int n, int p, int c
 #define PSD_WL_NT 64
 #define PSD_WL_LINES 64
 #define PSD_WL_LD 33
-PSD_HD size_t psd_wl_lds_bytes() {
-    return PSD_TR_LDS_BYTES + (size_t)PSD_WL_LINES * PSD_WL_LD * sizeof(double) + (size_t)(3 * PSD_SLOTS + 4) * sizeof(int);
+// ld: pitch of a line in the tile (odd, >= the longest list span: W + 2 for windows of width W <= 30, PSD_WL_LD otherwise):
+// at p = 64 (W = 17) the tile takes 9.5 instead of 16.5 KiB and twice as many workgroups fit a CU
+PSD_HD int psd_wl_pitch(int W) { return (W + 2 < PSD_WL_LD) ? ((W + 2) | 1) : PSD_WL_LD; }
+PSD_HD size_t psd_wl_lds_bytes(int ld = PSD_WL_LD) {
+    return PSD_TR_LDS_BYTES + (size_t)PSD_WL_LINES * ld * sizeof(double) + (size_t)(3 * PSD_SLOTS + 4) * sizeof(int);
 }
 
 // the three-element window of one line moving up (UP) or down through positions; L: the line in LDS (S elements)
@@ -2947,15 +2950,18 @@ PSD_D void psd_wl_stream(double* L, int S, const psd_tr* ltr, int cnt, int plo) 
 // plo..phi, contiguous in memory): lane = (row pair 2 (t & 15), column t >> 4 of every group of four), sixteen 16-byte
 // accesses.  Column roles (lines = rows l0.., elements = columns plo..): lane = row l0 + t, one 8-byte access per
 // element, 512 contiguous bytes per wavefront and column.
+// (spans of at most 16 rows — p = 64: 15 — take 8 row-pair lanes x 8 columns per access instead of 16 x 4: with 16 row-pair
+//  lanes half of the wavefront idled in the rows role's transfers)
 PSD_D void psd_wl_load(bool rowsrole, const psd_mat<double>& Mx, int plo, int S, int l0, int nl, int t, double (&v)[32]) {
     if (rowsrole) {
-        const int rr = 2 * (t & 15), cq = t >> 4;
+        const bool narrow = S <= 16;
+        const int rr = narrow ? 2 * (t & 7) : 2 * (t & 15), cq = narrow ? (t >> 3) : (t >> 4), cs = narrow ? 8 : 4;
         const bool pair = rr + 1 < S;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            const int c = 4 * u + cq;
+            const int c = cs * u + cq;
             v[2 * u] = v[2 * u + 1] = 0.0;
-            if (rr < S && c < nl) {
+            if (rr < S && c < nl && c < PSD_WL_LINES) {
                 const double* src = &Mx(plo + rr, l0 + c);
                 if (pair) {
                     const psd_pair x = psd_pair_load(src);
@@ -2971,16 +2977,18 @@ PSD_D void psd_wl_load(bool rowsrole, const psd_mat<double>& Mx, int plo, int S,
         for (int u = 0; u < 32; ++u) v[u] = (t < nl && u < S) ? Mx(l0 + t, plo + u) : 0.0;
     }
 }
-PSD_D void psd_wl_to_tile(bool rowsrole, double* tile, int S, int nl, int t, const double (&v)[32]) {
-    const int LD = PSD_WL_LD;
+PSD_D void psd_wl_to_tile(bool rowsrole, double* tile, int LD, int S, int nl, int t, const double (&v)[32]) {
     if (rowsrole) {
-        const int rr = 2 * (t & 15), cq = t >> 4;
+        const bool narrow = S <= 16;
+        const int rr = narrow ? 2 * (t & 7) : 2 * (t & 15), cq = narrow ? (t >> 3) : (t >> 4), cs = narrow ? 8 : 4;
         if (rr < S) {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const int c = 4 * u + cq;
-                tile[c * LD + rr] = v[2 * u];
-                if (rr + 1 < S) tile[c * LD + rr + 1] = v[2 * u + 1];
+                const int c = cs * u + cq;
+                if (c < PSD_WL_LINES) {
+                    tile[c * LD + rr] = v[2 * u];
+                    if (rr + 1 < S) tile[c * LD + rr + 1] = v[2 * u + 1];
+                }
             }
         }
     } else if (t < nl) {
@@ -2989,16 +2997,16 @@ PSD_D void psd_wl_to_tile(bool rowsrole, double* tile, int S, int nl, int t, con
             if (u < S) tile[t * LD + u] = v[u];
     }
 }
-PSD_D void psd_wl_store(bool rowsrole, const psd_mat<double>& Mx, const double* tile, int plo, int S, int l0, int nl, int t) {
-    const int LD = PSD_WL_LD;
+PSD_D void psd_wl_store(bool rowsrole, const psd_mat<double>& Mx, const double* tile, int LD, int plo, int S, int l0, int nl, int t) {
     if (rowsrole) {
-        const int rr = 2 * (t & 15), cq = t >> 4;
+        const bool narrow = S <= 16;
+        const int rr = narrow ? 2 * (t & 7) : 2 * (t & 15), cq = narrow ? (t >> 3) : (t >> 4), cs = narrow ? 8 : 4;
         if (rr < S) {
             const bool pair = rr + 1 < S;
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const int c = 4 * u + cq;
-                if (c < nl) {
+                const int c = cs * u + cq;
+                if (c < nl && c < PSD_WL_LINES) {
                     double* dst = &Mx(plo + rr, l0 + c);
                     if (pair) {
                         psd_pair x;
@@ -3017,9 +3025,9 @@ PSD_D void psd_wl_store(bool rowsrole, const psd_mat<double>& Mx, const double* 
             if (u < S) Mx(l0 + t, plo + u) = tile[t * LD + u];
     }
 }
-PSD_D void psd_wl_compute(double* tile, int S, int nl, int t, int order, const psd_tr* ltr, int cnt, int plo) {
+PSD_D void psd_wl_compute(double* tile, int LD, int S, int nl, int t, int order, const psd_tr* ltr, int cnt, int plo) {
     if (t >= nl) return;
-    double* L = tile + t * PSD_WL_LD;
+    double* L = tile + t * LD;
     if (order > 0) {
         psd_wl_stream<true>(L, S, ltr, cnt, plo);
     } else if (order < 0) {
@@ -3057,12 +3065,12 @@ PSD_HD void psd_wl_ranges(psd_apply_desc& d, int mode, int cut) {
 // Nothing reads Z_m before the iteration ends and only owner m's lists touch it, so the Z updates of a tick only have to
 // stay in tick order among themselves: they run on a second stream beside the following ticks' chases.
 PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride, int pass, int M, int zlo, int zhi,
-                                        int mode) {
+                                        int mode, int ld) {
     PSD_LDS_DECL;
     psd_tr* ltr = (psd_tr*)psd_lds;
     int* flags = (int*)(psd_lds + sizeof(psd_tr) * PSD_TR_LDS_RECS);
     double* tile = (double*)(psd_lds + PSD_TR_LDS_BYTES);
-    int* ioff = (int*)(tile + (size_t)PSD_WL_LINES * PSD_WL_LD);  // [M + 1] item offsets, [M] groups A, [M] groups B
+    int* ioff = (int*)(tile + (size_t)PSD_WL_LINES * ld);  // [M + 1] item offsets, [M] groups A, [M] groups B
     int* tA = ioff + PSD_SLOTS + 2;
     int* tB = tA + PSD_SLOTS;
     const int TL = PSD_WL_LINES;
@@ -3202,15 +3210,15 @@ PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride
         for (int k = 0; k < ns; ++k) {
             const int l0 = g0 + k * TL;
             const int nl = (gl - k * TL < TL) ? (gl - k * TL) : TL;
-            psd_wl_to_tile(rowsrole, tile, S, nl, t, v);
+            psd_wl_to_tile(rowsrole, tile, ld, S, nl, t, v);
             PSD_SYNC();
             if (k + 1 < ns) {
                 const int nl1 = (gl - (k + 1) * TL < TL) ? (gl - (k + 1) * TL) : TL;
                 psd_wl_load(rowsrole, Mx, d.plo, S, l0 + TL, nl1, t, v);
             }
-            psd_wl_compute(tile, S, nl, t, order, ltr, cnt, d.plo);
+            psd_wl_compute(tile, ld, S, nl, t, order, ltr, cnt, d.plo);
             PSD_SYNC();
-            psd_wl_store(rowsrole, Mx, tile, d.plo, S, l0, nl, t);
+            psd_wl_store(rowsrole, Mx, tile, ld, d.plo, S, l0, nl, t);
             PSD_SYNC();
         }
 #else
@@ -3222,12 +3230,12 @@ PSD_KERNEL_B(PSD_WL_NT) psd_rq_apply_wl(psd_rparams P, int n, int p, int cstride
             PSD_PAR_FOR(t, PSD_WL_NT) {
                 double v[32];
                 psd_wl_load(rowsrole, Mx, d.plo, S, l0, nl, t, v);
-                psd_wl_to_tile(rowsrole, tile, S, nl, t, v);
+                psd_wl_to_tile(rowsrole, tile, ld, S, nl, t, v);
             }
             PSD_SYNC();
-            PSD_PAR_FOR(t, PSD_WL_NT) { psd_wl_compute(tile, S, nl, t, order, ltr, cnt, d.plo); }
+            PSD_PAR_FOR(t, PSD_WL_NT) { psd_wl_compute(tile, ld, S, nl, t, order, ltr, cnt, d.plo); }
             PSD_SYNC();
-            PSD_PAR_FOR(t, PSD_WL_NT) { psd_wl_store(rowsrole, Mx, tile, d.plo, S, l0, nl, t); }
+            PSD_PAR_FOR(t, PSD_WL_NT) { psd_wl_store(rowsrole, Mx, tile, ld, d.plo, S, l0, nl, t); }
             PSD_SYNC();
         }
 #endif
