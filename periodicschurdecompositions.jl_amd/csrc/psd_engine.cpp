@@ -500,7 +500,7 @@ struct psd_ctx {
             PSD_ALLOC(dZ, double, nn * p);
         }
         PSD_ALLOC(tau, double, (size_t)n * p);
-        PSD_ALLOC(vbuf, double, n + 8);
+        PSD_ALLOC(vbuf, double, 2 * (n + 8));  // (two reflectors: the QR sweeps of the signed reduction form the next one behind the panel update)
         PSD_ALLOC(hdiag, double, n + 8);
         PSD_ALLOC(hsub, double, n + 8);
         PSD_ALLOC(hsup, double, n + 8);
@@ -3129,8 +3129,10 @@ int sghess_dev(psd_ctx* c, int n, int p, double* dA, double* dQ, const uint8_t* 
             if (Ql) PSD_LAUNCH(psd_flip, psd_dim3(n), 256, 0, c->stream, Ql, n, 0);
         }
         for (int i = 1; i <= n - 1; ++i) {
-            PSD_LAUNCH(psd_hess_refl, psd_dim3(1), PSD_HESS_NT, lds_refl, c->stream, Al, n, i, i, c->vbuf,
-                       (double*)nullptr);
+            // (reflector i: by its own launch for the first column, behind the panel update of link i - 1 otherwise)
+            double* vcur = c->vbuf + (size_t)(i & 1) * (n + 8);
+            double* vnext = (i < n - 1) ? (c->vbuf + (size_t)((i + 1) & 1) * (n + 8)) : nullptr;
+            if (i == 1) PSD_LAUNCH(psd_hess_refl, psd_dim3(1), PSD_HESS_NT, lds_refl, c->stream, Al, n, i, i, vcur, (double*)nullptr);
             const int nL = (n - i + 3) / 4;   // columns i+1..n of A_l
             const int nR = (n + PSD_HESS_RS - 1) / PSD_HESS_RS;
             // one launch: A_l (+ Q_l) and the neighbour A_{l-1} (different matrices, same reflector)
@@ -3138,10 +3140,10 @@ int sghess_dev(psd_ctx* c, int n, int p, double* dA, double* dQ, const uint8_t* 
             const int nLm = (n + 3) / 4;
             if (mrows == 0) {
                 PSD_LAUNCH(psd_hess_apply2, psd_dim3(g1 + nR), PSD_HESS_NT, lds_apply, c->stream, Al, Ql, i + 1, nL, g1,
-                           (double*)nullptr, Am, 1, 0, n, i, (const double*)c->vbuf);
+                           (double*)nullptr, Am, 1, 0, n, i, (const double*)vcur, vnext);
             } else {
                 PSD_LAUNCH(psd_hess_apply2, psd_dim3(g1 + nLm), PSD_HESS_NT, lds_apply, c->stream, Al, Ql, i + 1, nL, g1, Am,
-                           (double*)nullptr, 1, nLm, n, i, (const double*)c->vbuf);
+                           (double*)nullptr, 1, nLm, n, i, (const double*)vcur, vnext);
             }
         }
         PSD_LAUNCH(psd_tril_zero, psd_dim3(n), 256, 0, c->stream, Al, n);

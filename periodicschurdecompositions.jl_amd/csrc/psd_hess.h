@@ -195,11 +195,18 @@ PSD_KERNEL psd_hess_apply(double* AL, double* AR, int n, int r0, int lc0, const 
 
 // two independent panel updates with the same reflector in one launch (stage 1 of the signed reduction: the factor
 // itself + its Q, and the neighbouring factor): blocks [0, g1) run the first operand set, the rest the second
+// vnext != nullptr: workgroup 0 — the one that has just updated column lc1 of AL1, the next reflector's column — forms that
+// reflector behind its update (rows r0 + 1.., into vnext; the launch of psd_hess_refl between two panel updates, one
+// workgroup, cost 5 us plus a launch gap per link of the QR sweeps)
 PSD_KERNEL psd_hess_apply2(double* AL1, double* AR1, int lc1, int nL1, int g1, double* AL2, double* AR2, int lc2, int nL2,
-                           int n, int r0, const double* vbuf) {
+                           int n, int r0, const double* vbuf, double* vnext) {
     const int b = PSD_BLOCK_X;
     if (b < g1) psd_hess_apply_body(AL1, AR1, n, r0, lc1, vbuf, nL1, b);
     else psd_hess_apply_body(AL2, AR2, n, r0, lc2, vbuf, nL2, b - g1);
+    if (b == 0 && vnext != nullptr) {
+        PSD_SYNC();
+        psd_hess_refl_body(AL1, n, r0 + 1, lc1, vnext, (double*)nullptr);
+    }
 }
 
 // Graph-replay form of one column of the reduction.  The reduction is n-1 columns x p links x 2 launches of small
