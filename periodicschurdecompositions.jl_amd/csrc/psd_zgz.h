@@ -27,6 +27,7 @@ struct psd_zgstate {
     long long cyc[6];
     // multishift train (as psd_gstate); -2: explicit-shift start without a train (test hook)
     int train_want, train_n, train_id, cursor, train_tick0, ntrainsweeps;
+    int cstart, cfirst;  // cursor: the tick of its first window and that window's number of positions (cursors W positions apart)
     int Wmax, train_oc;  // LDS layout width (W is the running sweep's, <= Wmax); o / c of the width rule (psd_rq_shift)
     psd_z sh;  // this bulge's shift
 };
@@ -370,7 +371,7 @@ PSD_D void psd_zgq_chain(const psd_zgparams& P, const psd_zgstate& st, const psd
 // generalized.jl:808-852: one window of the single-shift sweep
 PSD_D void psd_zgq_sweep_window(const psd_zgparams& P, psd_zgstate& st, psd_z* ldsz, int* lcnt) {
     const int n = st.n, p = st.p, ifirst = st.ifirst, ilast = st.ilast, ifirstm = st.ifirstm, ilastm = st.ilastm;
-    const int nb = st.W - 3;
+    const int nb = (st.cursor > 0 && st.cfirst > 0 && st.kcur == st.ifirst) ? st.cfirst : (st.W - 3);  // (a cursor's first window: the part inside the block)
     const int ks = st.kcur;
     const int ke = (ks + nb - 1 < ilast - 1) ? (ks + nb - 1) : (ilast - 1);
     psd_zwin w;
@@ -909,10 +910,10 @@ PSD_D void psd_zgq_check(const psd_zgparams& P, psd_zgstate& st, int* redi, psd_
         int nb = st.Wmax - 3, m = 1;
         double best = 1e300;
         for (int nbc = (st.Wmax - 3 < 8) ? ((st.Wmax > 4) ? st.Wmax - 3 : 1) : 8; nbc <= st.Wmax - 3 && mt >= 2; ++nbc) {
-            int mc = 1 + (w - nbc) / (2 * nbc);
+            int mc = 1 + (w - nbc) / (nbc + 3);  // (cursors nbc + 3 = W positions apart, as psd_zqz.h; two windows apart before)
             if (mc > mt) mc = mt;
             if (mc < 2) break;
-            const double cost = (double)((w + nbc - 1) / nbc + 2 * (mc - 1)) * (double)(nbc * p + st.train_oc) / mc;
+            const double cost = (double)((w + nbc - 1) / nbc + ((mc - 1) * (nbc + 3) + nbc - 1) / nbc) * (double)(nbc * p + st.train_oc) / mc;
             if (cost < best) {
                 best = cost;
                 nb = nbc;
@@ -953,6 +954,12 @@ PSD_D void psd_zgq_check(const psd_zgparams& P, psd_zgstate& st, int* redi, psd_
             for (int b = 1; b < st.train_n; ++b) {
                 psd_zgstate cs = st;
                 cs.cursor = b;
+                {
+                    const int nbw = st.W - 3, spc = st.W;
+                    const int d = (b * spc - nbw + 1 + nbw - 1) / nbw;  // ceil((b W - nb + 1) / nb) >= 1
+                    cs.cstart = st.train_tick0 + d;
+                    cs.cfirst = d * nbw - b * spc + nbw;                 // 1 .. nb positions
+                }
                 cs.phase = PSD_GPH_CWAIT;
                 cs.sh = P.tshift[b];
                 cs.kcur = 0;
@@ -1041,7 +1048,7 @@ PSD_D void psd_zgq_cursor_body(const psd_zgparams& P, int b) {
     const size_t winb = (size_t)st.p * st.Wmax * (st.Wmax + 1);
     int* lcnt = (int*)((double*)(ldsz + winb) + NT) + 2 * NT;
     if (st.phase == PSD_GPH_CWAIT) {
-        if (P.tick < st.train_tick0 + 2 * b) return;
+        if (P.tick < st.cstart) return;
         double c;
         psd_z s;
         if (!psd_zgq_start_rot_mu(P, st.n, st.p, st.ifirst, st.sh, c, s)) {
@@ -1224,7 +1231,7 @@ PSD_KERNEL psd_zgq_init(psd_zgparams P, int n, int p, int wantT, int wantZ, int 
         st.nsweeps = st.nzshift = st.nsplit = st.ncase2 = st.ncase3 = st.nwindows = st.nlog = 0;
         st.maxlog = maxlog;
         st.c0 = 1.0; st.s0 = zmk(0.0, 0.0);
-        st.train_want = hessmode ? 0 : train_want; st.train_n = 1; st.train_id = 0; st.cursor = 0; st.train_tick0 = 0;
+        st.train_want = hessmode ? 0 : train_want; st.train_n = 1; st.train_id = 0; st.cursor = 0; st.train_tick0 = 0; st.cstart = 0; st.cfirst = 0;
         st.ntrainsweeps = 0; st.sh = zmk(0.0, 0.0);
         st.ulp = PSD_DBL_EPS;
         st.safmin = PSD_DBL_MIN;
