@@ -469,7 +469,7 @@ struct psd_ctx {
             PSD_ALLOC(zZ, psd_z, nn * p);
         }
         PSD_ALLOC(ztau, psd_z, (size_t)n * p);
-        PSD_ALLOC(zvbuf, psd_z, n + 8);
+        PSD_ALLOC(zvbuf, psd_z, 2 * (n + 8));  // (two reflectors, as vbuf)
         PSD_ALLOC(zalpha, psd_z, n + 8);
         PSD_ALLOC(zbeta, double, n + 8);
         PSD_ALLOC(zascale, int, n + 8);
@@ -2352,7 +2352,9 @@ int zsghess_dev(psd_ctx* c, int n, int p, psd_z* dA, psd_z* dQ, const uint8_t* S
             if (Ql) PSD_LAUNCH(psd_zflip, psd_dim3(n), 256, 0, c->stream, Ql, n, 0);
         }
         for (int i = 1; i <= n - 1; ++i) {
-            PSD_LAUNCH(psd_zhess_refl, psd_dim3(1), PSD_HESS_NT, lds_refl, c->stream, Al, n, i, i, c->zvbuf, (psd_z*)nullptr);
+            psd_z* vcur = c->zvbuf + (size_t)(i & 1) * (n + 8);
+            psd_z* vnext = (i < n - 1) ? (c->zvbuf + (size_t)((i + 1) & 1) * (n + 8)) : nullptr;
+            if (i == 1) PSD_LAUNCH(psd_zhess_refl, psd_dim3(1), PSD_HESS_NT, lds_refl, c->stream, Al, n, i, i, vcur, (psd_z*)nullptr);
             const int nL = (n - i + 3) / 4;
             const int nR = (n + PSD_HESS_RS - 1) / PSD_HESS_RS;
             // one launch: A_l (+ Q_l) and the neighbour A_{l-1} (see sghess_dev)
@@ -2360,10 +2362,10 @@ int zsghess_dev(psd_ctx* c, int n, int p, psd_z* dA, psd_z* dQ, const uint8_t* S
             const int nLm = (n + 3) / 4;
             if (mrows == 0) {
                 PSD_LAUNCH(psd_zhess_apply2, psd_dim3(g1 + nR), PSD_HESS_NT, lds_apply, c->stream, Al, Ql, i + 1, nL, g1,
-                           (psd_z*)nullptr, Am, 1, 0, n, i, (const psd_z*)c->zvbuf);
+                           (psd_z*)nullptr, Am, 1, 0, n, i, (const psd_z*)vcur, vnext);
             } else {
                 PSD_LAUNCH(psd_zhess_apply2, psd_dim3(g1 + nLm), PSD_HESS_NT, lds_apply, c->stream, Al, Ql, i + 1, nL, g1, Am,
-                           (psd_z*)nullptr, 1, nLm, n, i, (const psd_z*)c->zvbuf);
+                           (psd_z*)nullptr, 1, nLm, n, i, (const psd_z*)vcur, vnext);
             }
         }
         PSD_LAUNCH(psd_ztril_zero, psd_dim3(n), 256, 0, c->stream, Al, n);

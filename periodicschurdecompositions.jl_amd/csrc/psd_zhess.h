@@ -7,7 +7,7 @@
 #include "psd_hess.h"
 
 // x = A[r0:n, c] -> (beta, v); vbuf[0] = tau, vbuf[1..m-1] = v
-PSD_KERNEL psd_zhess_refl(psd_z* A, int n, int r0, int c, psd_z* vbuf, psd_z* tau_out) {
+PSD_D void psd_zhess_refl_body(psd_z* A, int n, int r0, int c, psd_z* vbuf, psd_z* tau_out) {
     PSD_LDS_DECL;
     double* red = (double*)psd_lds;
     const int NT = PSD_NTHREADS;
@@ -83,6 +83,8 @@ PSD_KERNEL psd_zhess_refl(psd_z* A, int n, int r0, int c, psd_z* vbuf, psd_z* ta
         if (tau_out) *tau_out = tau;
     }
 }
+
+PSD_KERNEL psd_zhess_refl(psd_z* A, int n, int r0, int c, psd_z* vbuf, psd_z* tau_out) { psd_zhess_refl_body(A, n, r0, c, vbuf, tau_out); }
 
 // blocks [0,nL): AL[r0:n, lc0:n] <- H' AL ; blocks [nL,..): AR[:, r0:n] <- AR H
 PSD_D void psd_zhess_apply_body(psd_z* AL, psd_z* AR, int n, int r0, int lc0, const psd_z* vbuf, int nL, int b) {
@@ -163,10 +165,14 @@ PSD_KERNEL psd_zhess_apply(psd_z* AL, psd_z* AR, int n, int r0, int lc0, const p
 }
 // two independent panel updates with the same reflector in one launch (see psd_hess_apply2)
 PSD_KERNEL psd_zhess_apply2(psd_z* AL1, psd_z* AR1, int lc1, int nL1, int g1, psd_z* AL2, psd_z* AR2, int lc2, int nL2, int n,
-                            int r0, const psd_z* vbuf) {
+                            int r0, const psd_z* vbuf, psd_z* vnext) {
     const int b = PSD_BLOCK_X;
     if (b < g1) psd_zhess_apply_body(AL1, AR1, n, r0, lc1, vbuf, nL1, b);
     else psd_zhess_apply_body(AL2, AR2, n, r0, lc2, vbuf, nL2, b - g1);
+    if (b == 0 && vnext != nullptr) {  // (the next reflector behind the update of its column, see psd_hess_apply2)
+        PSD_SYNC();
+        psd_zhess_refl_body(AL1, n, r0 + 1, lc1, vnext, (psd_z*)nullptr);
+    }
 }
 
 PSD_KERNEL psd_zset_identity(psd_z* Q, int n) {
