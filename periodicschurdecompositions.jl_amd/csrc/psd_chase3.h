@@ -1,0 +1,425 @@
+// Scan chase (round 4): one position of the double-shift periodic QR sweep (PSD.jl:806-886) for ALL factors at once.
+//
+// The reference walks the factors one after the other: the reflector of factor j - 1 comes from column k of H_{j-1} as
+// the right update by the reflector of factor j left it (PSD.jl:846-861) — a chain of p dependent (reflector, update)
+// links per position, which is what the one- and two-wave chases of rounds 1-3 execute (~650 cycles per link).
+// But a reflector Q = I - tau v v' that maps x to beta e_1 has Q e_1 = x / beta: the column the next factor sees is
+//     H_{j-1}[k:k+2, k:k+2] Q_j e_1  =  U_{j-1} x(j) / beta_j ,     U_{j-1} the (upper triangular) 3 x 3 diagonal block,
+// and a reflector does not change when its vector is scaled.  So the DIRECTIONS of all p bulge vectors of a position are
+//     z(p) = U_p x(1),   z(j-1) = U_{j-1} z(j):   a chain of 3 x 3 triangular matrix-vector products,
+// three dependent multiply-adds per factor, with no reflector, no square root and no update on it.  The same holds for
+// the 2-reflectors (PSD.jl:865-881): y(j-1) = B_{j-1} y(j) / beta'_j with B_{j-1} the trailing 2 x 2 block of
+// Q_{j-1}' U_{j-1} Q_j, which each factor forms from its own and its neighbour's 3-reflector.  Then every reflector is
+// generated at once (one lane per factor), and all p factors are updated side by side by every wavefront of the workgroup:
+// a left and a right transformation of one block commute, and different factors share nothing.
+//
+// Per position: scan 1 (p - 1 steps) -> 3-reflectors -> B blocks -> scan 2 (p - 1 steps) -> 2-reflectors   [wavefront 0]
+//               barrier; right updates of H_2..H_p and the left update of H_1; barrier; left updates of H_2..H_p and the
+//               right update of H_1; barrier                                                               [all waves]
+// Numerics: the vector a reflector is generated from is U z (a product) instead of the updated column read back.  Both are
+// U_{j-1} times the SAME computed first column of Q_j, so they agree to rounding in the scale of U_{j-1} — the size of the
+// rounding errors of the reference's own update — and the entries the reflector is meant to annihilate are set to zero
+// exactly as the reference does (:851-854,869).  Every transformation is orthogonal to working precision whatever its
+// vector, so a loss of accuracy in a direction can cost convergence, never the decomposition.  The chain vectors are kept
+// in range by powers of two (blocks scaled to unit maximum, the vector every 16 steps).
+//
+// Lanes of the scan wavefront: lane j - 1 = factor j.  The chain runs 1 -> p -> p - 1 -> ... -> 2, so the scan is a
+// systolic array over lanes p - 1 .. 1 fed by wave_rol:1 (lane i reads lane i + 1): the lanes that are not factors 2..p
+// (lane 0 and lanes >= p) are constant sources that emit x(1), which lane p - 1 picks up; step s is valid in lane
+// p - 1 - s, and every lane keeps what it received and produced in ITS step.
+#pragma once
+
+#define PSD_C3_TAB 8      // doubles per factor in the reflector table: v2, v3, tau, w2, tau2, beta (factor 1), -, -
+#define PSD_C3_MAXP 64    // one lane per factor
+#define PSD_C3_MINP 2
+#define PSD_C3_WAVES 4    // wavefronts of a chase workgroup under the scan chase (one per SIMD)
+
+// exponent e with m 2^-e in [0.5, 1) for finite m > 0, else 0
+PSD_D int psd_c3_expo(double m) {
+    if (!(m > 0.0) || !(m < 1.7e308)) return 0;
+#ifdef PSD_HOSTSIM
+    int e = 0;
+    (void)frexp(m, &e);
+    return e;
+#else
+    return __builtin_amdgcn_frexp_exp(m);
+#endif
+}
+PSD_D double psd_c3_ldexp(double x, int e) {
+#ifdef PSD_HOSTSIM
+    return ldexp(x, e);
+#else
+    return __builtin_amdgcn_ldexp(x, e);
+#endif
+}
+PSD_D double psd_c3_max3(double a, double b, double c) { return fmax(fabs(a), fmax(fabs(b), fabs(c))); }
+
+// trailing 2 x 2 block of Q' U Qn: Q = I - tau [1;v1;v2][1;v1;v2]' this factor's 3-reflector, Qn the one that acts on
+// its columns (the next factor's, or H_1's for factor p), U upper triangular
+PSD_D void psd_c3_bblock(double u00, double u01, double u02, double u11, double u12, double u22, double v1, double v2,
+                         double tau, double v1n, double v2n, double taun, double& b00, double& b01, double& b10,
+                         double& b11) {
+    // R = U Qn = U - taun (U vn) vn'
+    const double s0 = taun * (u00 + u01 * v1n + u02 * v2n);
+    const double s1 = taun * (u11 * v1n + u12 * v2n);
+    const double s2 = taun * (u22 * v2n);
+    const double r01 = u01 - s0 * v1n, r02 = u02 - s0 * v2n;
+    const double r11 = u11 - s1 * v1n, r12 = u12 - s1 * v2n;
+    const double r21 = -s2 * v1n, r22 = u22 - s2 * v2n;
+    // C = Q' R = R - tau v (v' R), rows 1..2, columns 1..2
+    const double g1 = tau * (r01 + v1 * r11 + v2 * r21);
+    const double g2 = tau * (r02 + v1 * r12 + v2 * r22);
+    b00 = r11 - v1 * g1;
+    b01 = r12 - v1 * g2;
+    b10 = r21 - v2 * g1;
+    b11 = r22 - v2 * g2;
+}
+
+// the two kinds of update items of the apply phase (window image in LDS; q points at the first of the three elements,
+// sd is their stride: 1 along a column, ld along a row)
+//   three elements under a 3-reflector, then (with2) the last two under a 2-reflector
+PSD_D void psd_c3_item(double* q, int sd, double v1, double v2, double tau, bool with2, double w2, double tau2,
+                       int fix /* 0 none, 1: (a1, 0, 0), 2: (a1, a2, 0) */) {
+    double a1 = q[0], a2 = q[sd], a3 = q[2 * sd];
+    const double xx = tau * (a1 + v1 * a2 + v2 * a3);
+    a1 -= xx;
+    a2 -= xx * v1;
+    a3 -= xx * v2;
+    if (with2) {
+        const double yy = tau2 * (a2 + w2 * a3);
+        a2 -= yy;
+        a3 -= yy * w2;
+    }
+    if (fix == 1) a2 = 0.0;
+    if (fix >= 1) a3 = 0.0;
+    q[0] = a1;
+    q[sd] = a2;
+    q[2 * sd] = a3;
+}
+
+// the apply phase of one position for the items it (first, stride) of a workgroup-wide index space.  tab: reflector
+// table.  sub = 0: right updates of H_2..H_p, left update of H_1 (+ its annihilated column k - 1); sub = 1: left
+// updates of H_2..H_p, right update of H_1.
+PSD_D void psd_c3_apply(double* wb, const double* tab, int sub, int first, int stride, int p, int ld, int bsz, int bs,
+                        int k, int l, int r0, int nrw, int ncl) {
+    if (sub == 0) {
+        const int nA = (p - 1) * nrw;          // (factor j = 2 + it / nrw, row r0 + it % nrw)
+        const int nB = ncl + ((k > l) ? 1 : 0);  // H_1: columns k .. c1max, then column k - 1
+        for (int it = first; it < nA + nB; it += stride) {
+            if (it < nA) {
+                const int jf = it / nrw, r = r0 + (it - jf * nrw);
+                const int j = 2 + jf, jo = (j == p) ? 1 : (j + 1);
+                const double* t = tab + (jo - 1) * PSD_C3_TAB;
+                psd_c3_item(wb + (j - 1) * bsz + (k - bs) * ld + (r - bs), ld, t[0], t[1], t[2], jo != 1, t[3], t[4], 0);
+            } else {
+                const int cc = it - nA;
+                const double* t = tab;
+                if (cc < ncl) {
+                    psd_c3_item(wb + (k + cc - bs) * ld + (k - bs), 1, t[0], t[1], t[2], false, 0.0, 0.0, 0);
+                } else {  // PSD.jl:822-827
+                    double* q = wb + (k - 1 - bs) * ld + (k - bs);
+                    q[0] = t[5];
+                    q[1] = 0.0;
+                    q[2] = 0.0;
+                }
+            }
+        }
+    } else {
+        const int nA = (p - 1) * ncl;  // (factor j = 2 + it / ncl, column k + it % ncl)
+        const int nB = nrw;            // H_1: rows r0 .. rlim under Q_2, P_2
+        for (int it = first; it < nA + nB; it += stride) {
+            if (it < nA) {
+                const int jf = it / ncl, cc = it - jf * ncl;
+                const int j = 2 + jf;
+                const double* t = tab + (j - 1) * PSD_C3_TAB;
+                // column k: (beta, 0, 0) (PSD.jl:851-854); column k + 1: (., beta', 0) (:869); the others: both reflectors
+                psd_c3_item(wb + (j - 1) * bsz + (k + cc - bs) * ld + (k - bs), 1, t[0], t[1], t[2], cc >= 1, t[3], t[4],
+                            (cc == 0) ? 1 : ((cc == 1) ? 2 : 0));
+            } else {
+                const int r = r0 + (it - nA);
+                const double* t = tab + PSD_C3_TAB;  // owner 2
+                psd_c3_item(wb + (k - bs) * ld + (r - bs), ld, t[0], t[1], t[2], true, t[3], t[4], 0);
+            }
+        }
+    }
+}
+
+#ifndef PSD_HOSTSIM
+// lane i <- lane (i + 1) mod 64
+PSD_D double psd_c3_rol(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x134, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x134, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// full barrier of the chase workgroup: every LDS operation of every wavefront is done behind it
+#define PSD_C3_BARRIER() PSD_PAIR_BARRIER()
+
+// One run = positions ks .. ks + npos - 1 of a window, all with three-row bulges.  Called by every wavefront of the
+// workgroup (wv = its index, nw their number) with the same command block.
+PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_) {
+    PSD_LDS_DECL;
+    const int wv = PSD_C2_UNI(wv_), nw = PSD_C2_UNI(nw_), taboff = PSD_C2_UNI(taboff_);
+    const int p = PSD_C2_UNI(Cin.p), ld = PSD_C2_UNI(Cin.ld), bsz = PSD_C2_UNI(Cin.bsz), bs = PSD_C2_UNI(Cin.bs);
+    const int l = PSD_C2_UNI(Cin.l), ie = PSD_C2_UNI(Cin.i), ks = PSD_C2_UNI(Cin.ks), npos = PSD_C2_UNI(Cin.npos);
+    const int c1max = PSD_C2_UNI(Cin.c1max), r0 = PSD_C2_UNI(Cin.r0), n1 = PSD_C2_UNI(Cin.n1), nj = PSD_C2_UNI(Cin.nj);
+    double* const wb = (double*)(psd_lds + PSD_C2_UNI(Cin.wboff));
+    double* const tab = (double*)(psd_lds + taboff);
+    psd_tr* const trb = Cin.tr;
+    const int lane = (int)threadIdx.x;
+    const int tid = wv * 64 + lane, NT = nw * 64;
+    for (int kk = 0; kk < npos; ++kk) {
+        const int k = ks + kk;
+        const int rlim = (k + 3 < ie) ? (k + 3) : ie;
+        const int nrw = rlim - r0 + 1;
+        int ncl = c1max - k + 1;
+        if (ncl < 0) ncl = 0;
+        if (wv == 0) {
+            const bool fac = lane >= 1 && lane < p;  // factors 2..p; the other lanes emit x(1)
+            double x0, x1, x2;
+            if (k > l) {
+                const double* q = wb + (k - 1 - bs) * ld + (k - bs);
+                x0 = q[0];
+                x1 = q[1];
+                x2 = q[2];
+            } else {
+                x0 = Cin.v0;
+                x1 = Cin.v1;
+                x2 = Cin.v2;
+            }
+            const int ex = psd_c3_expo(psd_c3_max3(x0, x1, x2));
+            double u00 = 0.0, u01 = 0.0, u02 = 0.0, u11 = 0.0, u12 = 0.0, u22 = 0.0;
+            if (fac) {
+                const double* q = wb + lane * bsz + (k - bs) * ld + (k - bs);
+                u00 = q[0];
+                u01 = q[ld];
+                u11 = q[ld + 1];
+                u02 = q[2 * ld];
+                u12 = q[2 * ld + 1];
+                u22 = q[2 * ld + 2];
+                const int eu = psd_c3_expo(fmax(psd_c3_max3(u00, u01, u02), psd_c3_max3(u11, u12, u22)));
+                u00 = psd_c3_ldexp(u00, -eu);
+                u01 = psd_c3_ldexp(u01, -eu);
+                u02 = psd_c3_ldexp(u02, -eu);
+                u11 = psd_c3_ldexp(u11, -eu);
+                u12 = psd_c3_ldexp(u12, -eu);
+                u22 = psd_c3_ldexp(u22, -eu);
+            }
+            const double c0 = fac ? 0.0 : psd_c3_ldexp(x0, -ex), c1 = fac ? 0.0 : psd_c3_ldexp(x1, -ex),
+                         c2 = fac ? 0.0 : psd_c3_ldexp(x2, -ex);
+            // ---- scan 1
+            double z0 = c0, z1 = c1, z2 = c2, zo0 = 0.0, zo1 = 0.0, zo2 = 0.0;
+            const int mystep = p - 1 - lane;
+            for (int s = 0; s < p - 1; ++s) {
+                const double w0 = psd_c3_rol(z0), w1 = psd_c3_rol(z1), w2 = psd_c3_rol(z2);
+                z0 = __builtin_fma(u00, w0, __builtin_fma(u01, w1, __builtin_fma(u02, w2, c0)));
+                z1 = __builtin_fma(u11, w1, __builtin_fma(u12, w2, c1));
+                z2 = __builtin_fma(u22, w2, c2);
+                if (s == mystep) {
+                    zo0 = z0;
+                    zo1 = z1;
+                    zo2 = z2;
+                }
+                if ((s & 15) == 15) {
+                    const int e = psd_c3_expo(psd_c3_max3(z0, z1, z2));
+                    z0 = psd_c3_ldexp(z0, -e);
+                    z1 = psd_c3_ldexp(z1, -e);
+                    z2 = psd_c3_ldexp(z2, -e);
+                }
+            }
+            // ---- 3-reflectors: factor lanes from their chain vector, the others Q_1 from x(1)
+            double a0 = fac ? zo0 : x0, a1 = fac ? zo1 : x1, a2 = fac ? zo2 : x2;
+            const double tau = psd_refl3(a0, a1, a2);  // (a0, a1, a2) <- (beta, v2, v3)
+            const double v1 = a1, v2 = a2;
+            const double v1n = psd_c3_rol(v1), v2n = psd_c3_rol(v2), taun = psd_c3_rol(tau);
+            // ---- scan 2 on the trailing 2 x 2 blocks
+            double b00 = 0.0, b01 = 0.0, b10 = 0.0, b11 = 0.0;
+            if (fac) psd_c3_bblock(u00, u01, u02, u11, u12, u22, v1, v2, tau, v1n, v2n, taun, b00, b01, b10, b11);
+            const double d0 = fac ? 0.0 : 1.0;
+            double t0 = d0, t1 = 0.0, to0 = 0.0, to1 = 0.0;
+            for (int s = 0; s < p - 1; ++s) {
+                const double w0 = psd_c3_rol(t0), w1 = psd_c3_rol(t1);
+                t0 = __builtin_fma(b00, w0, __builtin_fma(b01, w1, d0));
+                t1 = __builtin_fma(b10, w0, b11 * w1);
+                if (s == mystep) {
+                    to0 = t0;
+                    to1 = t1;
+                }
+                if ((s & 15) == 15) {
+                    const int e = psd_c3_expo(fmax(fabs(t0), fabs(t1)));
+                    t0 = psd_c3_ldexp(t0, -e);
+                    t1 = psd_c3_ldexp(t1, -e);
+                }
+            }
+            double y0 = to0, y1 = to1;
+            const double tau2 = fac ? psd_refl2(y0, y1) : 0.0;  // (y0, y1) <- (beta', w2)
+            const double w2v = fac ? y1 : 0.0;
+            if (lane < p) {
+                double* t = tab + lane * PSD_C3_TAB;
+                t[0] = v1;
+                t[1] = v2;
+                t[2] = tau;
+                t[3] = w2v;
+                t[4] = tau2;
+                t[5] = a0;  // (beta of this lane's vector: used for factor 1 only, whose vector is the true x(1))
+                psd_tr tr;
+                tr.pos = k;
+                tr.kind = PSD_TR_R3;
+                tr.c0 = v1;
+                tr.c1 = v2;
+                tr.c2 = tau;
+                const int slot = (lane == 0) ? (n1 + kk) : (nj + 2 * kk);
+                if (slot < PSD_TR_CAP) psd_tr_store_global(trb + (size_t)lane * PSD_TR_CAP + slot, tr);
+                if (lane >= 1 && slot + 1 < PSD_TR_CAP) {
+                    tr.pos = k + 1;
+                    tr.kind = PSD_TR_H2;
+                    tr.c0 = w2v;
+                    tr.c1 = 0.0;
+                    tr.c2 = tau2;
+                    psd_tr_store_global(trb + (size_t)lane * PSD_TR_CAP + slot + 1, tr);
+                }
+            }
+        }
+        PSD_C3_BARRIER();
+        psd_c3_apply(wb, tab, 0, tid, NT, p, ld, bsz, bs, k, l, r0, nrw, ncl);
+        PSD_C3_BARRIER();
+        psd_c3_apply(wb, tab, 1, tid, NT, p, ld, bsz, bs, k, l, r0, nrw, ncl);
+        PSD_C3_BARRIER();
+    }
+}
+#else
+// The simulated tier: the same steps, the lanes of the scan wavefront as array slots.
+PSD_D void psd_c3_run(const psd_c2& Cin, int, int, int taboff) {
+    PSD_LDS_DECL;
+    const int p = Cin.p, ld = Cin.ld, bsz = Cin.bsz, bs = Cin.bs, l = Cin.l, ie = Cin.i, ks = Cin.ks, npos = Cin.npos;
+    const int c1max = Cin.c1max, r0 = Cin.r0, n1 = Cin.n1, nj = Cin.nj;
+    double* const wb = (double*)(psd_lds + Cin.wboff);
+    double* const tab = (double*)(psd_lds + taboff);
+    psd_tr* const trb = Cin.tr;
+    for (int kk = 0; kk < npos; ++kk) {
+        const int k = ks + kk;
+        const int rlim = (k + 3 < ie) ? (k + 3) : ie;
+        const int nrw = rlim - r0 + 1;
+        int ncl = c1max - k + 1;
+        if (ncl < 0) ncl = 0;
+        double x0, x1, x2;
+        if (k > l) {
+            const double* q = wb + (k - 1 - bs) * ld + (k - bs);
+            x0 = q[0];
+            x1 = q[1];
+            x2 = q[2];
+        } else {
+            x0 = Cin.v0;
+            x1 = Cin.v1;
+            x2 = Cin.v2;
+        }
+        const int ex = psd_c3_expo(psd_c3_max3(x0, x1, x2));
+        double U[64][6], c[64][3], z[64][3], zo[64][3];
+        bool fac[64];
+        for (int lane = 0; lane < 64; ++lane) {
+            fac[lane] = lane >= 1 && lane < p;
+            for (int q = 0; q < 6; ++q) U[lane][q] = 0.0;
+            if (fac[lane]) {
+                const double* q = wb + lane * bsz + (k - bs) * ld + (k - bs);
+                double u[6] = {q[0], q[ld], q[2 * ld], q[ld + 1], q[2 * ld + 1], q[2 * ld + 2]};  // u00 u01 u02 u11 u12 u22
+                const int eu = psd_c3_expo(fmax(psd_c3_max3(u[0], u[1], u[2]), psd_c3_max3(u[3], u[4], u[5])));
+                for (int t = 0; t < 6; ++t) U[lane][t] = psd_c3_ldexp(u[t], -eu);
+            }
+            c[lane][0] = fac[lane] ? 0.0 : psd_c3_ldexp(x0, -ex);
+            c[lane][1] = fac[lane] ? 0.0 : psd_c3_ldexp(x1, -ex);
+            c[lane][2] = fac[lane] ? 0.0 : psd_c3_ldexp(x2, -ex);
+            for (int t = 0; t < 3; ++t) {
+                z[lane][t] = c[lane][t];
+                zo[lane][t] = 0.0;
+            }
+        }
+        for (int s = 0; s < p - 1; ++s) {
+            double w[64][3];
+            for (int lane = 0; lane < 64; ++lane)
+                for (int t = 0; t < 3; ++t) w[lane][t] = z[(lane + 1) & 63][t];
+            for (int lane = 0; lane < 64; ++lane) {
+                const double* u = U[lane];
+                z[lane][0] = u[0] * w[lane][0] + (u[1] * w[lane][1] + (u[2] * w[lane][2] + c[lane][0]));
+                z[lane][1] = u[3] * w[lane][1] + (u[4] * w[lane][2] + c[lane][1]);
+                z[lane][2] = u[5] * w[lane][2] + c[lane][2];
+                if (s == p - 1 - lane)
+                    for (int t = 0; t < 3; ++t) zo[lane][t] = z[lane][t];
+                if ((s & 15) == 15) {
+                    const int e = psd_c3_expo(psd_c3_max3(z[lane][0], z[lane][1], z[lane][2]));
+                    for (int t = 0; t < 3; ++t) z[lane][t] = psd_c3_ldexp(z[lane][t], -e);
+                }
+            }
+        }
+        double v1[64], v2[64], tau[64], beta[64];
+        for (int lane = 0; lane < 64; ++lane) {
+            double a0 = fac[lane] ? zo[lane][0] : x0, a1 = fac[lane] ? zo[lane][1] : x1, a2 = fac[lane] ? zo[lane][2] : x2;
+            tau[lane] = psd_refl3(a0, a1, a2);
+            v1[lane] = a1;
+            v2[lane] = a2;
+            beta[lane] = a0;
+        }
+        double B[64][4], d0[64], t2[64][2], to[64][2];
+        for (int lane = 0; lane < 64; ++lane) {
+            for (int q = 0; q < 4; ++q) B[lane][q] = 0.0;
+            const int nb = (lane + 1) & 63;
+            if (fac[lane]) {
+                const double* u = U[lane];
+                psd_c3_bblock(u[0], u[1], u[2], u[3], u[4], u[5], v1[lane], v2[lane], tau[lane], v1[nb], v2[nb], tau[nb],
+                              B[lane][0], B[lane][1], B[lane][2], B[lane][3]);
+            }
+            d0[lane] = fac[lane] ? 0.0 : 1.0;
+            t2[lane][0] = d0[lane];
+            t2[lane][1] = 0.0;
+            to[lane][0] = to[lane][1] = 0.0;
+        }
+        for (int s = 0; s < p - 1; ++s) {
+            double w[64][2];
+            for (int lane = 0; lane < 64; ++lane)
+                for (int t = 0; t < 2; ++t) w[lane][t] = t2[(lane + 1) & 63][t];
+            for (int lane = 0; lane < 64; ++lane) {
+                t2[lane][0] = B[lane][0] * w[lane][0] + (B[lane][1] * w[lane][1] + d0[lane]);
+                t2[lane][1] = B[lane][2] * w[lane][0] + B[lane][3] * w[lane][1];
+                if (s == p - 1 - lane) {
+                    to[lane][0] = t2[lane][0];
+                    to[lane][1] = t2[lane][1];
+                }
+                if ((s & 15) == 15) {
+                    const int e = psd_c3_expo(fmax(fabs(t2[lane][0]), fabs(t2[lane][1])));
+                    t2[lane][0] = psd_c3_ldexp(t2[lane][0], -e);
+                    t2[lane][1] = psd_c3_ldexp(t2[lane][1], -e);
+                }
+            }
+        }
+        for (int lane = 0; lane < p; ++lane) {
+            double y0 = to[lane][0], y1 = to[lane][1];
+            const double tau2 = fac[lane] ? psd_refl2(y0, y1) : 0.0;
+            const double w2v = fac[lane] ? y1 : 0.0;
+            double* t = tab + lane * PSD_C3_TAB;
+            t[0] = v1[lane];
+            t[1] = v2[lane];
+            t[2] = tau[lane];
+            t[3] = w2v;
+            t[4] = tau2;
+            t[5] = beta[lane];
+            psd_tr tr;
+            tr.pos = k;
+            tr.kind = PSD_TR_R3;
+            tr.c0 = v1[lane];
+            tr.c1 = v2[lane];
+            tr.c2 = tau[lane];
+            const int slot = (lane == 0) ? (n1 + kk) : (nj + 2 * kk);
+            if (slot < PSD_TR_CAP) psd_tr_store_global(trb + (size_t)lane * PSD_TR_CAP + slot, tr);
+            if (lane >= 1 && slot + 1 < PSD_TR_CAP) {
+                tr.pos = k + 1;
+                tr.kind = PSD_TR_H2;
+                tr.c0 = w2v;
+                tr.c1 = 0.0;
+                tr.c2 = tau2;
+                psd_tr_store_global(trb + (size_t)lane * PSD_TR_CAP + slot + 1, tr);
+            }
+        }
+        psd_c3_apply(wb, tab, 0, 0, 1, p, ld, bsz, bs, k, l, r0, nrw, ncl);
+        psd_c3_apply(wb, tab, 1, 0, 1, p, ld, bsz, bs, k, l, r0, nrw, ncl);
+    }
+}
+#endif

@@ -82,9 +82,15 @@ int choose_window(int p, int esize = 8, bool even = false) {
         if (step_lds_bytes(p, W, esize, even) <= (size_t)160 * 1024) return W;
     return 0;
 }
-size_t step_lds_bytes(int p, int W, int esize = 8, bool even = false) {
+// (real standard engine, even = true: the reflector table of the scan chase, psd_chase3.h, sits behind the scratch)
+size_t step_lds_scratch_end(int p, int W, int esize, bool even) {
     const size_t area = even ? (size_t)psd_win_area(W) : (size_t)W * (W + 1);
     size_t b = (size_t)p * area * esize + PSD_STEP_NT * 8 + (2 * PSD_STEP_NT + (size_t)p) * 4;
+    return (b + 15) & ~(size_t)15;
+}
+size_t step_lds_bytes(int p, int W, int esize = 8, bool even = false) {
+    size_t b = step_lds_scratch_end(p, W, esize, even);
+    if (even && p <= PSD_C3_MAXP) b += (size_t)p * PSD_C3_TAB * sizeof(double);
     return (b + 15) & ~(size_t)15;
 }
 // ordschur! alignments (ordschur.jl:20-33, rordschur.jl:15-27, utils.jl:6-85): the swap kernels work on the right-
@@ -243,6 +249,8 @@ struct psd_ctx {
                            // gate by 3.6 % (tests/gpu_fuzz_real.py; worst case 0.80 of the gate with 8) - not kept
     int train_long = 256;  // bulges per train of the multi-block scheduler when slots can be recycled (PSD_TRAIN_LONG; 0: one bulge per slot)
     int band_helper = 1;  // PSD_BAND_HELPER=0: a leader computes the product band of its decisions itself
+    int cdefer = 1;   // far rows of the column roles on stream2 beside the next tick's chases (psd_cdefer_edge): 0 off, 1 where the
+                      // Schur vectors go there too (`overlap`), 2 always (PSD_CDEFER)
     int overlap = 3;  // Schur-vector updates on stream2 beside the next tick's chases: 0 off, 2 on, 3 = on for n >= 1024 (PSD_OVERLAP)
     int far_grid = 0;  // grid of the far bulk-update launches (0: apply_wl_grid)
     bool counted = false;  // (this context is in g_live_contexts)
@@ -251,10 +259,11 @@ struct psd_ctx {
     hipStream_t stream3 = nullptr;  // the panel updates of the Hessenberg reduction (beside its chain)
     hipStream_t stream4 = nullptr;  // every other chain launch of the Hessenberg reduction in pipe mode (hessenberg2_pipe)
     int hess_pipe = 1;              // PSD_H2_PIPE=0: chain launches back to back on one stream; 2: pipe form also beside other contexts
-    hipEvent_t evE[2] = {nullptr, nullptr}, evF[2] = {nullptr, nullptr};
+    hipEvent_t evE[2] = {nullptr, nullptr}, evF[2] = {nullptr, nullptr}, evG[2] = {nullptr, nullptr};
 #endif
     int apply_worklist = 1;   // PSD_APPLY_WL=0: the grid-per-cursor bulk-apply kernels
     int apply_wl_grid = 2048; // workgroups of the work-list bulk apply (PSD_APPLY_WL_GRID)
+    int chase3 = 1;           // scan chase of the real periodic QR sweep (psd_chase3.h; PSD_C3=0: the two-wave / one-wave chases)
     int chase2 = 1;           // two-wave chase of the real periodic QR sweep (psd_c2_run; PSD_C2=0: one wavefront per bulge)
     int apply_wl2 = 1;        // register-line form of the work-list bulk apply (psd_apply2.h) where it is the faster one; PSD_APPLY_WL2=0: never, 2: always
     int apply_wl2_grid = 1024;  // its grid of four-wave workgroups (PSD_APPLY_WL2_GRID)
@@ -1042,8 +1051,13 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     P.ccancel = nullptr;
     P.plan = nullptr;
     // two-wave chase (psd_c2_run): the command block sits in the reduction scratch behind the window image
-    P.c2off = (c->chase2 && p >= PSD_C2_MINP) ? (int)((size_t)p * psd_win_area(W) * sizeof(double)) : 0;
-    const int c2waves = P.c2off ? 2 : 1;
+    // scan chase (psd_chase3.h, the default): PSD_C3_WAVES wavefronts per chase workgroup, the command block where the
+    // two-wave chase has it, the reflector table behind the scratch
+    const bool scan3 = c->chase3 && p >= PSD_C3_MINP && p <= PSD_C3_MAXP;
+    P.c2off = (scan3 || (c->chase2 && p >= PSD_C2_MINP)) ? (int)((size_t)p * psd_win_area(W) * sizeof(double)) : 0;
+    P.c3off = scan3 ? (int)step_lds_scratch_end(p, W, 8, true) : 0;
+    P.cdefer = 0;
+    const int c2waves = scan3 ? PSD_C3_WAVES : (P.c2off ? 2 : 1);
     (void)c2waves;
     // Every way out of this function (the runaway cap, a failed runtime call) first waits for the second stream — its
     // Schur-vector launches read the caller's dZ and the lists — and frees the tick log.
@@ -1082,7 +1096,11 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     // leaders of independent active ranges and the cursors of their trains
     const bool mb = ((M > 1) && c->mblock) || bws != nullptr;  // (a batch always runs on the slot scheduler)
     const int NSL = mb ? PSD_SLOTS : M;
-    const bool zdef = mb && wantZ && (c->overlap == 2 || (c->overlap == 3 && n >= 1024));  // Schur-vector updates on the second stream, beside the next chases
+    const bool ovl2 = mb && (c->overlap == 2 || (c->overlap == 3 && n >= 1024));
+    const bool zdef = ovl2 && wantZ;  // Schur-vector updates on the second stream, beside the next chases
+    const bool cdef = mb && c->cdefer && (c->cdefer == 2 || ovl2) && nprob == 1;  // far rows of the column roles likewise (psd_cdefer_edge)
+    bool far_pending = false;  // (the far column roles of the previous tick have been launched / are still to run)
+    P.cdefer = cdef ? 1 : 0;
     if (M > 1 || mb) {
         PSD_CHECK(c->treserve(p));
         PSD_CHECK(psd_rt_memset(c->tgl, 0, sizeof(psd_rglobal), c->stream));
@@ -1145,7 +1163,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     for (;;) {
         for (int b = 0; b < batch; ++b) {
 #ifndef PSD_HOSTSIM
-            if (zdef && launched >= 2) PSD_CHECK(hipStreamWaitEvent(c->stream, c->evF[(int)(launched & 1)], 0));
+            if ((zdef || cdef) && launched >= 2) PSD_CHECK(hipStreamWaitEvent(c->stream, c->evF[(int)(launched & 1)], 0));
 #endif
             P.tick = (int)launched;
             // ticks alternate between two sets of descriptors / counts / lists (multi-block mode)
@@ -1186,21 +1204,45 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 pend.emplace_back(ev0, ev1);
             }
 #endif
-            if (zdef) {
+            if (zdef || cdef) {
                 // Schur-vector updates one stream over (psd_rq_apply_wl modes 3 / 4): the Z launch of this tick starts on
                 // stream2 when the tick's H updates are done (evE) — beside the NEXT tick's chases, which leave most of the
                 // chip idle — and its lists must not be rewritten before it is done (evF, awaited in front of the chase
                 // that reuses this parity's lists, two ticks on).  The serial simulation runs the Z launch last.
+                // The far rows of the column roles (modes 5 / 6, psd_cdefer_edge) go the same way, in front of the Z launch:
+                // the next tick's rows roles cross them, so that launch waits for them (evG); nothing else reads them
+                // earlier.  The serial simulation runs them at the latest point the streams allow — behind the next
+                // tick's chases — which shows that no chase, band or decision depends on them.
                 const int wl_grid = c->apply_wl_grid;
-                PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 3, W, wl_grid));
-                PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 1, NSL, zlo1, zhi1, 3, W, wl_grid));
+                const int hmode = cdef ? 5 : 3;
+                if (cdef && far_pending) {
+#ifndef PSD_HOSTSIM
+                    PSD_CHECK(hipStreamWaitEvent(c->stream, c->evG[par ^ 1], 0));
+#else
+                    PSD_CHECK(launch_apply_wl(c, c->stream, Pprev, n, p, 1, NSL, zlo1, zhi1, 6, W, wl_grid));
+#endif
+                    far_pending = false;
+                }
+                if (!zdef && wantZ) {  // (the Schur vectors stay on this stream)
+                    PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 0, W, wl_grid));
+                } else {
+                    PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 3, W, wl_grid));
+                }
+                PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 1, NSL, zlo1, zhi1, hmode, W, wl_grid));
 #ifndef PSD_HOSTSIM
                 PSD_CHECK(hipEventRecord(c->evE[par], c->stream));
                 PSD_CHECK(hipStreamWaitEvent(c->stream2, c->evE[par], 0));
-                PSD_CHECK(launch_apply_wl(c, c->stream2, Pq, n, p, 0, NSL, zlo1, zhi1, 4, W, c->far_grid > 0 ? c->far_grid : wl_grid));
+                const int fgrid = c->far_grid > 0 ? c->far_grid : wl_grid;
+                if (cdef) {
+                    PSD_CHECK(launch_apply_wl(c, c->stream2, Pq, n, p, 1, NSL, zlo1, zhi1, 6, W, fgrid));
+                    PSD_CHECK(hipEventRecord(c->evG[par], c->stream2));
+                    far_pending = true;
+                }
+                if (zdef) PSD_CHECK(launch_apply_wl(c, c->stream2, Pq, n, p, 0, NSL, zlo1, zhi1, 4, W, fgrid));
                 PSD_CHECK(hipEventRecord(c->evF[par], c->stream2));
 #else
-                PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 4, W, wl_grid));
+                if (cdef) far_pending = true;
+                if (zdef) PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 4, W, wl_grid));
 #endif
             } else if (c->apply_worklist || c->shard_world > 1 || mb) {
                 // work-list form: one grid of single-wave workgroups loops over the items of the tick
@@ -1283,7 +1325,17 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
         }
     }
 #ifndef PSD_HOSTSIM
-    if (zdef) PSD_CHECK(hipStreamSynchronize(c->stream2));
+    if (zdef || cdef) PSD_CHECK(hipStreamSynchronize(c->stream2));
+#else
+    if (cdef && far_pending) {  // (the last tick's far column roles: its parity is the one the last launch used)
+        psd_rparams Pl = P;
+        const int parl = (int)((launched - 1) & 1);
+        Pl.desc = P.desc + (size_t)parl * PSD_SLOTS;
+        Pl.cnt = P.cnt + (size_t)parl * PSD_SLOTS * (p + 8);
+        Pl.tr = P.tr + (size_t)parl * PSD_SLOTS * p * PSD_TR_CAP;
+        PSD_CHECK(launch_apply_wl(c, c->stream, Pl, n, p, 1, NSL, zlo1, zhi1, 6, W, c->apply_wl_grid));
+        far_pending = false;
+    }
 #endif
 #ifndef PSD_HOSTSIM
     PSD_CHECK(poller.finish(pend));
@@ -1394,7 +1446,8 @@ int psd_create(psd_ctx** ctx, int device) {
         if (hipHostMalloc(&c->pin[q], 4096, hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&c->pev[q], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->evE[q], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->evF[q], hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&c->evF[q], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->evG[q], hipEventDisableTiming) != hipSuccess) {
             psd_destroy(c);
             return PSD_INFO_RUNTIME + 5;
         }
@@ -1448,6 +1501,7 @@ int psd_create(psd_ctx** ctx, int device) {
 #ifdef PSD_HOSTSIM
     if (const char* e = getenv("PSD_OVERLAP")) c->overlap = atoi(e);
 #endif
+    if (const char* e = getenv("PSD_CDEFER")) c->cdefer = atoi(e);
     if (const char* e = getenv("PSD_FORMQ_BLOCKED")) c->formq_blocked = atoi(e);
     if (const char* e = getenv("PSD_BAND_HELPER")) c->band_helper = atoi(e);
     if (const char* e = getenv("PSD_TRAIN_LONG")) c->train_long = atoi(e);
@@ -1460,6 +1514,7 @@ int psd_create(psd_ctx** ctx, int device) {
     if (const char* e = getenv("PSD_APPLY_WL_GRID")) c->apply_wl_grid = atoi(e) > 0 ? atoi(e) : 2048;
     if (const char* e = getenv("PSD_APPLY_WL2")) c->apply_wl2 = atoi(e);
     if (const char* e = getenv("PSD_C2")) c->chase2 = atoi(e);
+    if (const char* e = getenv("PSD_C3")) c->chase3 = atoi(e);
 #ifndef PSD_HOSTSIM
     if (const char* e = getenv("PSD_H2_XCD")) c->hess_xcd = atoi(e);
 #endif
@@ -1516,6 +1571,7 @@ int psd_destroy(psd_ctx* c) {
         if (c->pev[q]) (void)hipEventDestroy(c->pev[q]);
         if (c->evE[q]) (void)hipEventDestroy(c->evE[q]);
         if (c->evF[q]) (void)hipEventDestroy(c->evF[q]);
+        if (c->evG[q]) (void)hipEventDestroy(c->evG[q]);
         if (c->pin[q]) (void)hipHostFree(c->pin[q]);
     }
     for (auto& e : c->h2ev)

@@ -143,6 +143,9 @@ struct psd_rstate {
     int train_S, train_ms, train_long, train_wdiv;  // (train_wdiv: a long train has at most w / train_wdiv bulges)
     // slots of this leader's share of the tick's slot plan (psd_rq_plan) already taken in launch plan_tick
     int plan_tick, plan_used;
+    // deferred column roles (psd_rparams::cdefer): tick in which a decision of this range found that it needs
+    // opnorm(H_1[l:i, l:i]) and put itself off by one launch (see psd_rq_decide)
+    int opn_tick;
 };
 
 // global words of the multi-block scheduler
@@ -215,7 +218,23 @@ struct psd_rparams {
     // byte offset of the two-wave chase's command block in dynamic LDS (the reduction scratch behind the window image,
     // idle while a window is chased); 0: the chase kernels run single wavefronts (psd_qr_micro3)
     int c2off;
+    // scan chase (psd_chase3.h): byte offset of its reflector table in dynamic LDS (behind the scratch of the state
+    // machine); 0: off.  The chase workgroups then have PSD_C3_WAVES wavefronts, and c2off names the command block.
+    int c3off;
+    // 1: the far part of a tick's column roles (rows more than PSD_CDEFER_EDGE above the window, psd_apply_desc::rcut) runs
+    // on the second stream beside the NEXT tick's chases (iterate_dev; psd_rq_apply_wl modes 5 / 6)
+    int cdefer;
 };
+// Deferred column roles.  The column role of a window (owner m's transformations on columns plo..phi of H_{m-1}) reaches
+// from the top of the matrix down to the window.  What the next launch of chases, bands, shift blocks and decisions reads
+// of it lies within a window's width of the diagonal (diagonal blocks of order <= W, the band of the product within two of
+// the diagonal, trailing blocks of order <= 16 for the shifts), so rows more than max(W + 2, 16) above the window can wait
+// until the next tick's ROWS roles need them (they cross these columns): that part runs on the second stream while the
+// next tick chases.  Every element still sees the same sequence of operations (rows roles of tick t, column roles of tick
+// t, rows roles of tick t + 1, ...), so the results are the same bits as with everything on one stream.  The one reader
+// of far entries is psd_h1_opnorm (a fallback of the deflation tests when a diagonal pair of the product is exactly zero):
+// a decision that needs it waits one launch (psd_rstate::opn_tick).
+PSD_HD int psd_cdefer_edge(int Wmax) { return (Wmax + 2 > 16) ? (Wmax + 2) : 16; }
 // layout of psd_rparams::plan (ints): share of leader slot s = free slots PSD_PLAN_FREE[first[s] .. first[s] + count[s])
 #define PSD_PLAN_FIRST 0
 #define PSD_PLAN_COUNT (PSD_SLOTS)
@@ -552,6 +571,7 @@ PSD_D void psd_mb_spawn(const psd_rparams& P, psd_rstate& st, int* bc) {
             cs.ntrains = cs.ntrainsweeps = 0;
             cs.plan_tick = -1;
             cs.plan_used = 0;
+            cs.opn_tick = -2;
             for (int q = 0; q < 6; ++q) cs.cyc[q] = 0;
             P.cst[s] = cs;
             psd_atomic_add(&P.gl->nactive, 1);
@@ -796,7 +816,8 @@ PSD_D double psd_h1_opnorm(const psd_rparams& P, const psd_rstate& st, double* r
 // ------------------------------------------------------------------------------------------------
 // PSD.jl:471-672: product band, deflation search, RQ decision
 // stage: LDS free during the decision (the window area), stage_doubles of it
-PSD_D void psd_rq_decide(const psd_rparams& P, psd_rstate& st, double* red, int* redi, double* stage, size_t stage_doubles) {
+// Returns true when the decision put itself off by one launch (deferred column roles: psd_cdefer_edge).
+PSD_D bool psd_rq_decide(const psd_rparams& P, psd_rstate& st, double* red, int* redi, double* stage, size_t stage_doubles) {
     const int n = st.n, p = st.p, i = st.i, lo = st.l;
     const int NT = PSD_NTHREADS;
     if (!(st.its < st.maxitleft)) {  // PSD.jl:471,891-893
@@ -805,7 +826,7 @@ PSD_D void psd_rq_decide(const psd_rparams& P, psd_rstate& st, double* red, int*
             // leader counts itself out, the slot goes back), the other problems of the call run on.
             PSD_ONE { psd_atomic_store(&P.gl->pinfo[st.prob], i); }
             st.phase = PSD_PH_FINAL;
-            return;
+            return false;
         }
         st.info = i;
         st.phase = PSD_PH_DONE;
@@ -817,7 +838,7 @@ PSD_D void psd_rq_decide(const psd_rparams& P, psd_rstate& st, double* red, int*
                 psd_atomic_store(&P.gl->done, 1);
             }
         }
-        return;
+        return false;
     }
     const psd_mat<double> H1 = psd_fac(P, n, 1);
     // band of P = H_2 H_3 ... H_p on rows lo..i (PSD.jl:475-495,507-516, evaluated per row).  The entries a row needs —
@@ -942,6 +963,10 @@ PSD_D void psd_rq_decide(const psd_rparams& P, psd_rstate& st, double* red, int*
         }
         PSD_SYNC();
         if (!need) break;
+        if (P.cdefer && st.opn_tick != P.tick - 1) {  // far column updates of this range's last windows may be in flight
+            st.opn_tick = P.tick;
+            return true;
+        }
         h1norm = psd_h1_opnorm(P, st, red, lo, i);
     }
     const bool found = klast > 0;
@@ -950,7 +975,15 @@ PSD_D void psd_rq_decide(const psd_rparams& P, psd_rstate& st, double* red, int*
     st.phase = PSD_PH_SHIFT;
     if (l > 1 && st.wantT) {  // PSD.jl:589-665
         double tst1 = fabs(H1(l - 1, l - 1)) + fabs(H1(l, l));
-        if (tst1 == 0) tst1 = psd_h1_opnorm(P, st, red, l, i);
+        if (tst1 == 0) {
+            if (P.cdefer && st.opn_tick != P.tick - 1) {
+                st.opn_tick = P.tick;
+                st.l = lo;
+                st.phase = PSD_PH_DECIDE;
+                return true;
+            }
+            tst1 = psd_h1_opnorm(P, st, red, l, i);
+        }
         if (fabs(H1(l, l - 1)) > fmax(st.ulp * tst1, st.smlnum)) {
             st.phase = PSD_PH_RQ;
             st.kcur = i;
@@ -962,6 +995,7 @@ PSD_D void psd_rq_decide(const psd_rparams& P, psd_rstate& st, double* red, int*
             PSD_SYNC();
         }
     }
+    return false;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1396,7 +1430,12 @@ PSD_D void psd_desc_write(const psd_rparams& P, psd_rstate& st, const int* lcnt,
         d.prob = st.prob;
         d.split = (split && st.wantT) ? 1 : 0;
         d.cut = lc1 + 1;
-        d.rcut = rr0;
+        {   // first near row of the column role (psd_cdefer_edge): rows rr0 .. rcut - 1 may run one tick late
+            int rc = plo - psd_cdefer_edge(st.Wmax);
+            if (rc < rr0) rc = rr0;
+            if (rc > rr1 + 1) rc = rr1 + 1;
+            d.rcut = rc;
+        }
         d.plo = plo;
         d.phi = phi;
         d.lc0 = lc0;
@@ -1978,14 +2017,16 @@ PSD_D void psd_c2_lead(const psd_rparams& P, psd_c2& C) {
 }
 #ifndef PSD_HOSTSIM
 // the helper wavefront of a chase workgroup (threadIdx.y == 1)
-PSD_D void psd_c2_helper(int c2off) {
+PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_);
+PSD_D void psd_c2_helper(int c2off, int c3off) {
     PSD_LDS_DECL;
     const psd_c2* cmd = (const psd_c2*)(psd_lds + c2off);
     for (;;) {
         PSD_PAIR_BARRIER();
         const psd_c2 C = *cmd;
         if (C.cmd == 0) return;
-        psd_c2_run(C, 2);
+        if (C.cmd == 2) psd_c3_run(C, PSD_WAVE_ROLE, (int)blockDim.y, c3off);  // scan chase: every wavefront takes part
+        else psd_c2_run(C, 2);                                                  // two-wave chase: 64 x 2 workgroups
     }
 }
 // wavefront A, last thing before it leaves the kernel
@@ -1996,6 +2037,22 @@ PSD_D void psd_c2_release(int c2off) {
     PSD_PAIR_BARRIER();
 }
 #endif
+
+#include "psd_chase3.h"
+// wavefront 0's side of a scan-chase run (the other wavefronts of the workgroup wait at the command barrier)
+PSD_D void psd_c3_lead(const psd_rparams& P, psd_c2& C) {
+#ifdef PSD_HOSTSIM
+    psd_c3_run(C, 0, 1, P.c3off);
+#else
+    PSD_LDS_DECL;
+    psd_c2* cmd = (psd_c2*)(psd_lds + P.c2off);
+    C.cmd = 2;
+    PSD_ONE { *cmd = C; }
+    PSD_PAIR_BARRIER();
+    psd_c3_run(C, 0, (int)blockDim.y, P.c3off);
+    PSD_ONE { cmd->cmd = 0; }
+#endif
+}
 
 // PSD.jl:806-886: one window (steps kcur .. kcur+nb-1) of the double-shift periodic QR sweep
 PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, int* lcnt) {
@@ -2018,8 +2075,9 @@ PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
     const int r0 = (w.bs > i1) ? w.bs : i1;
     int n1 = 0, nj = 0;  // list lengths: owner 1, owners 2..p
     int kfirst = ks;
-    if (P.c2off != 0 && p >= PSD_C2_MINP) {
-        // the positions with three-row bulges (all but possibly the last of a sweep) on the two-wave chase
+    const bool scan3 = P.c3off != 0 && p >= PSD_C3_MINP && p <= PSD_C3_MAXP;
+    if (scan3 || (P.c2off != 0 && P.c3off == 0 && p >= PSD_C2_MINP)) {
+        // the positions with three-row bulges (all but possibly the last of a sweep) on the scan chase / two-wave chase
         const int klast = (ke < i - 2) ? ke : (i - 2);
         if (klast >= ks) {
             psd_c2 C;
@@ -2035,7 +2093,8 @@ PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
             C.tr = P.tr;
             C.v0 = st.v[0]; C.v1 = st.v[1]; C.v2 = st.v[2];
             PSD_SYNC();
-            psd_c2_lead(P, C);
+            if (scan3) psd_c3_lead(P, C);
+            else psd_c2_lead(P, C);
             PSD_SYNC();
             n1 = C.npos;
             nj = 2 * C.npos;
@@ -2313,6 +2372,7 @@ PSD_D bool psd_rq_deflate(const psd_rparams& P, psd_rstate& st, double* ldsd, in
         } else if (hsub_im1 == 0) {
             if (fmin(a1, a2) / fmax(a1, a2) < PSD_DBL_EPS) replaceG = true;
         }
+        bool guarded = false;  // the first pass left a subdiagonal entry that is not negligible in H_1 (see below)
         for (int its2 = 1; its2 <= 20; ++its2) {
             if (replaceG) {
                 double rr;
@@ -2351,8 +2411,25 @@ PSD_D bool psd_rq_deflate(const psd_rparams& P, psd_rstate& st, double* ldsd, in
                 psd_record(P, lcnt, j, tr);
             }
             const double h21 = w.at(1, i, i - 1);
+            // what zeroing H_1(i, i-1) would cost, measured in the factor that carries it (the reference measures against
+            // the eigenvalues of the PRODUCT, which says nothing about H_1 when the pair is orders of magnitude apart)
+            const double h1sc = fabs(w.at(1, i - 1, i - 1)) + fabs(w.at(1, i - 1, i)) + fabs(w.at(1, i, i));
             PSD_SYNC();
-            if (!replaceG || (fabs(h21) < fmax(st.smlnum, st.ulp * fmax(a1, a2)))) break;
+            if (replaceG) {
+                if (fabs(h21) < fmax(st.smlnum, st.ulp * fmax(a1, a2))) break;
+                if (guarded && fabs(h21) <= fmax(st.smlnum, 8.0 * st.ulp * h1sc)) break;
+            } else {
+                // Guard (not in the reference, which zeroes whatever the one pass leaves, PSD.jl:1031-1037,1066-1073): a
+                // real pair whose rotation came from the explicitly formed product can leave a subdiagonal entry far
+                // above rounding level when the two eigenvalues are many orders of magnitude apart (but less than
+                // 1 / eps, so that :996-1003 does not switch to the rotation from H_1 itself).  Zeroing it would put that
+                // entry into the residual; instead the block takes the reference's own fallback, rotations from
+                // H_1's column (an unshifted periodic QR step on the 2 x 2 block, which converges with the ratio of the
+                // pair per pass), until the entry is negligible in H_1.
+                if (hsub_im1 != 0 || jmax > 0) break;
+                if (fabs(h21) <= fmax(st.smlnum, 8.0 * st.ulp * h1sc)) break;
+                guarded = true;
+            }
             replaceG = true;
         }
         PSD_ONE {
@@ -2411,7 +2488,7 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
                 const long long td0 = psd_clock();
                 {
                     PSD_DBG_T0();
-                    psd_rq_decide(P, st, red, redi, ldsd, winb);
+                    if (psd_rq_decide(P, st, red, redi, ldsd, winb)) emitted = true;  // (put off: nothing emitted, the descriptor stays inactive)
                     PSD_DBG_ADD(0);
                 }
                 st.cyc[0] += psd_clock() - td0;
@@ -2526,8 +2603,8 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
 // the two-wave chase (psd_c2_helper) and takes no part in anything else.
 #ifndef PSD_HOSTSIM
 #define PSD_C2_ENTER(P)                                 \
-    if ((P).c2off != 0 && PSD_WAVE_ROLE == 1) {         \
-        psd_c2_helper((P).c2off);                       \
+    if ((P).c2off != 0 && PSD_WAVE_ROLE >= 1) {         \
+        psd_c2_helper((P).c2off, (P).c3off);            \
         return;                                         \
     }
 #define PSD_C2_LEAVE(P) \
@@ -2536,7 +2613,7 @@ PSD_D void psd_rq_step_body(const psd_rparams& P) {
 #define PSD_C2_ENTER(P) ((void)0)
 #define PSD_C2_LEAVE(P) ((void)0)
 #endif
-PSD_KERNEL_B(2 * PSD_STEP_NT) psd_rq_step(psd_rparams P) {
+PSD_KERNEL_B(PSD_C3_WAVES * PSD_STEP_NT) psd_rq_step(psd_rparams P) {
     PSD_C2_ENTER(P);
     psd_rq_step_body(P);
     PSD_C2_LEAVE(P);
@@ -2629,7 +2706,7 @@ PSD_D void psd_rq_cursor_body(const psd_rparams& P, int b) {
 // All cursors of a tick in ONE launch: workgroup 0 is the ordinary state machine (the leader), workgroup b >= 1 is cursor
 // b.  P holds the leader's state and slot 0 of the cursor arrays (see psd_rq_apply_train).  No cross-stream events: the
 // chases of a tick run side by side on different compute units, the tick ends with the kernel.
-PSD_KERNEL_B(2 * PSD_STEP_NT) psd_rq_step_train(psd_rparams P, int p, int cstride) {
+PSD_KERNEL_B(PSD_C3_WAVES * PSD_STEP_NT) psd_rq_step_train(psd_rparams P, int p, int cstride) {
     PSD_C2_ENTER(P);
     const int b = PSD_BLOCK_X;
     if (b == 0) {
@@ -2683,7 +2760,7 @@ PSD_D void psd_rq_step_mb_body(const psd_rparams& P, int p, int cstride) {
         psd_rq_cursor_body(Q, P.cst[s].cursor);
     }
 }
-PSD_KERNEL_B(2 * PSD_STEP_NT) psd_rq_step_mb(psd_rparams P, int p, int cstride) {
+PSD_KERNEL_B(PSD_C3_WAVES * PSD_STEP_NT) psd_rq_step_mb(psd_rparams P, int p, int cstride) {
     PSD_C2_ENTER(P);
     psd_rq_step_mb_body(P, p, cstride);
     PSD_C2_LEAVE(P);
@@ -3056,11 +3133,20 @@ PSD_HD void psd_wl_ranges(psd_apply_desc& d, int mode, int cut) {
     } else if (mode == 4) {  // the Schur vectors only (pass 0)
         d.lc1 = d.lc0 - 1;
         d.rr1 = d.rr0 - 1;
+    } else if (mode == 5) {  // the two H roles, the column role on its near rows only (rcut .. rr1)
+        d.zr1 = d.zr0 - 1;
+        if (d.rr0 < d.rcut) d.rr0 = d.rcut;
+    } else if (mode == 6) {  // the far rows of the column role only (pass 1): rr0 .. rcut - 1
+        d.lc1 = d.lc0 - 1;
+        d.zr1 = d.zr0 - 1;
+        if (d.rr1 > d.rcut - 1) d.rr1 = d.rcut - 1;
     }
 }
 
 #define PSD_WL_GROUP 4  // 64-line tiles per item: the owner's list is staged once for all of them
 // mode 0: everything.
+// Modes 5 / 6 split the column roles by rows (psd_cdefer_edge): mode 5 = the H roles without the far rows of the column
+// roles, mode 6 = those far rows (pass 1), which run on the second stream beside the next tick's chases.
 // Modes 3 / 4 split off the Schur vectors alone: mode 3 = the two H roles (both passes), mode 4 = the Z role (pass 0).
 // Nothing reads Z_m before the iteration ends and only owner m's lists touch it, so the Z updates of a tick only have to
 // stay in tick order among themselves: they run on a second stream beside the following ticks' chases.
@@ -3288,6 +3374,7 @@ PSD_KERNEL psd_rq_init(psd_rparams P, int n, int p, int wantT, int wantZ, int W,
             st.train_key = 0;
             st.plan_tick = -1;
             st.plan_used = 0;
+            st.opn_tick = -2;
             st.prob = pr;
             for (int q = 0; q < PSD_TRAIN_MAX; ++q) st.cslots[q] = 0;
             if (mb) {

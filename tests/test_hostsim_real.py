@@ -97,26 +97,40 @@ def test_pschur_hess_batch_one_fails(sim_engine):
     ec.case_pschur_hess_batch_one_fails(sim_engine)
 
 
-def test_far_apply_overlap_order(built, monkeypatch):
-    """PSD_OVERLAP=1 (opt-in): the far part of a tick's bulk update — the rows role beyond the columns the next windows
-    reach, cut so that it never splits another window's column range, and the Z role — is applied one tick late, after
-    the next tick's chases (the latest order the two streams of the HIP build allow); same invariants."""
+def test_column_roles_deferred(built, monkeypatch):
+    """PSD_CDEFER=2 (what the HIP build does by itself for n >= 1024): the rows of a window's column role that lie more
+    than a window's width above it (psd_cdefer_edge) are their own launch (psd_rq_apply_wl mode 6) — on the GPU on the
+    second stream beside the next tick's chases; the serial simulation runs it at the latest point the streams allow,
+    BEHIND the next tick's chases and decisions, which shows that none of those reads what it writes.  Every element
+    still sees the same sequence of operations, so T, Z and the eigenvalues are those of the one-stream order to the
+    last bit, with and without the Schur vectors on the second stream as well (PSD_OVERLAP=2)."""
     import os
 
     import numpy as np
     import psd_amd
     import psdtest as pt
 
-    monkeypatch.setenv("PSD_OVERLAP", "1")
-    eng = psd_amd.Engine(libpath=os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim", "_build",
-                                              "libpsd_hostsim.so"))
-    for (n, p, lr) in [(100, 1, "R"), (150, 7, "L"), (200, 2, "R")]:
+    lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim", "_build", "libpsd_hostsim.so")
+    monkeypatch.setenv("PSD_OVERLAP", "0")
+    monkeypatch.setenv("PSD_CDEFER", "0")
+    ref = psd_amd.Engine(libpath=lib)
+    engs = []
+    for ovl in ("0", "2"):
+        monkeypatch.setenv("PSD_OVERLAP", ovl)
+        monkeypatch.setenv("PSD_CDEFER", "2")
+        engs.append(psd_amd.Engine(libpath=lib))
+    for (n, p, lr, win) in [(100, 1, "R", None), (150, 7, "L", None), (200, 2, "R", None), (180, 3, "R", "10")]:
         A = pt.bench_factors(n, p, seed=7)
-        ps = eng.pschur(A, lr)
-        ok, err = pt.checkpsd(ps, A, thresh=100 * np.sqrt(n / 32))
-        assert ok, (n, p, err.max())
-        P = pt.product(A, left=(lr == "L"))
-        assert pt.match_eigs(np.linalg.eigvals(P), ps.values) <= 1e-10 * np.linalg.norm(P, 2)
+        pr = ref.pschur(A, lr)
+        for eng in engs:
+            ps = eng.pschur(A, lr)
+            ok, err = pt.checkpsd(ps, A, thresh=100 * np.sqrt(n / 32))
+            assert ok, (n, p, err.max())
+            assert ps.stats.nsweeps == pr.stats.nsweeps
+            for j in range(p):
+                assert np.array_equal(ps.Z[j], pr.Z[j])
+                assert np.array_equal(ps.Ts[j], pr.Ts[j])
+            assert np.array_equal(ps.values, pr.values)
 
 
 def test_schur_vector_updates_deferred(built, monkeypatch):
