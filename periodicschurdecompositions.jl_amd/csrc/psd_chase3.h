@@ -33,6 +33,7 @@
 #define PSD_C3_MAXP 64    // one lane per factor
 #define PSD_C3_MINP 2
 #define PSD_C3_WAVES 4    // wavefronts of a chase workgroup under the scan chase (one per SIMD)
+#define PSD_C3_FPL 4      // links of the factor chain per lane of the scan (16 lanes x 4 >= 63)
 
 // exponent e with m 2^-e in [0.5, 1) for finite m > 0, else 0
 PSD_D int psd_c3_expo(double m) {
@@ -97,59 +98,62 @@ PSD_D void psd_c3_item(double* q, int sd, double v1, double v2, double tau, bool
     q[2 * sd] = a3;
 }
 
-// the apply phase of one position for the items it (first, stride) of a workgroup-wide index space.  tab: reflector
-// table.  sub = 0: right updates of H_2..H_p, left update of H_1 (+ its annihilated column k - 1); sub = 1: left
-// updates of H_2..H_p, right update of H_1.
-PSD_D void psd_c3_apply(double* wb, const double* tab, int sub, int first, int stride, int p, int ld, int bsz, int bs,
+// The apply phase of one position.  The threads of the workgroup are dealt to the factors once per run: thread (f, q) is
+// the q-th of the tpf threads of factor f + 1 and takes that factor's items q, q + tpf, ... — no index arithmetic per item,
+// and a factor's reflectors are read from the table once per phase.  sub = 0: right updates of H_2..H_p (by the
+// reflectors of the factor behind them in the chain: owner j + 1, or H_1's for factor p) and the left update of H_1 with
+// its annihilated column k - 1; sub = 1: left updates of H_2..H_p, right update of H_1 (owner 2).  A left and a right
+// update of one factor never share a phase, and within a phase the items of a factor are disjoint rows / columns.
+PSD_D void psd_c3_apply(double* wb, const double* tab, int sub, int f, int q, int tpf, int p, int ld, int bsz, int bs,
                         int k, int l, int r0, int nrw, int ncl) {
-    if (sub == 0) {
-        const int nA = (p - 1) * nrw;          // (factor j = 2 + it / nrw, row r0 + it % nrw)
-        const int nB = ncl + ((k > l) ? 1 : 0);  // H_1: columns k .. c1max, then column k - 1
-        for (int it = first; it < nA + nB; it += stride) {
-            if (it < nA) {
-                const int jf = it / nrw, r = r0 + (it - jf * nrw);
-                const int j = 2 + jf, jo = (j == p) ? 1 : (j + 1);
-                const double* t = tab + (jo - 1) * PSD_C3_TAB;
-                psd_c3_item(wb + (j - 1) * bsz + (k - bs) * ld + (r - bs), ld, t[0], t[1], t[2], jo != 1, t[3], t[4], 0);
-            } else {
-                const int cc = it - nA;
-                const double* t = tab;
-                if (cc < ncl) {
-                    psd_c3_item(wb + (k + cc - bs) * ld + (k - bs), 1, t[0], t[1], t[2], false, 0.0, 0.0, 0);
-                } else {  // PSD.jl:822-827
-                    double* q = wb + (k - 1 - bs) * ld + (k - bs);
-                    q[0] = t[5];
-                    q[1] = 0.0;
-                    q[2] = 0.0;
-                }
-            }
-        }
+    if (f >= p) return;
+    const int j = f + 1;
+    double* const blk = wb + f * bsz;
+    const bool right = (j >= 2) == (sub == 0);
+    if (right) {
+        const int jo = (j == p) ? 1 : (j + 1);
+        const double* t = tab + (jo - 1) * PSD_C3_TAB;
+        const double v1 = t[0], v2 = t[1], tau = t[2], w2 = t[3], tau2 = t[4];
+        double* const col = blk + (k - bs) * ld + (r0 - bs);
+        for (int r = q; r < nrw; r += tpf) psd_c3_item(col + r, ld, v1, v2, tau, jo != 1, w2, tau2, 0);
     } else {
-        const int nA = (p - 1) * ncl;  // (factor j = 2 + it / ncl, column k + it % ncl)
-        const int nB = nrw;            // H_1: rows r0 .. rlim under Q_2, P_2
-        for (int it = first; it < nA + nB; it += stride) {
-            if (it < nA) {
-                const int jf = it / ncl, cc = it - jf * ncl;
-                const int j = 2 + jf;
-                const double* t = tab + (j - 1) * PSD_C3_TAB;
-                // column k: (beta, 0, 0) (PSD.jl:851-854); column k + 1: (., beta', 0) (:869); the others: both reflectors
-                psd_c3_item(wb + (j - 1) * bsz + (k + cc - bs) * ld + (k - bs), 1, t[0], t[1], t[2], cc >= 1, t[3], t[4],
-                            (cc == 0) ? 1 : ((cc == 1) ? 2 : 0));
-            } else {
-                const int r = r0 + (it - nA);
-                const double* t = tab + PSD_C3_TAB;  // owner 2
-                psd_c3_item(wb + (k - bs) * ld + (r - bs), ld, t[0], t[1], t[2], true, t[3], t[4], 0);
+        const double* t = tab + f * PSD_C3_TAB;
+        const double v1 = t[0], v2 = t[1], tau = t[2], w2 = t[3], tau2 = t[4];
+        double* const row = blk + (k - bs) * ld + (k - bs);
+        if (j == 1) {
+            for (int cc = q; cc < ncl; cc += tpf) psd_c3_item(row + cc * ld, 1, v1, v2, tau, false, 0.0, 0.0, 0);
+            if (k > l && q == tpf - 1) {  // PSD.jl:822-827
+                double* c = blk + (k - 1 - bs) * ld + (k - bs);
+                c[0] = t[5];
+                c[1] = 0.0;
+                c[2] = 0.0;
             }
+        } else {
+            // column k: (beta, 0, 0) (PSD.jl:851-854); column k + 1: (., beta', 0) (:869); the others: both reflectors
+            for (int cc = q; cc < ncl; cc += tpf)
+                psd_c3_item(row + cc * ld, 1, v1, v2, tau, cc >= 1, w2, tau2, (cc == 0) ? 1 : ((cc == 1) ? 2 : 0));
         }
     }
 }
 
 #ifndef PSD_HOSTSIM
-// lane i <- lane (i + 1) mod 64
+// lane i <- lane (i + 1) mod 64.  (Inline assembly: through the builtin the compiler first copies the old value into the
+// destination — a rotation has no lane without a source —, which doubled the moves on the scan's critical path.)
 PSD_D double psd_c3_rol(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    int rlo, rhi;
+    // (s_nop 1: a DPP read of a register a vector instruction has just written needs two wait states, and the
+    //  compiler's hazard pass does not look into inline assembly)
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 wave_rol:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %3 wave_rol:1 row_mask:0xf bank_mask:0xf"
+                 : "=&v"(rlo), "=&v"(rhi)
+                 : "v"(lo), "v"(hi));
+    return __hiloint2double(rhi, rlo);
+}
+// lane i <- lane i - 1 inside a row of 16 lanes; lane 0 of a row (no source) gets `first`
+PSD_D double psd_c3_shr(double v, double first) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x134, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x134, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(first), lo, 0x111, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(first), hi, 0x111, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 // full barrier of the chase workgroup: every LDS operation of every wavefront is done behind it
@@ -168,12 +172,18 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_) {
     psd_tr* const trb = Cin.tr;
     const int lane = (int)threadIdx.x;
     const int tid = wv * 64 + lane, NT = nw * 64;
+    const int tpf = (NT / p > 0) ? (NT / p) : 1;  // threads per factor in the apply phases (p <= 64 <= NT)
+    const int af = tid / tpf, aq = tid - af * tpf;
+    long long* const dbg = Cin.dbg;
+    long long dacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PSD_C3_T(i) do { if (dbg) { const long long t__ = psd_clock(); dacc[i] += t__ - dt0; dt0 = t__; } } while (0)
     for (int kk = 0; kk < npos; ++kk) {
         const int k = ks + kk;
         const int rlim = (k + 3 < ie) ? (k + 3) : ie;
         const int nrw = rlim - r0 + 1;
         int ncl = c1max - k + 1;
         if (ncl < 0) ncl = 0;
+        long long dt0 = dbg ? psd_clock() : 0;
         if (wv == 0) {
             const bool fac = lane >= 1 && lane < p;  // factors 2..p; the other lanes emit x(1)
             double x0, x1, x2;
@@ -188,6 +198,8 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_) {
                 x2 = Cin.v2;
             }
             const int ex = psd_c3_expo(psd_c3_max3(x0, x1, x2));
+            const double xs0 = psd_c3_ldexp(x0, -ex), xs1 = psd_c3_ldexp(x1, -ex), xs2 = psd_c3_ldexp(x2, -ex);
+            // this lane's own factor (the B block below needs it)
             double u00 = 0.0, u01 = 0.0, u02 = 0.0, u11 = 0.0, u12 = 0.0, u22 = 0.0;
             if (fac) {
                 const double* q = wb + lane * bsz + (k - bs) * ld + (k - bs);
@@ -197,60 +209,161 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_) {
                 u02 = q[2 * ld];
                 u12 = q[2 * ld + 1];
                 u22 = q[2 * ld + 2];
-                const int eu = psd_c3_expo(fmax(psd_c3_max3(u00, u01, u02), psd_c3_max3(u11, u12, u22)));
-                u00 = psd_c3_ldexp(u00, -eu);
-                u01 = psd_c3_ldexp(u01, -eu);
-                u02 = psd_c3_ldexp(u02, -eu);
-                u11 = psd_c3_ldexp(u11, -eu);
-                u12 = psd_c3_ldexp(u12, -eu);
-                u22 = psd_c3_ldexp(u22, -eu);
-            }
-            const double c0 = fac ? 0.0 : psd_c3_ldexp(x0, -ex), c1 = fac ? 0.0 : psd_c3_ldexp(x1, -ex),
-                         c2 = fac ? 0.0 : psd_c3_ldexp(x2, -ex);
-            // ---- scan 1
-            double z0 = c0, z1 = c1, z2 = c2, zo0 = 0.0, zo1 = 0.0, zo2 = 0.0;
-            const int mystep = p - 1 - lane;
-            for (int s = 0; s < p - 1; ++s) {
-                const double w0 = psd_c3_rol(z0), w1 = psd_c3_rol(z1), w2 = psd_c3_rol(z2);
-                z0 = __builtin_fma(u00, w0, __builtin_fma(u01, w1, __builtin_fma(u02, w2, c0)));
-                z1 = __builtin_fma(u11, w1, __builtin_fma(u12, w2, c1));
-                z2 = __builtin_fma(u22, w2, c2);
-                if (s == mystep) {
-                    zo0 = z0;
-                    zo1 = z1;
-                    zo2 = z2;
-                }
-                if ((s & 15) == 15) {
-                    const int e = psd_c3_expo(psd_c3_max3(z0, z1, z2));
-                    z0 = psd_c3_ldexp(z0, -e);
-                    z1 = psd_c3_ldexp(z1, -e);
-                    z2 = psd_c3_ldexp(z2, -e);
+                const double um = fmax(psd_c3_max3(u00, u01, u02), psd_c3_max3(u11, u12, u22));
+                if (!(um > 1e-18 && um < 1e18)) {  // (far from unit scale: see the chain lanes' blocks below)
+                    const int eu = psd_c3_expo(um);
+                    u00 = psd_c3_ldexp(u00, -eu);
+                    u01 = psd_c3_ldexp(u01, -eu);
+                    u02 = psd_c3_ldexp(u02, -eu);
+                    u11 = psd_c3_ldexp(u11, -eu);
+                    u12 = psd_c3_ldexp(u12, -eu);
+                    u22 = psd_c3_ldexp(u22, -eu);
                 }
             }
+            // ---- scan 1 on the chain lanes.  The chain 1 -> p -> p - 1 -> ... -> 2 has p - 1 links; chain lane i < 16 does
+            // links 4 i .. 4 i + 3 (factors p - 4 i, ...) one after the other in registers and hands its last vector to lane
+            // i + 1 by row_shr:1 — a full-rate DPP move inside a row of 16 lanes (a wave-wide shift measured four times
+            // slower: with one factor per lane the six moves of a step were most of it).  Lane i is fed valid data in step
+            // i; it recomputes while s <= i and keeps its four vectors from then on.  Links beyond the chain are identities.
+            double U[PSD_C3_FPL][6], zq[PSD_C3_FPL][3];
+            const bool chl = lane < 16;
+#pragma unroll
+            for (int q4 = 0; q4 < PSD_C3_FPL; ++q4) {
+                const int c = PSD_C3_FPL * lane + q4, jf = p - c;  // link c = factor jf
+                double a00 = 1.0, a01 = 0.0, a02 = 0.0, a11 = 1.0, a12 = 0.0, a22 = 1.0;
+                if (chl && c < p - 1) {
+                    const double* q = wb + (jf - 1) * bsz + (k - bs) * ld + (k - bs);
+                    a00 = q[0];
+                    a01 = q[ld];
+                    a11 = q[ld + 1];
+                    a02 = q[2 * ld];
+                    a12 = q[2 * ld + 1];
+                    a22 = q[2 * ld + 2];
+                    const double um = fmax(psd_c3_max3(a00, a01, a02), psd_c3_max3(a11, a12, a22));
+                    // (blocks are brought to unit scale only when they are far from it: the vector is rescaled after
+                    //  every lane's four links anyway, and the scaling is a dozen instructions per block)
+                    if (!(um > 1e-18 && um < 1e18)) {
+                        const int eu = psd_c3_expo(um);
+                        a00 = psd_c3_ldexp(a00, -eu);
+                        a01 = psd_c3_ldexp(a01, -eu);
+                        a02 = psd_c3_ldexp(a02, -eu);
+                        a11 = psd_c3_ldexp(a11, -eu);
+                        a12 = psd_c3_ldexp(a12, -eu);
+                        a22 = psd_c3_ldexp(a22, -eu);
+                    }
+                }
+                U[q4][0] = a00; U[q4][1] = a01; U[q4][2] = a02; U[q4][3] = a11; U[q4][4] = a12; U[q4][5] = a22;
+                zq[q4][0] = zq[q4][1] = zq[q4][2] = 0.0;
+            }
+            const int nsteps = (p - 1 + PSD_C3_FPL - 1) / PSD_C3_FPL;
+            double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+            for (int s = 0; s < nsteps; ++s) {
+                // (lane 0 of a row has no lane to its right... left: it keeps the "old" operand, the start vector)
+                double w0 = psd_c3_shr(z0, xs0), w1 = psd_c3_shr(z1, xs1), w2 = psd_c3_shr(z2, xs2);
+                if (s <= lane) {
+#pragma unroll
+                    for (int q4 = 0; q4 < PSD_C3_FPL; ++q4) {
+                        const double n0 = __builtin_fma(U[q4][0], w0, __builtin_fma(U[q4][1], w1, U[q4][2] * w2));
+                        const double n1_ = __builtin_fma(U[q4][3], w1, U[q4][4] * w2);
+                        const double n2 = U[q4][5] * w2;
+                        w0 = n0;
+                        w1 = n1_;
+                        w2 = n2;
+                        zq[q4][0] = n0;
+                        zq[q4][1] = n1_;
+                        zq[q4][2] = n2;
+                    }
+                    const int e = psd_c3_expo(psd_c3_max3(w0, w1, w2));
+                    z0 = psd_c3_ldexp(w0, -e);
+                    z1 = psd_c3_ldexp(w1, -e);
+                    z2 = psd_c3_ldexp(w2, -e);
+                }
+            }
+            // the chain vectors to their factors' lanes through the table (slots 5..7 of a factor: free until the end)
+#pragma unroll
+            for (int q4 = 0; q4 < PSD_C3_FPL; ++q4) {
+                const int c = PSD_C3_FPL * lane + q4, jf = p - c;
+                if (chl && c < p - 1) {
+                    double* t = tab + (jf - 1) * PSD_C3_TAB;
+                    t[5] = zq[q4][0];
+                    t[6] = zq[q4][1];
+                    t[7] = zq[q4][2];
+                }
+            }
+            double zo0 = 0.0, zo1 = 0.0, zo2 = 0.0;
+            if (fac) {
+                const double* t = tab + lane * PSD_C3_TAB;
+                zo0 = t[5];
+                zo1 = t[6];
+                zo2 = t[7];
+            }
+            PSD_C3_T(0);
             // ---- 3-reflectors: factor lanes from their chain vector, the others Q_1 from x(1)
             double a0 = fac ? zo0 : x0, a1 = fac ? zo1 : x1, a2 = fac ? zo2 : x2;
             const double tau = psd_refl3(a0, a1, a2);  // (a0, a1, a2) <- (beta, v2, v3)
             const double v1 = a1, v2 = a2;
             const double v1n = psd_c3_rol(v1), v2n = psd_c3_rol(v2), taun = psd_c3_rol(tau);
-            // ---- scan 2 on the trailing 2 x 2 blocks
-            double b00 = 0.0, b01 = 0.0, b10 = 0.0, b11 = 0.0;
-            if (fac) psd_c3_bblock(u00, u01, u02, u11, u12, u22, v1, v2, tau, v1n, v2n, taun, b00, b01, b10, b11);
-            const double d0 = fac ? 0.0 : 1.0;
-            double t0 = d0, t1 = 0.0, to0 = 0.0, to1 = 0.0;
-            for (int s = 0; s < p - 1; ++s) {
-                const double w0 = psd_c3_rol(t0), w1 = psd_c3_rol(t1);
-                t0 = __builtin_fma(b00, w0, __builtin_fma(b01, w1, d0));
-                t1 = __builtin_fma(b10, w0, b11 * w1);
-                if (s == mystep) {
-                    to0 = t0;
-                    to1 = t1;
+            // ---- scan 2 on the trailing 2 x 2 blocks: B blocks by the factors' lanes, through the table (slots 3, 4, 6, 7)
+            // to the chain lanes, the same systolic chain with 2-vectors, the results back through slots 6, 7
+            if (fac) {
+                double b00, b01, b10, b11;
+                psd_c3_bblock(u00, u01, u02, u11, u12, u22, v1, v2, tau, v1n, v2n, taun, b00, b01, b10, b11);
+                double* t = tab + lane * PSD_C3_TAB;
+                t[3] = b00;
+                t[4] = b01;
+                t[6] = b10;
+                t[7] = b11;
+            }
+            PSD_C3_T(1);
+            double Bq[PSD_C3_FPL][4], tq[PSD_C3_FPL][2];
+#pragma unroll
+            for (int q4 = 0; q4 < PSD_C3_FPL; ++q4) {
+                const int c = PSD_C3_FPL * lane + q4, jf = p - c;
+                double b00 = 1.0, b01 = 0.0, b10 = 0.0, b11 = 1.0;
+                if (chl && c < p - 1) {
+                    const double* t = tab + (jf - 1) * PSD_C3_TAB;
+                    b00 = t[3];
+                    b01 = t[4];
+                    b10 = t[6];
+                    b11 = t[7];
                 }
-                if ((s & 15) == 15) {
-                    const int e = psd_c3_expo(fmax(fabs(t0), fabs(t1)));
-                    t0 = psd_c3_ldexp(t0, -e);
-                    t1 = psd_c3_ldexp(t1, -e);
+                Bq[q4][0] = b00; Bq[q4][1] = b01; Bq[q4][2] = b10; Bq[q4][3] = b11;
+                tq[q4][0] = tq[q4][1] = 0.0;
+            }
+            double t0 = 0.0, t1 = 0.0;
+            for (int s = 0; s < nsteps; ++s) {
+                double w0 = psd_c3_shr(t0, 1.0), w1 = psd_c3_shr(t1, 0.0);
+                if (s <= lane) {
+#pragma unroll
+                    for (int q4 = 0; q4 < PSD_C3_FPL; ++q4) {
+                        const double n0 = __builtin_fma(Bq[q4][0], w0, Bq[q4][1] * w1);
+                        const double n1_ = __builtin_fma(Bq[q4][2], w0, Bq[q4][3] * w1);
+                        w0 = n0;
+                        w1 = n1_;
+                        tq[q4][0] = n0;
+                        tq[q4][1] = n1_;
+                    }
+                    const int e = psd_c3_expo(fmax(fabs(w0), fabs(w1)));
+                    t0 = psd_c3_ldexp(w0, -e);
+                    t1 = psd_c3_ldexp(w1, -e);
                 }
             }
+#pragma unroll
+            for (int q4 = 0; q4 < PSD_C3_FPL; ++q4) {
+                const int c = PSD_C3_FPL * lane + q4, jf = p - c;
+                if (chl && c < p - 1) {
+                    double* t = tab + (jf - 1) * PSD_C3_TAB;
+                    t[6] = tq[q4][0];
+                    t[7] = tq[q4][1];
+                }
+            }
+            double to0 = 0.0, to1 = 0.0;
+            if (fac) {
+                const double* t = tab + lane * PSD_C3_TAB;
+                to0 = t[6];
+                to1 = t[7];
+            }
+            PSD_C3_T(2);
             double y0 = to0, y1 = to1;
             const double tau2 = fac ? psd_refl2(y0, y1) : 0.0;  // (y0, y1) <- (beta', w2)
             const double w2v = fac ? y1 : 0.0;
@@ -280,12 +393,21 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_) {
                 }
             }
         }
+        if (wv == 0) PSD_C3_T(3);
         PSD_C3_BARRIER();
-        psd_c3_apply(wb, tab, 0, tid, NT, p, ld, bsz, bs, k, l, r0, nrw, ncl);
+        if (wv == 0) PSD_C3_T(4);
+        psd_c3_apply(wb, tab, 0, af, aq, tpf, p, ld, bsz, bs, k, l, r0, nrw, ncl);
         PSD_C3_BARRIER();
-        psd_c3_apply(wb, tab, 1, tid, NT, p, ld, bsz, bs, k, l, r0, nrw, ncl);
+        if (wv == 0) PSD_C3_T(5);
+        psd_c3_apply(wb, tab, 1, af, aq, tpf, p, ld, bsz, bs, k, l, r0, nrw, ncl);
         PSD_C3_BARRIER();
+        if (wv == 0) PSD_C3_T(6);
     }
+    if (dbg && wv == 0 && lane == 0) {
+        for (int q = 0; q < 7; ++q) psd_atomic_add_ll(dbg + q, dacc[q]);
+        psd_atomic_add_ll(dbg + 7, (long long)npos);
+    }
+#undef PSD_C3_T
 }
 #else
 // The simulated tier: the same steps, the lanes of the scan wavefront as array slots.
@@ -418,8 +540,12 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int, int, int taboff) {
                 psd_tr_store_global(trb + (size_t)lane * PSD_TR_CAP + slot + 1, tr);
             }
         }
-        psd_c3_apply(wb, tab, 0, 0, 1, p, ld, bsz, bs, k, l, r0, nrw, ncl);
-        psd_c3_apply(wb, tab, 1, 0, 1, p, ld, bsz, bs, k, l, r0, nrw, ncl);
+        {
+            const int NT = 64 * PSD_C3_WAVES, tpf = (NT / p > 0) ? (NT / p) : 1;
+            for (int sub = 0; sub < 2; ++sub)
+                for (int tid = 0; tid < NT; ++tid)
+                    psd_c3_apply(wb, tab, sub, tid / tpf, tid % tpf, tpf, p, ld, bsz, bs, k, l, r0, nrw, ncl);
+        }
     }
 }
 #endif

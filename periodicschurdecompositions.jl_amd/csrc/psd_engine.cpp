@@ -1348,6 +1348,11 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
         fprintf(stderr, "psd ticklog: phase cycles (decide, spawn, train shifts, small QR, claims, cursor states, deflate, RQ window):");
         for (int q = 0; q < 8; ++q) fprintf(stderr, " %lld/%d", hgl.dbg[q], hgl.dbgn[q]);
         fprintf(stderr, "\n");
+        if (hgl.c3dbg[7] > 0) {
+            fprintf(stderr, "psd ticklog: scan chase, cycles per position (loads + scan 1, reflectors + B, scan 2, 2-reflectors + records, barrier, apply 0, apply 1) over %lld positions:", hgl.c3dbg[7]);
+            for (int q = 0; q < 7; ++q) fprintf(stderr, " %.0f", (double)hgl.c3dbg[q] / (double)hgl.c3dbg[7]);
+            fprintf(stderr, "\n");
+        }
         if (FILE* fh = fopen(ticklog_path, "w")) {
             for (long long t = 0; t < launched && t < ticklog_cap; ++t) fprintf(fh, "%lld %d %d\n", t, tl[(size_t)t] >> 12, tl[(size_t)t] & 0xfff);
             fclose(fh);

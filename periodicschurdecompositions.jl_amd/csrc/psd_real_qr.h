@@ -166,6 +166,10 @@ struct psd_rglobal {
     // [5] cursor states, [6] deflate, [7] RQ window; dbgn: calls
     long long dbg[8];
     int dbgn[8];
+    // diagnostics (PSD_TICKLOG): shader cycles of the scan chase (psd_chase3.h), wavefront 0, summed over all positions:
+    // [0] loads + scan 1, [1] reflectors + B blocks, [2] scan 2, [3] 2-reflectors + table + records, [4] barrier wait,
+    // [5] apply phase 0, [6] apply phase 1, [7] positions
+    long long c3dbg[8];
 };
 
 struct psd_rparams {
@@ -310,7 +314,8 @@ PSD_D void psd_pair_store(double* q, const psd_pair& x) {
     *(psd_v2u*)q = v;
 }
 #endif
-PSD_D void psd_win_load(const psd_rparams& P, const psd_win& w, int n, int p) {
+// (j0, jstep: the factors j0, j0 + jstep, ... only — the wavefronts of a scan-chase workgroup share the window)
+PSD_D void psd_win_load(const psd_rparams& P, const psd_win& w, int n, int p, int j0 = 0, int jstep = 1) {
     const int m = w.be - w.bs + 1;
 #ifndef PSD_HOSTSIM
     if ((w.ld & 1) == 0 && w.ld <= 64) {
@@ -329,17 +334,17 @@ PSD_D void psd_win_load(const psd_rparams& P, const psd_win& w, int n, int p) {
         for (int c0 = 0; c0 < m; c0 += cpi) {  // (column group outside, factors inside: the inner loop is a pointer step and the load)
             const int c = c0 + cl;
             const bool act = on && c < m && c + PSD_WIN_BAND >= r;
-            const double* q = P.H + (size_t)(w.bs - 1 + (act ? c : 0)) * n + (w.bs - 1 + (act ? r : 0));
-            double* dst = w.b + c0 * w.ld;
+            const double* q = P.H + (size_t)(w.bs - 1 + (act ? c : 0)) * n + (w.bs - 1 + (act ? r : 0)) + (size_t)j0 * fstride;
+            double* dst = w.b + c0 * w.ld + j0 * w.bsz;
             if (act && pair_ok) {
-                for (int j = 0; j < p; ++j) {
+                for (int j = j0; j < p; j += jstep) {
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)q,
                                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-                    q += fstride;
-                    dst += w.bsz;
+                    q += fstride * jstep;
+                    dst += w.bsz * jstep;
                 }
             } else if (act) {
-                for (int j = 0; j < p; ++j) w.b[j * w.bsz + c * w.ld + r] = q[(size_t)j * fstride];
+                for (int j = j0; j < p; j += jstep) w.b[j * w.bsz + c * w.ld + r] = q[(size_t)(j - j0) * fstride];
             }
         }
         PSD_SYNC();
@@ -352,7 +357,7 @@ PSD_D void psd_win_load(const psd_rparams& P, const psd_win& w, int n, int p) {
             const bool pair = r + 1 < m;
             const int back = (pair || r == 0) ? 0 : 1;  // (m == 1: the single element twice, second copy dropped)
             const bool one = !pair && r == 0;
-            for (int j = 0; j < p; j += PSD_WIN_LF) {
+            for (int j = j0 * PSD_WIN_LF; j < p; j += jstep * PSD_WIN_LF) {
                 const double* src = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r - back);
                 double* dst = w.b + j * w.bsz + r;
                 psd_pair v[PSD_WIN_LF][8];
@@ -388,14 +393,14 @@ PSD_D void psd_win_load(const psd_rparams& P, const psd_win& w, int n, int p) {
     }
     PSD_SYNC();
 }
-PSD_D void psd_win_store(const psd_rparams& P, const psd_win& w, int n, int p) {
+PSD_D void psd_win_store(const psd_rparams& P, const psd_win& w, int n, int p, int j0 = 0, int jstep = 1) {
     const int m = w.be - w.bs + 1;
     PSD_SYNC();
     PSD_PAR_FOR(t, PSD_STEP_NT) {
         const int r = 2 * (t & 15), g = t >> 4;
         if (r < m) {
             const bool pair = r + 1 < m;
-            for (int j = 0; j < p; ++j) {
+            for (int j = j0; j < p; j += jstep) {
                 double* dst = P.H + (size_t)j * n * n + (size_t)(w.bs - 1) * n + (w.bs - 1 + r);
                 const double* src = w.b + j * w.bsz + r;
 #pragma unroll
@@ -1692,6 +1697,9 @@ struct psd_c2 {
                               // LDS traffic FLAT instructions)
     psd_tr* tr;               // this slot's lists
     double v0, v1, v2;        // the sweep's start vector (used when ks == l)
+    long long* dbg;           // diagnostics (scan chase): psd_rglobal::c3dbg or nullptr
+    double* H;                // commands 3 / 4 (window load / store shared by the wavefronts): factors, order, window width
+    int n, W;
 };
 #define PSD_C2_MINP 8
 #ifndef PSD_C2_STAMP
@@ -2025,8 +2033,20 @@ PSD_D void psd_c2_helper(int c2off, int c3off) {
         PSD_PAIR_BARRIER();
         const psd_c2 C = *cmd;
         if (C.cmd == 0) return;
-        if (C.cmd == 2) psd_c3_run(C, PSD_WAVE_ROLE, (int)blockDim.y, c3off);  // scan chase: every wavefront takes part
-        else psd_c2_run(C, 2);                                                  // two-wave chase: 64 x 2 workgroups
+        if (C.cmd == 2) {
+            psd_c3_run(C, PSD_WAVE_ROLE, (int)blockDim.y, c3off);  // scan chase: every wavefront takes part
+        } else if (C.cmd == 3 || C.cmd == 4) {  // this wavefront's share of a window load / store
+            psd_rparams R;
+            R.H = C.H;
+            psd_win w;
+            w.b = (double*)(psd_lds + C.wboff);
+            w.W = C.W; w.ld = C.ld; w.bsz = C.bsz; w.bs = C.bs; w.be = C.be;
+            if (C.cmd == 3) psd_win_load(R, w, C.n, C.p, PSD_WAVE_ROLE, (int)blockDim.y);
+            else psd_win_store(R, w, C.n, C.p, PSD_WAVE_ROLE, (int)blockDim.y);
+            PSD_PAIR_BARRIER();
+        } else {
+            psd_c2_run(C, 2);  // two-wave chase: 64 x 2 workgroups
+        }
     }
 }
 // wavefront A, last thing before it leaves the kernel
@@ -2054,6 +2074,33 @@ PSD_D void psd_c3_lead(const psd_rparams& P, psd_c2& C) {
 #endif
 }
 
+// a window load / store by all wavefronts of a scan-chase workgroup, each its share of the factors (wavefront 0's side)
+PSD_D void psd_c3_winio(const psd_rparams& P, const psd_win& w, int n, int p, bool store) {
+#ifndef PSD_HOSTSIM
+    if (P.c3off != 0 && blockDim.y > 1) {
+        PSD_LDS_DECL;
+        psd_c2* cmd = (psd_c2*)(psd_lds + P.c2off);
+        PSD_SYNC();
+        PSD_ONE {
+            psd_c2 C;
+            C.cmd = store ? 4 : 3;
+            C.ld = w.ld; C.bsz = w.bsz; C.bs = w.bs; C.be = w.be; C.W = w.W;
+            C.p = p; C.n = n; C.H = P.H;
+            C.wboff = (int)((char*)w.b - (char*)psd_lds);
+            *cmd = C;
+        }
+        PSD_PAIR_BARRIER();
+        if (store) psd_win_store(P, w, n, p, 0, (int)blockDim.y);
+        else psd_win_load(P, w, n, p, 0, (int)blockDim.y);
+        PSD_PAIR_BARRIER();
+        PSD_ONE { cmd->cmd = 0; }
+        return;
+    }
+#endif
+    if (store) psd_win_store(P, w, n, p);
+    else psd_win_load(P, w, n, p);
+}
+
 // PSD.jl:806-886: one window (steps kcur .. kcur+nb-1) of the double-shift periodic QR sweep
 PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, int* lcnt) {
     const int n = st.n, p = st.p, i = st.i, l = st.l, i1 = st.i1, i2 = st.i2;
@@ -2069,7 +2116,7 @@ PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
     w.bs = (ks > l) ? (ks - 1) : l;
     w.be = (ke + 3 < i) ? (ke + 3) : i;
     const long long tc0 = psd_clock();
-    psd_win_load(P, w, n, p);
+    psd_c3_winio(P, w, n, p, false);
     const long long tc1 = psd_clock();
     const int c1max = (w.be < i2) ? w.be : i2;
     const int r0 = (w.bs > i1) ? w.bs : i1;
@@ -2091,6 +2138,7 @@ PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
                 C.wboff = (int)((char*)w.b - (char*)psd_lds);
             }
             C.tr = P.tr;
+            C.dbg = (P.ticklog != nullptr && P.gl != nullptr) ? P.gl->c3dbg : nullptr;
             C.v0 = st.v[0]; C.v1 = st.v[1]; C.v2 = st.v[2];
             PSD_SYNC();
             if (scan3) psd_c3_lead(P, C);
@@ -2168,7 +2216,7 @@ PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
     }
     PSD_PAR_FOR(m, p) { lcnt[m] = (m == 0) ? n1 : nj; }
     const long long tc2 = psd_clock();
-    psd_win_store(P, w, n, p);
+    psd_c3_winio(P, w, n, p, true);
     const long long tc3 = psd_clock();
     st.cyc[1] += tc1 - tc0;
     st.cyc[2] += tc2 - tc1;
@@ -2220,7 +2268,7 @@ PSD_D void psd_rq_rq_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
     w.bs = ke - 1;
     w.be = (ks + 1 < i) ? (ks + 1) : i;
     PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
-    psd_win_load(P, w, n, p);
+    psd_c3_winio(P, w, n, p, false);
     for (int k = ks; k >= ke; --k) {
         for (int j = 1; j <= p - 1; ++j) {
             double x[2] = {w.at(j, k, k), w.at(j, k, k - 1)};
@@ -2265,7 +2313,7 @@ PSD_D void psd_rq_rq_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
             psd_record(P, lcnt, 1, tr);
         }
     }
-    psd_win_store(P, w, n, p);
+    psd_c3_winio(P, w, n, p, true);
     psd_desc_write(P, st, lcnt, w.bs, w.be, w.be + 1, i2, i1, w.bs - 1);
     st.nwindows += 1;
     st.kcur = ke - 1;
@@ -2305,7 +2353,7 @@ PSD_D bool psd_rq_deflate(const psd_rparams& P, psd_rstate& st, double* ldsd, in
     double hh11, hh12, hh21, hh22;
     if (st.wantT) {
         PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
-        psd_win_load(P, w, n, p);
+        psd_c3_winio(P, w, n, p, false);
         double hp22 = 1.0, hp12 = 0.0, hp11 = 1.0;  // PSD.jl:908-920
         for (int j = 2; j <= p; ++j) {
             hp22 *= w.at(j, i, i);
@@ -2456,7 +2504,7 @@ PSD_D bool psd_rq_deflate(const psd_rparams& P, psd_rstate& st, double* ldsd, in
         P.wr[i - 2] = w1r; P.wi[i - 2] = w1i;
         P.wr[i - 1] = w2r; P.wi[i - 1] = w2i;
     }
-    psd_win_store(P, w, n, p);
+    psd_c3_winio(P, w, n, p, true);
     psd_desc_write(P, st, lcnt, i - 1, i, i + 1, i2, i1, i - 2);
     return true;
 }
