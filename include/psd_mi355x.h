@@ -84,6 +84,13 @@ int psd_get_train_z(psd_ctx* ctx);
 int psd_set_train_g(psd_ctx* ctx, int bulges);
 int psd_get_train_g(psd_ctx* ctx);
 const char* psd_version(void);
+/* 1 if the multi-stream periodic Hessenberg reductions of this context (phessenberg!, PSD.jl:213-259, for p >= 32,
+ * n >= 512 or when forced) take the pipe form — consecutive chain launches overlapping on two streams —, 0 if they run
+ * back to back.  Fixed for the life of the context at psd_create (a context created while no other context of the
+ * process is alive gets the pipe form; PSD_H2_PIPE=0 / 2 in the environment forbids / forces it) and forced on by
+ * psd_set_shard with world > 1, so that every rank of a period-sharded call runs the same form: the two forms round
+ * differently (plain sum of squares against the scaled form of the norm). */
+int psd_get_hess_pipe(psd_ctx* ctx);
 /* Period sharding over `world` contexts (one per GPU, one process each): every context runs the
  * latency-bound chains (Hessenberg links, window chases) and the updates of the factors H_j they read — identical on
  * all ranks, bit for bit (the tick schedule is reproducible: tests/test_gpu_headline.py, tests/test_gpu_shard.py) — while the

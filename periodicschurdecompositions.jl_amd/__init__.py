@@ -17,6 +17,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpsd_mi355x.so")
+# the diagnostic build (-DPSD_DIAG: timing experiments, tuning knobs, fault injection behind environment variables).
+# Only tools/ and the fault-injection test pass it as `libpath`; the package itself never loads it.
+DIAG_LIB_PATH = os.path.join(_HERE, "libpsd_mi355x_diag.so")
 
 INFO_NOCONV = 1000000
 INFO_NOTIMPL = 2000000
@@ -223,6 +226,12 @@ class Engine:
     def get_train(self):
         self.lib.psd_get_train.argtypes = [C.c_void_p]
         return int(self.lib.psd_get_train(self.ctx))
+
+    def hess_pipe(self):
+        """1 if this engine's multi-stream Hessenberg reductions take the pipe form (psd_get_hess_pipe): fixed at
+        creation, forced on by set_shard with world > 1."""
+        self.lib.psd_get_hess_pipe.argtypes = [C.c_void_p]
+        return int(self.lib.psd_get_hess_pipe(self.ctx))
 
     def set_shard(self, rank, world):
         """Period sharding (include/psd_mi355x.h, psd_set_shard): this engine keeps the Schur vectors Z_j of its

@@ -29,7 +29,11 @@
 psd_simctx psd_sim;
 #define PSD_LIB_FLAVOUR "hostsim"
 #else
+#ifdef PSD_DIAG
+#define PSD_LIB_FLAVOUR "hip-gfx950, diagnostic build"
+#else
 #define PSD_LIB_FLAVOUR "hip-gfx950"
+#endif
 #endif
 
 #define PSD_CHECK(expr)                                  \
@@ -37,6 +41,21 @@ psd_simctx psd_sim;
         int _e = (int)(expr);                            \
         if (_e != 0) return PSD_INFO_RUNTIME + (_e & 0xffff); \
     } while (0)
+
+// Environment switches (INTEGRATION.md lists them).
+//  * psd_env(): selectors between code paths that ALL return a correct decomposition (the tests use them to reach every
+//    path of the product library).
+//  * psd_env_diag(): diagnostics, timing experiments and tuning knobs, some of which void the results (the Hessenberg chain
+//    without its panel updates, the panel kernel run on finished matrices, a hand-over that never validates).  They exist
+//    only in a build with -DPSD_DIAG: libpsd_mi355x_diag.so, built beside the product library for tools/ and the
+//    fault-injection test, and the test-only serial simulation.  In the product library a stray environment variable
+//    cannot change what a call returns.
+static inline const char* psd_env(const char* k) { return getenv(k); }
+#ifdef PSD_DIAG
+static inline const char* psd_env_diag(const char* k) { return getenv(k); }
+#else
+static inline const char* psd_env_diag(const char*) { return nullptr; }
+#endif
 
 namespace {
 
@@ -74,7 +93,7 @@ int choose_window(int p, int esize = 8, bool even = false) {
     // largest W <= 32 with p blocks of W x (W+1) elements (+ scratch) inside the 160 KiB LDS of one CU;
     // PSD_WINDOW (test hook) lowers it
     int cap = 32;
-    if (const char* e = getenv("PSD_WINDOW")) {
+    if (const char* e = psd_env("PSD_WINDOW")) {
         const int w = atoi(e);
         if (w >= 6 && w < cap) cap = w;
     }
@@ -254,6 +273,7 @@ struct psd_ctx {
     int overlap = 3;  // Schur-vector updates on stream2 beside the next tick's chases: 0 off, 2 on, 3 = on for n >= 1024 (PSD_OVERLAP)
     int far_grid = 0;  // grid of the far bulk-update launches (0: apply_wl_grid)
     bool counted = false;  // (this context is in g_live_contexts)
+    bool pipe_ok = false;  // created while no other context of the process was alive: its Hessenberg reductions may take the pipe form
 #ifndef PSD_HOSTSIM
     hipStream_t stream2 = nullptr;  // the far parts of the bulk updates (beside the next tick's chases)
     hipStream_t stream3 = nullptr;  // the panel updates of the Hessenberg reduction (beside its chain)
@@ -608,6 +628,19 @@ void fill_bytes(psd_stats* s, int n, int p, int wantT, int wantZ, const std::vec
     s->bytes_sweeps = b;
 }
 
+// Which form the multi-stream Hessenberg reductions of this context take (see psd_create): the pipe form needs the
+// fourth stream; PSD_H2_PIPE=2 forces it, =0 forbids it; a period-sharded context always takes it (every rank must
+// run the same form: the replicated chains have to agree bit for bit, and a rank is one process with one GPU).
+static inline bool psd_pipe_form(const psd_ctx* c) {
+#ifndef PSD_HOSTSIM
+    if (!c->stream4 || c->hess_pipe == 0) return false;
+    return c->hess_pipe == 2 || c->shard_world > 1 || c->pipe_ok;
+#else
+    (void)c;
+    return false;
+#endif
+}
+
 #ifndef PSD_HOSTSIM
 // look-ahead form (psd_hess2.h): one launch per chain link, the panel updates ride one launch behind the chain
 template <int NK, int CR>
@@ -630,6 +663,16 @@ int hessenberg2_launches(psd_ctx* c, int n, int p, const psd_hess2_args& ha) {
 // matrix — its update by the previous link on it, p links earlier — is awaited by event before the launch that reads it.
 template <int NK, int CR>
 int hessenberg2_async(psd_ctx* c, int n, int p, const psd_hess2_args& ha, int K) {
+    // Every way out (a failed runtime call in the middle of the launch sequence included) first waits for the side streams:
+    // their launches read and write the caller's factors and this context's ring.
+    struct SideStreams {
+        psd_ctx* c;
+        ~SideStreams() {
+            if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+            if (c->stream4) (void)hipStreamSynchronize(c->stream4);
+        }
+    } side_streams{c};
+
     const int nC = ((ha.xcd && CR < 16) ? (((n + CR - 1) / CR + 128 / CR - 1) / (128 / CR)) * (128 / CR) : (n + CR - 1) / CR) + 1, nT = (n + PSD_H2_ROWS - 1) / PSD_H2_ROWS, nB = (n + 3) / 4;
     const size_t lds = ((size_t)n + 8 + 2 * PSD_H2_NT + 64) * sizeof(double);
     const int Q = (n - 1) * p;
@@ -647,7 +690,7 @@ int hessenberg2_async(psd_ctx* c, int n, int p, const psd_hess2_args& ha, int K)
     hipLaunchKernelGGL((psd_hess2_link<NK, CR>), dim3(nC), dim3(PSD_H2_NT), lds, c->stream, ha, n, 0, 1, nC, 0);  // staging
     const int lag = 0;  // (launching a batch later than it could be — so that the chain finds its matrix in the Infinity Cache — was measured in rounds 2 and 3: no gain)
     int nextb = 0;  // next batch to launch
-    const bool nobulk = getenv("PSD_H2_NOBULK") != nullptr;  // (timing experiment: the chain alone; results are wrong)
+    const bool nobulk = psd_env_diag("PSD_H2_NOBULK") != nullptr;  // (timing experiment: the chain alone; results are wrong)
     auto batch = [&](int b) -> int {
         PSD_CHECK(hipEventRecord(evA[b & 7], c->stream));
         PSD_CHECK(hipStreamWaitEvent(c->stream3, evA[b & 7], 0));
@@ -680,6 +723,16 @@ int hessenberg2_async(psd_ctx* c, int n, int p, const psd_hess2_args& ha, int K)
 // stored v and tau), and what the chain needs of a batch is awaited on both streams.
 template <int NK, int CR>
 int hessenberg2_pipe(psd_ctx* c, int n, int p, const psd_hess2_args& ha, int K) {
+    // Every way out (a failed runtime call in the middle of the launch sequence included) first waits for the side streams:
+    // their launches read and write the caller's factors and this context's ring.
+    struct SideStreams {
+        psd_ctx* c;
+        ~SideStreams() {
+            if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+            if (c->stream4) (void)hipStreamSynchronize(c->stream4);
+        }
+    } side_streams{c};
+
     const int nC = ((ha.xcd && CR < 16) ? (((n + CR - 1) / CR + 128 / CR - 1) / (128 / CR)) * (128 / CR) : (n + CR - 1) / CR) + 1, nT = (n + PSD_H2_ROWS - 1) / PSD_H2_ROWS, nB = (n + 3) / 4;
     const size_t lds = ((size_t)n + 8 + 2 * PSD_H2_NT + 64) * sizeof(double);
     const int Q = (n - 1) * p;
@@ -699,7 +752,7 @@ int hessenberg2_pipe(psd_ctx* c, int n, int p, const psd_hess2_args& ha, int K) 
     PSD_CHECK(hipStreamWaitEvent(c->stream4, evJ, 0));
     hipLaunchKernelGGL((psd_hess2_link<NK, CR>), dim3(nC), dim3(PSD_H2_NT), lds, S[0], ha, n, 0, 1, nC, 0);  // staging
     int nextb = 0;
-    const bool nobulk = getenv("PSD_H2_NOBULK") != nullptr;  // (timing experiment: the chain alone; results are wrong)
+    const bool nobulk = psd_env_diag("PSD_H2_NOBULK") != nullptr;  // (timing experiment: the chain alone; results are wrong)
     auto batch = [&](int b) -> int {
         PSD_CHECK(hipEventRecord(evA[b & 7], S[0]));
         PSD_CHECK(hipEventRecord(evC[b & 7], S[1]));
@@ -728,7 +781,7 @@ int hessenberg2_pipe(psd_ctx* c, int n, int p, const psd_hess2_args& ha, int K) 
     PSD_CHECK(hipEventRecord(evK, S[1]));
     PSD_CHECK(hipStreamWaitEvent(c->stream, evK, 0));
     PSD_CHECK(hipStreamWaitEvent(c->stream, evB[(nbatch - 1) & 7], 0));
-    if (getenv("PSD_H2_BULKBENCH")) {
+    if (psd_env_diag("PSD_H2_BULKBENCH")) {
         // diagnostics: the panel kernel ALONE on the finished matrices (the transformations it applies are the ring's
         // leftovers: results void), the first 100 batches back to back on the panel stream
         PSD_CHECK(hipDeviceSynchronize());
@@ -774,11 +827,11 @@ int hessenberg2_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
     ha.trace_hi = 0x7fffffff;
     ha.pipe = 0;
     ha.fault = -1;
-    if (const char* e = getenv("PSD_H2_FAULT")) ha.fault = atoi(e);  // (test hook: the hand-over to this link never validates)
+    if (const char* e = psd_env_diag("PSD_H2_FAULT")) ha.fault = atoi(e);  // (test hook: the hand-over to this link never validates)
     ha.err = (int*)(c->h2ring + PSD_H2_RING * psd_h2_slot_doubles(c->h2ring_n));
-    if (const char* e = getenv("PSD_H2_TRACE")) { if (atoi(e) > 1) ha.trace_hi = atoi(e); }
+    if (const char* e = psd_env_diag("PSD_H2_TRACE")) { if (atoi(e) > 1) ha.trace_hi = atoi(e); }
     long long* h2trace = nullptr;
-    if (getenv("PSD_H2_TRACE") && psd_rt_malloc((void**)&h2trace, (1024 * 8 + 1024 * 4) * sizeof(long long)) == 0) {
+    if (psd_env_diag("PSD_H2_TRACE") && psd_rt_malloc((void**)&h2trace, (1024 * 8 + 1024 * 4) * sizeof(long long)) == 0) {
         PSD_CHECK(psd_rt_memset(h2trace, 0, (1024 * 8 + 1024 * 4) * sizeof(long long), c->stream));
         ha.trace = h2trace;
     }
@@ -830,10 +883,9 @@ int hessenberg2_dev(psd_ctx* c, int n, int p, double* dH, double* dtau) {
     if (K > 0 && p >= 9 * K) K = (p + 7) / 8;
     if (K > 0 && p >= 2 * K && p + K + 2 <= PSD_H2_RING && c->stream3) {
         ha.ringmask = PSD_H2_RING - 1;
-        if (c->stream4 && (c->hess_pipe == 2 || (c->hess_pipe && g_live_contexts.load() <= 1))) {  // (PSD_H2_PIPE=2: also beside other contexts)
+        if (c->stream4 && psd_pipe_form(c)) {  // (PSD_H2_PIPE=2: also beside other contexts)
             ha.pipe = 2;  // (every poll round reads the whole column; 1: a watch round on one record per strip first — one more round trip per link, 477 against 442 ms)
-            if (const char* e = getenv("PSD_H2_POLL")) ha.pipe = (atoi(e) == 1) ? 1 : 2;
-            if (const char* e = getenv("PSD_H2_XCD")) ha.xcd = atoi(e); else if (n > 512 && n <= 1024) ha.xcd = 0;  // (8-row strips: two per line, the mapping no longer pays: 482 -> 474 ms)
+            if (n > 512 && n <= 1024) ha.xcd = 0;  // (8-row strips: two per line, the mapping no longer pays: 482 -> 474 ms)
             int rc;
             if (n <= 256) rc = hessenberg2_pipe<4, 8>(c, n, p, ha, K);
             else if (n <= 512) rc = hessenberg2_pipe<8, 8>(c, n, p, ha, K);
@@ -1074,7 +1126,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
             }
         }
     } exit_guard{c, &P.ticklog};
-    const char* ticklog_path = getenv("PSD_TICKLOG");  // diagnostics: per tick the longest workgroup of the chase launch
+    const char* ticklog_path = psd_env_diag("PSD_TICKLOG");  // diagnostics: per tick the longest workgroup of the chase launch
     const int ticklog_cap = 1 << 16;
     if (ticklog_path && nprob == 1) {
         if (psd_rt_malloc((void**)&P.ticklog, sizeof(int) * ticklog_cap) == 0) {
@@ -1135,7 +1187,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
 #endif
     }
     int train_oc = 104;
-    if (const char* e = getenv("PSD_TRAIN_OC")) train_oc = atoi(e);  // (tuning hook)
+    if (const char* e = psd_env_diag("PSD_TRAIN_OC")) train_oc = atoi(e);  // (tuning hook)
     int Mw = M;
     if (mb && c->train_mb_m > Mw && c->train_m >= 32) Mw = (c->train_mb_m > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : c->train_mb_m;
     PSD_LAUNCH(psd_rq_init, psd_dim3(p, nprob), 256, 256 * 8, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, Mw, train_oc,
@@ -1457,7 +1509,7 @@ int psd_create(psd_ctx** ctx, int device) {
             return PSD_INFO_RUNTIME + 5;
         }
     }
-    if (const char* e = getenv("PSD_OVERLAP")) c->overlap = atoi(e);
+    if (const char* e = psd_env("PSD_OVERLAP")) c->overlap = atoi(e);
     {
         // The far bulk updates run beside the next tick's chases.  A chase workgroup takes the whole LDS of a compute
         // unit (p*W*(W+1) doubles), so it can only start on a CU that holds no bulk-update workgroup: the second stream
@@ -1465,7 +1517,7 @@ int psd_create(psd_ctx** ctx, int device) {
         int ncu = 0;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
         int keep = PSD_SLOTS;
-        if (const char* e = getenv("PSD_OVERLAP_CUS")) keep = atoi(e);
+        if (const char* e = psd_env_diag("PSD_OVERLAP_CUS")) keep = atoi(e);
         hipError_t rc = hipErrorInvalidValue;
         if (c->overlap && ncu > keep + 32 && keep > 0 && ncu <= 1024) {
             uint32_t mask[32];
@@ -1482,7 +1534,7 @@ int psd_create(psd_ctx** ctx, int device) {
         // the same for the panel updates of the Hessenberg reduction: its chain launches are HBM-latency chains that
         // slow down under the panel traffic; half of the chip for the panels measured best (PSD_HESS_CUS)
         int keeph = 64;  // (128 until the chain launches overlapped: hessenberg2_pipe)
-        if (const char* e = getenv("PSD_HESS_CUS")) keeph = atoi(e);
+        if (const char* e = psd_env_diag("PSD_HESS_CUS")) keeph = atoi(e);
         rc = hipErrorInvalidValue;
         if (ncu > keeph + 32 && keeph > 0 && ncu <= 1024) {
             uint32_t mask[32];
@@ -1496,42 +1548,44 @@ int psd_create(psd_ctx** ctx, int device) {
             return PSD_INFO_RUNTIME + 4;
         }
         if (hipStreamCreate(&c->stream4) != hipSuccess) c->stream4 = nullptr;
-        if (const char* e = getenv("PSD_H2_PIPE")) c->hess_pipe = atoi(e);
+        if (const char* e = psd_env("PSD_H2_PIPE")) c->hess_pipe = atoi(e);
     }
 #endif
 #ifndef PSD_HOSTSIM
-    if (const char* e = getenv("PSD_HESS_LOOKAHEAD")) c->hess_lookahead = atoi(e);
-    if (const char* e = getenv("PSD_HESS_ASYNC")) c->hess_async = atoi(e);
+    if (const char* e = psd_env("PSD_HESS_LOOKAHEAD")) c->hess_lookahead = atoi(e);
+    if (const char* e = psd_env("PSD_HESS_ASYNC")) c->hess_async = atoi(e);
 #endif
 #ifdef PSD_HOSTSIM
-    if (const char* e = getenv("PSD_OVERLAP")) c->overlap = atoi(e);
+    if (const char* e = psd_env("PSD_OVERLAP")) c->overlap = atoi(e);
 #endif
-    if (const char* e = getenv("PSD_CDEFER")) c->cdefer = atoi(e);
-    if (const char* e = getenv("PSD_FORMQ_BLOCKED")) c->formq_blocked = atoi(e);
-    if (const char* e = getenv("PSD_BAND_HELPER")) c->band_helper = atoi(e);
-    if (const char* e = getenv("PSD_TRAIN_LONG")) c->train_long = atoi(e);
-    if (const char* e = getenv("PSD_TRAIN_STOP")) c->train_stop = atoi(e);
-    if (const char* e = getenv("PSD_TRAIN_WDIV")) c->train_wdiv = atoi(e) > 0 ? atoi(e) : 8;
-    if (const char* e = getenv("PSD_MB")) c->mblock = atoi(e);
-    if (const char* e = getenv("PSD_TRAIN_MB")) c->train_mb_m = atoi(e);
-    if (const char* e = getenv("PSD_CGAP")) c->cgap = (atoi(e) == 2) ? 2 : 1;
-    if (const char* e = getenv("PSD_APPLY_WL")) c->apply_worklist = atoi(e);
-    if (const char* e = getenv("PSD_APPLY_WL_GRID")) c->apply_wl_grid = atoi(e) > 0 ? atoi(e) : 2048;
-    if (const char* e = getenv("PSD_APPLY_WL2")) c->apply_wl2 = atoi(e);
-    if (const char* e = getenv("PSD_C2")) c->chase2 = atoi(e);
-    if (const char* e = getenv("PSD_C3")) c->chase3 = atoi(e);
+    if (const char* e = psd_env("PSD_CDEFER")) c->cdefer = atoi(e);
+    if (const char* e = psd_env("PSD_FORMQ_BLOCKED")) c->formq_blocked = atoi(e);
+    if (const char* e = psd_env("PSD_BAND_HELPER")) c->band_helper = atoi(e);
+    if (const char* e = psd_env_diag("PSD_TRAIN_LONG")) c->train_long = atoi(e);
+    if (const char* e = psd_env_diag("PSD_TRAIN_STOP")) c->train_stop = atoi(e);
+    if (const char* e = psd_env_diag("PSD_TRAIN_WDIV")) c->train_wdiv = atoi(e) > 0 ? atoi(e) : 8;
+    if (const char* e = psd_env("PSD_MB")) c->mblock = atoi(e);
+    if (const char* e = psd_env_diag("PSD_TRAIN_MB")) c->train_mb_m = atoi(e);
+    if (const char* e = psd_env_diag("PSD_APPLY_WL")) c->apply_worklist = atoi(e);
+    if (const char* e = psd_env_diag("PSD_APPLY_WL_GRID")) c->apply_wl_grid = atoi(e) > 0 ? atoi(e) : 2048;
+    if (const char* e = psd_env_diag("PSD_APPLY_WL2")) c->apply_wl2 = atoi(e);
+    if (const char* e = psd_env("PSD_C2")) c->chase2 = atoi(e);
+    if (const char* e = psd_env("PSD_C3")) c->chase3 = atoi(e);
 #ifndef PSD_HOSTSIM
-    if (const char* e = getenv("PSD_H2_XCD")) c->hess_xcd = atoi(e);
 #endif
-    if (const char* e = getenv("PSD_APPLY_WL2_GRID")) c->apply_wl2_grid = atoi(e) > 0 ? atoi(e) : 1024;
+    if (const char* e = psd_env_diag("PSD_APPLY_WL2_GRID")) c->apply_wl2_grid = atoi(e) > 0 ? atoi(e) : 1024;
 #ifdef PSD_HOSTSIM
     c->apply_wl_grid = 3;  // (serial simulation: a few workgroups exercise the item loop)
 #endif
-    if (const char* e = getenv("PSD_TRAIN")) c->train_m = c->ztrain_m = c->gtrain_m = atoi(e);
-    if (const char* e = getenv("PSD_TRAIN_Z")) c->ztrain_m = atoi(e);
-    if (const char* e = getenv("PSD_TRAIN_G")) c->gtrain_m = atoi(e);
+    if (const char* e = psd_env("PSD_TRAIN")) c->train_m = c->ztrain_m = c->gtrain_m = atoi(e);
+    if (const char* e = psd_env("PSD_TRAIN_Z")) c->ztrain_m = atoi(e);
+    if (const char* e = psd_env("PSD_TRAIN_G")) c->gtrain_m = atoi(e);
     c->counted = true;
-    g_live_contexts.fetch_add(1);
+    // The form of the multi-stream Hessenberg reductions is a property of the context, fixed here: the pipe form for a
+    // context that is created while no other context of the process is alive, the back-to-back form for every other one
+    // (the two forms round differently — plain sum of squares against dlassq —, so a context must not change form from
+    // call to call depending on what else happens to exist at that moment).  psd_get_hess_pipe reports it.
+    c->pipe_ok = g_live_contexts.fetch_add(1) == 0;
     *ctx = c;
     return 0;
 }
@@ -1557,6 +1611,7 @@ int psd_set_train_g(psd_ctx* c, int bulges) {
     return 0;
 }
 int psd_get_train_g(psd_ctx* c) { return c ? c->gtrain_m : -1; }
+int psd_get_hess_pipe(psd_ctx* c) { return c ? (psd_pipe_form(c) ? 1 : 0) : -1; }
 
 int psd_destroy(psd_ctx* c) {
     if (!c) return 0;
@@ -1797,6 +1852,16 @@ int zhessenberg2_launches(psd_ctx* c, int n, int p, const psd_zhess2_args& ha) {
 }
 template <int NK, int CR>
 int zhessenberg2_async(psd_ctx* c, int n, int p, const psd_zhess2_args& ha, int K) {
+    // Every way out (a failed runtime call in the middle of the launch sequence included) first waits for the side streams:
+    // their launches read and write the caller's factors and this context's ring.
+    struct SideStreams {
+        psd_ctx* c;
+        ~SideStreams() {
+            if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+            if (c->stream4) (void)hipStreamSynchronize(c->stream4);
+        }
+    } side_streams{c};
+
     constexpr int LG = 64 / CR;
     const int nC = ((ha.xcd && CR < 8) ? (((n + CR - 1) / CR + LG - 1) / LG) * LG : (n + CR - 1) / CR) + 1, nT = (n + PSD_ZH2_ROWS - 1) / PSD_ZH2_ROWS, nB = (n + 3) / 4;
     const size_t lds = ((size_t)n + 8 + 2 * PSD_ZH2_NT + 64) * sizeof(psd_z);
@@ -1837,6 +1902,16 @@ int zhessenberg2_async(psd_ctx* c, int n, int p, const psd_zhess2_args& ha, int 
 // pipe form for ComplexF64 (see hessenberg2_pipe)
 template <int NK, int CR>
 int zhessenberg2_pipe(psd_ctx* c, int n, int p, const psd_zhess2_args& ha, int K) {
+    // Every way out (a failed runtime call in the middle of the launch sequence included) first waits for the side streams:
+    // their launches read and write the caller's factors and this context's ring.
+    struct SideStreams {
+        psd_ctx* c;
+        ~SideStreams() {
+            if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+            if (c->stream4) (void)hipStreamSynchronize(c->stream4);
+        }
+    } side_streams{c};
+
     constexpr int LG = 64 / CR;
     const int nC = ((ha.xcd && CR < 8) ? (((n + CR - 1) / CR + LG - 1) / LG) * LG : (n + CR - 1) / CR) + 1, nT = (n + PSD_ZH2_ROWS - 1) / PSD_ZH2_ROWS, nB = (n + 3) / 4;
     const size_t lds = ((size_t)n + 8 + 2 * PSD_ZH2_NT + 64) * sizeof(psd_z);
@@ -1910,7 +1985,7 @@ int zhessenberg2_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dtau) {
     if (K > 0 && p >= 9 * K) K = (p + 7) / 8;
     if (K > 0 && p >= 2 * K && p + K + 2 <= PSD_H2_RING && c->stream3) {
         ha.ringmask = PSD_H2_RING - 1;
-        if (c->stream4 && n <= 1024 && (c->hess_pipe == 2 || (c->hess_pipe && g_live_contexts.load() <= 1))) {
+        if (c->stream4 && n <= 1024 && psd_pipe_form(c)) {
             ha.pipe = 1;
             int rc;
             if (n <= 256) rc = zhessenberg2_pipe<4, 8>(c, n, p, ha, K);
@@ -2048,7 +2123,7 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
 #endif
     }
     int train_oc = 200;  // (100 until the cursors moved to W positions apart; 200-400 measured alike)
-    if (const char* e = getenv("PSD_TRAIN_OC")) train_oc = atoi(e);  // (tuning hook)
+    if (const char* e = psd_env_diag("PSD_TRAIN_OC")) train_oc = atoi(e);  // (tuning hook)
     PSD_LAUNCH(psd_zq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, M, train_oc);
 #ifndef PSD_HOSTSIM
     const bool zdef = M > 1 && wantZ && c->stream2 && c->evE[0] && (c->overlap == 2 || (c->overlap == 3 && n >= 1024));
@@ -2061,7 +2136,7 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
     const size_t lds_wl = lds_apply + sizeof(int) * 2 * (PSD_TRAIN_MAX + 2);  // (+ the work list's item table)
 #ifndef PSD_HOSTSIM
     int wl_grid = 2048;  // (single-wave workgroups; 1024 .. 2560 measured alike, 3072 and more slower)
-    if (const char* e = getenv("PSD_ZWL_GRID")) wl_grid = atoi(e);
+    if (const char* e = psd_env_diag("PSD_ZWL_GRID")) wl_grid = atoi(e);
 #else
     const int wl_grid = 6;
 #endif
@@ -2268,7 +2343,7 @@ int zgiterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
     // stage 2 of the signed Hessenberg reduction: pipeline over the factors (see giterate_dev)
     const size_t lds_hess = psd_zghess_lds_bytes(p, W);
     const int hess_links = psd_ghess_links(p), hess_waves = psd_ghess_waves(p);
-    const char* hserial = getenv("PSD_HESS_SERIAL");
+    const char* hserial = psd_env("PSD_HESS_SERIAL");
     const bool hess_pipe = hessmode && lds_hess <= (size_t)160 * 1024 && !(hserial && hserial[0] == '1');
 #ifndef PSD_HOSTSIM
     if (hess_pipe && lds_hess > c->zghess_lds_set) {
@@ -2303,7 +2378,7 @@ int zgiterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
         }
     }
     int train_oc = 50;
-    if (const char* e = getenv("PSD_TRAIN_OC")) train_oc = atoi(e);  // (tuning hook)
+    if (const char* e = psd_env_diag("PSD_TRAIN_OC")) train_oc = atoi(e);  // (tuning hook)
     PSD_LAUNCH(psd_zgq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, hessmode,
                (tw == -2) ? -2 : M, train_oc);
     const size_t lds_apply = sizeof(psd_ztr) * PSD_GTR_CAP + (size_t)32 * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
@@ -3003,7 +3078,7 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
     // (window + mailboxes) fits; PSD_HESS_SERIAL=1 (test hook) keeps the single-wave chase
     const size_t lds_hess = psd_ghess_lds_bytes(p, W);
     const int hess_links = psd_ghess_links(p), hess_waves = psd_ghess_waves(p);
-    const char* hserial = getenv("PSD_HESS_SERIAL");
+    const char* hserial = psd_env("PSD_HESS_SERIAL");
     const bool hess_pipe = hessmode && lds_hess <= (size_t)160 * 1024 && !(hserial && hserial[0] == '1');
 #ifndef PSD_HOSTSIM
     if (hess_pipe && lds_hess > c->ghess_lds_set) {
@@ -3037,7 +3112,7 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
         }
     }
     int train_oc = 50;  // (a position of a signed factor costs about 1 us, a tick's overhead about 50 us)
-    if (const char* e = getenv("PSD_TRAIN_OC")) train_oc = atoi(e);  // (tuning hook)
+    if (const char* e = psd_env_diag("PSD_TRAIN_OC")) train_oc = atoi(e);  // (tuning hook)
     PSD_LAUNCH(psd_gq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, hessmode,
                (tw == -2) ? -2 : M, train_oc);
     const size_t lds_apply = PSD_GTR_LDS_BYTES + (size_t)32 * (PSD_GAPPLY_NT + 1) * sizeof(double);
@@ -3103,7 +3178,7 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
 #ifndef PSD_HOSTSIM
     PSD_CHECK(poller.finish(pend));
 #endif
-    if (getenv("PSD_GDBG")) {
+    if (psd_env_diag("PSD_GDBG")) {
         fprintf(stderr, "psd signed check stages (cycles/calls: test 1, tests 2-3, start rotations, train shifts, explicit start, cursor states, 2x2 block, split):");
         for (int q = 0; q < 8; ++q) fprintf(stderr, " %lld/%d", hst.dbg[q], hst.dbgn[q]);
         fprintf(stderr, " | cyc decide %lld load %lld chase %lld store %lld total %lld\n", hst.cyc[0], hst.cyc[1], hst.cyc[2], hst.cyc[3], hst.cyc[4]);

@@ -29,6 +29,23 @@
 #define PSD_H2_ROWS 8
 #define PSD_H2_RING 256  // slots of the per-link ring (power of two)
 
+// The bounded wait of the pipe form (hand-over records that do not validate): bounded in TIME, not in poll rounds — a
+// predecessor launch can be held back by a tracer that serialises dispatches, by another process on the GPU or by a long
+// panel batch on the masked compute units, and a bound in rounds (2^17 of them, about a second when nothing else runs)
+// would then give up on a healthy chain.  s_memrealtime counts at 100 MHz; the clock is looked at every 256 rounds only,
+// the first look sets the start.  About three seconds, then the error word is set, every later launch stops waiting and
+// the host returns PSD_INFO_RUNTIME: the factors passed in are destroyed at that point (the reduction works in place).
+#define PSD_H2_WAIT_TICKS 300000000LL
+__device__ __forceinline__ bool psd_h2_wait_expired(int& spins, long long& t0) {
+    if ((++spins & 255) != 0) return false;
+    const long long now = (long long)__builtin_amdgcn_s_memrealtime();
+    if (t0 == 0) {
+        t0 = now;
+        return false;
+    }
+    return now - t0 > PSD_H2_WAIT_TICKS;
+}
+
 struct psd_hess2_args {
     double* H;     // [p][n][n]
     double* tau;   // [p][n]
@@ -463,6 +480,7 @@ __global__ void __launch_bounds__(PSD_H2_NT, ((NK > 16 || NK * CR > 128) ? ((NK 
             const unsigned long long* rec = S.rec + 2 * (size_t)r0;
             unsigned long long xb[NV], ab = 0;
             int spins = 0;
+            long long wait_t0 = 0;
             // pipe == 1: first a cheap watch on one record per strip of the previous launch (thread t: the first row of
             // strip t at or below r0), then the column.  With 129 workgroups of 8-row strips polling the whole column costs
             // less than the extra round trip, so this is off by default (PSD_H2_POLL=1 turns it on)
@@ -479,7 +497,7 @@ __global__ void __launch_bounds__(PSD_H2_NT, ((NK > 16 || NK * CR > 128) ? ((NK 
                     }
                     const bool giveup = __hip_atomic_load(G->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
                     if (__syncthreads_and((okr || giveup) ? 1 : 0)) break;
-                    if (++spins > (1 << 17)) {
+                    if (psd_h2_wait_expired(spins, wait_t0)) {  // (every wave reaches an exit; the results are then void and the host says so)
                         if (tid == 0) __hip_atomic_store(G->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     __builtin_amdgcn_s_sleep(2);
@@ -505,7 +523,7 @@ __global__ void __launch_bounds__(PSD_H2_NT, ((NK > 16 || NK * CR > 128) ? ((NK 
                 asm volatile("" ::: "memory");
                 const bool giveup = __hip_atomic_load(G->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
                 if (__syncthreads_and((okr || giveup) ? 1 : 0)) break;
-                if (++spins > (1 << 17)) {  // (every wave reaches an exit: about a second; the results are then void and the host says so)
+                if (psd_h2_wait_expired(spins, wait_t0)) {  // (every wave reaches an exit; the results are then void and the host says so)
                     if (tid == 0) __hip_atomic_store(G->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 __builtin_amdgcn_s_sleep(2);

@@ -306,6 +306,7 @@ __global__ void __launch_bounds__(PSD_ZH2_NT, (NK > 8 ? 2 : 4)) psd_zhess2_link(
             const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, m * 32, 0x00020000);
             unsigned long long xr[NV], xi[NV];
             int spins = 0;
+            long long wait_t0 = 0;
             for (;;) {
                 bool okr = true;
 #pragma unroll
@@ -326,7 +327,7 @@ __global__ void __launch_bounds__(PSD_ZH2_NT, (NK > 8 ? 2 : 4)) psd_zhess2_link(
                 asm volatile("" ::: "memory");
                 const bool giveup = __hip_atomic_load(G->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
                 if (__syncthreads_and((okr || giveup) ? 1 : 0)) break;
-                if (++spins > (1 << 17)) {  // (every wave reaches an exit; the results are then void and the host says so)
+                if (psd_h2_wait_expired(spins, wait_t0)) {  // (every wave reaches an exit; the results are then void and the host says so)
                     if (tid == 0) __hip_atomic_store(G->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 __builtin_amdgcn_s_sleep(2);

@@ -38,7 +38,9 @@ def pschur_sharded(eng, A, lr="R", dist=None, gather=True, **kw):
     # all-gather of the owned blocks, padded to the largest slice (slices differ by at most one factor)
     per = max(sum(_owned(p, lr, world, r)) for r in range(world))
     mine = [j for j in range(p) if ps.owned[j]]
-    send = torch.zeros((per, n, n), dtype=torch.float64)
+    # (the element type of the Schur vectors: complex128 for psd_z_pschur — a float64 buffer would drop the imaginary parts)
+    tdtype = torch.complex128 if np.iscomplexobj(ps.Z[mine[0]] if mine else ps.Z[0]) else torch.float64
+    send = torch.zeros((per, n, n), dtype=tdtype)
     for k, j in enumerate(mine):
         send[k] = torch.from_numpy(np.ascontiguousarray(ps.Z[j].T))  # (column-major block as a row-major tensor)
     recv = [torch.zeros_like(send) for _ in range(world)]

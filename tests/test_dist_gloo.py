@@ -48,8 +48,10 @@ rank, world = dist.get_rank(), dist.get_world_size()
 # TEST-ONLY serial simulation of the device code (tests/hostsim): one engine per rank, as one process per GPU would have
 eng = psd_amd.Engine(libpath=os.path.join(ROOT, "tests", "hostsim", "_build", "libpsd_hostsim.so"))
 out = {}
-for (n, p, lr) in CASES:
-    A = pt.bench_factors(n, p, seed=77 + n + p)
+for case in CASES:
+    n, p, lr = case[:3]
+    cplx = len(case) > 3 and case[3] == "c"  # ComplexF64 (psd_z_pschur: BASELINE configs[2])
+    A = pt.bench_factors(n, p, seed=77 + n + p, dtype=(np.complex128 if cplx else np.float64))
     ref = eng.pschur(A, lr)                               # one rank holding everything
     part = sharded.pschur_sharded(eng, A, lr, dist=dist, gather=False)
     owned = part.owned
@@ -67,7 +69,9 @@ for (n, p, lr) in CASES:
     assert ok, err
     P = pt.product(A, left=(lr == "L"))
     assert pt.match_eigs(np.linalg.eigvals(P), full.values) <= 1e-10 * np.linalg.norm(P, 2)
-    out[f"{n}x{p}{lr}"] = {"owned": int(sum(owned)), "resid": float(err.max())}
+    if cplx:
+        assert all(np.iscomplexobj(z) and np.abs(z.imag).max() > 0 for z in full.Z)  # (the gather keeps the imaginary parts)
+    out[f"{n}x{p}{lr}" + ("c" if cplx else "")] = {"owned": int(sum(owned)), "resid": float(err.max())}
 if rank == 0:
     print(json.dumps(out))
 dist.destroy_process_group()
@@ -98,8 +102,9 @@ def test_period_sharded_pschur_gloo_world2(tmp_path):
     """The period-sharded engine (psd_set_shard: Z_j of a contiguous slice of the period per rank, chains replicated,
     one all-gather of the slices at the end) on two ranks: same decomposition as one rank, bit for bit, both
     orientations, a period the ranks split evenly and one they do not."""
-    res = _run_sharded(tmp_path, 2, [(24, 4, "R"), (30, 5, "L"), (40, 3, "R"), (70, 4, "L")], 29541)  # (n >= 64: blocked Q formation of a slice)
+    res = _run_sharded(tmp_path, 2, [(24, 4, "R"), (30, 5, "L"), (40, 3, "R"), (70, 4, "L"), (26, 5, "R", "c"), (22, 4, "L", "c")], 29541)  # (n >= 64: blocked Q formation of a slice)
     assert res["24x4R"]["owned"] == 2 and res["30x5L"]["owned"] == 3 and res["40x3R"]["owned"] == 2
+    assert res["26x5Rc"]["owned"] == 3 and res["22x4Lc"]["owned"] == 2
 
 
 def test_period_sharded_pschur_gloo_world3(tmp_path):

@@ -265,25 +265,31 @@ def test_phessenberg_two_stream_vs_oracle(monkeypatch, n, p, K, pipe):
     {"PSD_BAND_HELPER": "0"},
     {"PSD_OVERLAP": "0"},
     {"PSD_OVERLAP": "2"},
-    {"PSD_OVERLAP": "1"},
+    {"PSD_OVERLAP": "2", "PSD_CDEFER": "2"},
+    {"PSD_CDEFER": "0", "PSD_OVERLAP": "2"},
+    {"PSD_C3": "0"},
+    {"PSD_C3": "0", "PSD_C2": "0"},
     {"PSD_HESS_ASYNC": "4"},
     {"PSD_HESS_LOOKAHEAD": "0", "PSD_FORMQ_BLOCKED": "0"},
     {"PSD_MB": "0"},
-    {"PSD_OVERLAP_CUS": "0", "PSD_HESS_CUS": "0", "PSD_OVERLAP": "2", "PSD_HESS_ASYNC": "4"},
+    {"PSD_OVERLAP_CUS": "0", "PSD_HESS_CUS": "0", "PSD_OVERLAP": "2", "PSD_HESS_ASYNC": "4", "_diag": "1"},
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_pschur_switches(monkeypatch, env):
-    """Every tuning switch of the real path still gives a decomposition: the default-on pieces turned off one at a time
-    (band helper, second-stream Schur vectors, two-stream Hessenberg, look-ahead, blocked Q, multi-block scheduler), the
-    size-gated ones forced on a small problem (PSD_OVERLAP=2, PSD_HESS_ASYNC=4), the experiment (PSD_OVERLAP=1) and the
-    unmasked second streams.  Invariants by checkpsd, eigenvalues against LAPACK on the explicit product."""
+    """Every path selector of the real engine still gives a decomposition: the default-on pieces turned off one at a time
+    (band helper, second-stream Schur vectors and column roles, scan chase, two-wave chase, two-stream Hessenberg,
+    look-ahead, blocked Q, multi-block scheduler), the size-gated ones forced on a small problem (PSD_OVERLAP=2,
+    PSD_CDEFER=2, PSD_HESS_ASYNC=4) and — in the diagnostic build, where such knobs exist — the unmasked second streams.
+    Invariants by checkpsd, eigenvalues against LAPACK on the explicit product."""
     import torch
 
     torch.cuda.init()
     import psd_amd
 
+    env = dict(env)
+    diag = env.pop("_diag", None)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    eng = psd_amd.Engine(device=0)
+    eng = psd_amd.Engine(device=0, libpath=psd_amd.DIAG_LIB_PATH if diag else None)
     for (n, p, lr) in [(260, 9, "R"), (150, 3, "L")]:
         A = pt.bench_factors(n, p, seed=400 + n)
         ps = eng.pschur(A, lr)
@@ -306,7 +312,7 @@ def test_pipe_form_gives_up_loudly(monkeypatch):
     monkeypatch.setenv("PSD_HESS_ASYNC", "4")
     monkeypatch.setenv("PSD_H2_PIPE", "2")
     monkeypatch.setenv("PSD_H2_FAULT", "200")
-    bad = psd_amd.Engine(device=0)
+    bad = psd_amd.Engine(device=0, libpath=psd_amd.DIAG_LIB_PATH)  # (the hook exists in the diagnostic build only)
     A = pt.bench_factors(96, 12, seed=5)
     t0 = time.time()
     with pytest.raises(RuntimeError):
@@ -319,3 +325,54 @@ def test_pipe_form_gives_up_loudly(monkeypatch):
     Ho, Qo, packed, tauo = pt.oracle_phessenberg(A)
     for j in range(len(A)):
         assert np.linalg.norm(W[j] - packed[j]) < 1e-11 * max(np.linalg.norm(packed[j]), 1.0)
+
+
+def test_2x2_standardisation_guard(gpu_engine):
+    """Real eigenvalue pairs many orders of magnitude apart (eps = 0.8, long periods, tiny orders): the rotation that the
+    reference takes from the explicitly formed 2 x 2 product (PSD.jl:900-1054) can leave a subdiagonal entry in T1 far
+    above rounding level, which :1066-1073 then zeroes.  Round 3's records hold such inputs — the seed-777 fuzz case
+    (n = 7, p = 39: residual 5.4e5 eps on the device while the CPU oracle passed) and 14 of the 800 problems of
+    tools/micro/repro_scan.py, 10 of which the CPU oracle fails as well.  With the guard of psd_rq_deflate (rotations
+    from H_1's own column until the entry is negligible in H_1) every one of them passes on the device, with the scan
+    chase, the two-wave chase and the one-wave chase alike (tools/r04/scan2x2.py is the full scan)."""
+    cases = [(7, 39, "L", 0.8, 658499203)]
+    for n in (4, 5, 6, 7, 8, 9, 10, 12):
+        for p in (39, 64):
+            for lr in "RL":
+                for seed in (1, 2, 3, 658499203):
+                    cases.append((n, p, lr, 0.8, seed))
+    worst = 0.0
+    for (n, p, lr, eps_, seed) in cases:
+        A = pt.bench_factors(n, p, seed=seed, eps=eps_)
+        ps = gpu_engine.pschur(A, lr)
+        ok, err = gpu_engine.checkpsd(ps, A, thresh=100 * np.sqrt(max(n / 32, 1)))
+        worst = max(worst, float(np.max(err)))
+        assert ok, (n, p, lr, eps_, seed, float(np.max(err)))
+    assert worst < 100.0
+
+
+def test_hess_pipe_is_a_property_of_the_context(monkeypatch):
+    """The form of the multi-stream Hessenberg reduction is fixed when the context is created (psd_get_hess_pipe): the
+    session's engine came first and has the pipe form; one created beside it runs back to back — whatever is alive when
+    a call is made —, PSD_H2_PIPE=2 / 0 force / forbid it, and a period-sharded context always has it."""
+    import torch
+
+    torch.cuda.init()
+    import psd_amd
+
+    first = psd_amd.Engine(device=0)
+    second = psd_amd.Engine(device=0)
+    # (whether `first` has it depends on what the test session created before; `second` was created beside `first`)
+    assert second.hess_pipe() == 0
+    second.set_shard(0, 2)
+    assert second.hess_pipe() == 1
+    second.set_shard(0, 1)
+    assert second.hess_pipe() == 0
+    monkeypatch.setenv("PSD_H2_PIPE", "2")
+    forced = psd_amd.Engine(device=0)
+    assert forced.hess_pipe() == 1
+    monkeypatch.setenv("PSD_H2_PIPE", "0")
+    forbidden = psd_amd.Engine(device=0)
+    forbidden.set_shard(1, 2)
+    assert forbidden.hess_pipe() == 0
+    del first

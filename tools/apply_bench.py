@@ -13,7 +13,7 @@ torch.cuda.init()
 import psd_amd
 
 n, p, W = (int(x) for x in sys.argv[1:4]) if len(sys.argv) >= 4 else (1024, 64, 17)
-eng = psd_amd.Engine(0)
+eng = psd_amd.Engine(0, libpath=psd_amd.DIAG_LIB_PATH)  # (tuning knobs exist in the diagnostic build only)
 f = eng.lib.psd_dbg_apply_bench
 f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
 f.restype = C.c_int
