@@ -110,6 +110,9 @@ size_t step_lds_scratch_end(int p, int W, int esize, bool even) {
 size_t step_lds_bytes(int p, int W, int esize = 8, bool even = false) {
     size_t b = step_lds_scratch_end(p, W, esize, even);
     if (even && p <= PSD_C3_MAXP) b += (size_t)p * PSD_C3_TAB * sizeof(double);
+    // (complex standard engine — the only caller with 16-byte elements and the plain pitch that launches psd_zq_step —:
+    //  the rotation table of its scan chase, psd_zchase3.h)
+    if (esize == 16 && !even && p <= PSD_ZC3_MAXP) b += (size_t)p * PSD_ZC3_TAB * sizeof(double);
     return (b + 15) & ~(size_t)15;
 }
 // ordschur! alignments (ordschur.jl:20-33, rordschur.jl:15-27, utils.jl:6-85): the swap kernels work on the right-
@@ -2094,6 +2097,12 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
     P.ascale = c->zascale;
     P.log = c->zlog;
     const size_t lds_step = step_lds_bytes(p, W, 16);
+    // scan chase (psd_zchase3.h, the default): PSD_ZC3_WAVES wavefronts per chase workgroup, the command block in the
+    // reduction scratch behind the window image (idle while a window is chased), the rotation table behind the scratch
+    const bool zscan3 = c->chase3 && p >= PSD_ZC3_MINP && p <= PSD_ZC3_MAXP;
+    P.zcoff = zscan3 ? (int)((size_t)p * W * (W + 1) * sizeof(psd_z)) : 0;
+    P.zc3off = zscan3 ? (int)step_lds_scratch_end(p, W, 16, false) : 0;
+    const int zwaves = zscan3 ? PSD_ZC3_WAVES : 1;
 #ifndef PSD_HOSTSIM
     if (lds_step > c->zstep_lds_set) {
         PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_zq_step),
@@ -2185,9 +2194,9 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
                 Pq.tr = P.tr + (size_t)par * PSD_TRAIN_MAX * p * PSD_ZTR_CAP;
             }
             if (M == 1)
-                PSD_LAUNCH(psd_zq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
+                PSD_LAUNCH2(psd_zq_step, psd_dim3(1), PSD_STEP_NT, zwaves, lds_step, c->stream, P);
             else
-                PSD_LAUNCH(psd_zq_step_train, psd_dim3(M), PSD_STEP_NT, lds_step, c->stream, Pq, p, p + 8);
+                PSD_LAUNCH2(psd_zq_step_train, psd_dim3(M), PSD_STEP_NT, zwaves, lds_step, c->stream, Pq, p, p + 8);
 #ifndef PSD_HOSTSIM
             if (sample) {
                 (void)hipEventRecord(ev1, c->stream);
@@ -2800,6 +2809,7 @@ int zordschur_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
     O.z.H = dH;
     O.z.zlo = 1;  // (ordschur! is not sharded: every Z_m is this context's)
     O.z.zhi = p;
+    O.z.zcoff = O.z.zc3off = 0;
     O.z.Z = wantZ ? dZ : nullptr;
     O.z.st = c->zst;
     O.z.desc = c->zdesc;

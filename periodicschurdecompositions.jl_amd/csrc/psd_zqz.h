@@ -86,6 +86,9 @@ struct psd_zparams {
     // period sharding (psd_set_shard): the owners m (1-based, inclusive) whose Schur vectors Z_m this context holds;
     // the updates of the others are some other rank's work (1..p without sharding)
     int zlo, zhi;
+    // scan chase (psd_zchase3.h): byte offsets of the command block and of the rotation table in dynamic LDS; 0: off
+    // (one wavefront per chase workgroup).  With it the chase workgroups have PSD_ZC3_WAVES wavefronts.
+    int zcoff, zc3off;
 };
 
 PSD_HD psd_mat<psd_z> psd_zfac(const psd_zparams& P, int n, int j) {
@@ -99,6 +102,88 @@ struct psd_zwin {
 };
 
 #include "psd_zqz_win.inl"
+#include "psd_zchase3.h"
+
+// The helper wavefronts of a scan-chase workgroup (threadIdx.y >= 1) park at the command barrier between runs; code
+// written in terms of PSD_TID / PSD_SYNC never sees them (as the two-wave chase of the real engine).
+#ifndef PSD_HOSTSIM
+PSD_D void psd_zc_helper(int zcoff, int zc3off) {
+    PSD_LDS_DECL;
+    const psd_zc* cmd = (const psd_zc*)(psd_lds + zcoff);
+    for (;;) {
+        PSD_PAIR_BARRIER();
+        const psd_zc C = *cmd;
+        if (C.cmd == 0) return;
+        if (C.cmd == 2) {
+            psd_zc3_run(C, PSD_WAVE_ROLE, (int)blockDim.y, zc3off);
+        } else {  // this wavefront's share of a window load (3) / store (4)
+            psd_zparams R;
+            R.H = C.H;
+            psd_zwin w;
+            w.b = (psd_z*)(psd_lds + C.wboff);
+            w.W = C.W; w.ld = C.ld; w.bsz = C.bsz; w.bs = C.bs; w.be = C.be;
+            if (C.cmd == 3) psd_zwin_load(R, w, C.n, C.p, PSD_WAVE_ROLE, (int)blockDim.y);
+            else psd_zwin_store(R, w, C.n, C.p, PSD_WAVE_ROLE, (int)blockDim.y);
+            PSD_PAIR_BARRIER();
+        }
+    }
+}
+#define PSD_ZC_ENTER(P)                                 \
+    if ((P).zcoff != 0 && PSD_WAVE_ROLE >= 1) {         \
+        psd_zc_helper((P).zcoff, (P).zc3off);           \
+        return;                                         \
+    }
+#define PSD_ZC_LEAVE(P)                                         \
+    if ((P).zcoff != 0) {                                       \
+        PSD_LDS_DECL;                                           \
+        psd_zc* cmd__ = (psd_zc*)(psd_lds + (P).zcoff);         \
+        PSD_ONE { cmd__->cmd = 0; }                             \
+        PSD_PAIR_BARRIER();                                     \
+    }
+#else
+#define PSD_ZC_ENTER(P) ((void)0)
+#define PSD_ZC_LEAVE(P) ((void)0)
+#endif
+// wavefront 0's side of a run / of a shared window transfer
+PSD_D void psd_zc3_lead(const psd_zparams& P, psd_zc& C) {
+#ifdef PSD_HOSTSIM
+    psd_zc3_run(C, 0, 1, P.zc3off);
+#else
+    PSD_LDS_DECL;
+    psd_zc* cmd = (psd_zc*)(psd_lds + P.zcoff);
+    C.cmd = 2;
+    PSD_SYNC();
+    PSD_ONE { *cmd = C; }
+    PSD_PAIR_BARRIER();
+    psd_zc3_run(C, 0, (int)blockDim.y, P.zc3off);
+    PSD_ONE { cmd->cmd = 0; }
+#endif
+}
+PSD_D void psd_zc3_winio(const psd_zparams& P, const psd_zwin& w, int n, int p, bool store) {
+#ifndef PSD_HOSTSIM
+    if (P.zcoff != 0 && blockDim.y > 1) {
+        PSD_LDS_DECL;
+        psd_zc* cmd = (psd_zc*)(psd_lds + P.zcoff);
+        PSD_SYNC();
+        PSD_ONE {
+            psd_zc C;
+            C.cmd = store ? 4 : 3;
+            C.ld = w.ld; C.bsz = w.bsz; C.bs = w.bs; C.be = w.be; C.W = w.W;
+            C.p = p; C.n = n; C.H = P.H;
+            C.wboff = (int)((char*)w.b - (char*)psd_lds);
+            *cmd = C;
+        }
+        PSD_PAIR_BARRIER();
+        if (store) psd_zwin_store(P, w, n, p, 0, (int)blockDim.y);
+        else psd_zwin_load(P, w, n, p, 0, (int)blockDim.y);
+        PSD_PAIR_BARRIER();
+        PSD_ONE { cmd->cmd = 0; }
+        return;
+    }
+#endif
+    if (store) psd_zwin_store(P, w, n, p);
+    else psd_zwin_load(P, w, n, p);
+}
 
 PSD_D void psd_zrecord(const psd_zparams& P, int* lcnt, int m, int pos, double c, psd_z s) {
     PSD_ONE {
@@ -655,9 +740,28 @@ PSD_D void psd_zq_sweep_window(const psd_zparams& P, psd_zstate& st, psd_z* ldsz
     w.be = (ke + 2 < ilast) ? (ke + 2) : ilast;
     const long long tc0 = psd_clock();
     PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
-    psd_zwin_load(P, w, n, p);
+    psd_zc3_winio(P, w, n, p, false);
     const long long tc1 = psd_clock();
-    for (int j = ks; j <= ke; ++j) {
+    const bool scan3 = P.zc3off != 0 && p >= PSD_ZC3_MINP && p <= PSD_ZC3_MAXP && ke >= ks;
+    if (scan3) {  // every factor of a position at once (psd_zchase3.h)
+        psd_zc C;
+        C.ld = w.ld; C.bsz = w.bsz; C.bs = w.bs; C.be = w.be; C.W = w.W;
+        C.p = p; C.n = n; C.ifirst = ifirst; C.ifirstm = ifirstm; C.ilast = ilast; C.ilastm = ilastm;
+        C.ks = ks; C.npos = ke - ks + 1;
+        {
+            PSD_LDS_DECL;
+            C.wboff = (int)((char*)w.b - (char*)psd_lds);
+        }
+        C.tr = P.tr;
+        C.H = P.H;
+        C.c0 = st.c0;
+        C.s0 = st.s0;
+        psd_zc3_lead(P, C);
+        PSD_SYNC();
+        PSD_ONE { lcnt[0] = ke - ks + 1; }
+        PSD_SYNC();
+    }
+    for (int j = scan3 ? (ke + 1) : ks; j <= ke; ++j) {
         double c;
         psd_z s, r;
         if (j > ifirst) {
@@ -705,7 +809,7 @@ PSD_D void psd_zq_sweep_window(const psd_zparams& P, psd_zstate& st, psd_z* ldsz
         PSD_WAVE_SYNC();
     }
     const long long tc2 = psd_clock();
-    psd_zwin_store(P, w, n, p);
+    psd_zc3_winio(P, w, n, p, true);
     st.cyc[1] += tc1 - tc0;
     st.cyc[2] += tc2 - tc1;
     st.cyc[3] += psd_clock() - tc2;
@@ -940,7 +1044,11 @@ PSD_D void psd_zq_step_body(const psd_zparams& P) {
     PSD_SYNC();
     PSD_ONE { *P.st = st; }
 }
-PSD_KERNEL_B(PSD_STEP_NT) psd_zq_step(psd_zparams P) { psd_zq_step_body(P); }
+PSD_KERNEL_B(PSD_ZC3_WAVES * PSD_STEP_NT) psd_zq_step(psd_zparams P) {
+    PSD_ZC_ENTER(P);
+    psd_zq_step_body(P);
+    PSD_ZC_LEAVE(P);
+}
 
 // cursor b >= 1 of a multishift train (see psd_rq_cursor_body)
 PSD_D void psd_zq_cursor_body(const psd_zparams& P, int b) {
@@ -974,10 +1082,12 @@ PSD_D void psd_zq_cursor_body(const psd_zparams& P, int b) {
 }
 
 // all cursors of a tick in one launch (see psd_rq_step_train)
-PSD_KERNEL_B(PSD_STEP_NT) psd_zq_step_train(psd_zparams P, int p, int cstride) {
+PSD_KERNEL_B(PSD_ZC3_WAVES * PSD_STEP_NT) psd_zq_step_train(psd_zparams P, int p, int cstride) {
+    PSD_ZC_ENTER(P);
     const int b = PSD_BLOCK_X;
     if (b == 0) {
         psd_zq_step_body(P);
+        PSD_ZC_LEAVE(P);
         return;
     }
     psd_zparams Q = P;
@@ -986,6 +1096,7 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_zq_step_train(psd_zparams P, int p, int cstride) {
     Q.cnt = P.cnt + (size_t)b * cstride;
     Q.tr = P.tr + (size_t)b * p * PSD_ZTR_CAP;
     psd_zq_cursor_body(Q, b);
+    PSD_ZC_LEAVE(P);
 }
 
 // Bulk application of one window's rotation lists.  grid = (tiles, p owners, 3 roles) as in the

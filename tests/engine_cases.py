@@ -158,7 +158,9 @@ def expected_window(p, esize=8):
         cap = int(e)
     for W in range(cap, 5, -1):
         pitch = W + 1 if (esize != 8 or (W + 1) % 2 == 0) else W + 2
-        need = p * W * pitch * esize + 64 * 8 + (2 * 64 + p) * 4
+        need = (p * W * pitch * esize + 64 * 8 + (2 * 64 + p) * 4 + 15) // 16 * 16
+        if p <= 64:  # the reflector / rotation table of the scan chase (psd_chase3.h: 8 doubles per factor, psd_zchase3.h: 4)
+            need += p * (8 if esize == 8 else 4) * 8
         if (need + 15) // 16 * 16 <= 160 * 1024:
             return W
     return 0
