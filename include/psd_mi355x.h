@@ -91,6 +91,17 @@ const char* psd_version(void);
  * psd_set_shard with world > 1, so that every rank of a period-sharded call runs the same form: the two forms round
  * differently (plain sum of squares against the scaled form of the norm). */
 int psd_get_hess_pipe(psd_ctx* ctx);
+/* Factor-sliced sweep windows of the real periodic QR iteration (PSD.jl:806-886): `slices` = G >= 2 workgroups chase one
+ * window, workgroup g holding the diagonal window blocks of the factors of ITS contiguous slice of the period,
+ * (g p/G, (g+1) p/G], and the chain vectors of a position handed from slice to slice as tagged records in the receiver's
+ * inbox — the north_star partition (H_j by period, hand-off at slice boundaries) with the G compute
+ * units of a slot as the ranks; an inbox is a plain device pointer, across GPUs it would be a peer mapping.  The
+ * result does not depend on the number of slices (the reflectors are functions of the vectors handed over: G = 2 and
+ * G = 4 agree to the bit) and agrees with slices = 1 to rounding.  1 (default): off.
+ * Honoured for p <= 64 and at least two factors per slice; every wait is bounded, a hand-over that never arrives ends
+ * the call with PSD_INFO_RUNTIME.  DESIGN.md section 7c. */
+int psd_set_slices(psd_ctx* ctx, int slices);
+int psd_get_slices(psd_ctx* ctx);
 /* Period sharding over `world` contexts (one per GPU, one process each): every context runs the
  * latency-bound chains (Hessenberg links, window chases) and the updates of the factors H_j they read — identical on
  * all ranks, bit for bit (the tick schedule is reproducible: tests/test_gpu_headline.py, tests/test_gpu_shard.py) — while the

@@ -227,6 +227,18 @@ class Engine:
         self.lib.psd_get_train.argtypes = [C.c_void_p]
         return int(self.lib.psd_get_train(self.ctx))
 
+    def set_slices(self, slices):
+        """Factor-sliced sweep windows of the real engine (psd_set_slices): `slices` workgroups per window, each with the
+        window blocks of its contiguous slice of the period; 1 = off."""
+        self.lib.psd_set_slices.argtypes = [C.c_void_p, C.c_int]
+        rc = self.lib.psd_set_slices(self.ctx, int(slices))
+        if rc != 0:
+            raise ValueError(f"psd_set_slices({slices}): argument {-rc} invalid")
+
+    def get_slices(self):
+        self.lib.psd_get_slices.argtypes = [C.c_void_p]
+        return int(self.lib.psd_get_slices(self.ctx))
+
     def hess_pipe(self):
         """1 if this engine's multi-stream Hessenberg reductions take the pipe form (psd_get_hess_pipe): fixed at
         creation, forced on by set_shard with world > 1."""

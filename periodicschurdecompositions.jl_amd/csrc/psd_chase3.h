@@ -79,8 +79,13 @@ PSD_D void psd_c3_bblock(double u00, double u01, double u02, double u11, double 
 // the two kinds of update items of the apply phase (window image in LDS; q points at the first of the three elements,
 // sd is their stride: 1 along a column, ld along a row)
 //   three elements under a 3-reflector, then (with2) the last two under a 2-reflector
+//   fix 1: the column the 3-reflector was made for becomes (bfix, 0, 0); fix 2: the column of the 2-reflector becomes
+//   (., bfix, 0).  bfix is the scan's own value of that entry (see "beta" in psd_c3_run): the reflector annihilates the
+//   scan's vector exactly, so (beta, 0, 0) is the transformed column to the accuracy of one matrix-vector product; what
+//   the update formulas leave in these three entries differs from it by the representation error of the neighbour's
+//   reflector (several eps) and is not used.
 PSD_D void psd_c3_item(double* q, int sd, double v1, double v2, double tau, bool with2, double w2, double tau2,
-                       int fix /* 0 none, 1: (a1, 0, 0), 2: (a1, a2, 0) */) {
+                       int fix /* 0 none, 1: (bfix, 0, 0), 2: (a1, bfix, 0) */, double bfix = 0.0) {
     double a1 = q[0], a2 = q[sd], a3 = q[2 * sd];
     const double xx = tau * (a1 + v1 * a2 + v2 * a3);
     a1 -= xx;
@@ -91,7 +96,11 @@ PSD_D void psd_c3_item(double* q, int sd, double v1, double v2, double tau, bool
         a2 -= yy;
         a3 -= yy * w2;
     }
-    if (fix == 1) a2 = 0.0;
+    if (fix == 1) {
+        a1 = bfix;
+        a2 = 0.0;
+    }
+    if (fix == 2) a2 = bfix;
     if (fix >= 1) a3 = 0.0;
     q[0] = a1;
     q[sd] = a2;
@@ -130,10 +139,19 @@ PSD_D void psd_c3_apply(double* wb, const double* tab, int sub, int f, int q, in
             }
         } else {
             // column k: (beta, 0, 0) (PSD.jl:851-854); column k + 1: (., beta', 0) (:869); the others: both reflectors
+            const double b3 = t[5], b2 = t[6];
             for (int cc = q; cc < ncl; cc += tpf)
-                psd_c3_item(row + cc * ld, 1, v1, v2, tau, cc >= 1, w2, tau2, (cc == 0) ? 1 : ((cc == 1) ? 2 : 0));
+                psd_c3_item(row + cc * ld, 1, v1, v2, tau, cc >= 1, w2, tau2, (cc == 0) ? 1 : ((cc == 1) ? 2 : 0), (cc == 0) ? b3 : b2);
         }
     }
+}
+
+// beta of a chain vector from the beta of the vector that produced it: the column a reflector is made for is
+// U z_in / beta(z_in) (first column of the exact reflector of z_in), the scan computed z = 2^-e U z_in, so the transformed
+// column's leading entry is beta(z) 2^e / beta(z_in)
+PSD_D double psd_c3_beta(double bz, double bin, int e) {
+    if (bin == 0.0) return 0.0;
+    return psd_c3_ldexp(bz / bin, e);
 }
 
 #ifndef PSD_HOSTSIM
@@ -201,6 +219,7 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_) {
             const double xs0 = psd_c3_ldexp(x0, -ex), xs1 = psd_c3_ldexp(x1, -ex), xs2 = psd_c3_ldexp(x2, -ex);
             // this lane's own factor (the B block below needs it)
             double u00 = 0.0, u01 = 0.0, u02 = 0.0, u11 = 0.0, u12 = 0.0, u22 = 0.0;
+            int euo = 0;
             if (fac) {
                 const double* q = wb + lane * bsz + (k - bs) * ld + (k - bs);
                 u00 = q[0];
@@ -212,6 +231,7 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_) {
                 const double um = fmax(psd_c3_max3(u00, u01, u02), psd_c3_max3(u11, u12, u22));
                 if (!(um > 1e-18 && um < 1e18)) {  // (far from unit scale: see the chain lanes' blocks below)
                     const int eu = psd_c3_expo(um);
+                    euo = eu;
                     u00 = psd_c3_ldexp(u00, -eu);
                     u01 = psd_c3_ldexp(u01, -eu);
                     u02 = psd_c3_ldexp(u02, -eu);
@@ -226,11 +246,13 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_) {
             // slower: with one factor per lane the six moves of a step were most of it).  Lane i is fed valid data in step
             // i; it recomputes while s <= i and keeps its four vectors from then on.  Links beyond the chain are identities.
             double U[PSD_C3_FPL][6], zq[PSD_C3_FPL][3];
+            int Ue[PSD_C3_FPL];
             const bool chl = lane < 16;
 #pragma unroll
             for (int q4 = 0; q4 < PSD_C3_FPL; ++q4) {
                 const int c = PSD_C3_FPL * lane + q4, jf = p - c;  // link c = factor jf
                 double a00 = 1.0, a01 = 0.0, a02 = 0.0, a11 = 1.0, a12 = 0.0, a22 = 1.0;
+                Ue[q4] = 0;
                 if (chl && c < p - 1) {
                     const double* q = wb + (jf - 1) * bsz + (k - bs) * ld + (k - bs);
                     a00 = q[0];
@@ -244,6 +266,7 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_) {
                     //  every lane's four links anyway, and the scaling is a dozen instructions per block)
                     if (!(um > 1e-18 && um < 1e18)) {
                         const int eu = psd_c3_expo(um);
+                        Ue[q4] = eu;
                         a00 = psd_c3_ldexp(a00, -eu);
                         a01 = psd_c3_ldexp(a01, -eu);
                         a02 = psd_c3_ldexp(a02, -eu);
@@ -257,6 +280,7 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_) {
             }
             const int nsteps = (p - 1 + PSD_C3_FPL - 1) / PSD_C3_FPL;
             double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+            int eout = 0;  // power of two this lane took out of the vector it handed on
             for (int s = 0; s < nsteps; ++s) {
                 // (lane 0 of a row has no lane to its right... left: it keeps the "old" operand, the start vector)
                 double w0 = psd_c3_shr(z0, xs0), w1 = psd_c3_shr(z1, xs1), w2 = psd_c3_shr(z2, xs2);
@@ -273,13 +297,16 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_) {
                         zq[q4][1] = n1_;
                         zq[q4][2] = n2;
                     }
-                    const int e = psd_c3_expo(psd_c3_max3(w0, w1, w2));
-                    z0 = psd_c3_ldexp(w0, -e);
-                    z1 = psd_c3_ldexp(w1, -e);
-                    z2 = psd_c3_ldexp(w2, -e);
+                    eout = psd_c3_expo(psd_c3_max3(w0, w1, w2));
+                    z0 = psd_c3_ldexp(w0, -eout);
+                    z1 = psd_c3_ldexp(w1, -eout);
+                    z2 = psd_c3_ldexp(w2, -eout);
                 }
             }
-            // the chain vectors to their factors' lanes through the table (slots 5..7 of a factor: free until the end)
+            // the chain vectors to their factors' lanes through the table (slots 5..7 of a factor: free until the end),
+            // with the powers of two between a factor's vector and the product it stands for: slot 4 the scaling of its
+            // block, slot 3 what the vector that ENTERED its link had been scaled by (the start vector's ex for factor p,
+            // a lane's hand-over scaling for the first link of the next lane, nothing inside a lane)
 #pragma unroll
             for (int q4 = 0; q4 < PSD_C3_FPL; ++q4) {
                 const int c = PSD_C3_FPL * lane + q4, jf = p - c;
@@ -288,14 +315,23 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_) {
                     t[5] = zq[q4][0];
                     t[6] = zq[q4][1];
                     t[7] = zq[q4][2];
+                    t[4] = (double)Ue[q4];
+                    if (q4 > 0) t[3] = 0.0;
+                    else if (c == 0) t[3] = (double)ex;
                 }
             }
+            if (chl) {
+                const int cn = PSD_C3_FPL * (lane + 1);  // first link of the next lane
+                if (cn < p - 1) tab[(p - cn - 1) * PSD_C3_TAB + 3] = (double)eout;
+            }
             double zo0 = 0.0, zo1 = 0.0, zo2 = 0.0;
+            int ecor = 0;
             if (fac) {
                 const double* t = tab + lane * PSD_C3_TAB;
                 zo0 = t[5];
                 zo1 = t[6];
                 zo2 = t[7];
+                ecor = (int)t[3] + (int)t[4];
             }
             PSD_C3_T(0);
             // ---- 3-reflectors: factor lanes from their chain vector, the others Q_1 from x(1)
@@ -303,6 +339,10 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_) {
             const double tau = psd_refl3(a0, a1, a2);  // (a0, a1, a2) <- (beta, v2, v3)
             const double v1 = a1, v2 = a2;
             const double v1n = psd_c3_rol(v1), v2n = psd_c3_rol(v2), taun = psd_c3_rol(tau);
+            // the entry the reflector leaves in the annihilated column (psd_c3_beta): from this lane's and its chain
+            // neighbour's beta (lane + 1: the factor above, H_1's true x(1) above factor p)
+            const double a0n = psd_c3_rol(a0);
+            const double beta3 = fac ? psd_c3_beta(a0, a0n, ecor) : a0;
             // ---- scan 2 on the trailing 2 x 2 blocks: B blocks by the factors' lanes, through the table (slots 3, 4, 6, 7)
             // to the chain lanes, the same systolic chain with 2-vectors, the results back through slots 6, 7
             if (fac) {
@@ -331,6 +371,7 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_) {
                 tq[q4][0] = tq[q4][1] = 0.0;
             }
             double t0 = 0.0, t1 = 0.0;
+            int eout2 = 0;
             for (int s = 0; s < nsteps; ++s) {
                 double w0 = psd_c3_shr(t0, 1.0), w1 = psd_c3_shr(t1, 0.0);
                 if (s <= lane) {
@@ -343,9 +384,9 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_) {
                         tq[q4][0] = n0;
                         tq[q4][1] = n1_;
                     }
-                    const int e = psd_c3_expo(fmax(fabs(w0), fabs(w1)));
-                    t0 = psd_c3_ldexp(w0, -e);
-                    t1 = psd_c3_ldexp(w1, -e);
+                    eout2 = psd_c3_expo(fmax(fabs(w0), fabs(w1)));
+                    t0 = psd_c3_ldexp(w0, -eout2);
+                    t1 = psd_c3_ldexp(w1, -eout2);
                 }
             }
 #pragma unroll
@@ -355,18 +396,28 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_) {
                     double* t = tab + (jf - 1) * PSD_C3_TAB;
                     t[6] = tq[q4][0];
                     t[7] = tq[q4][1];
+                    if (q4 > 0 || c == 0) t[3] = 0.0;  // (scaling of the vector that entered the link: slot 3 as in scan 1)
                 }
             }
+            if (chl) {
+                const int cn = PSD_C3_FPL * (lane + 1);
+                if (cn < p - 1) tab[(p - cn - 1) * PSD_C3_TAB + 3] = (double)eout2;
+            }
             double to0 = 0.0, to1 = 0.0;
+            int ecor2 = 0;
             if (fac) {
                 const double* t = tab + lane * PSD_C3_TAB;
                 to0 = t[6];
                 to1 = t[7];
+                ecor2 = (int)t[3] + euo;  // (the B block was formed from this lane's own copy of the factor's block)
             }
             PSD_C3_T(2);
             double y0 = to0, y1 = to1;
             const double tau2 = fac ? psd_refl2(y0, y1) : 0.0;  // (y0, y1) <- (beta', w2)
             const double w2v = fac ? y1 : 0.0;
+            // (the 2-vector that entered factor p's link is e_1 itself: its "beta" is 1)
+            const double y0n = psd_c3_rol(fac ? y0 : 1.0);
+            const double beta2 = fac ? psd_c3_beta(y0, y0n, ecor2) : 0.0;
             if (lane < p) {
                 double* t = tab + lane * PSD_C3_TAB;
                 t[0] = v1;
@@ -374,7 +425,8 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_) {
                 t[2] = tau;
                 t[3] = w2v;
                 t[4] = tau2;
-                t[5] = a0;  // (beta of this lane's vector: used for factor 1 only, whose vector is the true x(1))
+                t[5] = beta3;  // (H_1: beta of the true x(1))
+                t[6] = beta2;
                 psd_tr tr;
                 tr.pos = k;
                 tr.kind = PSD_TR_R3;
@@ -410,7 +462,8 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_) {
 #undef PSD_C3_T
 }
 #else
-// The simulated tier: the same steps, the lanes of the scan wavefront as array slots.
+// The simulated tier: the same steps with the chain as a plain loop over the factors (rescaled after every PSD_C3_FPL
+// links, where the device's chain lanes hand over).
 PSD_D void psd_c3_run(const psd_c2& Cin, int, int, int taboff) {
     PSD_LDS_DECL;
     const int p = Cin.p, ld = Cin.ld, bsz = Cin.bsz, bs = Cin.bs, l = Cin.l, ie = Cin.i, ks = Cin.ks, npos = Cin.npos;
@@ -436,107 +489,103 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int, int, int taboff) {
             x2 = Cin.v2;
         }
         const int ex = psd_c3_expo(psd_c3_max3(x0, x1, x2));
-        double U[64][6], c[64][3], z[64][3], zo[64][3];
-        bool fac[64];
-        for (int lane = 0; lane < 64; ++lane) {
-            fac[lane] = lane >= 1 && lane < p;
-            for (int q = 0; q < 6; ++q) U[lane][q] = 0.0;
-            if (fac[lane]) {
-                const double* q = wb + lane * bsz + (k - bs) * ld + (k - bs);
-                double u[6] = {q[0], q[ld], q[2 * ld], q[ld + 1], q[2 * ld + 1], q[2 * ld + 2]};  // u00 u01 u02 u11 u12 u22
-                const int eu = psd_c3_expo(fmax(psd_c3_max3(u[0], u[1], u[2]), psd_c3_max3(u[3], u[4], u[5])));
-                for (int t = 0; t < 6; ++t) U[lane][t] = psd_c3_ldexp(u[t], -eu);
-            }
-            c[lane][0] = fac[lane] ? 0.0 : psd_c3_ldexp(x0, -ex);
-            c[lane][1] = fac[lane] ? 0.0 : psd_c3_ldexp(x1, -ex);
-            c[lane][2] = fac[lane] ? 0.0 : psd_c3_ldexp(x2, -ex);
-            for (int t = 0; t < 3; ++t) {
-                z[lane][t] = c[lane][t];
-                zo[lane][t] = 0.0;
-            }
+        // factor j at index j (1..p); index 1 = H_1
+        double U[65][6], zo[65][3], v1[65], v2[65], tau[65], beta[65], bz[65];
+        int ecor[65], eu[65];
+        for (int j = 2; j <= p; ++j) {
+            const double* q = wb + (j - 1) * bsz + (k - bs) * ld + (k - bs);
+            double u[6] = {q[0], q[ld], q[2 * ld], q[ld + 1], q[2 * ld + 1], q[2 * ld + 2]};  // u00 u01 u02 u11 u12 u22
+            const double um = fmax(psd_c3_max3(u[0], u[1], u[2]), psd_c3_max3(u[3], u[4], u[5]));
+            eu[j] = (um > 1e-18 && um < 1e18) ? 0 : psd_c3_expo(um);
+            for (int t = 0; t < 6; ++t) U[j][t] = psd_c3_ldexp(u[t], -eu[j]);
         }
-        for (int s = 0; s < p - 1; ++s) {
-            double w[64][3];
-            for (int lane = 0; lane < 64; ++lane)
-                for (int t = 0; t < 3; ++t) w[lane][t] = z[(lane + 1) & 63][t];
-            for (int lane = 0; lane < 64; ++lane) {
-                const double* u = U[lane];
-                z[lane][0] = u[0] * w[lane][0] + (u[1] * w[lane][1] + (u[2] * w[lane][2] + c[lane][0]));
-                z[lane][1] = u[3] * w[lane][1] + (u[4] * w[lane][2] + c[lane][1]);
-                z[lane][2] = u[5] * w[lane][2] + c[lane][2];
-                if (s == p - 1 - lane)
-                    for (int t = 0; t < 3; ++t) zo[lane][t] = z[lane][t];
-                if ((s & 15) == 15) {
-                    const int e = psd_c3_expo(psd_c3_max3(z[lane][0], z[lane][1], z[lane][2]));
-                    for (int t = 0; t < 3; ++t) z[lane][t] = psd_c3_ldexp(z[lane][t], -e);
+        {   // scan 1
+            double w[3] = {psd_c3_ldexp(x0, -ex), psd_c3_ldexp(x1, -ex), psd_c3_ldexp(x2, -ex)};
+            int ein = ex;
+            for (int c = 0; c < p - 1; ++c) {
+                const int j = p - c;
+                const double* u = U[j];
+                const double n0 = u[0] * w[0] + (u[1] * w[1] + u[2] * w[2]);
+                const double n1_ = u[3] * w[1] + u[4] * w[2];
+                const double n2 = u[5] * w[2];
+                zo[j][0] = n0; zo[j][1] = n1_; zo[j][2] = n2;
+                ecor[j] = ein + eu[j];
+                if ((c % PSD_C3_FPL) == PSD_C3_FPL - 1) {
+                    ein = psd_c3_expo(psd_c3_max3(n0, n1_, n2));
+                    w[0] = psd_c3_ldexp(n0, -ein); w[1] = psd_c3_ldexp(n1_, -ein); w[2] = psd_c3_ldexp(n2, -ein);
+                } else {
+                    ein = 0;
+                    w[0] = n0; w[1] = n1_; w[2] = n2;
                 }
             }
         }
-        double v1[64], v2[64], tau[64], beta[64];
-        for (int lane = 0; lane < 64; ++lane) {
-            double a0 = fac[lane] ? zo[lane][0] : x0, a1 = fac[lane] ? zo[lane][1] : x1, a2 = fac[lane] ? zo[lane][2] : x2;
-            tau[lane] = psd_refl3(a0, a1, a2);
-            v1[lane] = a1;
-            v2[lane] = a2;
-            beta[lane] = a0;
+        for (int j = 1; j <= p; ++j) {
+            double a0 = (j == 1) ? x0 : zo[j][0], a1 = (j == 1) ? x1 : zo[j][1], a2 = (j == 1) ? x2 : zo[j][2];
+            tau[j] = psd_refl3(a0, a1, a2);
+            v1[j] = a1;
+            v2[j] = a2;
+            bz[j] = a0;
         }
-        double B[64][4], d0[64], t2[64][2], to[64][2];
-        for (int lane = 0; lane < 64; ++lane) {
-            for (int q = 0; q < 4; ++q) B[lane][q] = 0.0;
-            const int nb = (lane + 1) & 63;
-            if (fac[lane]) {
-                const double* u = U[lane];
-                psd_c3_bblock(u[0], u[1], u[2], u[3], u[4], u[5], v1[lane], v2[lane], tau[lane], v1[nb], v2[nb], tau[nb],
-                              B[lane][0], B[lane][1], B[lane][2], B[lane][3]);
-            }
-            d0[lane] = fac[lane] ? 0.0 : 1.0;
-            t2[lane][0] = d0[lane];
-            t2[lane][1] = 0.0;
-            to[lane][0] = to[lane][1] = 0.0;
+        beta[1] = bz[1];
+        for (int j = 2; j <= p; ++j) beta[j] = psd_c3_beta(bz[j], bz[(j == p) ? 1 : (j + 1)], ecor[j]);
+        double B[65][4], to[65][2], w2v[65], tau2[65], beta2[65], by[65];
+        int ecor2[65];
+        for (int j = 2; j <= p; ++j) {
+            const int nb = (j == p) ? 1 : (j + 1);
+            const double* u = U[j];
+            psd_c3_bblock(u[0], u[1], u[2], u[3], u[4], u[5], v1[j], v2[j], tau[j], v1[nb], v2[nb], tau[nb], B[j][0], B[j][1],
+                          B[j][2], B[j][3]);
         }
-        for (int s = 0; s < p - 1; ++s) {
-            double w[64][2];
-            for (int lane = 0; lane < 64; ++lane)
-                for (int t = 0; t < 2; ++t) w[lane][t] = t2[(lane + 1) & 63][t];
-            for (int lane = 0; lane < 64; ++lane) {
-                t2[lane][0] = B[lane][0] * w[lane][0] + (B[lane][1] * w[lane][1] + d0[lane]);
-                t2[lane][1] = B[lane][2] * w[lane][0] + B[lane][3] * w[lane][1];
-                if (s == p - 1 - lane) {
-                    to[lane][0] = t2[lane][0];
-                    to[lane][1] = t2[lane][1];
-                }
-                if ((s & 15) == 15) {
-                    const int e = psd_c3_expo(fmax(fabs(t2[lane][0]), fabs(t2[lane][1])));
-                    t2[lane][0] = psd_c3_ldexp(t2[lane][0], -e);
-                    t2[lane][1] = psd_c3_ldexp(t2[lane][1], -e);
+        {   // scan 2
+            double w[2] = {1.0, 0.0};
+            int ein = 0;
+            for (int c = 0; c < p - 1; ++c) {
+                const int j = p - c;
+                const double n0 = B[j][0] * w[0] + B[j][1] * w[1];
+                const double n1_ = B[j][2] * w[0] + B[j][3] * w[1];
+                to[j][0] = n0; to[j][1] = n1_;
+                ecor2[j] = ein + eu[j];
+                if ((c % PSD_C3_FPL) == PSD_C3_FPL - 1) {
+                    ein = psd_c3_expo(fmax(fabs(n0), fabs(n1_)));
+                    w[0] = psd_c3_ldexp(n0, -ein); w[1] = psd_c3_ldexp(n1_, -ein);
+                } else {
+                    ein = 0;
+                    w[0] = n0; w[1] = n1_;
                 }
             }
         }
-        for (int lane = 0; lane < p; ++lane) {
-            double y0 = to[lane][0], y1 = to[lane][1];
-            const double tau2 = fac[lane] ? psd_refl2(y0, y1) : 0.0;
-            const double w2v = fac[lane] ? y1 : 0.0;
+        w2v[1] = 0.0; tau2[1] = 0.0; beta2[1] = 0.0;
+        for (int j = 2; j <= p; ++j) {
+            double y0 = to[j][0], y1 = to[j][1];
+            tau2[j] = psd_refl2(y0, y1);
+            w2v[j] = y1;
+            by[j] = y0;
+        }
+        for (int j = 2; j <= p; ++j) beta2[j] = psd_c3_beta(by[j], (j == p) ? 1.0 : by[j + 1], ecor2[j]);
+        for (int j = 1; j <= p; ++j) {
+            const int lane = j - 1;
             double* t = tab + lane * PSD_C3_TAB;
-            t[0] = v1[lane];
-            t[1] = v2[lane];
-            t[2] = tau[lane];
-            t[3] = w2v;
-            t[4] = tau2;
-            t[5] = beta[lane];
+            t[0] = v1[j];
+            t[1] = v2[j];
+            t[2] = tau[j];
+            t[3] = w2v[j];
+            t[4] = tau2[j];
+            t[5] = beta[j];
+            t[6] = beta2[j];
             psd_tr tr;
             tr.pos = k;
             tr.kind = PSD_TR_R3;
-            tr.c0 = v1[lane];
-            tr.c1 = v2[lane];
-            tr.c2 = tau[lane];
+            tr.c0 = v1[j];
+            tr.c1 = v2[j];
+            tr.c2 = tau[j];
             const int slot = (lane == 0) ? (n1 + kk) : (nj + 2 * kk);
             if (slot < PSD_TR_CAP) psd_tr_store_global(trb + (size_t)lane * PSD_TR_CAP + slot, tr);
             if (lane >= 1 && slot + 1 < PSD_TR_CAP) {
                 tr.pos = k + 1;
                 tr.kind = PSD_TR_H2;
-                tr.c0 = w2v;
+                tr.c0 = w2v[j];
                 tr.c1 = 0.0;
-                tr.c2 = tau2;
+                tr.c2 = tau2[j];
                 psd_tr_store_global(trb + (size_t)lane * PSD_TR_CAP + slot + 1, tr);
             }
         }

@@ -50,6 +50,7 @@ psd_simctx psd_sim;
 //    only in a build with -DPSD_DIAG: libpsd_mi355x_diag.so, built beside the product library for tools/ and the
 //    fault-injection test, and the test-only serial simulation.  In the product library a stray environment variable
 //    cannot change what a call returns.
+#define PSD_SL_MAXG_API 8  // (= PSD_SL_MAXG of psd_slice3.h, which the serial simulation does not see)
 static inline const char* psd_env(const char* k) { return getenv(k); }
 #ifdef PSD_DIAG
 static inline const char* psd_env_diag(const char* k) { return getenv(k); }
@@ -286,6 +287,8 @@ struct psd_ctx {
 #endif
     int apply_worklist = 1;   // PSD_APPLY_WL=0: the grid-per-cursor bulk-apply kernels
     int apply_wl_grid = 2048; // workgroups of the work-list bulk apply (PSD_APPLY_WL_GRID)
+    int slices = 1;           // factor-sliced sweep windows of the real engine (psd_set_slices, psd_slice3.h): workgroups per window
+    unsigned char* slmem = nullptr;  // command blocks and inboxes of the sliced windows, then the error word of their waits
     int chase3 = 1;           // scan chase of the real periodic QR sweep (psd_chase3.h; PSD_C3=0: the two-wave / one-wave chases)
     int chase2 = 1;           // two-wave chase of the real periodic QR sweep (psd_c2_run; PSD_C2=0: one wavefront per bulge)
     int apply_wl2 = 1;        // register-line form of the work-list bulk apply (psd_apply2.h) where it is the faster one; PSD_APPLY_WL2=0: never, 2: always
@@ -1112,6 +1115,9 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     P.c2off = (scan3 || (c->chase2 && p >= PSD_C2_MINP)) ? (int)((size_t)p * psd_win_area(W) * sizeof(double)) : 0;
     P.c3off = scan3 ? (int)step_lds_scratch_end(p, W, 8, true) : 0;
     P.cdefer = 0;
+    P.slG = 1;
+    P.slmem = nullptr;
+    P.slerr = nullptr;
     const int c2waves = scan3 ? PSD_C3_WAVES : (P.c2off ? 2 : 1);
     (void)c2waves;
     // Every way out of this function (the runaway cap, a failed runtime call) first waits for the second stream — its
@@ -1156,6 +1162,20 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     const bool cdef = mb && c->cdefer && (c->cdefer == 2 || ovl2) && nprob == 1;  // far rows of the column roles likewise (psd_cdefer_edge)
     bool far_pending = false;  // (the far column roles of the previous tick have been launched / are still to run)
     P.cdefer = cdef ? 1 : 0;
+    // factor-sliced sweep windows (psd_set_slices; psd_slice3.h): G workgroups per slot, each with the window blocks of
+    // its contiguous slice of the period; needs the scan chase, the slot scheduler and at least two factors per slice
+    int slG = 1;
+#ifndef PSD_HOSTSIM
+    if (c->slices > 1 && mb && scan3 && nprob == 1 && p / c->slices >= 2 && c->slices <= PSD_SL_MAXG) {
+        slG = c->slices;
+        const size_t slbytes = (size_t)PSD_SLOTS * (PSD_SL_CMD_BYTES + PSD_SL_MAXG * PSD_SL_BOX_BYTES) + 64;
+        if (!c->slmem) PSD_CHECK(psd_rt_malloc((void**)&c->slmem, slbytes));
+        PSD_CHECK(psd_rt_memset(c->slmem, 0, slbytes, c->stream));
+        P.slG = slG;
+        P.slmem = c->slmem;
+        P.slerr = (int*)(c->slmem + slbytes - 64);
+    }
+#endif
     if (M > 1 || mb) {
         PSD_CHECK(c->treserve(p));
         PSD_CHECK(psd_rt_memset(c->tgl, 0, sizeof(psd_rglobal), c->stream));
@@ -1250,7 +1270,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
             if (M == 1 && !mb)
                 PSD_LAUNCH2(psd_rq_step, psd_dim3(1), PSD_STEP_NT, c2waves, lds_step, c->stream, P);
             else if (mb)  // every slot of the scheduler in one launch
-                PSD_LAUNCH2(psd_rq_step_mb, psd_dim3(PSD_SLOTS), PSD_STEP_NT, c2waves, lds_step, c->stream, Pq, p, p + 8);
+                PSD_LAUNCH2(psd_rq_step_mb, psd_dim3(PSD_SLOTS, slG), PSD_STEP_NT, c2waves, lds_step, c->stream, Pq, p, p + 8);
             else  // every cursor of the tick in one launch, one workgroup each
                 PSD_LAUNCH2(psd_rq_step_train, psd_dim3(M), PSD_STEP_NT, c2waves, lds_step, c->stream, P, p, p + 8);
 #ifndef PSD_HOSTSIM
@@ -1396,6 +1416,17 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     PSD_CHECK(poller.finish(pend));
 #endif
     PSD_CHECK(psd_rt_last_error());
+#ifndef PSD_HOSTSIM
+    if (slG > 1) {  // (a sliced window whose hand-over never arrived: the results are void, say so)
+        int serr = 0;
+        PSD_CHECK(psd_rt_d2h(&serr, P.slerr, sizeof(int), c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+        if (serr) {
+            *st_out = hst;
+            return PSD_INFO_RUNTIME + 0xfffa;
+        }
+    }
+#endif
     if (P.ticklog) {
         std::vector<int> tl((size_t)ticklog_cap);
         PSD_CHECK(psd_rt_d2h(tl.data(), P.ticklog, sizeof(int) * ticklog_cap, c->stream));
@@ -1615,9 +1646,18 @@ int psd_set_train_g(psd_ctx* c, int bulges) {
 }
 int psd_get_train_g(psd_ctx* c) { return c ? c->gtrain_m : -1; }
 int psd_get_hess_pipe(psd_ctx* c) { return c ? (psd_pipe_form(c) ? 1 : 0) : -1; }
+int psd_set_slices(psd_ctx* c, int slices) {
+    if (!c) return -1;
+    if (slices < 1 || slices > PSD_SL_MAXG_API) return -2;
+    c->slices = slices;
+    return 0;
+}
+int psd_get_slices(psd_ctx* c) { return c ? c->slices : -1; }
 
 int psd_destroy(psd_ctx* c) {
     if (!c) return 0;
+    if (c->slmem) psd_rt_free(c->slmem);
+    c->slmem = nullptr;
     if (c->counted) g_live_contexts.fetch_sub(1);
     c->counted = false;
     c->grelease();

@@ -225,6 +225,11 @@ struct psd_rparams {
     // scan chase (psd_chase3.h): byte offset of its reflector table in dynamic LDS (behind the scratch of the state
     // machine); 0: off.  The chase workgroups then have PSD_C3_WAVES wavefronts, and c2off names the command block.
     int c3off;
+    // factor-sliced scan chase (psd_slice3.h): slices per slot (1: off); per slot PSD_SL_CMD_BYTES of command block and
+    // slG inboxes of PSD_SL_BOX_BYTES in device memory; the error word of its bounded waits
+    int slG;
+    unsigned char* slmem;
+    int* slerr;
     // 1: the far part of a tick's column roles (rows more than PSD_CDEFER_EDGE above the window, psd_apply_desc::rcut) runs
     // on the second stream beside the NEXT tick's chases (iterate_dev; psd_rq_apply_wl modes 5 / 6)
     int cdefer;
@@ -1700,6 +1705,11 @@ struct psd_c2 {
     long long* dbg;           // diagnostics (scan chase): psd_rglobal::c3dbg or nullptr
     double* H;                // commands 3 / 4 (window load / store shared by the wavefronts): factors, order, window width
     int n, W;
+    // factor-sliced scan chase (psd_slice3.h; command 5): slices, this workgroup's slice, the tick, the slot's inboxes,
+    // the error word of the bounded waits
+    int slG, slg, sltick;
+    unsigned char* slbox;
+    int* slerr;
 };
 #define PSD_C2_MINP 8
 #ifndef PSD_C2_STAMP
@@ -2026,6 +2036,7 @@ PSD_D void psd_c2_lead(const psd_rparams& P, psd_c2& C) {
 #ifndef PSD_HOSTSIM
 // the helper wavefront of a chase workgroup (threadIdx.y == 1)
 PSD_D void psd_c3_run(const psd_c2& Cin, int wv_, int nw_, int taboff_);
+PSD_D void psd_c3s_run(const psd_c2& Cin, int wv_, int nw_, int taboff_);
 PSD_D void psd_c2_helper(int c2off, int c3off) {
     PSD_LDS_DECL;
     const psd_c2* cmd = (const psd_c2*)(psd_lds + c2off);
@@ -2035,6 +2046,8 @@ PSD_D void psd_c2_helper(int c2off, int c3off) {
         if (C.cmd == 0) return;
         if (C.cmd == 2) {
             psd_c3_run(C, PSD_WAVE_ROLE, (int)blockDim.y, c3off);  // scan chase: every wavefront takes part
+        } else if (C.cmd == 5) {
+            psd_c3s_run(C, PSD_WAVE_ROLE, (int)blockDim.y, c3off);  // this workgroup's slice of a factor-sliced run
         } else if (C.cmd == 3 || C.cmd == 4) {  // this wavefront's share of a window load / store
             psd_rparams R;
             R.H = C.H;
@@ -2059,6 +2072,7 @@ PSD_D void psd_c2_release(int c2off) {
 #endif
 
 #include "psd_chase3.h"
+#include "psd_slice3.h"
 // wavefront 0's side of a scan-chase run (the other wavefronts of the workgroup wait at the command barrier)
 PSD_D void psd_c3_lead(const psd_rparams& P, psd_c2& C) {
 #ifdef PSD_HOSTSIM
@@ -2101,6 +2115,132 @@ PSD_D void psd_c3_winio(const psd_rparams& P, const psd_win& w, int n, int p, bo
     else psd_win_load(P, w, n, p);
 }
 
+#ifndef PSD_HOSTSIM
+// ---- factor-sliced runs (psd_slice3.h): a slot's command block and inboxes in device memory
+PSD_D unsigned char* psd_sl_cmd(const psd_rparams& P, int slot) {
+    return P.slmem + (size_t)slot * (PSD_SL_CMD_BYTES + PSD_SL_MAXG * PSD_SL_BOX_BYTES);
+}
+// slice 0 publishes the tick's command to the slot's workers: a run (the psd_c2 block behind a release fence) or nothing
+PSD_D void psd_sl_publish(const psd_rparams& P, int slot, const psd_c2* C) {  // (one lane)
+    unsigned char* cm = psd_sl_cmd(P, slot);
+    if (C != nullptr) {
+        *(psd_c2*)(cm + 64) = *C;
+        psd_release_fence();
+    }
+    __hip_atomic_store((unsigned long long*)cm, psd_sl_tag(P.tick, 0, (C != nullptr) ? 1 : 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// slice 0, at the end of its launch: workers of a slot that chased no sweep window in this tick are sent home
+PSD_D void psd_sl_finish(const psd_rparams& P, int slot) {
+    PSD_ONE {
+        const unsigned long long v = __hip_atomic_load((unsigned long long*)psd_sl_cmd(P, slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v != psd_sl_tag(P.tick, 0, 1)) psd_sl_publish(P, slot, nullptr);
+    }
+}
+// slice 0 waits until the workers of the slot have stored their window blocks (the tail of a sweep is not sliced)
+PSD_D void psd_sl_wait_stored(const psd_rparams& P, int slot) {
+    const unsigned long long* fl = (const unsigned long long*)(psd_sl_cmd(P, slot) + 384);
+    const unsigned long long want = psd_sl_tag(P.tick, 0, 6);
+    for (int g = 1; g < P.slG; ++g) {
+        int spins = 0;
+        long long t0 = 0;
+        while (__hip_atomic_load(fl + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+            if ((++spins & 255) == 0) {
+                if (__hip_atomic_load(P.slerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                const long long now = (long long)__builtin_amdgcn_s_memrealtime();
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > PSD_SL_WAIT_TICKS) {
+                    __hip_atomic_store(P.slerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    psd_acquire_fence();
+}
+// A worker workgroup (slice g >= 1 of the slot): every wavefront enters.  Waits for the tick's command, loads the window
+// blocks of its own factors, runs its slice of the scan chase, stores its blocks, says so, leaves.
+PSD_D void psd_sl_worker(const psd_rparams& P, int slot, int g) {
+    PSD_LDS_DECL;
+    psd_c2* cmd = (psd_c2*)(psd_lds + P.c2off);
+    const int wv = PSD_WAVE_ROLE, nw = (int)blockDim.y;
+    if (wv == 0) {
+        unsigned char* cm = psd_sl_cmd(P, slot);
+        const unsigned long long trun = psd_sl_tag(P.tick, 0, 1), tidle = psd_sl_tag(P.tick, 0, 4);
+        int kind = 4, spins = 0;
+        long long t0 = 0;
+        for (;;) {
+            const unsigned long long v = __hip_atomic_load((unsigned long long*)cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v == trun) {
+                kind = 1;
+                break;
+            }
+            if (v == tidle) break;
+            if ((++spins & 255) == 0) {
+                if (__hip_atomic_load(P.slerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                const long long now = (long long)__builtin_amdgcn_s_memrealtime();
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > PSD_SL_WAIT_TICKS) {
+                    __hip_atomic_store(P.slerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (kind == 1) {
+            psd_acquire_fence();
+            psd_c2 C = *(const psd_c2*)(cm + 64);
+            C.cmd = 5;
+            C.slg = g;
+            C.wboff = 0;
+            PSD_ONE { *cmd = C; }
+        } else {
+            PSD_ONE { cmd->cmd = 0; }
+        }
+    }
+    PSD_PAIR_BARRIER();
+    const psd_c2 C = *cmd;
+    if (C.cmd != 5) return;
+    int jlo, jhi;
+    psd_sl_range(C.p, C.slG, g, jlo, jhi);
+    psd_rparams R;
+    R.H = C.H + (size_t)(jlo - 1) * C.n * C.n;
+    psd_win w;
+    w.b = (double*)psd_lds;
+    w.W = C.W; w.ld = C.ld; w.bsz = C.bsz; w.bs = C.bs; w.be = C.be;
+    psd_win_load(R, w, C.n, jhi - jlo + 1, wv, nw);
+    PSD_PAIR_BARRIER();
+    psd_c3s_run(C, wv, nw, P.c3off);
+    psd_win_store(R, w, C.n, jhi - jlo + 1, wv, nw);
+    psd_release_fence();  // (this wavefront's stores are out)
+    PSD_PAIR_BARRIER();
+    if (wv == 0) {
+        PSD_ONE {
+            __hip_atomic_store((unsigned long long*)(psd_sl_cmd(P, slot) + 384) + g, psd_sl_tag(P.tick, 0, 6), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// slice 0's side of a sliced run: the command to the slot's workers, then its own slice (with its helper wavefronts)
+PSD_D void psd_c3s_lead(const psd_rparams& P, psd_c2& C, int slot) {
+    PSD_LDS_DECL;
+    psd_c2* cmd = (psd_c2*)(psd_lds + P.c2off);
+    C.cmd = 5;
+    C.slG = P.slG;
+    C.slg = 0;
+    C.sltick = P.tick;
+    C.slbox = psd_sl_cmd(P, slot) + PSD_SL_CMD_BYTES;
+    C.slerr = P.slerr;
+    PSD_ONE {
+        psd_sl_publish(P, slot, &C);
+        *cmd = C;
+    }
+    PSD_PAIR_BARRIER();
+    psd_c3s_run(C, 0, (int)blockDim.y, P.c3off);
+    PSD_ONE { cmd->cmd = 0; }
+}
+#endif
+
 // PSD.jl:806-886: one window (steps kcur .. kcur+nb-1) of the double-shift periodic QR sweep
 PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, int* lcnt) {
     const int n = st.n, p = st.p, i = st.i, l = st.l, i1 = st.i1, i2 = st.i2;
@@ -2116,16 +2256,28 @@ PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
     w.bs = (ks > l) ? (ks - 1) : l;
     w.be = (ke + 3 < i) ? (ke + 3) : i;
     const long long tc0 = psd_clock();
-    psd_c3_winio(P, w, n, p, false);
+    const bool scan3 = P.c3off != 0 && p >= PSD_C3_MINP && p <= PSD_C3_MAXP;
+    const int klast = (ke < i - 2) ? ke : (i - 2);  // last position with a three-row bulge
+    // factor-sliced window (psd_slice3.h): this workgroup is slice 0 and holds the blocks of its own factors 1..p0 only
+    // while the sweep positions run; the slot's other workgroups hold theirs
+    int p0 = p;
+#ifndef PSD_HOSTSIM
+    const bool sliced = scan3 && P.slG > 1 && st.mb && klast >= ks;
+    if (sliced) {
+        int jlo0;
+        psd_sl_range(p, P.slG, 0, jlo0, p0);
+    }
+#else
+    const bool sliced = false;
+#endif
+    psd_c3_winio(P, w, n, p0, false);
     const long long tc1 = psd_clock();
     const int c1max = (w.be < i2) ? w.be : i2;
     const int r0 = (w.bs > i1) ? w.bs : i1;
     int n1 = 0, nj = 0;  // list lengths: owner 1, owners 2..p
     int kfirst = ks;
-    const bool scan3 = P.c3off != 0 && p >= PSD_C3_MINP && p <= PSD_C3_MAXP;
     if (scan3 || (P.c2off != 0 && P.c3off == 0 && p >= PSD_C2_MINP)) {
         // the positions with three-row bulges (all but possibly the last of a sweep) on the scan chase / two-wave chase
-        const int klast = (ke < i - 2) ? ke : (i - 2);
         if (klast >= ks) {
             psd_c2 C;
             C.cmd = 1;
@@ -2140,7 +2292,12 @@ PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
             C.tr = P.tr;
             C.dbg = (P.ticklog != nullptr && P.gl != nullptr) ? P.gl->c3dbg : nullptr;
             C.v0 = st.v[0]; C.v1 = st.v[1]; C.v2 = st.v[2];
+            C.H = P.H; C.n = n; C.W = st.W;
             PSD_SYNC();
+#ifndef PSD_HOSTSIM
+            if (sliced) psd_c3s_lead(P, C, st.slot);
+            else
+#endif
             if (scan3) psd_c3_lead(P, C);
             else psd_c2_lead(P, C);
             PSD_SYNC();
@@ -2149,6 +2306,19 @@ PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
             kfirst = klast + 1;
         }
     }
+#ifndef PSD_HOSTSIM
+    if (sliced && kfirst <= ke) {
+        // The last position of a sweep (a two-row bulge) is not sliced: the workers have stored their blocks (they say
+        // so), this workgroup fetches them and finishes the window on all factors as the unsliced engine does.
+        psd_sl_wait_stored(P, st.slot);
+        psd_rparams R = P;
+        R.H = P.H + (size_t)p0 * n * n;
+        psd_win w2 = w;
+        w2.b = w.b + (size_t)p0 * w.bsz;
+        psd_c3_winio(R, w2, n, p - p0, false);
+        p0 = p;
+    }
+#endif
     for (int k = kfirst; k <= ke; ++k) {
         const int nr = (3 < i - k + 1) ? 3 : (i - k + 1);
         const int rlim = (k + nr < i) ? (k + nr) : i;
@@ -2216,7 +2386,7 @@ PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
     }
     PSD_PAR_FOR(m, p) { lcnt[m] = (m == 0) ? n1 : nj; }
     const long long tc2 = psd_clock();
-    psd_c3_winio(P, w, n, p, true);
+    psd_c3_winio(P, w, n, p0, true);  // (a sliced window: this slice's blocks; the workers store theirs)
     const long long tc3 = psd_clock();
     st.cyc[1] += tc1 - tc0;
     st.cyc[2] += tc2 - tc1;
@@ -2809,8 +2979,17 @@ PSD_D void psd_rq_step_mb_body(const psd_rparams& P, int p, int cstride) {
     }
 }
 PSD_KERNEL_B(PSD_C3_WAVES * PSD_STEP_NT) psd_rq_step_mb(psd_rparams P, int p, int cstride) {
+#ifndef PSD_HOSTSIM
+    if (P.slG > 1 && PSD_BLOCK_Y >= 1) {  // grid (slots, slices): a worker of slot blockIdx.x (psd_slice3.h)
+        psd_sl_worker(P, PSD_BLOCK_X, PSD_BLOCK_Y);
+        return;
+    }
+#endif
     PSD_C2_ENTER(P);
     psd_rq_step_mb_body(P, p, cstride);
+#ifndef PSD_HOSTSIM
+    if (P.slG > 1) psd_sl_finish(P, PSD_BLOCK_X);
+#endif
     PSD_C2_LEAVE(P);
 }
 

@@ -1,0 +1,66 @@
+"""GPU tier: factor-sliced sweep windows (csrc/psd_slice3.h, psd_set_slices) — the north_star partition (SURVEY.md section
+8e: factors sharded by period, the chain handed over at slice boundaries) as device code, with the G workgroups of a window
+slot as the ranks and the inboxes as plain device pointers."""
+import numpy as np
+import pytest
+
+import psdtest as pt
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sliced_windows_real(gpu_engine):
+    """pschur!(A, lr) with G = 2 and G = 4 workgroups per sweep window, each holding the window blocks of its slice of the
+    period only, against the unsliced engine and the CPU oracle (eigenvalues at 1e-10 ||prod A||) and checkpsd; periods the
+    slices split evenly and raggedly, both orientations, the longest period the scan chase serves.  What crosses a slice
+    boundary is a chain vector, and a reflector is a function of it, so the result does not depend on the NUMBER of
+    slices: G = 2 and G = 4 agree to the bit (the unsliced kernel is a different instruction stream — the compiler
+    contracts its multiply-adds in its own way — and agrees to rounding)."""
+    import torch
+
+    torch.cuda.init()
+    import psd_amd
+
+    engs = {}
+    for G in (2, 4):
+        engs[G] = psd_amd.Engine(device=0)
+        engs[G].set_slices(G)
+        assert engs[G].get_slices() == G
+    for (n, p, lr, oracle) in [(96, 8, "R", True), (130, 10, "L", True), (200, 12, "R", False), (150, 64, "L", False), (260, 16, "R", False)]:
+        A = pt.bench_factors(n, p, seed=900 + n + p)
+        ref = gpu_engine.pschur(A, lr)
+        P = pt.product(A, left=(lr == "L"))
+        nP = np.linalg.norm(P, 2)
+        lam = np.linalg.eigvals(P)
+        res = {}
+        for G in (2, 4):
+            ps = engs[G].pschur(A, lr)
+            res[G] = ps
+            ok, err = engs[G].checkpsd(ps, A, thresh=100 * np.sqrt(max(n / 32, 1)))
+            assert ok, (G, n, p, lr, float(err.max()))
+            assert pt.match_eigs(lam, ps.values) <= 1e-10 * nP
+            assert pt.match_eigs(ref.values, ps.values) <= 1e-10 * nP
+            if oracle:
+                po = pt.oracle_pschur(A, lr)
+                assert pt.match_eigs(po.values, ps.values) <= 1e-10 * nP
+        assert res[2].stats.nsweeps == res[4].stats.nsweeps
+        assert np.array_equal(res[2].values, res[4].values)
+        for j in range(p):
+            assert np.array_equal(res[2].Ts[j], res[4].Ts[j]), (n, p, lr, j)
+            assert np.array_equal(res[2].Z[j], res[4].Z[j]), (n, p, lr, j)
+
+
+def test_slices_argument_checks(gpu_engine):
+    import psd_amd
+
+    eng = psd_amd.Engine(device=0)
+    with pytest.raises(ValueError):
+        eng.set_slices(0)
+    with pytest.raises(ValueError):
+        eng.set_slices(9)
+    # fewer than two factors per slice: the call runs unsliced
+    eng.set_slices(4)
+    A = pt.bench_factors(60, 5, seed=3)
+    ps = eng.pschur(A, "R")
+    ok, err = eng.checkpsd(ps, A, thresh=100 * np.sqrt(60 / 32))
+    assert ok
