@@ -2143,6 +2143,9 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
     P.zcoff = zscan3 ? (int)((size_t)p * W * (W + 1) * sizeof(psd_z)) : 0;
     P.zc3off = zscan3 ? (int)step_lds_scratch_end(p, W, 16, false) : 0;
     const int zwaves = zscan3 ? PSD_ZC3_WAVES : 1;
+    P.zslG = 1;
+    P.zslmem = nullptr;
+    P.zslerr = nullptr;
 #ifndef PSD_HOSTSIM
     if (lds_step > c->zstep_lds_set) {
         PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_zq_step),
@@ -2171,6 +2174,20 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
 #endif
     }
+    // factor-sliced sweep windows (psd_set_slices; psd_zslice3.h): G workgroups per cursor slot; needs the scan chase,
+    // the train kernel and at least two factors per slice
+    int zslG = 1;
+#ifndef PSD_HOSTSIM
+    if (c->slices > 1 && M > 1 && zscan3 && p / c->slices >= 2 && c->slices <= PSD_SL_MAXG) {
+        zslG = c->slices;
+        const size_t slbytes = (size_t)PSD_SLOTS * (PSD_SL_CMD_BYTES + PSD_SL_MAXG * PSD_SL_BOX_BYTES) + 64;
+        if (!c->slmem) PSD_CHECK(psd_rt_malloc((void**)&c->slmem, slbytes));
+        PSD_CHECK(psd_rt_memset(c->slmem, 0, slbytes, c->stream));
+        P.zslG = zslG;
+        P.zslmem = c->slmem;
+        P.zslerr = (int*)(c->slmem + slbytes - 64);
+    }
+#endif
     int train_oc = 200;  // (100 until the cursors moved to W positions apart; 200-400 measured alike)
     if (const char* e = psd_env_diag("PSD_TRAIN_OC")) train_oc = atoi(e);  // (tuning hook)
     PSD_LAUNCH(psd_zq_init, psd_dim3(1), 256, 0, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, M, train_oc);
@@ -2236,7 +2253,7 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
             if (M == 1)
                 PSD_LAUNCH2(psd_zq_step, psd_dim3(1), PSD_STEP_NT, zwaves, lds_step, c->stream, P);
             else
-                PSD_LAUNCH2(psd_zq_step_train, psd_dim3(M), PSD_STEP_NT, zwaves, lds_step, c->stream, Pq, p, p + 8);
+                PSD_LAUNCH2(psd_zq_step_train, psd_dim3(M, zslG), PSD_STEP_NT, zwaves, lds_step, c->stream, Pq, p, p + 8);
 #ifndef PSD_HOSTSIM
             if (sample) {
                 (void)hipEventRecord(ev1, c->stream);
@@ -2288,6 +2305,15 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
 #ifndef PSD_HOSTSIM
     if (zdef) PSD_CHECK(hipStreamSynchronize(c->stream2));  // (the phase pass below scales columns of Z)
     PSD_CHECK(poller.finish(pend));
+    if (zslG > 1) {  // (a sliced window whose hand-over never arrived: the results are void, say so)
+        int serr = 0;
+        PSD_CHECK(psd_rt_d2h(&serr, P.zslerr, sizeof(int), c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+        if (serr) {
+            *st_out = hst;
+            return PSD_INFO_RUNTIME + 0xfffa;
+        }
+    }
 #endif
     if (hst.info == 0 && wantT) {  // generalized.jl:860-908
         for (int l = p; l >= 2; --l)
@@ -2850,6 +2876,9 @@ int zordschur_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
     O.z.zlo = 1;  // (ordschur! is not sharded: every Z_m is this context's)
     O.z.zhi = p;
     O.z.zcoff = O.z.zc3off = 0;
+    O.z.zslG = 1;
+    O.z.zslmem = nullptr;
+    O.z.zslerr = nullptr;
     O.z.Z = wantZ ? dZ : nullptr;
     O.z.st = c->zst;
     O.z.desc = c->zdesc;

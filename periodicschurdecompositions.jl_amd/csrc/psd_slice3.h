@@ -45,7 +45,7 @@ PSD_D void psd_sl_put(psd_vrec* q, double x, unsigned long long tag) {
     __hip_atomic_store(&q->a, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&q->b, bits ^ tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// nval <= 3 records from `q` (every lane of the wavefront polls the same words); false: gave up
+// nval records from `q` (every lane of the wavefront polls the same words); false: gave up
 PSD_D bool psd_sl_get(const psd_vrec* q, int nval, unsigned long long tag, double* out, int* err) {
     int spins = 0;
     long long t0 = 0;

@@ -32,6 +32,11 @@ struct psd_zc {
     psd_z* H;      // factors (commands 3 / 4)
     double c0;     // the sweep's start rotation (used when ks == ifirst)
     psd_z s0;
+    // factor-sliced runs (psd_zslice3.h; command 5): slices, this workgroup's slice, the tick, the slot's inboxes, the
+    // error word of the bounded waits
+    int slG, slg, sltick;
+    unsigned char* slbox;
+    int* slerr;
 };
 
 // the pair (x1, x2) under a rotation from the right (columns) or from the left (rows); fix: the second entry becomes 0

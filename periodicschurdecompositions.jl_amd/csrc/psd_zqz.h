@@ -89,6 +89,11 @@ struct psd_zparams {
     // scan chase (psd_zchase3.h): byte offsets of the command block and of the rotation table in dynamic LDS; 0: off
     // (one wavefront per chase workgroup).  With it the chase workgroups have PSD_ZC3_WAVES wavefronts.
     int zcoff, zc3off;
+    // factor-sliced sweep windows (psd_zslice3.h): slices per window (1: off), the slots' command blocks and inboxes in
+    // device memory, the error word of the bounded waits
+    int zslG;
+    unsigned char* zslmem;
+    int* zslerr;
 };
 
 PSD_HD psd_mat<psd_z> psd_zfac(const psd_zparams& P, int n, int j) {
@@ -103,6 +108,7 @@ struct psd_zwin {
 
 #include "psd_zqz_win.inl"
 #include "psd_zchase3.h"
+#include "psd_zslice3.h"
 
 // The helper wavefronts of a scan-chase workgroup (threadIdx.y >= 1) park at the command barrier between runs; code
 // written in terms of PSD_TID / PSD_SYNC never sees them (as the two-wave chase of the real engine).
@@ -116,6 +122,8 @@ PSD_D void psd_zc_helper(int zcoff, int zc3off) {
         if (C.cmd == 0) return;
         if (C.cmd == 2) {
             psd_zc3_run(C, PSD_WAVE_ROLE, (int)blockDim.y, zc3off);
+        } else if (C.cmd == 5) {
+            psd_zc3s_run(C, PSD_WAVE_ROLE, (int)blockDim.y, zc3off);
         } else {  // this wavefront's share of a window load (3) / store (4)
             psd_zparams R;
             R.H = C.H;
@@ -184,6 +192,95 @@ PSD_D void psd_zc3_winio(const psd_zparams& P, const psd_zwin& w, int n, int p, 
     if (store) psd_zwin_store(P, w, n, p);
     else psd_zwin_load(P, w, n, p);
 }
+
+#ifndef PSD_HOSTSIM
+// ---- factor-sliced sweep windows (psd_zslice3.h): slice 0's command to the slot's workers, the workers themselves
+PSD_D void psd_zsl_publish(const psd_zparams& P, int slot, const psd_zc* C) {  // (one lane)
+    unsigned char* cm = psd_zsl_cmd(P.zslmem, slot);
+    if (C != nullptr) {
+        *(psd_zc*)(cm + 64) = *C;
+        psd_release_fence();
+    }
+    __hip_atomic_store((unsigned long long*)cm, psd_sl_tag(P.tick, 0, (C != nullptr) ? 1 : 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+PSD_D void psd_zsl_finish(const psd_zparams& P, int slot) {  // slice 0, at the end of its launch
+    PSD_ONE {
+        const unsigned long long v = __hip_atomic_load((unsigned long long*)psd_zsl_cmd(P.zslmem, slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v != psd_sl_tag(P.tick, 0, 1)) psd_zsl_publish(P, slot, nullptr);
+    }
+}
+PSD_D void psd_zsl_worker(const psd_zparams& P, int slot, int g) {  // every wavefront of a worker workgroup
+    PSD_LDS_DECL;
+    psd_zc* cmd = (psd_zc*)(psd_lds + P.zcoff);
+    const int wv = PSD_WAVE_ROLE, nw = (int)blockDim.y;
+    if (wv == 0) {
+        unsigned char* cm = psd_zsl_cmd(P.zslmem, slot);
+        const unsigned long long trun = psd_sl_tag(P.tick, 0, 1), tidle = psd_sl_tag(P.tick, 0, 4);
+        int kind = 4, spins = 0;
+        long long t0 = 0;
+        for (;;) {
+            const unsigned long long v = __hip_atomic_load((unsigned long long*)cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v == trun) {
+                kind = 1;
+                break;
+            }
+            if (v == tidle) break;
+            if ((++spins & 255) == 0) {
+                if (__hip_atomic_load(P.zslerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                const long long now = (long long)__builtin_amdgcn_s_memrealtime();
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > PSD_SL_WAIT_TICKS) {
+                    __hip_atomic_store(P.zslerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (kind == 1) {
+            psd_acquire_fence();
+            psd_zc C = *(const psd_zc*)(cm + 64);
+            C.cmd = 5;
+            C.slg = g;
+            C.wboff = 0;
+            PSD_ONE { *cmd = C; }
+        } else {
+            PSD_ONE { cmd->cmd = 0; }
+        }
+    }
+    PSD_PAIR_BARRIER();
+    const psd_zc C = *cmd;
+    if (C.cmd != 5) return;
+    int jlo, jhi;
+    psd_sl_range(C.p, C.slG, g, jlo, jhi);
+    psd_zparams R;
+    R.H = C.H + (size_t)(jlo - 1) * C.n * C.n;
+    psd_zwin w;
+    w.b = (psd_z*)psd_lds;
+    w.W = C.W; w.ld = C.ld; w.bsz = C.bsz; w.bs = C.bs; w.be = C.be;
+    psd_zwin_load(R, w, C.n, jhi - jlo + 1, wv, nw);
+    PSD_PAIR_BARRIER();
+    psd_zc3s_run(C, wv, nw, P.zc3off);
+    psd_zwin_store(R, w, C.n, jhi - jlo + 1, wv, nw);
+}
+PSD_D void psd_zc3s_lead(const psd_zparams& P, psd_zc& C, int slot) {
+    PSD_LDS_DECL;
+    psd_zc* cmd = (psd_zc*)(psd_lds + P.zcoff);
+    C.cmd = 5;
+    C.slG = P.zslG;
+    C.slg = 0;
+    C.sltick = P.tick;
+    C.slbox = psd_zsl_cmd(P.zslmem, slot) + PSD_SL_CMD_BYTES;
+    C.slerr = P.zslerr;
+    PSD_SYNC();
+    PSD_ONE {
+        psd_zsl_publish(P, slot, &C);
+        *cmd = C;
+    }
+    PSD_PAIR_BARRIER();
+    psd_zc3s_run(C, 0, (int)blockDim.y, P.zc3off);
+    PSD_ONE { cmd->cmd = 0; }
+}
+#endif
 
 PSD_D void psd_zrecord(const psd_zparams& P, int* lcnt, int m, int pos, double c, psd_z s) {
     PSD_ONE {
@@ -740,9 +837,20 @@ PSD_D void psd_zq_sweep_window(const psd_zparams& P, psd_zstate& st, psd_z* ldsz
     w.be = (ke + 2 < ilast) ? (ke + 2) : ilast;
     const long long tc0 = psd_clock();
     PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
-    psd_zc3_winio(P, w, n, p, false);
-    const long long tc1 = psd_clock();
     const bool scan3 = P.zc3off != 0 && p >= PSD_ZC3_MINP && p <= PSD_ZC3_MAXP && ke >= ks;
+    // factor-sliced window (psd_zslice3.h): this workgroup is slice 0 with the blocks of its own factors 1..p0
+    int p0 = p;
+#ifndef PSD_HOSTSIM
+    const bool sliced = scan3 && P.zslG > 1;
+    if (sliced) {
+        int jlo0;
+        psd_sl_range(p, P.zslG, 0, jlo0, p0);
+    }
+#else
+    const bool sliced = false;
+#endif
+    psd_zc3_winio(P, w, n, p0, false);
+    const long long tc1 = psd_clock();
     if (scan3) {  // every factor of a position at once (psd_zchase3.h)
         psd_zc C;
         C.ld = w.ld; C.bsz = w.bsz; C.bs = w.bs; C.be = w.be; C.W = w.W;
@@ -756,6 +864,10 @@ PSD_D void psd_zq_sweep_window(const psd_zparams& P, psd_zstate& st, psd_z* ldsz
         C.H = P.H;
         C.c0 = st.c0;
         C.s0 = st.s0;
+#ifndef PSD_HOSTSIM
+        if (sliced) psd_zc3s_lead(P, C, (st.cursor > 0) ? st.cursor : 0);
+        else
+#endif
         psd_zc3_lead(P, C);
         PSD_SYNC();
         PSD_ONE { lcnt[0] = ke - ks + 1; }
@@ -809,7 +921,7 @@ PSD_D void psd_zq_sweep_window(const psd_zparams& P, psd_zstate& st, psd_z* ldsz
         PSD_WAVE_SYNC();
     }
     const long long tc2 = psd_clock();
-    psd_zc3_winio(P, w, n, p, true);
+    psd_zc3_winio(P, w, n, p0, true);  // (a sliced window: this slice's blocks; the workers store theirs)
     st.cyc[1] += tc1 - tc0;
     st.cyc[2] += tc2 - tc1;
     st.cyc[3] += psd_clock() - tc2;
@@ -1083,10 +1195,19 @@ PSD_D void psd_zq_cursor_body(const psd_zparams& P, int b) {
 
 // all cursors of a tick in one launch (see psd_rq_step_train)
 PSD_KERNEL_B(PSD_ZC3_WAVES * PSD_STEP_NT) psd_zq_step_train(psd_zparams P, int p, int cstride) {
+#ifndef PSD_HOSTSIM
+    if (P.zslG > 1 && PSD_BLOCK_Y >= 1) {  // grid (cursors, slices): a worker of cursor slot blockIdx.x (psd_zslice3.h)
+        psd_zsl_worker(P, PSD_BLOCK_X, PSD_BLOCK_Y);
+        return;
+    }
+#endif
     PSD_ZC_ENTER(P);
     const int b = PSD_BLOCK_X;
     if (b == 0) {
         psd_zq_step_body(P);
+#ifndef PSD_HOSTSIM
+        if (P.zslG > 1) psd_zsl_finish(P, 0);
+#endif
         PSD_ZC_LEAVE(P);
         return;
     }
@@ -1096,6 +1217,9 @@ PSD_KERNEL_B(PSD_ZC3_WAVES * PSD_STEP_NT) psd_zq_step_train(psd_zparams P, int p
     Q.cnt = P.cnt + (size_t)b * cstride;
     Q.tr = P.tr + (size_t)b * p * PSD_ZTR_CAP;
     psd_zq_cursor_body(Q, b);
+#ifndef PSD_HOSTSIM
+    if (P.zslG > 1) psd_zsl_finish(P, b);
+#endif
     PSD_ZC_LEAVE(P);
 }
 

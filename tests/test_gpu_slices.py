@@ -64,3 +64,38 @@ def test_slices_argument_checks(gpu_engine):
     ps = eng.pschur(A, "R")
     ok, err = eng.checkpsd(ps, A, thresh=100 * np.sqrt(60 / 32))
     assert ok
+
+
+def test_sliced_windows_complex(gpu_engine):
+    """The same partition for the ComplexF64 engine (csrc/psd_zslice3.h; BASELINE configs[2] names this element type):
+    G = 2 and G = 4 workgroups per sweep window against the unsliced engine and the CPU oracle at 1e-10 ||prod A||, and
+    checkpsd.  (Runs are reproducible; where the slices coincide with the unsliced chase's groups of four links the result
+    is the unsliced one to the bit, otherwise it agrees to rounding: tools/r04/zslice_dbg.py.)"""
+    import torch
+
+    torch.cuda.init()
+    import psd_amd
+
+    engs = {}
+    for G in (2, 4):
+        engs[G] = psd_amd.Engine(device=0)
+        engs[G].set_slices(G)
+    for (n, p, lr, oracle) in [(80, 8, "R", True), (110, 10, "L", True), (160, 12, "R", False), (140, 64, "L", False), (220, 16, "R", False)]:
+        A = pt.bench_factors(n, p, seed=700 + n + p, dtype=np.complex128)
+        ref = gpu_engine.pschur(A, lr)
+        P = pt.product(A, left=(lr == "L"))
+        nP = np.linalg.norm(P, 2)
+        lam = np.linalg.eigvals(P)
+        res = {}
+        for G in (2, 4):
+            ps = engs[G].pschur(A, lr)
+            res[G] = ps
+            ok, err = engs[G].checkpsd(ps, A, thresh=100 * np.sqrt(max(n / 32, 1)))
+            assert ok, (G, n, p, lr, float(err.max()))
+            assert pt.match_eigs(lam, ps.values) <= 1e-10 * nP
+            assert pt.match_eigs(ref.values, ps.values) <= 1e-10 * nP
+            if oracle:
+                po = pt.oracle_zpschur(A, lr)
+                assert pt.match_eigs(po.values, ps.values) <= 1e-10 * nP
+        again = engs[4].pschur(A, lr)  # reproducible
+        assert all(np.array_equal(a, b) for a, b in zip(again.Ts, res[4].Ts))
