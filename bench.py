@@ -503,6 +503,10 @@ def main():
                                         "frac": hess_gbs / HBM_PEAK_GBS if hess_gbs else None,
                                         "alg_bytes_per_launch": st.bytes_hess / links if links else None,
                                         "avg_launch_ms": st.ms_hess / links if links else None,
+                                        "traffic": None,
+                                        "traffic_note": "no counter evidence: a counter pass over a process that runs the multi-stream reduction ends in the "
+                                                        "profiler (profiles/r02/pmc_sigsegv_analysis.md, round-4 amendment); the one-stream form measured "
+                                                        "1.60 x algorithmic per link at p = 8 (profiles/r02/pmc_traffic_hess2_1024x8.json)",
                                         "note": "one chain launch per link, consecutive launches overlapping on two streams (DESIGN section 0e; the panel "
                                                 "updates of 24 links per launch run on a third, CU-masked stream beside them); algorithmic bytes "
                                                 "16*(m*(m+1) + n*m) per link / HIP-event duration of the whole reduction per link"},

@@ -2420,6 +2420,9 @@ int zgiterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
     const int hess_links = psd_ghess_links(p), hess_waves = psd_ghess_waves(p);
     const char* hserial = psd_env("PSD_HESS_SERIAL");
     const bool hess_pipe = hessmode && lds_hess <= (size_t)160 * 1024 && !(hserial && hserial[0] == '1');
+    // (scan form of the stage-2 kernel, the default; PSD_HESS_SCAN=0: the pipeline of beats over the factors of round 2)
+    int hess_scan = 1;
+    if (const char* e = psd_env("PSD_HESS_SCAN")) hess_scan = atoi(e);
 #ifndef PSD_HOSTSIM
     if (hess_pipe && lds_hess > c->zghess_lds_set) {
         PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_zgq_hess_step),
@@ -3159,6 +3162,9 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
     const int hess_links = psd_ghess_links(p), hess_waves = psd_ghess_waves(p);
     const char* hserial = psd_env("PSD_HESS_SERIAL");
     const bool hess_pipe = hessmode && lds_hess <= (size_t)160 * 1024 && !(hserial && hserial[0] == '1');
+    // (scan form of the stage-2 kernel, the default; PSD_HESS_SCAN=0: the pipeline of beats over the factors of round 2)
+    int hess_scan = 1;
+    if (const char* e = psd_env("PSD_HESS_SCAN")) hess_scan = atoi(e);
 #ifndef PSD_HOSTSIM
     if (hess_pipe && lds_hess > c->ghess_lds_set) {
         PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_gq_hess_step),
@@ -3222,7 +3228,7 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
 #endif
             P.tick = (int)launched;
             if (hess_pipe)
-                PSD_LAUNCH(psd_gq_hess_step, psd_dim3(1), 64 * hess_waves, lds_hess, c->stream, P, hess_links);
+                PSD_LAUNCH(psd_gq_hess_step, psd_dim3(1), 64 * ((hess_scan && p <= 64) ? 4 : hess_waves), lds_hess, c->stream, P, hess_links, hess_scan);  // (scan form: four wavefronts, one per SIMD)
             else if (M > 1)
                 PSD_LAUNCH(psd_gq_step_train, psd_dim3(M), PSD_STEP_NT, lds_step, c->stream, P, p, p + 8);
             else

@@ -946,15 +946,245 @@ PSD_D void psd_ghess_beat(const psd_gparams& P, const psd_gstate& st, const psd_
 #endif
 }  // namespace psd_wv
 
-// LDS of the pipelined kernel: window blocks, column hj of A_1 (<= 64 entries), mailboxes, list lengths
+// LDS of the pipelined kernel: window blocks, column hj of A_1 (<= 64 entries), mailboxes, list lengths, and the rotation
+// table of the scan form (4 doubles per factor)
 PSD_HD size_t psd_ghess_lds_bytes(int p, int W) {
     size_t b = (size_t)p * W * (W + 1) * 8 + 64 * 8 + (size_t)4 * (PSD_GHESS_MAXWAVES + 1) * 8 + (size_t)p * 4;
+    b = (b + 15) & ~(size_t)15;
+    b += (size_t)p * 4 * 8;
     return (b + 15) & ~(size_t)15;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 2 of the signed Hessenberg reduction, scan form (round 4; generalized.jl:1034-1079).  One rotation per position
+// travels through all factors (psd_gq_tail, mode 2).  As in the scan chases of the sweeps (psd_chase3.h, psd_zchase3.h)
+// the pairs the p rotations are made from form a chain of 2 x 2 triangular matrix-vector products that needs no rotation
+// and no update: with U_l = A_l[q:q+1, q:q+1] and the incoming rotation (c, s),
+//     S[l] true  (the rotation acts on the columns, rgeneralized.jl:980-991):   (f, g) = U_l (c, s)',
+//     S[l] false (it acts on the rows, the fill goes by a column rotation, :993-1004):
+//                (p11, -p10) = adj(U_l) (c, s)',   adj(U) = [u11 -u01; 0 u00]   (the inverted factor),
+// and the rotation made from a pair is its normalisation (up to the sign convention of givensAlgorithm, which does not
+// matter: whichever of the two rotations comes out is applied to both sides and recorded).  So: z_p = M_p (c_1, s_1)',
+// z_{l-1} = M_{l-1} z_l on the chain lanes, every rotation at once (one lane per factor), then all factors updated side by
+// side by every wavefront of the workgroup: first each factor's INCOMING rotation (columns for S true, rows for S
+// false; A_1: its own rotation on the rows), then the rotation made AT the factor (rows resp. columns, the annihilated
+// entry set to zero; A_1: the rotation that closes the lap, on its columns).  K positions = K rounds of (scan, two update
+// phases) instead of K + G beats of L dependent links each.
+// tab: [p][4] = (c, s) of the rotation made at factor l (l = 1: from column hj of A_1), then its pair (scratch).
+PSD_D void psd_ghess_scan_window(const psd_gparams& P, const psd_gstate& st, const psd_gwin& w, double* side, double* tab,
+                                 int qe, int K) {
+    const int p = st.p;
+    const int NT = PSD_NTHREADS;
+    const int r0 = (st.ifirstm > w.bs) ? st.ifirstm : w.bs;
+    const int c1 = (st.ilastm < w.be) ? st.ilastm : w.be;
+    const int tpf = (NT / p > 0) ? (NT / p) : 1;  // threads per factor in the update phases
+#ifndef PSD_HOSTSIM
+    // (per thread, once per window: its factor, its place among the factor's threads, the factor's signature)
+    const int myf = PSD_TID / tpf, myq = PSD_TID - myf * tpf;
+    const bool mysg = (myf >= 1 && myf < p) ? psd_gsig(P, myf + 1) : false;
+    // chain lanes: the signatures of their four links
+    bool lsg[4] = {true, true, true, true};
+    if (PSD_TID < 16) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int c = 4 * PSD_TID + q4;
+            if (c < p - 1) lsg[q4] = psd_gsig(P, p - c);
+        }
+    }
+#endif
+    for (int b = 0; b < K; ++b) {
+        const int q = qe - b, slot = b;
+#ifndef PSD_HOSTSIM
+        if (PSD_TID < 64) {
+            // ---- the rotation of A_1 (generalized.jl:1036-1044) and the chain of pairs
+            const int lane = PSD_TID;
+            double c1r, s1r, r1;
+            psd_givens(side[q - w.bs], side[q + 1 - w.bs], c1r, s1r, r1);
+            PSD_WAVE_SYNC();
+            if (lane == 0) {
+                side[q - w.bs] = r1;
+                side[q + 1 - w.bs] = 0.0;
+            }
+            double M0[4], M1[4], M2[4], zq0[4], zq1[4];
+            const bool chl = lane < 16;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int c = 4 * lane + q4, lf = p - c;
+                M0[q4] = 1.0; M1[q4] = 0.0; M2[q4] = 1.0;
+                if (chl && c < p - 1) {
+                    const double* u = w.b + (lf - 1) * w.bsz + (q - w.bs) * w.ld + (q - w.bs);
+                    const double u00 = u[0], u01 = u[w.ld], u11 = u[w.ld + 1];
+                    if (lsg[q4]) { M0[q4] = u00; M1[q4] = u01; M2[q4] = u11; }
+                    else { M0[q4] = u11; M1[q4] = -u01; M2[q4] = u00; }
+                }
+                zq0[q4] = zq1[q4] = 0.0;
+            }
+            const int nsteps = (p - 1 + 3) / 4;
+            double z0 = 0.0, z1 = 0.0;
+            for (int s = 0; s < nsteps; ++s) {
+                double w0 = psd_c3_shr(z0, c1r), w1 = psd_c3_shr(z1, s1r);
+                if (s <= lane) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const double n0 = __builtin_fma(M0[q4], w0, M1[q4] * w1);
+                        const double n1 = M2[q4] * w1;
+                        w0 = n0;
+                        w1 = n1;
+                        zq0[q4] = n0;
+                        zq1[q4] = n1;
+                    }
+                    const int e = psd_c3_expo(fmax(fabs(w0), fabs(w1)));
+                    z0 = psd_c3_ldexp(w0, -e);
+                    z1 = psd_c3_ldexp(w1, -e);
+                }
+            }
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int c = 4 * lane + q4, lf = p - c;
+                if (chl && c < p - 1) {
+                    tab[(lf - 1) * 4 + 2] = zq0[q4];
+                    tab[(lf - 1) * 4 + 3] = zq1[q4];
+                }
+            }
+            // The pair the reference sees at factor l is M_l applied to the ROTATION of factor l + 1, (c, s) = pair / r, and
+            // givensAlgorithm's r is negative when |f| > |g| and f < 0: the chain's vector is that pair up to the signs of
+            // the r's above it.  sigma_l = (the factor above with |z_0| > |z_1| nearest to l decides: sign of its z_0; none:
+            // +), so that the rotations come out with the reference's signs (two ballots instead of a serial product).
+            double zf = 0.0, zg = 0.0;
+            if (lane >= 1 && lane < p) {
+                zf = tab[lane * 4 + 2];
+                zg = tab[lane * 4 + 3];
+            }
+            const unsigned long long bigm = __ballot(lane >= 1 && lane < p && fabs(zf) > fabs(zg));
+            const unsigned long long negm = __ballot(zf < 0.0);
+            if (lane < p) {
+                double c = c1r, s = s1r;
+                if (lane >= 1) {
+                    const unsigned long long above = (lane < 63) ? (bigm & ~((2ull << lane) - 1ull)) : 0ull;
+                    double sg = 1.0;
+                    if (above != 0ull) {
+                        const int bpos = __ffsll((long long)above) - 1;
+                        if ((negm >> bpos) & 1ull) sg = -1.0;
+                    }
+                    double r;
+                    psd_givens(sg * zf, sg * zg, c, s, r);
+                }
+                tab[lane * 4 + 0] = c;
+                tab[lane * 4 + 1] = s;
+                if (slot < PSD_GTR_CAP) {
+                    psd_gtr tr;
+                    tr.pos = q;
+                    tr.pad = 0;
+                    tr.c = c;
+                    tr.s = s;
+                    P.tr[(size_t)lane * PSD_GTR_CAP + slot] = tr;
+                }
+            }
+        }
+#else
+        {
+            double c1r, s1r, r1;
+            psd_givens(side[q - w.bs], side[q + 1 - w.bs], c1r, s1r, r1);
+            side[q - w.bs] = r1;
+            side[q + 1 - w.bs] = 0.0;
+            double z0 = c1r, z1 = s1r, sigma = 1.0;  // (sigma: see the device form)
+            int since = 0;
+            tab[0] = c1r;
+            tab[1] = s1r;
+            for (int lf = p; lf >= 2; --lf) {
+                const double u00 = w.at(lf, q, q), u01 = w.at(lf, q, q + 1), u11 = w.at(lf, q + 1, q + 1);
+                const bool sg = psd_gsig(P, lf);
+                const double m0 = sg ? u00 : u11, m1 = sg ? u01 : -u01, m2 = sg ? u11 : u00;
+                const double n0 = m0 * z0 + m1 * z1, n1 = m2 * z1;
+                double c, s, r;
+                psd_givens(sigma * n0, sigma * n1, c, s, r);
+                if (fabs(n0) > fabs(n1)) sigma = (n0 < 0.0) ? -1.0 : 1.0;
+                tab[(lf - 1) * 4 + 0] = c;
+                tab[(lf - 1) * 4 + 1] = s;
+                z0 = n0;
+                z1 = n1;
+                if (++since == 4) {
+                    since = 0;
+                    const int e = psd_c3_expo(fmax(fabs(z0), fabs(z1)));
+                    z0 = psd_c3_ldexp(z0, -e);
+                    z1 = psd_c3_ldexp(z1, -e);
+                }
+            }
+            for (int l = 1; l <= p; ++l) {
+                if (slot < PSD_GTR_CAP) {
+                    psd_gtr tr;
+                    tr.pos = q;
+                    tr.pad = 0;
+                    tr.c = tab[(l - 1) * 4 + 0];
+                    tr.s = tab[(l - 1) * 4 + 1];
+                    P.tr[(size_t)(l - 1) * PSD_GTR_CAP + slot] = tr;
+                }
+            }
+        }
+#endif
+        PSD_SYNC();
+        // ---- the two update phases: thread (f, qq) is the qq-th of the tpf threads of factor f + 1
+        for (int sub = 0; sub < 2; ++sub) {
+            PSD_PAR_FOR(t, NT) {
+#ifndef PSD_HOSTSIM
+                const int f = myf, qq = myq;
+                (void)t;
+#else
+                const int f = t / tpf, qq = t - f * tpf;
+#endif
+                if (f < p) {
+                    const int l = f + 1;
+#ifndef PSD_HOSTSIM
+                    const bool sg = mysg;
+#else
+                    const bool sg = (l == 1) ? false : psd_gsig(P, l);
+#endif
+                    // which rotation, from which side: sub 0 = the incoming one, sub 1 = the one made at this factor (A_1:
+                    // sub 0 its own on the rows, sub 1 the one of factor 2 — the end of the chain — on the columns)
+                    int src;
+                    bool rows;  // true: lmul on rows (q, q+1); false: rmul on columns (q, q+1)
+                    if (l == 1) {
+                        src = (sub == 0) ? 0 : ((p >= 2) ? 1 : 0);
+                        rows = sub == 0;
+                    } else {
+                        src = (sub == 0) ? ((l == p) ? 0 : l) : (l - 1);
+                        rows = (sub == 0) ? !sg : sg;
+                    }
+                    const double c = tab[src * 4 + 0], s = tab[src * 4 + 1];
+                    double* const blk = w.b + (l - 1) * w.bsz;
+                    if (rows) {
+                        // columns: A_1 takes its rotation on every window column (it is still full to the left of the
+                        // position), a factor from q on
+                        const int ca = (l == 1) ? w.bs : q;
+                        const int cb = (l == 1) ? ((st.ilastm < w.be) ? st.ilastm : w.be) : c1;
+                        const bool fix = l >= 2 && sub == 1;  // (S true: column q becomes (r, 0), rgeneralized.jl:985-987)
+                        for (int cc = ca + qq; cc <= cb; cc += tpf) {
+                            double* e = blk + (cc - w.bs) * w.ld + (q - w.bs);
+                            const double a1 = e[0], a2 = e[1];
+                            e[0] = c * a1 + s * a2;
+                            e[1] = (fix && cc == q) ? 0.0 : (c * a2 - s * a1);
+                        }
+                    } else {
+                        const int ra = (l == 1) ? ((st.ifirstm > w.bs) ? st.ifirstm : w.bs) : r0;
+                        const int rb = (l == 1) ? ((st.ilastm < w.be) ? st.ilastm : w.be) : (q + 1);
+                        const bool fix = l >= 2 && sub == 1;  // (S false: (q+1, q) becomes 0, (q+1, q+1) = r, :998-1000)
+                        for (int r = ra + qq; r <= rb; r += tpf) {
+                            double* e = blk + (q - w.bs) * w.ld + (r - w.bs);
+                            const double a1 = e[0], a2 = e[w.ld];
+                            e[0] = (fix && r == q + 1) ? 0.0 : (c * a1 + s * a2);
+                            e[w.ld] = c * a2 - s * a1;
+                        }
+                    }
+                }
+            }
+            PSD_SYNC();
+        }
+    }
 }
 
 // One window (positions qs..qe of column hj, processed downwards) of stage 2; blockDim = 64 G, L links per wave
 // (psd_ghess_waves / psd_ghess_links).  Same state, lists and descriptor as psd_gq_hess_window.
-PSD_KERNEL_B(64 * PSD_GHESS_MAXWAVES) psd_gq_hess_step(psd_gparams P, int L) {
+PSD_KERNEL_B(64 * PSD_GHESS_MAXWAVES) psd_gq_hess_step(psd_gparams P, int L, int scan) {
     PSD_LDS_DECL;
     psd_gstate st = *P.st;
     PSD_ONE { P.desc->active = 0; P.desc->defer_run = 0; }
@@ -981,9 +1211,15 @@ PSD_KERNEL_B(64 * PSD_GHESS_MAXWAVES) psd_gq_hess_step(psd_gparams P, int L) {
     PSD_PAR_FOR(m, p) { lcnt[m] = K; }
     PSD_PAR_FOR(t, w.be - w.bs + 1) { side[t] = A1(w.bs + t, hj); }
     PSD_WAVES_FOR(g, G) { psd_wv::psd_gwin_load(P, w, n, p, g, G); }
-    for (int b = 0; b < K + G; ++b) {
-        PSD_WAVES_FOR(g, G) { psd_wv::psd_ghess_beat(P, st, w, side, mail, g, G, b, K, L, qe); }
+    if (scan && p <= 64) {  // scan form: K rounds of (chain of pairs, two update phases)
+        double* tab = (double*)((char*)psd_lds + ((((size_t)((char*)(lcnt + p) - (char*)psd_lds)) + 15) & ~(size_t)15));
         PSD_SYNC();
+        psd_ghess_scan_window(P, st, w, side, tab, qe, K);
+    } else {
+        for (int b = 0; b < K + G; ++b) {
+            PSD_WAVES_FOR(g, G) { psd_wv::psd_ghess_beat(P, st, w, side, mail, g, G, b, K, L, qe); }
+            PSD_SYNC();
+        }
     }
     PSD_WAVES_FOR(g, G) { psd_wv::psd_gwin_store(P, w, n, p, g, G); }
     PSD_PAR_FOR(t, w.be - w.bs + 1) { A1(w.bs + t, hj) = side[t]; }
