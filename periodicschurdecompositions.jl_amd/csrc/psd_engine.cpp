@@ -272,6 +272,9 @@ struct psd_ctx {
                            // gate by 3.6 % (tests/gpu_fuzz_real.py; worst case 0.80 of the gate with 8) - not kept
     int train_long = 256;  // bulges per train of the multi-block scheduler when slots can be recycled (PSD_TRAIN_LONG; 0: one bulge per slot)
     int band_helper = 1;  // PSD_BAND_HELPER=0: a leader computes the product band of its decisions itself
+    int rdefer = 1;   // far columns of the rows roles on stream2 as well, in front of the far column roles (psd_rdefer_edge); needs cdefer.
+                      // 1: for n < 1536 (measured: iteration 358 -> 346 ms at n = 1024, p = 64; 1641 -> 1661 ms at n = 2048: the tick
+                      // is bound by the bytes of the bulk updates there, whatever runs beside what), 2: always, 0: never (PSD_RDEFER)
     int cdefer = 1;   // far rows of the column roles on stream2 beside the next tick's chases (psd_cdefer_edge): 0 off, 1 where the
                       // Schur vectors go there too (`overlap`), 2 always (PSD_CDEFER)
     int overlap = 3;  // Schur-vector updates on stream2 beside the next tick's chases: 0 off, 2 on, 3 = on for n >= 1024 (PSD_OVERLAP)
@@ -284,6 +287,8 @@ struct psd_ctx {
     hipStream_t stream4 = nullptr;  // every other chain launch of the Hessenberg reduction in pipe mode (hessenberg2_pipe)
     int hess_pipe = 1;              // PSD_H2_PIPE=0: chain launches back to back on one stream; 2: pipe form also beside other contexts
     hipEvent_t evE[2] = {nullptr, nullptr}, evF[2] = {nullptr, nullptr}, evG[2] = {nullptr, nullptr};
+    hipEvent_t evC[2] = {nullptr, nullptr};  // a tick's chase launch is done (rows-role deferral: psd_rdefer_edge)
+    hipStream_t stream5 = nullptr;           // the Schur-vector updates when stream2 carries both far parts of the H updates
 #endif
     int apply_worklist = 1;   // PSD_APPLY_WL=0: the grid-per-cursor bulk-apply kernels
     int apply_wl_grid = 2048; // workgroups of the work-list bulk apply (PSD_APPLY_WL_GRID)
@@ -1160,6 +1165,10 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     const bool ovl2 = mb && (c->overlap == 2 || (c->overlap == 3 && n >= 1024));
     const bool zdef = ovl2 && wantZ;  // Schur-vector updates on the second stream, beside the next chases
     const bool cdef = mb && c->cdefer && (c->cdefer == 2 || ovl2) && nprob == 1;  // far rows of the column roles likewise (psd_cdefer_edge)
+    bool rdef = cdef && (c->rdefer == 2 || (c->rdefer == 1 && n < 1536));  // and the far columns of the rows roles in front of them (psd_rdefer_edge)
+#ifndef PSD_HOSTSIM
+    if (zdef && !c->stream5) rdef = false;
+#endif
     bool far_pending = false;  // (the far column roles of the previous tick have been launched / are still to run)
     P.cdefer = cdef ? 1 : 0;
     // factor-sliced sweep windows (psd_set_slices; psd_slice3.h): G workgroups per slot, each with the window blocks of
@@ -1279,7 +1288,49 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 pend.emplace_back(ev0, ev1);
             }
 #endif
-            if (zdef || cdef) {
+            if (rdef) {
+                // Both far parts of the H updates on stream2 (psd_rdefer_edge, psd_cdefer_edge), in the order rows, columns:
+                // the far columns of this tick's rows roles start as soon as the chases are done (evC) and run beside the
+                // near parts on this stream, the far rows of the column roles follow when those near parts are done (evE);
+                // the NEXT tick's near parts wait for both (evG).  The Schur vectors go to a stream of their own (stream5)
+                // so that they do not hold up the far H updates the next tick waits for.  The serial simulation runs both
+                // far parts at the latest point the streams allow, behind the next tick's chases.
+                const int wl_grid = c->apply_wl_grid;
+#ifndef PSD_HOSTSIM
+                PSD_CHECK(hipEventRecord(c->evC[par], c->stream));
+#endif
+                if (far_pending) {
+#ifndef PSD_HOSTSIM
+                    PSD_CHECK(hipStreamWaitEvent(c->stream, c->evG[par ^ 1], 0));
+#else
+                    PSD_CHECK(launch_apply_wl(c, c->stream, Pprev, n, p, 0, NSL, zlo1, zhi1, 8, W, wl_grid));
+                    PSD_CHECK(launch_apply_wl(c, c->stream, Pprev, n, p, 1, NSL, zlo1, zhi1, 6, W, wl_grid));
+#endif
+                    far_pending = false;
+                }
+                PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 7, W, wl_grid));
+                if (wantZ && !zdef) PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 4, W, wl_grid));
+                PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 1, NSL, zlo1, zhi1, 5, W, wl_grid));
+#ifndef PSD_HOSTSIM
+                PSD_CHECK(hipEventRecord(c->evE[par], c->stream));
+                const int fgrid = c->far_grid > 0 ? c->far_grid : wl_grid;
+                PSD_CHECK(hipStreamWaitEvent(c->stream2, c->evC[par], 0));
+                PSD_CHECK(launch_apply_wl(c, c->stream2, Pq, n, p, 0, NSL, zlo1, zhi1, 8, W, fgrid));
+                PSD_CHECK(hipStreamWaitEvent(c->stream2, c->evE[par], 0));
+                PSD_CHECK(launch_apply_wl(c, c->stream2, Pq, n, p, 1, NSL, zlo1, zhi1, 6, W, fgrid));
+                PSD_CHECK(hipEventRecord(c->evG[par], c->stream2));
+                if (zdef) {
+                    PSD_CHECK(hipStreamWaitEvent(c->stream5, c->evC[par], 0));
+                    PSD_CHECK(launch_apply_wl(c, c->stream5, Pq, n, p, 0, NSL, zlo1, zhi1, 4, W, fgrid));
+                    PSD_CHECK(hipEventRecord(c->evF[par], c->stream5));
+                } else {
+                    PSD_CHECK(hipEventRecord(c->evF[par], c->stream2));
+                }
+#else
+                if (zdef) PSD_CHECK(launch_apply_wl(c, c->stream, Pq, n, p, 0, NSL, zlo1, zhi1, 4, W, wl_grid));
+#endif
+                far_pending = true;
+            } else if (zdef || cdef) {
                 // Schur-vector updates one stream over (psd_rq_apply_wl modes 3 / 4): the Z launch of this tick starts on
                 // stream2 when the tick's H updates are done (evE) — beside the NEXT tick's chases, which leave most of the
                 // chip idle — and its lists must not be rewritten before it is done (evF, awaited in front of the chase
@@ -1401,6 +1452,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     }
 #ifndef PSD_HOSTSIM
     if (zdef || cdef) PSD_CHECK(hipStreamSynchronize(c->stream2));
+    if (rdef && zdef) PSD_CHECK(hipStreamSynchronize(c->stream5));
 #else
     if (cdef && far_pending) {  // (the last tick's far column roles: its parity is the one the last launch used)
         psd_rparams Pl = P;
@@ -1408,6 +1460,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
         Pl.desc = P.desc + (size_t)parl * PSD_SLOTS;
         Pl.cnt = P.cnt + (size_t)parl * PSD_SLOTS * (p + 8);
         Pl.tr = P.tr + (size_t)parl * PSD_SLOTS * p * PSD_TR_CAP;
+        if (rdef) PSD_CHECK(launch_apply_wl(c, c->stream, Pl, n, p, 0, NSL, zlo1, zhi1, 8, W, c->apply_wl_grid));
         PSD_CHECK(launch_apply_wl(c, c->stream, Pl, n, p, 1, NSL, zlo1, zhi1, 6, W, c->apply_wl_grid));
         far_pending = false;
     }
@@ -1538,7 +1591,8 @@ int psd_create(psd_ctx** ctx, int device) {
             hipEventCreateWithFlags(&c->pev[q], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->evE[q], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->evF[q], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->evG[q], hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&c->evG[q], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->evC[q], hipEventDisableTiming) != hipSuccess) {
             psd_destroy(c);
             return PSD_INFO_RUNTIME + 5;
         }
@@ -1559,6 +1613,8 @@ int psd_create(psd_ctx** ctx, int device) {
             for (int q = keep; q < ncu; ++q) mask[q >> 5] |= (1u << (q & 31));
             rc = hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)((ncu + 31) / 32), mask);
             if (rc == hipSuccess) c->far_grid = (ncu - keep) * 8;
+            if (rc == hipSuccess && hipExtStreamCreateWithCUMask(&c->stream5, (uint32_t)((ncu + 31) / 32), mask) != hipSuccess)
+                c->stream5 = nullptr;
         }
         if (rc != hipSuccess) rc = hipStreamCreate(&c->stream2);
         if (rc != hipSuccess) {
@@ -1593,6 +1649,7 @@ int psd_create(psd_ctx** ctx, int device) {
     if (const char* e = psd_env("PSD_OVERLAP")) c->overlap = atoi(e);
 #endif
     if (const char* e = psd_env("PSD_CDEFER")) c->cdefer = atoi(e);
+    if (const char* e = psd_env("PSD_RDEFER")) c->rdefer = atoi(e);
     if (const char* e = psd_env("PSD_FORMQ_BLOCKED")) c->formq_blocked = atoi(e);
     if (const char* e = psd_env("PSD_BAND_HELPER")) c->band_helper = atoi(e);
     if (const char* e = psd_env_diag("PSD_TRAIN_LONG")) c->train_long = atoi(e);
@@ -1675,12 +1732,14 @@ int psd_destroy(psd_ctx* c) {
         if (c->evE[q]) (void)hipEventDestroy(c->evE[q]);
         if (c->evF[q]) (void)hipEventDestroy(c->evF[q]);
         if (c->evG[q]) (void)hipEventDestroy(c->evG[q]);
+        if (c->evC[q]) (void)hipEventDestroy(c->evC[q]);
         if (c->pin[q]) (void)hipHostFree(c->pin[q]);
     }
     for (auto& e : c->h2ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
+    if (c->stream5) (void)hipStreamDestroy(c->stream5);
     if (c->stream4) (void)hipStreamDestroy(c->stream4);
     if (c->stream) (void)hipStreamDestroy(c->stream);
 #endif

@@ -91,7 +91,7 @@ PSD_D void psd_tr_store_global(psd_tr* dst, const psd_tr& tr) {
 struct psd_apply_desc {
     int active;
     int prob;      // batch: problem the window belongs to
-    int cut;       // (unused since the far / near split of round 2 went: kept for the layout of the descriptor)
+    int cut;       // first far column of its rows role (columns lc0 .. cut - 1 are near: psd_rdefer_edge)
     int rcut;      // first near row of its column role (rows rr0 .. rcut - 1 are far)
     int split;     // 1: a window in the middle of a sweep: the far part of its bulk update (rows role beyond `cut`, column
                    // role above `rcut`, the whole Z role) may run while the next tick chases (psd_rq_apply_wl modes)
@@ -244,6 +244,13 @@ struct psd_rparams {
 // of far entries is psd_h1_opnorm (a fallback of the deflation tests when a diagonal pair of the product is exactly zero):
 // a decision that needs it waits one launch (psd_rstate::opn_tick).
 PSD_HD int psd_cdefer_edge(int Wmax) { return (Wmax + 2 > 16) ? (Wmax + 2) : 16; }
+// The same for the rows roles (psd_rparams::rdefer): the columns of a window's rows role that lie psd_rdefer_edge or more
+// to the right of the window.  Until that bulge's next window but one nothing reads them: a chase reads diagonal window
+// blocks (at most Wmax columns past the window's end), a decision the product band and the trailing block of the shifts
+// (at most 16 off the diagonal), and the near rows of any other window's column role (psd_cdefer_edge above that window)
+// can only meet these rows in columns less than Wmax + psd_cdefer_edge past this window.  The far rows of other windows'
+// column roles DO cross them, which is why both far parts run on one stream in the order rows, columns.
+PSD_HD int psd_rdefer_edge(int Wmax) { return (2 * Wmax + 8 > 48) ? (2 * Wmax + 8) : 48; }
 // layout of psd_rparams::plan (ints): share of leader slot s = free slots PSD_PLAN_FREE[first[s] .. first[s] + count[s])
 #define PSD_PLAN_FIRST 0
 #define PSD_PLAN_COUNT (PSD_SLOTS)
@@ -1439,7 +1446,12 @@ PSD_D void psd_desc_write(const psd_rparams& P, psd_rstate& st, const int* lcnt,
         d.active = over ? 0 : 1;
         d.prob = st.prob;
         d.split = (split && st.wantT) ? 1 : 0;
-        d.cut = lc1 + 1;
+        {   // first far column of the rows role (psd_rdefer_edge)
+            int cc = phi + 1 + psd_rdefer_edge(st.Wmax);
+            if (cc < lc0) cc = lc0;
+            if (cc > lc1 + 1) cc = lc1 + 1;
+            d.cut = cc;
+        }
         {   // first near row of the column role (psd_cdefer_edge): rows rr0 .. rcut - 1 may run one tick late
             int rc = plo - psd_cdefer_edge(st.Wmax);
             if (rc < rr0) rc = rr0;
@@ -3367,6 +3379,12 @@ PSD_HD void psd_wl_ranges(psd_apply_desc& d, int mode, int cut) {
         d.lc1 = d.lc0 - 1;
         d.zr1 = d.zr0 - 1;
         if (d.rr1 > d.rcut - 1) d.rr1 = d.rcut - 1;
+    } else if (mode == 7) {  // pass 0: the rows role on its near columns only (lc0 .. cut - 1)
+        d.zr1 = d.zr0 - 1;
+        if (d.lc1 > d.cut - 1) d.lc1 = d.cut - 1;
+    } else if (mode == 8) {  // pass 0: the far columns of the rows role only (cut .. lc1)
+        d.zr1 = d.zr0 - 1;
+        if (d.lc0 < d.cut) d.lc0 = d.cut;
     }
 }
 
@@ -3374,6 +3392,7 @@ PSD_HD void psd_wl_ranges(psd_apply_desc& d, int mode, int cut) {
 // mode 0: everything.
 // Modes 5 / 6 split the column roles by rows (psd_cdefer_edge): mode 5 = the H roles without the far rows of the column
 // roles, mode 6 = those far rows (pass 1), which run on the second stream beside the next tick's chases.
+// Modes 7 / 8 split the rows roles by columns (psd_rdefer_edge) in the same way: mode 7 = near columns, mode 8 = far columns.
 // Modes 3 / 4 split off the Schur vectors alone: mode 3 = the two H roles (both passes), mode 4 = the Z role (pass 0).
 // Nothing reads Z_m before the iteration ends and only owner m's lists touch it, so the Z updates of a tick only have to
 // stay in tick order among themselves: they run on a second stream beside the following ticks' chases.

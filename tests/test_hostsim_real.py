@@ -103,7 +103,9 @@ def test_column_roles_deferred(built, monkeypatch):
     second stream beside the next tick's chases; the serial simulation runs it at the latest point the streams allow,
     BEHIND the next tick's chases and decisions, which shows that none of those reads what it writes.  Every element
     still sees the same sequence of operations, so T, Z and the eigenvalues are those of the one-stream order to the
-    last bit, with and without the Schur vectors on the second stream as well (PSD_OVERLAP=2)."""
+    last bit, with and without the Schur vectors on the second stream as well (PSD_OVERLAP=2).  PSD_RDEFER=2 (the HIP build: for n < 1536)
+    does the same with the far columns of the rows roles (psd_rdefer_edge, modes 7 / 8): the serial simulation runs them
+    behind the next tick's chases too, in front of the far column roles."""
     import os
 
     import numpy as np
@@ -115,11 +117,12 @@ def test_column_roles_deferred(built, monkeypatch):
     monkeypatch.setenv("PSD_CDEFER", "0")
     ref = psd_amd.Engine(libpath=lib)
     engs = []
-    for ovl in ("0", "2"):
+    for ovl, rdef in (("0", "2"), ("2", "2"), ("2", "0")):
         monkeypatch.setenv("PSD_OVERLAP", ovl)
         monkeypatch.setenv("PSD_CDEFER", "2")
+        monkeypatch.setenv("PSD_RDEFER", rdef)
         engs.append(psd_amd.Engine(libpath=lib))
-    for (n, p, lr, win) in [(100, 1, "R", None), (150, 7, "L", None), (200, 2, "R", None), (180, 3, "R", "10")]:
+    for (n, p, lr, win) in [(100, 1, "R", None), (150, 7, "L", None), (200, 2, "R", None), (180, 3, "R", "10"), (260, 5, "R", None)]:
         A = pt.bench_factors(n, p, seed=7)
         pr = ref.pschur(A, lr)
         for eng in engs:
