@@ -303,6 +303,15 @@ struct psd_ctx {
     psd_tq* rotq = nullptr;
     unsigned char* rosel = nullptr;
     double* roxscr = nullptr;
+    // pipelined real ordschur! (psd_rord_plan / psd_rord_step_mb): scheduler state, slots, and PSD_RO_SLOTS sets of
+    // transforms, counts and descriptors
+    psd_romb* romb = nullptr;
+    psd_roslot* roslots = nullptr;
+    psd_tq* rotq_mb = nullptr;
+    int* rocnt_mb = nullptr;
+    psd_apply_desc* rodesc_mb = nullptr;
+    int ord_pipe = 1;  // PSD_ORD_PIPE=0: one selected block at a time (psd_rord_step)
+    size_t rostep_mb_lds_set = 0;
     int rocap_n = 0, rocap_p = 0;
     // complex path
     int zcap_n = 0, zcap_p = 0, zlogcap = 0;
@@ -466,7 +475,8 @@ struct psd_ctx {
     }
 
     void rorelease() {
-        void* ptrs[] = {rost, rotq, rosel, roxscr};
+        void* ptrs[] = {rost, rotq, rosel, roxscr, romb, roslots, rotq_mb, rocnt_mb, rodesc_mb};
+        romb = nullptr; roslots = nullptr; rotq_mb = nullptr; rocnt_mb = nullptr; rodesc_mb = nullptr;
         for (void* q : ptrs)
             if (q) psd_rt_free(q);
         rost = nullptr; rotq = nullptr; rosel = nullptr; roxscr = nullptr;
@@ -479,6 +489,11 @@ struct psd_ctx {
         PSD_CHECK(psd_rt_malloc((void**)&rotq, sizeof(psd_tq) * (size_t)p * PSD_RORD_CAP));
         PSD_CHECK(psd_rt_malloc((void**)&rosel, (size_t)n + 16));
         PSD_CHECK(psd_rt_malloc((void**)&roxscr, sizeof(double) * (size_t)n * p * 8 + 64));
+        PSD_CHECK(psd_rt_malloc((void**)&romb, sizeof(psd_romb)));
+        PSD_CHECK(psd_rt_malloc((void**)&roslots, sizeof(psd_roslot) * PSD_RO_SLOTS));
+        PSD_CHECK(psd_rt_malloc((void**)&rotq_mb, sizeof(psd_tq) * (size_t)PSD_RO_SLOTS * p * PSD_RORD_CAP));
+        PSD_CHECK(psd_rt_malloc((void**)&rocnt_mb, sizeof(int) * (size_t)PSD_RO_SLOTS * p));
+        PSD_CHECK(psd_rt_malloc((void**)&rodesc_mb, sizeof(psd_apply_desc) * PSD_RO_SLOTS));
         rocap_n = n;
         rocap_p = p;
         return 0;
@@ -1650,6 +1665,7 @@ int psd_create(psd_ctx** ctx, int device) {
 #endif
     if (const char* e = psd_env("PSD_CDEFER")) c->cdefer = atoi(e);
     if (const char* e = psd_env("PSD_RDEFER")) c->rdefer = atoi(e);
+    if (const char* e = psd_env("PSD_ORD_PIPE")) c->ord_pipe = atoi(e);
     if (const char* e = psd_env("PSD_FORMQ_BLOCKED")) c->formq_blocked = atoi(e);
     if (const char* e = psd_env("PSD_BAND_HELPER")) c->band_helper = atoi(e);
     if (const char* e = psd_env_diag("PSD_TRAIN_LONG")) c->train_long = atoi(e);
@@ -3056,9 +3072,17 @@ int choose_window_rord(int p) {
 int rordschur_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t* select, int wantZ, double* wr,
                   double* wi, psd_stats* stats, int* info, const uint8_t* Sint = nullptr, double* alpha = nullptr,
                   double* beta = nullptr, int32_t* ascale = nullptr) {
-    const int W = choose_window_rord(p);
+    int W = choose_window_rord(p);
     if (W == 0) return *info = PSD_INFO_NOTIMPL;
     if ((*info = c->roreserve(n, p)) != 0) return *info;
+    // Pipelined driver (psd_roslot): the selected blocks travel one window apart.  The tick lasts as long as its longest
+    // window, so with many blocks to move shorter windows (more blocks under way) are the faster schedule.
+    const bool pipe = c->ord_pipe != 0;
+    if (pipe) {
+        int nsel = 0;
+        for (int q = 0; q < n; ++q) nsel += select[q] ? 1 : 0;
+        if (nsel >= 8 && n >= 128 && W > 16) W = 16;
+    }
     if (Sint) {
         if ((*info = c->greserve(n, p, 16)) != 0) return *info;
         std::vector<unsigned char> hS(p, 1);
@@ -3068,6 +3092,8 @@ int rordschur_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_
     }
     PSD_CHECK(psd_rt_h2d(c->rosel, select, (size_t)n, c->stream));
     psd_roparams P;
+    P.mb = nullptr;
+    P.slots = nullptr;
     P.H = dH;
     P.Z = wantZ ? dZ : nullptr;
     P.st = c->rost;
@@ -3090,7 +3116,6 @@ int rordschur_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_
         c->rostep_lds_set = lds_step;
     }
 #endif
-    PSD_LAUNCH(psd_rord_init, psd_dim3(1), 64, 0, c->stream, P, n, p, wantZ, W);
     const size_t lds_apply = sizeof(psd_tq) * PSD_RORD_CAP + (size_t)32 * (PSD_APPLY_NT + 1) * 8;
     const int tiles = (n + PSD_APPLY_NT - 1) / PSD_APPLY_NT;
     psd_rostate hst;
@@ -3099,6 +3124,47 @@ int rordschur_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_
     const long long cap = 2LL * n * ((long long)n / (W > 4 ? W - 4 : 1) + 2) + 1024;
     Timer t;
     t.start(c->stream);
+    if (pipe) {
+        P.mb = c->romb;
+        P.slots = c->roslots;
+        P.tq = c->rotq_mb;
+        P.cnt = c->rocnt_mb;
+        P.desc = c->rodesc_mb;
+#ifndef PSD_HOSTSIM
+        if (lds_step > c->rostep_mb_lds_set) {
+            PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_rord_step_mb),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
+            c->rostep_mb_lds_set = lds_step;
+        }
+#endif
+        PSD_LAUNCH(psd_rord_init_mb, psd_dim3(1), 64, 0, c->stream, P, n, p, wantZ, W);
+        psd_romb hg;
+        memset(&hg, 0, sizeof(hg));
+        for (;;) {
+            for (int b = 0; b < 16; ++b) {
+                PSD_LAUNCH(psd_rord_plan, psd_dim3(1), 64, 0, c->stream, P);
+                PSD_LAUNCH(psd_rord_step_mb, psd_dim3(PSD_RO_SLOTS), PSD_STEP_NT, lds_step, c->stream, P);
+                PSD_LAUNCH(psd_rord_apply_mb, psd_dim3(tiles, p, 3 * PSD_RO_SLOTS), PSD_APPLY_NT, lds_apply, c->stream, P, n, p, 0);
+                PSD_LAUNCH(psd_rord_apply_mb, psd_dim3(tiles, p, 3 * PSD_RO_SLOTS), PSD_APPLY_NT, lds_apply, c->stream, P, n, p, 1);
+                ++launched;
+            }
+            PSD_CHECK(psd_rt_d2h(&hg, c->romb, sizeof(hg), c->stream));
+            PSD_CHECK(psd_rt_sync(c->stream));
+            if (hg.phase == PSD_ROPH_DONE) break;
+            if (launched > cap) return *info = PSD_INFO_RUNTIME + 0xfffc;
+        }
+        std::vector<psd_roslot> hs(PSD_RO_SLOTS);
+        PSD_CHECK(psd_rt_d2h(hs.data(), c->roslots, sizeof(psd_roslot) * PSD_RO_SLOTS, c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+        hst.phase = PSD_ROPH_DONE;
+        hst.info = hg.info;
+        for (const psd_roslot& q : hs) {
+            hst.nswaps += q.nswaps;
+            hst.nwindows += q.nwindows;
+            for (int e = 0; e < 6; ++e) hst.cyc[e] += q.cyc[e];
+        }
+    } else {
+    PSD_LAUNCH(psd_rord_init, psd_dim3(1), 64, 0, c->stream, P, n, p, wantZ, W);
     for (;;) {
         for (int b = 0; b < 32; ++b) {
             PSD_LAUNCH(psd_rord_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
@@ -3109,6 +3175,7 @@ int rordschur_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_
         PSD_CHECK(psd_rt_sync(c->stream));
         if (hst.phase == PSD_ROPH_DONE) break;
         if (launched > cap) return *info = PSD_INFO_RUNTIME + 0xfffc;
+    }
     }
     if (hst.info == 0 && Sint) {
         PSD_LAUNCH(psd_grord_values, psd_dim3((n + 63) / 64), 64, 0, c->stream, P, n, p);

@@ -39,6 +39,32 @@ struct psd_rostate {
     long long cyc[6];
 };
 
+// Pipelined driver: several selected blocks travel upwards at once, one workgroup (slot) each, a window apart.
+// rordschur.jl:77-110 moves one selected block at a time to the top; the blocks it passes are the unselected ones, and the
+// block selected next starts below everything moved so far.  So block k + 1 may start while block k is still under way,
+// as long as its windows stay below block k: the swaps of the two touch disjoint diagonal windows, their bulk updates
+// meet only in off-diagonal blocks where a row operation of one meets a column operation of the other (two passes, as in
+// the multishift trains).  Every block makes exactly the swaps of the serial order, in the same order; the target of a
+// block is known once its predecessor has arrived, until then its windows end below the predecessor's last known bottom.
+#define PSD_RO_SLOTS 64
+struct psd_roslot {
+    int active, seq;  // seq: number of the block in the order of selection (blocks arrive in that order)
+    int here, nbsrc, splitsrc, pend1x1, jsrc0;  // _moveblock! state (as psd_rostate)
+    int jtarget, tknown;  // target row, valid once every earlier block has arrived
+    int lim;              // top row its window of the coming tick may reach (jtarget, or the row below the predecessor)
+    int landed, fail, info;
+    int nswaps, nwindows, pad;
+    long long cyc[6];
+};
+struct psd_romb {
+    int n, p, wantZ, W;
+    int phase, info;
+    int j, pairskip, jdest;  // driver scan (rordschur.jl:77-110)
+    int scandone, nstarted, nfinished, nactive;
+    int failseq, failinfo;   // lowest block number with a rejected swap: later blocks stop, earlier ones finish
+    int nticks;
+};
+
 struct psd_roparams {
     double* H;
     double* Z;
@@ -56,6 +82,10 @@ struct psd_roparams {
     psd_z* alpha;
     double* beta;
     int* ascale;
+    // pipelined driver (psd_rord_plan / psd_rord_step_mb): scheduler state and the slots of the blocks in flight; desc, tq
+    // and cnt then hold PSD_RO_SLOTS sets, one per slot
+    struct psd_romb* mb;
+    struct psd_roslot* slots;
 };
 PSD_HD bool psd_rosig(const psd_roparams& P, int j) { return P.S == nullptr || P.S[j - 1] != 0; }
 
@@ -1063,6 +1093,109 @@ PSD_D int psd_rord_swap(const psd_roparams& P, const psd_rostate& st, const psd_
     return 0;
 }
 
+// One window of _moveblock! (rordschur.jl:181-247 restricted to the blocks that fit the window): the travelling block(s)
+// at st.here swap upwards until the window's top or st.jtarget; window store, transform counts and the descriptor of the
+// bulk update.  st.phase becomes PSD_ROPH_SCAN when the block has arrived, PSD_ROPH_DONE (with st.info) on a rejected swap.
+PSD_D void psd_rord_move(const psd_roparams& P, psd_rostate& st, double* ldsd, double* scr, double* wk, double* flagbuf,
+                         double* ws, int* lcnt, const unsigned char* SL, long long* cyc) {
+    const int n = st.n, p = st.p;
+    // window: bottom = end of the travelling block(s); top as high as the LDS window allows
+    const int width = st.splitsrc ? 2 : st.nbsrc;
+    psd_win w;
+    w.b = ldsd;
+    w.W = st.W;
+    w.ld = st.W + 1;
+    w.bsz = st.W * (st.W + 1);
+    w.be = st.here + width - 1;
+    w.bs = (w.be - st.W + 1 > st.jtarget) ? (w.be - st.W + 1) : st.jtarget;
+    PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
+    const long long tl0 = psd_clock();
+    psd_win_load(P_as_r(P), w, n, p);
+    cyc[1] += psd_clock() - tl0;
+    int fail = 0;
+    int here = st.here;
+    const int top0 = here;
+    // rordschur.jl:181-247 restricted to the blocks that fit the window
+    while (here > st.jtarget && !fail) {
+        if (st.pend1x1) {  // second 1x1 of a split pair follows its partner (rordschur.jl:207-215)
+            fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here, 1, 1, cyc, SL);
+            if (fail) break;
+            st.nswaps += 1;
+            st.pend1x1 = 0;
+            here -= 1;
+            continue;
+        }
+        int nbnext = 1;
+        if (here >= 3 && here - 2 >= w.bs) {
+            if (w.at(1, here - 1, here - 2) != 0) nbnext = 2;
+        } else if (here >= 3 && here - 1 != st.jtarget) {
+            break;  // the next block may start above the window (row jtarget itself is a block start)
+        }
+        if (here - nbnext < w.bs) break;
+        if (!st.splitsrc) {
+            fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - nbnext, nbnext, st.nbsrc, cyc, SL);
+            if (fail) break;
+            st.nswaps += 1;
+            here -= nbnext;
+            if (st.nbsrc == 2 && w.at(1, here + 1, here) == 0) st.splitsrc = 1;
+        } else {
+            fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - nbnext, nbnext, 1, cyc, SL);
+            if (fail) break;
+            st.nswaps += 1;
+            if (nbnext == 1) {
+                st.pend1x1 = 1;  // handled at the top of the loop (position `here`)
+            } else {
+                if (w.at(1, here, here - 1) == 0) nbnext = 1;
+                if (nbnext == 2) {
+                    fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - 1, 2, 1, cyc, SL);
+                    if (fail) break;
+                    st.nswaps += 1;
+                    here -= 2;
+                } else {
+                    fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here, 1, 1, cyc, SL);
+                    if (fail) break;
+                    st.nswaps += 1;
+                    fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - 1, 1, 1, cyc, SL);
+                    if (fail) break;
+                    st.nswaps += 1;
+                    here -= 2;
+                }
+            }
+        }
+    }
+    if (fail) {
+        st.info = (fail == 2) ? PSD_INFO_SINGULAR : (PSD_INFO_ILLCOND_BASE + st.jsrc0);
+        st.phase = PSD_ROPH_DONE;
+    } else {
+        const long long tl1 = psd_clock();
+        psd_win_store(P_as_r(P), w, n, p);
+        cyc[1] += psd_clock() - tl1;
+        PSD_SYNC();
+        PSD_PAR_FOR(m, p) { P.cnt[m] = lcnt[m]; }
+        PSD_ONE {
+            psd_apply_desc d;
+            d.active = 1;
+            d.plo = w.bs;
+            d.phi = w.be;
+            d.lc0 = w.be + 1;
+            d.lc1 = n;
+            d.rr0 = 1;
+            d.rr1 = w.bs - 1;
+            d.zr0 = 1;
+            d.zr1 = st.wantZ ? n : 0;
+            *P.desc = d;
+        }
+        st.nwindows += 1;
+        st.here = here;
+        (void)top0;
+        if (here <= st.jtarget && !st.pend1x1) {
+            st.jdest = here;  // _moveblock! returns jdest = here
+            if (st.nbsrc == 2) st.jdest += 1;
+            st.phase = PSD_ROPH_SCAN;
+        }
+    }
+}
+
 PSD_KERNEL_B(PSD_STEP_NT) psd_rord_step(psd_roparams P) {
     PSD_LDS_DECL;
     psd_rostate st = *P.st;
@@ -1124,103 +1257,7 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_rord_step(psd_roparams P) {
             }
         }
     }
-    if (st.phase == PSD_ROPH_MOVE) {
-        // window: bottom = end of the travelling block(s); top as high as the LDS window allows
-        const int width = st.splitsrc ? 2 : st.nbsrc;
-        psd_win w;
-        w.b = ldsd;
-        w.W = st.W;
-        w.ld = st.W + 1;
-        w.bsz = st.W * (st.W + 1);
-        w.be = st.here + width - 1;
-        w.bs = (w.be - st.W + 1 > st.jtarget) ? (w.be - st.W + 1) : st.jtarget;
-        PSD_PAR_FOR(m, p) { lcnt[m] = 0; }
-        const long long tl0 = psd_clock();
-        psd_win_load(P_as_r(P), w, n, p);
-        cyc[1] += psd_clock() - tl0;
-        int fail = 0;
-        int here = st.here;
-        const int top0 = here;
-        // rordschur.jl:181-247 restricted to the blocks that fit the window
-        while (here > st.jtarget && !fail) {
-            if (st.pend1x1) {  // second 1x1 of a split pair follows its partner (rordschur.jl:207-215)
-                fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here, 1, 1, cyc, SL);
-                if (fail) break;
-                st.nswaps += 1;
-                st.pend1x1 = 0;
-                here -= 1;
-                continue;
-            }
-            int nbnext = 1;
-            if (here >= 3 && here - 2 >= w.bs) {
-                if (w.at(1, here - 1, here - 2) != 0) nbnext = 2;
-            } else if (here >= 3 && here - 1 != st.jtarget) {
-                break;  // the next block may start above the window (row jtarget itself is a block start)
-            }
-            if (here - nbnext < w.bs) break;
-            if (!st.splitsrc) {
-                fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - nbnext, nbnext, st.nbsrc, cyc, SL);
-                if (fail) break;
-                st.nswaps += 1;
-                here -= nbnext;
-                if (st.nbsrc == 2 && w.at(1, here + 1, here) == 0) st.splitsrc = 1;
-            } else {
-                fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - nbnext, nbnext, 1, cyc, SL);
-                if (fail) break;
-                st.nswaps += 1;
-                if (nbnext == 1) {
-                    st.pend1x1 = 1;  // handled at the top of the loop (position `here`)
-                } else {
-                    if (w.at(1, here, here - 1) == 0) nbnext = 1;
-                    if (nbnext == 2) {
-                        fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - 1, 2, 1, cyc, SL);
-                        if (fail) break;
-                        st.nswaps += 1;
-                        here -= 2;
-                    } else {
-                        fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here, 1, 1, cyc, SL);
-                        if (fail) break;
-                        st.nswaps += 1;
-                        fail = psd_rord_swap(P, st, w, scr, wk, ws, flagbuf, lcnt, here - 1, 1, 1, cyc, SL);
-                        if (fail) break;
-                        st.nswaps += 1;
-                        here -= 2;
-                    }
-                }
-            }
-        }
-        if (fail) {
-            st.info = (fail == 2) ? PSD_INFO_SINGULAR : (PSD_INFO_ILLCOND_BASE + st.jsrc0);
-            st.phase = PSD_ROPH_DONE;
-        } else {
-            const long long tl1 = psd_clock();
-            psd_win_store(P_as_r(P), w, n, p);
-            cyc[1] += psd_clock() - tl1;
-            PSD_SYNC();
-            PSD_PAR_FOR(m, p) { P.cnt[m] = lcnt[m]; }
-            PSD_ONE {
-                psd_apply_desc d;
-                d.active = 1;
-                d.plo = w.bs;
-                d.phi = w.be;
-                d.lc0 = w.be + 1;
-                d.lc1 = n;
-                d.rr0 = 1;
-                d.rr1 = w.bs - 1;
-                d.zr0 = 1;
-                d.zr1 = st.wantZ ? n : 0;
-                *P.desc = d;
-            }
-            st.nwindows += 1;
-            st.here = here;
-            (void)top0;
-            if (here <= st.jtarget && !st.pend1x1) {
-                st.jdest = here;  // _moveblock! returns jdest = here
-                if (st.nbsrc == 2) st.jdest += 1;
-                st.phase = PSD_ROPH_SCAN;
-            }
-        }
-    }
+    if (st.phase == PSD_ROPH_MOVE) psd_rord_move(P, st, ldsd, scr, wk, flagbuf, ws, lcnt, SL, cyc);
     cyc[0] = psd_clock() - tk0;
     cyc[5] = psd_wallclock() - tw0;
     for (int q = 0; q < 6; ++q) st.cyc[q] += cyc[q];
@@ -1317,6 +1354,330 @@ PSD_KERNEL_B(PSD_APPLY_NT) psd_rord_apply(psd_roparams P, int n, int p) {
                     double s = 0.0;
                     for (int q = 0; q < mm; ++q) s += a[q] * tr.q[cc * 4 + q];
                     b[cc] = s;
+                }
+                for (int q = 0; q < mm; ++q) tile[(c + q) * T + r] = b[q];
+            }
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(t, S * T) {
+            const int r = t & (T - 1), c = t / T;
+            if (r >= nr) continue;
+            M(r0 + r, d.plo + c) = tile[c * T + r];
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// pipelined driver (see psd_roslot)
+
+PSD_D int psd_ro_find(const psd_roslot* S, int seq) {
+    for (int q = 0; q < PSD_RO_SLOTS; ++q)
+        if (S[q].active && S[q].seq == seq) return q;
+    return -1;
+}
+
+// One lane plans the coming tick from the state the previous tick left: arrivals in order, the head block's target, the
+// window limits of the followers, at most one new block, termination.  Nothing here races with the step launch: it runs
+// between two of them on the same stream.
+PSD_KERNEL psd_rord_plan(psd_roparams P) {
+    PSD_ONE {
+        psd_romb G = *P.mb;
+        psd_roslot* S = P.slots;
+        if (G.phase != PSD_ROPH_DONE) {
+            const int n = G.n;
+            const psd_mat<double> A1 = psd_mat<double>{P.H, n};
+            for (int q = 0; q < PSD_RO_SLOTS; ++q)
+                if (S[q].active && S[q].fail && S[q].seq < G.failseq) {
+                    G.failseq = S[q].seq;
+                    G.failinfo = S[q].info;
+                }
+            for (;;) {  // arrivals, in the order of selection (_moveblock! returns jdest = here, rordschur.jl:247)
+                const int q = psd_ro_find(S, G.nfinished);
+                if (q < 0 || !S[q].landed || S[q].fail) break;
+                G.jdest = S[q].here + ((S[q].nbsrc == 2) ? 1 : 0);
+                S[q].active = 0;
+                G.nfinished += 1;
+                G.nactive -= 1;
+            }
+            {   // the head block learns its target (rordschur.jl:100-104, 149-160)
+                const int q = psd_ro_find(S, G.nfinished);
+                if (q >= 0 && !S[q].tknown) {
+                    G.jdest += 1;
+                    int jd = G.jdest;
+                    if (jd > 1 && A1(jd, jd - 1) != 0) jd -= 1;
+                    S[q].jtarget = jd;
+                    S[q].tknown = 1;
+                }
+            }
+            for (int q = 0; q < PSD_RO_SLOTS; ++q) {
+                if (!S[q].active) continue;
+                if (S[q].tknown) {
+                    S[q].lim = S[q].jtarget;
+                } else {
+                    const int r = psd_ro_find(S, S[q].seq - 1);  // (in flight: blocks arrive in order)
+                    S[q].lim = (r >= 0) ? (S[r].here + (S[r].splitsrc ? 2 : S[r].nbsrc)) : S[q].here;
+                }
+            }
+            if (G.failseq == 0x7fffffff && !G.scandone) {
+                int f = -1;
+                for (int q = 0; q < PSD_RO_SLOTS && f < 0; ++q)
+                    if (!S[q].active) f = q;
+                while (f >= 0) {  // driver scan: rordschur.jl:77-110
+                    const int j = G.j + 1;
+                    if (j > n) {
+                        G.scandone = 1;
+                        break;
+                    }
+                    if (G.pairskip) {
+                        G.pairskip = 0;
+                        G.j = j;
+                        continue;
+                    }
+                    bool swap = P.select[j - 1] != 0;
+                    bool pair = false;
+                    if (j < n && A1(j + 1, j) != 0) {
+                        pair = true;
+                        swap = swap || (P.select[j] != 0);
+                    }
+                    if (!swap) {
+                        G.j = j;
+                        G.pairskip = pair ? 1 : 0;
+                        continue;
+                    }
+                    psd_roslot ns;
+                    ns.active = 1;
+                    ns.here = j;
+                    ns.nbsrc = pair ? 2 : 1;
+                    ns.splitsrc = 0;
+                    ns.pend1x1 = 0;
+                    ns.jsrc0 = j;
+                    ns.landed = ns.fail = ns.info = 0;
+                    ns.nswaps = S[f].nswaps;  // (the counters of a slot run on over the blocks it carries)
+                    ns.nwindows = S[f].nwindows;
+                    ns.pad = 0;
+                    for (int q = 0; q < 6; ++q) ns.cyc[q] = S[f].cyc[q];
+                    if (G.nactive == 0) {  // nothing under way: the serial driver's step
+                        G.j = j;
+                        G.pairskip = pair ? 1 : 0;
+                        G.jdest += 1;
+                        if (j != G.jdest) {
+                            int jd = G.jdest;
+                            if (jd > 1 && A1(jd, jd - 1) != 0) jd -= 1;
+                            if (jd < j) {
+                                ns.seq = G.nstarted;
+                                ns.jtarget = jd;
+                                ns.tknown = 1;
+                                ns.lim = jd;
+                                S[f] = ns;
+                                G.nstarted += 1;
+                                G.nactive += 1;
+                                break;
+                            }
+                            G.jdest = jd;
+                            if (pair) G.jdest += 1;
+                        } else if (pair) {
+                            G.jdest += 1;
+                        }
+                        continue;
+                    }
+                    // blocks under way: this one starts behind the last of them once two rows lie between
+                    const int r = psd_ro_find(S, G.nstarted - 1);
+                    const int tb = (r >= 0) ? (S[r].here + (S[r].splitsrc ? 2 : S[r].nbsrc) - 1) : n;
+                    if (j - 2 < tb + 1) break;  // (row j is looked at again in the next tick)
+                    G.j = j;
+                    G.pairskip = pair ? 1 : 0;
+                    ns.seq = G.nstarted;
+                    ns.jtarget = 0;
+                    ns.tknown = 0;
+                    ns.lim = tb + 1;
+                    S[f] = ns;
+                    G.nstarted += 1;
+                    G.nactive += 1;
+                    break;
+                }
+            }
+            if (G.failseq != 0x7fffffff) {
+                bool any = false;
+                for (int q = 0; q < PSD_RO_SLOTS; ++q)
+                    if (S[q].active && !S[q].fail && !S[q].landed && S[q].seq < G.failseq) any = true;
+                if (!any) {
+                    G.info = G.failinfo;
+                    G.phase = PSD_ROPH_DONE;
+                }
+            } else if (G.scandone && G.nactive == 0) {
+                G.phase = PSD_ROPH_DONE;
+            }
+            G.nticks += 1;
+        }
+        *P.mb = G;
+    }
+}
+
+// grid = PSD_RO_SLOTS workgroups: the block of slot s moves up by one window
+PSD_KERNEL_B(PSD_STEP_NT) psd_rord_step_mb(psd_roparams P) {
+    PSD_LDS_DECL;
+    const int s = PSD_BLOCK_X;
+    const psd_romb G = *P.mb;
+    const int n = G.n, p = G.p;
+    psd_roparams Q = P;
+    Q.tq = P.tq + (size_t)s * p * PSD_RORD_CAP;
+    Q.cnt = P.cnt + (size_t)s * p;
+    Q.desc = P.desc + s;
+    PSD_ONE { Q.desc->active = 0; }
+    if (G.phase == PSD_ROPH_DONE) return;
+    psd_roslot sl = P.slots[s];
+    if (!sl.active || sl.fail || sl.landed || sl.seq >= G.failseq) return;
+    const int jt = sl.tknown ? sl.jtarget : sl.lim;
+    if (sl.here <= jt && !sl.pend1x1) {
+        if (sl.tknown) {
+            PSD_SYNC();
+            PSD_ONE { P.slots[s].landed = 1; }
+        }
+        return;
+    }
+    long long cyc[6] = {0, 0, 0, 0, 0, 0};
+    const long long tk0 = psd_clock(), tw0 = psd_wallclock();
+    double* ldsd = (double*)psd_lds;
+    const size_t winb = (size_t)p * G.W * (G.W + 1);
+    double* scr = ldsd + winb;
+    double* wk = scr + (size_t)p * PSD_RORD_SCR;
+    double* flagbuf = wk + (size_t)p * 52;
+    double* ws = flagbuf + 4;
+    int* lcnt = (int*)(ws + 192 + psd_rord_tree_doubles(p));
+    unsigned char* SL = (unsigned char*)(lcnt + p);
+    PSD_PAR_FOR(t, p) { SL[t] = psd_rosig(P, psd_ord_sigma(p, t + 1)) ? 1 : 0; }
+    PSD_SYNC();
+    psd_rostate st;
+    st.n = n; st.p = p; st.wantZ = G.wantZ; st.W = G.W;
+    st.phase = PSD_ROPH_MOVE; st.info = 0;
+    st.j = 0; st.jdest = 0; st.pairskip = 0;
+    st.here = sl.here; st.nbsrc = sl.nbsrc; st.splitsrc = sl.splitsrc; st.jtarget = jt; st.jsrc0 = sl.jsrc0;
+    st.pend1x1 = sl.pend1x1;
+    st.nswaps = sl.nswaps; st.nwindows = sl.nwindows;
+    psd_rord_move(Q, st, ldsd, scr, wk, flagbuf, ws, lcnt, SL, cyc);
+    cyc[0] = psd_clock() - tk0;
+    cyc[5] = psd_wallclock() - tw0;
+    PSD_SYNC();
+    PSD_ONE {
+        sl.here = st.here; sl.splitsrc = st.splitsrc; sl.pend1x1 = st.pend1x1;
+        sl.nswaps = st.nswaps; sl.nwindows = st.nwindows;
+        for (int q = 0; q < 6; ++q) sl.cyc[q] += cyc[q];
+        if (st.phase == PSD_ROPH_DONE) {
+            sl.fail = 1;
+            sl.info = st.info;
+        } else if (st.phase == PSD_ROPH_SCAN && sl.tknown) {
+            sl.landed = 1;
+        }
+        P.slots[s] = sl;
+    }
+}
+
+PSD_KERNEL psd_rord_init_mb(psd_roparams P, int n, int p, int wantZ, int W) {
+    PSD_PAR_FOR(q, PSD_RO_SLOTS) {
+        psd_roslot z;
+        z.active = 0; z.seq = -1;
+        z.here = z.nbsrc = z.splitsrc = z.pend1x1 = z.jsrc0 = 0;
+        z.jtarget = z.tknown = z.lim = 0;
+        z.landed = z.fail = z.info = 0;
+        z.nswaps = z.nwindows = z.pad = 0;
+        for (int e = 0; e < 6; ++e) z.cyc[e] = 0;
+        P.slots[q] = z;
+        P.desc[q].active = 0;
+    }
+    PSD_ONE {
+        psd_romb G;
+        G.n = n; G.p = p; G.wantZ = wantZ; G.W = W;
+        G.phase = PSD_ROPH_SCAN; G.info = 0;
+        G.j = 0; G.pairskip = 0; G.jdest = 0;
+        G.scandone = 0; G.nstarted = 0; G.nfinished = 0; G.nactive = 0;
+        G.failseq = 0x7fffffff; G.failinfo = 0;
+        G.nticks = 0;
+        *P.mb = G;
+    }
+}
+
+// Bulk application for the pipelined driver: grid = (tiles, p owners, 3 roles x PSD_RO_SLOTS).  pass 0: the operations
+// from the left (rows of a factor) and the Schur vectors, pass 1: the operations from the right on the factors — a row
+// operation of one window and a column operation of another meet in off-diagonal blocks, so the two kinds are two launches.
+PSD_KERNEL_B(PSD_APPLY_NT) psd_rord_apply_mb(psd_roparams P, int n, int p, int pass) {
+    PSD_LDS_DECL;
+    const int slot = PSD_BLOCK_Z / 3;
+    const int role = PSD_BLOCK_Z - 3 * slot;
+    const psd_apply_desc d = P.desc[slot];
+    if (!d.active) return;
+    const int m = PSD_BLOCK_Y + 1;
+    const int mm1 = (m == 1) ? p : (m - 1);
+    const int fac = (role == 0) ? m : ((role == 1) ? mm1 : m);
+    const bool left = (role == 0) ? psd_rosig(P, m) : ((role == 1) ? !psd_rosig(P, mm1) : false);
+    const bool inpass0 = left || role == 2;
+    if ((pass == 0) != inpass0) return;
+    const int* pcnt = P.cnt + (size_t)slot * p;
+    const int cnt = pcnt[m - 1] < PSD_RORD_CAP ? pcnt[m - 1] : PSD_RORD_CAP;
+    if (cnt <= 0) return;
+    const psd_tq* gtq = P.tq + ((size_t)slot * p + (m - 1)) * PSD_RORD_CAP;
+    const int T = PSD_APPLY_NT;
+    const int S = d.phi - d.plo + 1;
+    psd_tq* ltr = (psd_tq*)psd_lds;
+    double* tile = (double*)(psd_lds + sizeof(psd_tq) * PSD_RORD_CAP);
+    if (left) {
+        const int c0 = d.lc0 + PSD_BLOCK_X * T;
+        if (c0 > d.lc1) return;
+        PSD_PAR_FOR(e, cnt) { ltr[e] = gtq[e]; }
+        const int nc = (d.lc1 - c0 + 1 < T) ? (d.lc1 - c0 + 1) : T;
+        const psd_mat<double> M = psd_mat<double>{P.H + (size_t)(fac - 1) * n * n, n};
+        const int ldt = T + 1;
+        PSD_PAR_FOR(t, 32 * nc) {
+            const int r = t & 31, c = t >> 5;
+            if (r >= S) continue;
+            tile[r * ldt + c] = M(d.plo + r, c0 + c);
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(c, nc) {
+            for (int e = 0; e < cnt; ++e) {
+                const psd_tq& tr = ltr[e];
+                const int r = tr.pos - d.plo, mm = tr.m;
+                double a[4], b[4];
+                for (int q = 0; q < mm; ++q) a[q] = tile[(r + q) * ldt + c];
+                for (int rr = 0; rr < mm; ++rr) {
+                    double sacc = 0.0;
+                    for (int q = 0; q < mm; ++q) sacc += tr.q[rr * 4 + q] * a[q];
+                    b[rr] = sacc;
+                }
+                for (int q = 0; q < mm; ++q) tile[(r + q) * ldt + c] = b[q];
+            }
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(t, 32 * nc) {
+            const int r = t & 31, c = t >> 5;
+            if (r >= S) continue;
+            M(d.plo + r, c0 + c) = tile[r * ldt + c];
+        }
+    } else {
+        const int lo = (role == 2) ? d.zr0 : d.rr0;
+        const int hi = (role == 2) ? d.zr1 : d.rr1;
+        const int r0 = lo + PSD_BLOCK_X * T;
+        if (r0 > hi) return;
+        PSD_PAR_FOR(e, cnt) { ltr[e] = gtq[e]; }
+        const int nr = (hi - r0 + 1 < T) ? (hi - r0 + 1) : T;
+        double* base = (role == 2) ? P.Z : P.H;
+        const psd_mat<double> M = psd_mat<double>{base + (size_t)(fac - 1) * n * n, n};
+        PSD_PAR_FOR(t, S * T) {
+            const int r = t & (T - 1), c = t / T;
+            if (r >= nr) continue;
+            tile[c * T + r] = M(r0 + r, d.plo + c);
+        }
+        PSD_SYNC();
+        PSD_PAR_FOR(r, nr) {
+            for (int e = 0; e < cnt; ++e) {
+                const psd_tq& tr = ltr[e];
+                const int c = tr.pos - d.plo, mm = tr.m;
+                double a[4], b[4];
+                for (int q = 0; q < mm; ++q) a[q] = tile[(c + q) * T + r];
+                for (int cc = 0; cc < mm; ++cc) {
+                    double sacc = 0.0;
+                    for (int q = 0; q < mm; ++q) sacc += a[q] * tr.q[cc * 4 + q];
+                    b[cc] = sacc;
                 }
                 for (int q = 0; q < mm; ++q) tile[(c + q) * T + r] = b[q];
             }

@@ -502,6 +502,38 @@ def case_rordschur_windows(eng, sizes):
             assert max(np.abs(a - b).max() for a, b in zip(ps2.Ts, ps1.Ts)) < 1e-12 * max(1.0, sc)
 
 
+def case_rordschur_pipelined(make_engine, sizes):
+    """The pipelined driver (psd_rord_plan / psd_rord_step_mb: several selected blocks under way at once, a window apart)
+    against the serial one (PSD_ORD_PIPE=0: rordschur.jl:77-110 block by block) and the oracle: every block makes the
+    serial order's swaps, so the swap counts agree, the eigenvalues keep their order inside both groups, and the
+    invariants hold.  `make_engine(env)` builds an engine under the given environment."""
+    e_pipe = make_engine({"PSD_ORD_PIPE": "1"})
+    e_ser = make_engine({"PSD_ORD_PIPE": "0"})
+    for (n, p, lr, frac) in sizes:
+        A = pt.bench_factors(n, p, seed=300 + n + p)
+        ps0 = e_pipe.pschur(A, lr)
+        lam0 = ps0.values.copy()
+        thr = np.sort(np.abs(lam0))[int(n * frac)]
+        select = np.abs(lam0) <= thr
+        ps1 = e_pipe.ordschur_(_clone(ps0), select)
+        ps2 = e_ser.ordschur_(_clone(ps0), select)
+        assert ps1.stats.nsweeps == ps2.stats.nsweeps > 0, (n, p, ps1.stats.nsweeps, ps2.stats.nsweeps)
+        assert ps1.stats.nlaunch_step < ps2.stats.nlaunch_step or ps2.stats.nlaunch_step <= 32
+        ok, err = pt.checkpsd(ps1, A, thresh=100 * np.sqrt(max(n / 32, 1)))
+        assert ok, (n, p, lr, err)
+        m = int(select.sum())
+        sc = abs(lam0).max()
+        assert pt.match_eigs(lam0[select], ps1.values[:m]) < 1e-8 * sc
+        assert pt.match_eigs(lam0[~select], ps1.values[m:]) < 1e-8 * sc
+        assert pt.match_eigs(ps2.values, ps1.values) < 1e-9 * sc
+        assert np.allclose(ps1.values, ps2.values, rtol=1e-6, atol=1e-8 * sc)  # same order, block by block
+        for i in range(n - 1):
+            if ps1.values[i].imag == 0 or ps1.values[i].imag < 0:
+                assert ps1.T1[i + 1, i] == 0
+        po = pt.oracle_ordschur(pt.PSD(ps0.Ts, ps0.Z, lam0, ps0.orientation, ps0.schurindex), select)
+        assert po.info == 0 and ps1.stats.nsweeps == po.nswaps
+
+
 def case_rordschur_edge(eng):
     import psd_amd
 

@@ -153,6 +153,19 @@ def test_rordschur_edge(gpu_engine):
     ec.case_rordschur_edge(gpu_engine)
 
 
+def test_rordschur_pipelined(monkeypatch):
+    """pipelined ordschur! driver against the serial one and the oracle, through the C ABI (PSD_ORD_PIPE is a path
+    selector of the product library: both drivers give valid results)"""
+    import psd_amd
+
+    def make(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        return psd_amd.Engine()
+
+    ec.case_rordschur_pipelined(make, [(140, 2, "R", 0.5), (160, 5, "L", 0.25), (300, 8, "R", 0.3), (256, 40, "L", 0.5)])
+
+
 def test_rphessenberg(gpu_engine):
     ec.case_rphessenberg(gpu_engine)
 
