@@ -323,6 +323,11 @@ struct psd_ctx {
     psd_zapply_desc* zdesc = nullptr;
     psd_ztr *ztr = nullptr, *zdG = nullptr;
     psd_ostate* ost = nullptr;
+    // pipelined complex ordschur! drivers (psd_ord1_plan): slot states, slot bookkeeping, scheduler state
+    psd_ostate* ombst = nullptr;
+    psd_oslot* oslots = nullptr;
+    psd_omb* omb = nullptr;
+    size_t ostep_mb_lds_set = 0, zgostep_mb_lds_set = 0;
     unsigned char* osel = nullptr;
     size_t ostep_lds_set = 0;
     // real generalized path
@@ -500,8 +505,9 @@ struct psd_ctx {
     }
 
     void zrelease() {
-        void* ptrs[] = {zH, zZ, ztau, zvbuf, zalpha, zbeta, zascale, zcnt, zlog, zst, zdesc, ztr, zdG, ost, osel};
+        void* ptrs[] = {zH, zZ, ztau, zvbuf, zalpha, zbeta, zascale, zcnt, zlog, zst, zdesc, ztr, zdG, ost, osel, ombst, oslots, omb};
         ost = nullptr;
+        ombst = nullptr; oslots = nullptr; omb = nullptr;
         osel = nullptr;
         for (void* q : ptrs)
             if (q) psd_rt_free(q);
@@ -535,6 +541,9 @@ struct psd_ctx {
         PSD_ALLOC(ztr, psd_ztr, (size_t)p * PSD_ZTR_CAP);
         PSD_ALLOC(zdG, psd_ztr, n + 8);
         PSD_ALLOC(ost, psd_ostate, 1);
+        PSD_ALLOC(ombst, psd_ostate, PSD_O_SLOTS);
+        PSD_ALLOC(oslots, psd_oslot, PSD_O_SLOTS);
+        PSD_ALLOC(omb, psd_omb, 1);
         PSD_ALLOC(osel, unsigned char, n + 16);
 #undef PSD_ALLOC
         zcap_n = n;
@@ -2946,8 +2955,17 @@ int choose_window_ord(int p) {
 // device arrays in internal right order; select on host
 int zordschur_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t* select, int wantZ, double* alpha,
                   double* beta, int32_t* ascale, psd_stats* stats, int* info) {
-    const int W = choose_window_ord(p);
+    int W = choose_window_ord(p);
     if (W == 0) return *info = PSD_INFO_NOTIMPL;
+    // pipelined driver (psd_oslot): the selected eigenvalues travel a window apart; with many of them shorter windows
+    // (the tick lasts as long as its longest window) are the faster schedule
+    const bool pipe = c->ord_pipe != 0;
+    if (pipe) {
+        int nsel = 0;
+        for (int q = 0; q < n; ++q) nsel += select[q] ? 1 : 0;
+        if (nsel >= 8 && n >= 128 && W > 16) W = 16;
+        PSD_CHECK(c->ztreserve(p));
+    }
     PSD_CHECK(psd_rt_h2d(c->osel, select, (size_t)n, c->stream));
     psd_oparams O;
     O.z.H = dH;
@@ -2977,7 +2995,6 @@ int zordschur_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
         c->ostep_lds_set = lds_step;
     }
 #endif
-    PSD_LAUNCH(psd_zord_init, psd_dim3(1), 64, 0, c->stream, O, n, p, wantZ, W);
     const size_t lds_apply = PSD_ZTR_LDS_BYTES + (size_t)32 * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
     const int tiles = (n + PSD_ZAPPLY_NT - 1) / PSD_ZAPPLY_NT;
     psd_ostate hst;
@@ -2986,6 +3003,52 @@ int zordschur_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
     const long long cap = (long long)n * ((long long)n / (W > 1 ? W - 1 : 1) + 2) + 1024;
     Timer t;
     t.start(c->stream);
+    if (pipe) {
+        O.st = c->ombst;
+        O.z.desc = c->ztdesc;
+        O.z.cnt = c->ztcnt;
+        O.z.tr = c->zttr;
+#ifndef PSD_HOSTSIM
+        if (lds_step > c->ostep_mb_lds_set) {
+            PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_zord_step_mb),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
+            c->ostep_mb_lds_set = lds_step;
+        }
+        const int wl_grid = 2048;
+#else
+        const int wl_grid = 6;
+#endif
+        const size_t lds_wl = lds_apply + sizeof(int) * 2 * (PSD_TRAIN_MAX + 2);
+        PSD_CHECK(psd_rt_memset(c->ztdesc, 0, sizeof(psd_zapply_desc) * PSD_TRAIN_MAX, c->stream));
+        PSD_LAUNCH(psd_ord1_init_mb, psd_dim3(1), 64, 0, c->stream, c->ombst, c->oslots, c->omb, n, p, wantZ, W);
+        psd_omb hg;
+        memset(&hg, 0, sizeof(hg));
+        for (;;) {
+            for (int b = 0; b < 16; ++b) {
+                PSD_LAUNCH(psd_ord1_plan, psd_dim3(1), 64, 0, c->stream, c->ombst, c->oslots, c->omb, c->osel);
+                PSD_LAUNCH(psd_zord_step_mb, psd_dim3(PSD_O_SLOTS), PSD_STEP_NT, lds_step, c->stream, O, p, p + 8);
+                // rows of every window, then columns (a row operation of one window meets a column operation of another in
+                // off-diagonal blocks), then the Schur vectors: the work-list form of the trains
+                for (int pass : {2, 1, 3})
+                    PSD_LAUNCH(psd_zq_apply_wl, psd_dim3(wl_grid), PSD_ZAPPLY_NT, lds_wl, c->stream, O.z, n, p, p + 8, pass, PSD_O_SLOTS, (int)lds_apply);
+                ++launched;
+            }
+            PSD_CHECK(psd_rt_d2h(&hg, c->omb, sizeof(hg), c->stream));
+            PSD_CHECK(psd_rt_sync(c->stream));
+            if (hg.phase == PSD_OPH_DONE) break;
+            if (launched > cap) return *info = PSD_INFO_RUNTIME + 0xfffd;
+        }
+        std::vector<psd_ostate> hs(PSD_O_SLOTS);
+        PSD_CHECK(psd_rt_d2h(hs.data(), c->ombst, sizeof(psd_ostate) * PSD_O_SLOTS, c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+        hst.phase = PSD_OPH_DONE;
+        hst.info = hg.info;
+        for (const psd_ostate& q : hs) {
+            hst.nswaps += q.nswaps;
+            hst.nwindows += q.nwindows;
+        }
+    } else {
+    PSD_LAUNCH(psd_zord_init, psd_dim3(1), 64, 0, c->stream, O, n, p, wantZ, W);
     for (;;) {
         for (int b = 0; b < 32; ++b) {
             PSD_LAUNCH(psd_zord_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, O);
@@ -2996,6 +3059,7 @@ int zordschur_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
         PSD_CHECK(psd_rt_sync(c->stream));
         if (hst.phase == PSD_OPH_DONE) break;
         if (launched > cap) return *info = PSD_INFO_RUNTIME + 0xfffd;
+    }
     }
     if (hst.info == 0) {
         PSD_LAUNCH(psd_zord_values, psd_dim3((n + 255) / 256), 256, 0, c->stream, O.z, n, p);
@@ -3672,6 +3736,13 @@ int zgordschur_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t
             }
     }
     if (W == 0) return *info = PSD_INFO_NOTIMPL;
+    const bool pipe = c->ord_pipe != 0;  // pipelined driver (psd_oslot), as zordschur_dev
+    if (pipe) {
+        int nsel = 0;
+        for (int q = 0; q < n; ++q) nsel += select[q] ? 1 : 0;
+        if (nsel >= 8 && n >= 128 && W > 16) W = 16;
+        PSD_CHECK(c->zgtreserve(p));
+    }
     PSD_CHECK(psd_rt_h2d(c->osel, select, (size_t)n, c->stream));
     std::vector<unsigned char> hS(p, 1);
     for (int l = 0; l < p; ++l) hS[l] = S[l] ? 1 : 0;
@@ -3702,7 +3773,6 @@ int zgordschur_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t
         c->zgostep_lds_set = lds_step;
     }
 #endif
-    PSD_LAUNCH(psd_zgord_init, psd_dim3(1), 64, 0, c->stream, O, n, p, wantZ, W);
     const size_t lds_apply = sizeof(psd_ztr) * PSD_GTR_CAP + (size_t)32 * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
     const int tiles = (n + PSD_ZAPPLY_NT - 1) / PSD_ZAPPLY_NT;
     psd_ostate hst;
@@ -3711,6 +3781,46 @@ int zgordschur_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t
     const long long cap = (long long)n * ((long long)n / (W > 1 ? W - 1 : 1) + 2) + 1024;
     Timer t;
     t.start(c->stream);
+    if (pipe) {
+        O.st = c->ombst;
+        O.z.desc = c->zgtdesc;
+        O.z.cnt = c->zgtcnt;
+        O.z.tr = c->zgttr;
+#ifndef PSD_HOSTSIM
+        if (lds_step > c->zgostep_mb_lds_set) {
+            PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_zgord_step_mb),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
+            c->zgostep_mb_lds_set = lds_step;
+        }
+#endif
+        PSD_CHECK(psd_rt_memset(c->zgtdesc, 0, sizeof(psd_gapply_desc) * PSD_TRAIN_MAX, c->stream));
+        PSD_LAUNCH(psd_ord1_init_mb, psd_dim3(1), 64, 0, c->stream, c->ombst, c->oslots, c->omb, n, p, wantZ, W);
+        psd_omb hg;
+        memset(&hg, 0, sizeof(hg));
+        for (;;) {
+            for (int b = 0; b < 16; ++b) {
+                PSD_LAUNCH(psd_ord1_plan, psd_dim3(1), 64, 0, c->stream, c->ombst, c->oslots, c->omb, c->osel);
+                PSD_LAUNCH(psd_zgord_step_mb, psd_dim3(PSD_O_SLOTS), PSD_STEP_NT, lds_step, c->stream, O, p, p + 8);
+                PSD_LAUNCH(psd_zgq_apply_train, psd_dim3(tiles, p, 2 * PSD_O_SLOTS), PSD_ZAPPLY_NT, lds_apply, c->stream, O.z, n, p, p + 8, 0);
+                PSD_LAUNCH(psd_zgq_apply_train, psd_dim3(tiles, p, PSD_O_SLOTS), PSD_ZAPPLY_NT, lds_apply, c->stream, O.z, n, p, p + 8, 1);
+                ++launched;
+            }
+            PSD_CHECK(psd_rt_d2h(&hg, c->omb, sizeof(hg), c->stream));
+            PSD_CHECK(psd_rt_sync(c->stream));
+            if (hg.phase == PSD_OPH_DONE) break;
+            if (launched > cap) return *info = PSD_INFO_RUNTIME + 0xfffb;
+        }
+        std::vector<psd_ostate> hs(PSD_O_SLOTS);
+        PSD_CHECK(psd_rt_d2h(hs.data(), c->ombst, sizeof(psd_ostate) * PSD_O_SLOTS, c->stream));
+        PSD_CHECK(psd_rt_sync(c->stream));
+        hst.phase = PSD_OPH_DONE;
+        hst.info = hg.info;
+        for (const psd_ostate& q : hs) {
+            hst.nswaps += q.nswaps;
+            hst.nwindows += q.nwindows;
+        }
+    } else {
+    PSD_LAUNCH(psd_zgord_init, psd_dim3(1), 64, 0, c->stream, O, n, p, wantZ, W);
     for (;;) {
         for (int b = 0; b < 32; ++b) {
             PSD_LAUNCH(psd_zgord_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, O);
@@ -3721,6 +3831,7 @@ int zgordschur_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t
         PSD_CHECK(psd_rt_sync(c->stream));
         if (hst.phase == PSD_OPH_DONE) break;
         if (launched > cap) return *info = PSD_INFO_RUNTIME + 0xfffb;
+    }
     }
     if (hst.info == 0) {
         PSD_LAUNCH(psd_zgord_values, psd_dim3((n + 255) / 256), 256, 0, c->stream, O.z, n, p);

@@ -22,12 +22,12 @@ struct psd_zgoparams {
     const unsigned char* select;  // [n]
 };
 
-PSD_KERNEL_B(PSD_STEP_NT) psd_zgord_step(psd_zgoparams O) {
+PSD_D void psd_zgord_step_body(const psd_zgoparams& O) {
     PSD_LDS_DECL;
     const psd_zgparams& P = O.z;
     psd_ostate st = *O.st;
     PSD_ONE { P.desc->active = 0; P.desc->defer_run = 0; }
-    if (st.phase == PSD_OPH_DONE) return;
+    if (st.phase == PSD_OPH_DONE || st.phase == PSD_OPH_IDLE) return;
     const int n = st.n, p = st.p;
     psd_z* ldsz = (psd_z*)psd_lds;
     const size_t winb = (size_t)p * st.W * (st.W + 1);
@@ -215,6 +215,18 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_zgord_step(psd_zgoparams O) {
     }
     PSD_SYNC();
     PSD_ONE { *O.st = st; }
+}
+
+PSD_KERNEL_B(PSD_STEP_NT) psd_zgord_step(psd_zgoparams O) { psd_zgord_step_body(O); }
+
+// pipelined driver: see psd_oslot (psd_zord.h)
+PSD_KERNEL_B(PSD_STEP_NT) psd_zgord_step_mb(psd_zgoparams O, int p, int cstride) {
+    const int s = PSD_BLOCK_X;
+    O.st += s;
+    O.z.desc += s;
+    O.z.cnt += (size_t)s * cstride;
+    O.z.tr += (size_t)s * p * PSD_GTR_CAP;
+    psd_zgord_step_body(O);
 }
 
 PSD_KERNEL psd_zgord_init(psd_zgoparams O, int n, int p, int wantZ, int W) {

@@ -19,7 +19,7 @@
 #pragma once
 #include "psd_zqz.h"
 
-enum { PSD_OPH_SCAN = 0, PSD_OPH_MOVE = 1, PSD_OPH_DONE = 7 };
+enum { PSD_OPH_SCAN = 0, PSD_OPH_MOVE = 1, PSD_OPH_IDLE = 5, PSD_OPH_DONE = 7 };
 #define PSD_INFO_ILLCOND_BASE 2000
 #define PSD_INFO_SINGULAR 3000
 
@@ -109,12 +109,12 @@ PSD_D bool psd_ord_cycsolve(int K, const psd_z* A, const psd_z* B, const psd_z* 
     return true;
 }
 
-PSD_KERNEL_B(PSD_STEP_NT) psd_zord_step(psd_oparams O) {
+PSD_D void psd_zord_step_body(const psd_oparams& O) {
     PSD_LDS_DECL;
     const psd_zparams& P = O.z;
     psd_ostate st = *O.st;
     PSD_ONE { P.desc->active = 0; P.desc->defer_run = 0; }
-    if (st.phase == PSD_OPH_DONE) return;
+    if (st.phase == PSD_OPH_DONE || st.phase == PSD_OPH_IDLE) return;
     const int n = st.n, p = st.p;
     psd_z* ldsz = (psd_z*)psd_lds;
     const size_t winb = (size_t)p * st.W * (st.W + 1);
@@ -276,6 +276,160 @@ PSD_KERNEL_B(PSD_STEP_NT) psd_zord_step(psd_oparams O) {
     }
     PSD_SYNC();
     PSD_ONE { *O.st = st; }
+}
+
+PSD_KERNEL_B(PSD_STEP_NT) psd_zord_step(psd_oparams O) { psd_zord_step_body(O); }
+
+// ------------------------------------------------------------------------------------------------
+// Pipelined driver (as psd_roslot of the real engine, simpler: blocks are 1 x 1 and the k-th selected eigenvalue goes to
+// row k, known when it starts).  Up to PSD_O_SLOTS selected eigenvalues travel upwards at once, one workgroup each, a
+// follower's window ending below its predecessor's last known row.  The step kernel is the serial one: slot s runs it on
+// its own state (phase MOVE, js = the top row its window may reach, j = its source row), descriptor, counts and lists; a
+// one-lane plan kernel in front of every tick reads what the slots did, retires arrivals in order, starts at most one
+// new eigenvalue and writes the slots' states for the coming tick.  Shared by the signed driver (psd_zgord_step_mb).
+#define PSD_O_SLOTS 64
+struct psd_oslot {
+    int active, seq, target, jsrc, landed, fail, info, pad;
+};
+struct psd_omb {
+    int n, phase, info;
+    int j, js;  // scan cursor and count of selected eigenvalues seen (ordschur.jl:53-65)
+    int scandone, nstarted, nfinished, nactive;
+    int failseq, failinfo;
+    int nticks;
+};
+
+PSD_D int psd_o_find(const psd_oslot* S, int seq) {
+    for (int q = 0; q < PSD_O_SLOTS; ++q)
+        if (S[q].active && S[q].seq == seq) return q;
+    return -1;
+}
+
+PSD_KERNEL psd_ord1_plan(psd_ostate* sts, psd_oslot* S, psd_omb* Gp, const unsigned char* select) {
+    PSD_ONE {
+        psd_omb G = *Gp;
+        if (G.phase != PSD_OPH_DONE) {
+            const int n = G.n;
+            for (int q = 0; q < PSD_O_SLOTS; ++q) {  // what the last tick did
+                if (!S[q].active || S[q].fail || S[q].landed) continue;
+                if (sts[q].phase == PSD_OPH_DONE) {
+                    S[q].fail = 1;
+                    S[q].info = sts[q].info;
+                    if (S[q].seq < G.failseq) {
+                        G.failseq = S[q].seq;
+                        G.failinfo = S[q].info;
+                    }
+                } else if (sts[q].here <= S[q].target) {
+                    S[q].landed = 1;
+                }
+            }
+            for (;;) {  // arrivals in the order of selection
+                const int q = psd_o_find(S, G.nfinished);
+                if (q < 0 || !S[q].landed) break;
+                S[q].active = 0;
+                G.nfinished += 1;
+                G.nactive -= 1;
+            }
+            if (G.failseq == 0x7fffffff && !G.scandone) {
+                int f = -1;
+                for (int q = 0; q < PSD_O_SLOTS && f < 0; ++q)
+                    if (!S[q].active) f = q;
+                while (f >= 0) {  // ordschur.jl:53-65
+                    const int j = G.j + 1;
+                    if (j > n) {
+                        G.scandone = 1;
+                        break;
+                    }
+                    if (!select[j - 1]) {
+                        G.j = j;
+                        continue;
+                    }
+                    if (j == G.js + 1) {  // already in place
+                        G.j = j;
+                        G.js += 1;
+                        continue;
+                    }
+                    if (G.nactive > 0) {  // behind the eigenvalue started last, once a row lies between
+                        const int r = psd_o_find(S, G.nstarted - 1);
+                        if (r >= 0 && j < sts[r].here + 2) break;  // (row j is looked at again in the next tick)
+                    }
+                    G.j = j;
+                    G.js += 1;
+                    psd_oslot ns;
+                    ns.active = 1;
+                    ns.seq = G.nstarted;
+                    ns.target = G.js;
+                    ns.jsrc = j;
+                    ns.landed = ns.fail = ns.info = ns.pad = 0;
+                    S[f] = ns;
+                    sts[f].here = j;
+                    sts[f].info = 0;
+                    G.nstarted += 1;
+                    G.nactive += 1;
+                    break;
+                }
+            }
+            for (int q = 0; q < PSD_O_SLOTS; ++q) {  // the coming tick
+                int ph = PSD_OPH_IDLE;
+                if (S[q].active && !S[q].fail && !S[q].landed && S[q].seq < G.failseq) {
+                    int lim = S[q].target;
+                    const int r = psd_o_find(S, S[q].seq - 1);
+                    if (r >= 0 && sts[r].here + 1 > lim) lim = sts[r].here + 1;
+                    if (sts[q].here > lim) {
+                        ph = PSD_OPH_MOVE;
+                        sts[q].js = lim;
+                        sts[q].j = S[q].jsrc;
+                    }
+                }
+                sts[q].phase = ph;
+            }
+            if (G.failseq != 0x7fffffff) {
+                bool any = false;
+                for (int q = 0; q < PSD_O_SLOTS; ++q)
+                    if (S[q].active && !S[q].fail && !S[q].landed && S[q].seq < G.failseq) any = true;
+                if (!any) {
+                    G.info = G.failinfo;
+                    G.phase = PSD_OPH_DONE;
+                }
+            } else if (G.scandone && G.nactive == 0) {
+                G.phase = PSD_OPH_DONE;
+            }
+            G.nticks += 1;
+        }
+        *Gp = G;
+    }
+}
+
+PSD_KERNEL psd_ord1_init_mb(psd_ostate* sts, psd_oslot* S, psd_omb* Gp, int n, int p, int wantZ, int W) {
+    PSD_PAR_FOR(q, PSD_O_SLOTS) {
+        psd_ostate st;
+        st.n = n; st.p = p; st.wantZ = wantZ; st.W = W;
+        st.phase = PSD_OPH_IDLE; st.info = 0;
+        st.j = 0; st.js = 0; st.here = 0; st.nswaps = 0; st.nwindows = 0;
+        sts[q] = st;
+        psd_oslot z;
+        z.active = 0; z.seq = -1; z.target = z.jsrc = z.landed = z.fail = z.info = z.pad = 0;
+        S[q] = z;
+    }
+    PSD_ONE {
+        psd_omb G;
+        G.n = n; G.phase = PSD_OPH_SCAN; G.info = 0;
+        G.j = 0; G.js = 0;
+        G.scandone = 0; G.nstarted = 0; G.nfinished = 0; G.nactive = 0;
+        G.failseq = 0x7fffffff; G.failinfo = 0;
+        G.nticks = 0;
+        *Gp = G;
+    }
+}
+
+// grid = PSD_O_SLOTS: slot s with its own state, descriptor, counts and lists (the layout of the trains' cursor arrays)
+PSD_KERNEL_B(PSD_STEP_NT) psd_zord_step_mb(psd_oparams O, int p, int cstride) {
+    const int s = PSD_BLOCK_X;
+    O.st += s;
+    O.z.desc += s;
+    O.z.cnt += (size_t)s * cstride;
+    O.z.tr += (size_t)s * p * PSD_ZTR_CAP;
+    psd_zord_step_body(O);
 }
 
 PSD_KERNEL psd_zord_init(psd_oparams O, int n, int p, int wantZ, int W) {

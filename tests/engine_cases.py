@@ -534,6 +534,57 @@ def case_rordschur_pipelined(make_engine, sizes):
         assert po.info == 0 and ps1.stats.nsweeps == po.nswaps
 
 
+def case_zordschur_pipelined(make_engine, sizes, gsizes):
+    """Pipelined ordschur! drivers of the ComplexF64 engines (psd_ord1_plan + psd_zord_step_mb / psd_zgord_step_mb:
+    selected eigenvalues under way together, a window apart) against the serial ones (PSD_ORD_PIPE=0: ordschur.jl:53-65
+    eigenvalue by eigenvalue): same swap counts (and the oracle's), same order, invariants.  gsizes: signed problems."""
+    e_pipe = make_engine({"PSD_ORD_PIPE": "1"})
+    e_ser = make_engine({"PSD_ORD_PIPE": "0"})
+    for (n, p, lr, frac) in sizes:
+        A = pt.bench_factors(n, p, seed=500 + n + p, dtype=np.complex128)
+        ps0 = e_pipe.pschur(A, lr)
+        lam0 = ps0.values.copy()
+        thr = np.sort(np.abs(lam0))[int(n * frac)]
+        select = np.abs(lam0) <= thr
+        ps1 = e_pipe.ordschur_(_clone(ps0), select)
+        ps2 = e_ser.ordschur_(_clone(ps0), select)
+        assert ps1.stats.nsweeps == ps2.stats.nsweeps > 0, (n, p, ps1.stats.nsweeps, ps2.stats.nsweeps)
+        assert ps1.stats.nlaunch_step < ps2.stats.nlaunch_step or ps2.stats.nlaunch_step <= 32
+        ok, err = pt.checkpsd(ps1, A, thresh=100 * np.sqrt(max(n / 32, 1)))
+        assert ok, (n, p, lr, err)
+        m = int(select.sum())
+        sc = abs(lam0).max()
+        assert np.allclose(ps1.values[:m], lam0[select], rtol=1e-7, atol=1e-9 * sc)
+        assert np.allclose(ps1.values[m:], lam0[~select], rtol=1e-7, atol=1e-9 * sc)
+        assert np.allclose(ps1.values, ps2.values, rtol=1e-7, atol=1e-9 * sc)
+        po = pt.oracle_ordschur(pt.PSD(ps0.Ts, ps0.Z, lam0, ps0.orientation, ps0.schurindex), select)
+        assert ps1.stats.nsweeps == po.nswaps
+    for (n, p, lr) in gsizes:
+        S = [bool((q * 7 + n) % 3) for q in range(p)]
+        if all(S):
+            S[p // 2] = False
+        S[p - 1 if lr == "R" else 0] = True
+        A = pt.gord_test_factors(n, p, S, seed=n + p, cplx=True)
+        if lr == "R":
+            A, S = A[::-1], S[::-1]
+        res = []
+        for e in (e_pipe, e_ser):
+            ps0 = e.pschur_([a.copy(order="F") for a in A], lr, S=S)
+            lam0 = ps0.values.copy()
+            order = np.argsort(np.abs(lam0))
+            select = np.zeros(n, dtype=bool)
+            select[order[: n // 2]] = True
+            ps1 = e.ordschur_(ps0, select)
+            pt.gpschur_check(A, S, ps1, tol=100 * max(1.0, np.sqrt(n / 32)), qtol=10 * max(1.0, np.sqrt(n / 32)))
+            m = int(select.sum())
+            assert pt.match_eigs(lam0[select], ps1.values[:m]) < 1e-7 * abs(lam0).max()
+            res.append(ps1)
+        assert res[0].stats.nsweeps == res[1].stats.nsweeps > 0
+        assert res[0].stats.nlaunch_step < res[1].stats.nlaunch_step or res[1].stats.nlaunch_step <= 32
+        fin = np.isfinite(res[1].values)
+        assert np.allclose(res[0].values[fin], res[1].values[fin], rtol=1e-6, atol=1e-8 * abs(res[1].values[fin]).max())
+
+
 def case_rordschur_edge(eng):
     import psd_amd
 

@@ -146,6 +146,20 @@ def test_zordschur_edge(gpu_engine):
     ec.case_zordschur_edge(gpu_engine)
 
 
+def test_zordschur_pipelined(monkeypatch):
+    """pipelined ordschur! drivers of the ComplexF64 engines (standard and signed) against the serial ones and the
+    oracle, through the C ABI"""
+    import psd_amd
+
+    def make(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        return psd_amd.Engine()
+
+    ec.case_zordschur_pipelined(make, [(130, 2, "R", 0.5), (150, 4, "L", 0.3), (300, 16, "R", 0.4), (256, 40, "L", 0.5)],
+                                [(130, 3, "R"), (140, 4, "L"), (200, 12, "R")])
+
+
 def test_ordschur_alignments(gpu_engine):
     ec.case_ordschur_alignments(gpu_engine)
 

@@ -87,6 +87,21 @@ def test_rordschur_pipelined(built, monkeypatch):
     ec.case_rordschur_pipelined(make, [(140, 2, "R", 0.5), (160, 5, "L", 0.25), (90, 3, "R", 0.6)])
 
 
+def test_zordschur_pipelined(built, monkeypatch):
+    import os
+
+    import psd_amd
+
+    lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim", "_build", "libpsd_hostsim.so")
+
+    def make(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        return psd_amd.Engine(libpath=lib)
+
+    ec.case_zordschur_pipelined(make, [(130, 2, "R", 0.5), (150, 4, "L", 0.3)], [(130, 3, "R"), (140, 4, "L")])
+
+
 def test_rphessenberg(sim_engine):
     ec.case_rphessenberg(sim_engine)
 
