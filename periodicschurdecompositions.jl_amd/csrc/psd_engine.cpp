@@ -3338,7 +3338,24 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
     P.ascale = c->gascale;
     P.log = c->glog;
     P.xscr = c->gxscr;
-    const size_t lds_step = step_lds_bytes(p, W, 8);
+    size_t lds_step = step_lds_bytes(p, W, 8);
+    // scan form of the sweep windows (psd_gs3_run; PSD_GSCAN=0: the single-wave sweep): rotation tables and the helper
+    // wavefronts' command block behind everything the state machine uses
+    P.gcoff = P.gtaboff = 0;
+    int gwaves = 1;
+    {
+        int gscan = 1;
+        if (const char* e = psd_env("PSD_GSCAN")) gscan = atoi(e);
+        const size_t need = lds_step + (size_t)p * 8 * sizeof(double) + 128;
+        if (gscan && !hessmode && p >= 2 && p <= 64 && need <= (size_t)160 * 1024) {
+            P.gtaboff = (int)lds_step;
+            P.gcoff = (int)(lds_step + (size_t)p * 8 * sizeof(double));
+            lds_step = need;
+#ifndef PSD_HOSTSIM
+            gwaves = 4;
+#endif
+        }
+    }
 #ifndef PSD_HOSTSIM
     if (lds_step > c->gstep_lds_set) {
         PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_gq_step),
@@ -3420,9 +3437,9 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
             if (hess_pipe)
                 PSD_LAUNCH(psd_gq_hess_step, psd_dim3(1), 64 * ((hess_scan && p <= 64) ? 4 : hess_waves), lds_hess, c->stream, P, hess_links, hess_scan);  // (scan form: four wavefronts, one per SIMD)
             else if (M > 1)
-                PSD_LAUNCH(psd_gq_step_train, psd_dim3(M), PSD_STEP_NT, lds_step, c->stream, P, p, p + 8);
+                PSD_LAUNCH2(psd_gq_step_train, psd_dim3(M), PSD_STEP_NT, gwaves, lds_step, c->stream, P, p, p + 8);
             else
-                PSD_LAUNCH(psd_gq_step, psd_dim3(1), PSD_STEP_NT, lds_step, c->stream, P);
+                PSD_LAUNCH2(psd_gq_step, psd_dim3(1), PSD_STEP_NT, gwaves, lds_step, c->stream, P);
 #ifndef PSD_HOSTSIM
             if (sample) {
                 (void)hipEventRecord(ev1, c->stream);

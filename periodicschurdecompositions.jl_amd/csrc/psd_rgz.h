@@ -86,6 +86,9 @@ struct psd_gparams {
     // period sharding (psd_set_shard): the owners m (1-based, inclusive) whose Schur vectors Z_m this context holds;
     // the updates of the others are some other rank's work (1..p without sharding)
     int zlo, zhi;
+    // scan form of the sweep windows (psd_gs3_run): byte offsets in LDS of the command block the helper wavefronts watch
+    // and of the rotation tables; 0: single-wave sweep (64 x 1 workgroups)
+    int gcoff, gtaboff;
 };
 
 PSD_HD psd_mat<double> psd_gfac(const psd_gparams& P, int n, int l) {
@@ -1182,6 +1185,403 @@ PSD_D void psd_ghess_scan_window(const psd_gparams& P, const psd_gstate& st, con
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The implicit double-shift sweep in scan form (round 4; rgeneralized.jl:955-1050).  Per position j two rotations leave
+// H_1 — A on (j+1, j+2), B on (j, j+1) — and each travels down the factors p..2 exactly as the single rotation of
+// stage 2 above (psd_ghess_scan_window): the pairs the rotations are made from are a chain of 2 x 2 triangular
+// matrix-vector products.  Chain B's blocks U_l[j:j+1, j:j+1] are the ones A's passage has left behind; the lane of
+// factor l forms the two entries that changed from its own 3 x 3 block and A's two rotations (a dozen operations), so both
+// chains are done before any factor is updated.  Then every factor takes its four rotations in two phases — every
+// column rotation (A then B), then every row rotation (A then B) — each over the full three rows / columns of the
+// position: U' = R_B R_A U C_A C_B whatever order the serial sweep applies them in.  H_1 is factor 1 of both phases (its
+// own rotations on the rows, the ends of the chains on the columns).  Four wavefronts: wavefront 0 owns the chains, all
+// update.  tab: [p][8] = A's (c, s) made at factor l, B's (c, s), chain B's (m0, m1, m2), spare.
+struct psd_gc {
+    int cmd;  // 0: leave, 1: run
+    int p, W, ld, bsz, bs, be;
+    int j0, j1, slot0;
+    int ifirstm, ilastm;
+    int wboff, taboff;
+    psd_gtr* tr;
+    const unsigned char* S;
+};
+
+#ifndef PSD_HOSTSIM
+// chain lanes 0..15 carry four links each (factors p - 4 lane - q4): pairs into tab[.][6..7], then the rotations with the
+// reference's signs (see psd_ghess_scan_window) into tab[.][col], tab[.][col + 1]; factor 1 gets (cs, ss) itself.
+PSD_D void psd_gs3_chain(double* tab, int p, int lane, const double (&M0)[4], const double (&M1)[4], const double (&M2)[4],
+                         double cs, double ss, int col) {
+    const bool chl = lane < 16;
+    double zq0[4] = {0.0, 0.0, 0.0, 0.0}, zq1[4] = {0.0, 0.0, 0.0, 0.0};
+    const int nsteps = (p - 1 + 3) / 4;
+    double z0 = 0.0, z1 = 0.0;
+    for (int s = 0; s < nsteps; ++s) {
+        double w0 = psd_c3_shr(z0, cs), w1 = psd_c3_shr(z1, ss);
+        if (s <= lane) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const double n0 = __builtin_fma(M0[q4], w0, M1[q4] * w1);
+                const double n1 = M2[q4] * w1;
+                w0 = n0;
+                w1 = n1;
+                zq0[q4] = n0;
+                zq1[q4] = n1;
+            }
+            const int e = psd_c3_expo(fmax(fabs(w0), fabs(w1)));
+            z0 = psd_c3_ldexp(w0, -e);
+            z1 = psd_c3_ldexp(w1, -e);
+        }
+    }
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const int c = 4 * lane + q4, lf = p - c;
+        if (chl && c < p - 1) {
+            tab[(lf - 1) * 8 + 6] = zq0[q4];
+            tab[(lf - 1) * 8 + 7] = zq1[q4];
+        }
+    }
+    PSD_WAVE_SYNC();
+    double zf = 0.0, zg = 0.0;
+    if (lane >= 1 && lane < p) {
+        zf = tab[lane * 8 + 6];
+        zg = tab[lane * 8 + 7];
+    }
+    const unsigned long long bigm = __ballot(lane >= 1 && lane < p && fabs(zf) > fabs(zg));
+    const unsigned long long negm = __ballot(zf < 0.0);
+    if (lane < p) {
+        double c = cs, s = ss;
+        if (lane >= 1) {
+            const unsigned long long above = (lane < 63) ? (bigm & ~((2ull << lane) - 1ull)) : 0ull;
+            double sg = 1.0;
+            if (above != 0ull) {
+                const int bpos = __ffsll((long long)above) - 1;
+                if ((negm >> bpos) & 1ull) sg = -1.0;
+            }
+            double r;
+            psd_givens(sg * zf, sg * zg, c, s, r);
+        }
+        tab[lane * 8 + col] = c;
+        tab[lane * 8 + col + 1] = s;
+    }
+    PSD_WAVE_SYNC();
+}
+#endif
+
+// wv: this wavefront (0 = the one that runs the state machine), nw: wavefronts of the workgroup
+PSD_D void psd_gs3_run(const psd_gc& C, int wv, int nw) {
+    PSD_LDS_DECL;
+    const int p = C.p;
+    psd_gwin w;
+    w.b = (double*)(psd_lds + C.wboff);
+    w.W = C.W; w.ld = C.ld; w.bsz = C.bsz; w.bs = C.bs; w.be = C.be;
+    double* tab = (double*)(psd_lds + C.taboff);
+    const int r0 = (C.ifirstm > w.bs) ? C.ifirstm : w.bs;
+    const int c1 = (C.ilastm < w.be) ? C.ilastm : w.be;
+#ifndef PSD_HOSTSIM
+    const int NT = 64 * nw;
+    const int tid = (int)threadIdx.x + 64 * wv;
+    const int lane = (int)threadIdx.x;
+#else
+    const int NT = PSD_NTHREADS;
+    (void)wv; (void)nw;
+#endif
+    const int tpf = (NT / p > 0) ? (NT / p) : 1;
+#ifndef PSD_HOSTSIM
+    const int myf = tid / tpf, myq = tid - myf * tpf;
+    const bool mysg = (myf >= 1 && myf < p) ? (C.S[myf] != 0) : false;
+    bool lsg[4] = {true, true, true, true};
+    bool lanesg = true;  // signature of factor lane + 1
+    if (wv == 0) {
+        if (lane < 16) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int c = 4 * lane + q4;
+                if (c < p - 1) lsg[q4] = C.S[p - c - 1] != 0;
+            }
+        }
+        if (lane >= 1 && lane < p) lanesg = C.S[lane] != 0;
+    }
+#endif
+    for (int j = C.j0; j <= C.j1; ++j) {
+        const int slot = C.slot0 + 2 * (j - C.j0);
+        double* const h1 = w.b;  // factor 1
+#ifndef PSD_HOSTSIM
+        if (wv == 0) {
+            // ---- rgeneralized.jl:960-968: the two rotations from column j - 1 of H_1
+            double* cj = h1 + (j - 1 - w.bs) * w.ld + (j - w.bs);
+            double c2, s2, r2, c1r, s1r, r1;
+            psd_givens(cj[1], cj[2], c2, s2, r2);
+            psd_givens(cj[0], r2, c1r, s1r, r1);
+            PSD_WAVE_SYNC();
+            if (lane == 0) {
+                cj[0] = r1;
+                cj[1] = 0.0;
+                cj[2] = 0.0;
+            }
+            // ---- chain A at q = j + 1
+            double M0[4], M1[4], M2[4];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int c = 4 * lane + q4, lf = p - c;
+                M0[q4] = 1.0; M1[q4] = 0.0; M2[q4] = 1.0;
+                if (lane < 16 && c < p - 1) {
+                    const double* u = w.b + (lf - 1) * w.bsz + (j + 1 - w.bs) * w.ld + (j + 1 - w.bs);
+                    const double u00 = u[0], u01 = u[w.ld], u11 = u[w.ld + 1];
+                    if (lsg[q4]) { M0[q4] = u00; M1[q4] = u01; M2[q4] = u11; }
+                    else { M0[q4] = u11; M1[q4] = -u01; M2[q4] = u00; }
+                }
+            }
+            psd_gs3_chain(tab, p, lane, M0, M1, M2, c2, s2, 0);
+            // ---- what A's passage leaves of U_l[j:j+1, j:j+1] (lane l - 1, l >= 2), as chain B's matrix
+            if (lane >= 1 && lane < p) {
+                const int l = lane + 1;
+                const double* u = w.b + (l - 1) * w.bsz + (j - w.bs) * w.ld + (j - w.bs);  // (j, j)
+                const double a = u[0], b1 = u[w.ld], b2 = u[2 * w.ld], d11 = u[w.ld + 1], d12 = u[2 * w.ld + 1], d22 = u[2 * w.ld + 2];
+                const int in = (l == p) ? 0 : l;  // (table row of the incoming rotation: made at factor l + 1, or H_1's own)
+                const double ci = tab[in * 8 + 0], si = tab[in * 8 + 1], co = tab[lane * 8 + 0], so = tab[lane * 8 + 1];
+                double u01, u11;
+                if (lanesg) {
+                    u01 = ci * b1 + si * b2;
+                    u11 = co * (ci * d11 + si * d12) + so * (si * d22);
+                } else {
+                    u01 = co * b1 + so * b2;
+                    u11 = co * (ci * d11) + so * (ci * d12 + si * d22);
+                }
+                tab[lane * 8 + 4] = lanesg ? a : u11;
+                tab[lane * 8 + 5] = lanesg ? u01 : -u01;
+                tab[lane * 8 + 6] = lanesg ? u11 : a;
+            }
+            PSD_WAVE_SYNC();
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int c = 4 * lane + q4, lf = p - c;
+                M0[q4] = 1.0; M1[q4] = 0.0; M2[q4] = 1.0;
+                if (lane < 16 && c < p - 1) {
+                    M0[q4] = tab[(lf - 1) * 8 + 4];
+                    M1[q4] = tab[(lf - 1) * 8 + 5];
+                    M2[q4] = tab[(lf - 1) * 8 + 6];
+                }
+            }
+            PSD_WAVE_SYNC();
+            psd_gs3_chain(tab, p, lane, M0, M1, M2, c1r, s1r, 2);
+            if (lane < p && slot + 1 < PSD_GTR_CAP) {
+                psd_gtr tr;
+                tr.pos = j + 1;
+                tr.pad = 0;
+                tr.c = tab[lane * 8 + 0];
+                tr.s = tab[lane * 8 + 1];
+                C.tr[(size_t)lane * PSD_GTR_CAP + slot] = tr;
+                tr.pos = j;
+                tr.c = tab[lane * 8 + 2];
+                tr.s = tab[lane * 8 + 3];
+                C.tr[(size_t)lane * PSD_GTR_CAP + slot + 1] = tr;
+            }
+        }
+        PSD_PAIR_BARRIER();
+#else
+        {
+            double* cj = h1 + (j - 1 - w.bs) * w.ld + (j - w.bs);
+            double c2, s2, r2, c1r, s1r, r1;
+            psd_givens(cj[1], cj[2], c2, s2, r2);
+            psd_givens(cj[0], r2, c1r, s1r, r1);
+            cj[0] = r1;
+            cj[1] = 0.0;
+            cj[2] = 0.0;
+            for (int ch = 0; ch < 2; ++ch) {
+                const int col = 2 * ch;
+                double z0 = ch ? c1r : c2, z1 = ch ? s1r : s2, sigma = 1.0;
+                int since = 0;
+                tab[col] = z0;
+                tab[col + 1] = z1;
+                if (ch == 1)  // chain B's matrices: what A's passage leaves of the blocks at (j, j + 1)
+                    for (int l = 2; l <= p; ++l) {
+                        const double* u = w.b + (l - 1) * w.bsz + (j - w.bs) * w.ld + (j - w.bs);
+                        const double a = u[0], b1 = u[w.ld], b2 = u[2 * w.ld], d11 = u[w.ld + 1], d12 = u[2 * w.ld + 1], d22 = u[2 * w.ld + 2];
+                        const int in = (l == p) ? 0 : l;
+                        const double ci = tab[in * 8 + 0], si = tab[in * 8 + 1], co = tab[(l - 1) * 8 + 0], so = tab[(l - 1) * 8 + 1];
+                        const bool sg = C.S[l - 1] != 0;
+                        double u01, u11;
+                        if (sg) {
+                            u01 = ci * b1 + si * b2;
+                            u11 = co * (ci * d11 + si * d12) + so * (si * d22);
+                        } else {
+                            u01 = co * b1 + so * b2;
+                            u11 = co * (ci * d11) + so * (ci * d12 + si * d22);
+                        }
+                        tab[(l - 1) * 8 + 4] = sg ? a : u11;
+                        tab[(l - 1) * 8 + 5] = sg ? u01 : -u01;
+                        tab[(l - 1) * 8 + 6] = sg ? u11 : a;
+                    }
+                for (int lf = p; lf >= 2; --lf) {
+                    double m0, m1, m2;
+                    if (ch == 0) {
+                        const double* u = w.b + (lf - 1) * w.bsz + (j + 1 - w.bs) * w.ld + (j + 1 - w.bs);
+                        const double u00 = u[0], u01 = u[w.ld], u11 = u[w.ld + 1];
+                        const bool sg = C.S[lf - 1] != 0;
+                        m0 = sg ? u00 : u11; m1 = sg ? u01 : -u01; m2 = sg ? u11 : u00;
+                    } else {
+                        m0 = tab[(lf - 1) * 8 + 4]; m1 = tab[(lf - 1) * 8 + 5]; m2 = tab[(lf - 1) * 8 + 6];
+                    }
+                    const double n0 = m0 * z0 + m1 * z1, n1 = m2 * z1;
+                    double c, s, r;
+                    psd_givens(sigma * n0, sigma * n1, c, s, r);
+                    if (fabs(n0) > fabs(n1)) sigma = (n0 < 0.0) ? -1.0 : 1.0;
+                    tab[(lf - 1) * 8 + col] = c;
+                    tab[(lf - 1) * 8 + col + 1] = s;
+                    z0 = n0;
+                    z1 = n1;
+                    if (++since == 4) {
+                        since = 0;
+                        const int e = psd_c3_expo(fmax(fabs(z0), fabs(z1)));
+                        z0 = psd_c3_ldexp(z0, -e);
+                        z1 = psd_c3_ldexp(z1, -e);
+                    }
+                }
+            }
+            for (int l = 1; l <= p; ++l)
+                if (slot + 1 < PSD_GTR_CAP) {
+                    psd_gtr tr;
+                    tr.pos = j + 1;
+                    tr.pad = 0;
+                    tr.c = tab[(l - 1) * 8 + 0];
+                    tr.s = tab[(l - 1) * 8 + 1];
+                    C.tr[(size_t)(l - 1) * PSD_GTR_CAP + slot] = tr;
+                    tr.pos = j;
+                    tr.c = tab[(l - 1) * 8 + 2];
+                    tr.s = tab[(l - 1) * 8 + 3];
+                    C.tr[(size_t)(l - 1) * PSD_GTR_CAP + slot + 1] = tr;
+                }
+        }
+        PSD_SYNC();
+#endif
+        // ---- the two update phases: thread (f, qq) is the qq-th of the tpf threads of factor f + 1
+        for (int sub = 0; sub < 2; ++sub) {
+#ifndef PSD_HOSTSIM
+            {  // (blockDim.x = 64: the data-parallel macros would run over one wavefront's lanes only)
+                const int f = myf, qq = myq;
+#else
+            PSD_PAR_FOR(t, NT) {
+                const int f = t / tpf, qq = t - f * tpf;
+#endif
+                if (f < p) {
+                    const int l = f + 1;
+#ifndef PSD_HOSTSIM
+                    const bool sg = mysg;
+#else
+                    const bool sg = (l == 1) ? false : (C.S[l - 1] != 0);
+#endif
+                    const int in = (l == p) ? 0 : l;  // table row of the incoming rotations
+                    // sub 0: the column rotations, sub 1: the row rotations.  S true: incoming on the columns, made on the
+                    // rows; S false the other way round; H_1: the chains' ends (made at factor 2) on the columns, its own
+                    // on the rows
+                    int src;
+                    if (l == 1) src = (sub == 0) ? ((p >= 2) ? 1 : 0) : 0;
+                    else src = ((sub == 0) == sg) ? in : (l - 1);
+                    const double ca = tab[src * 8 + 0], sa = tab[src * 8 + 1], cb = tab[src * 8 + 2], sb = tab[src * 8 + 3];
+                    double* const blk = w.b + (l - 1) * w.bsz;
+                    if (sub == 0) {
+                        const int ra = r0;
+                        int rb = (l == 1) ? (j + 3) : (j + 2);
+                        if (l == 1 && rb > C.ilastm) rb = C.ilastm;
+                        if (rb > w.be) rb = w.be;
+                        for (int r = ra + qq; r <= rb; r += tpf) {
+                            double* e = blk + (j - w.bs) * w.ld + (r - w.bs);
+                            double a0 = e[0], a1 = e[w.ld], a2 = e[2 * w.ld];
+                            const double t1 = ca * a1 + sa * a2;
+                            a2 = ca * a2 - sa * a1;
+                            a1 = t1;
+                            const double t0 = cb * a0 + sb * a1;
+                            a1 = cb * a1 - sb * a0;
+                            a0 = t0;
+                            e[0] = a0;
+                            e[w.ld] = a1;
+                            e[2 * w.ld] = a2;
+                        }
+                    } else {
+                        const int cA = j;
+                        for (int cc = cA + qq; cc <= c1; cc += tpf) {
+                            double* e = blk + (cc - w.bs) * w.ld + (j - w.bs);
+                            double a0 = e[0], a1 = e[1], a2 = e[2];
+                            const double t1 = ca * a1 + sa * a2;
+                            a2 = ca * a2 - sa * a1;
+                            a1 = t1;
+                            const double t0 = cb * a0 + sb * a1;
+                            a1 = cb * a1 - sb * a0;
+                            a0 = t0;
+                            if (l >= 2) {  // (the factors stay triangular: what the rotations annihilate is set to zero)
+                                if (cc == j) { a1 = 0.0; a2 = 0.0; }
+                                if (cc == j + 1) a2 = 0.0;
+                            }
+                            e[0] = a0;
+                            e[1] = a1;
+                            e[2] = a2;
+                        }
+                    }
+                }
+            }
+#ifndef PSD_HOSTSIM
+            PSD_PAIR_BARRIER();
+#else
+            PSD_SYNC();
+#endif
+        }
+    }
+}
+
+#ifndef PSD_HOSTSIM
+// the helper wavefronts of a sweep workgroup (threadIdx.y >= 1): they take part in the scan runs and in nothing else
+PSD_D void psd_gs3_helper(int gcoff) {
+    PSD_LDS_DECL;
+    const psd_gc* cmd = (const psd_gc*)(psd_lds + gcoff);
+    for (;;) {
+        PSD_PAIR_BARRIER();
+        const psd_gc C = *cmd;
+        if (C.cmd == 0) return;
+        psd_gs3_run(C, PSD_WAVE_ROLE, (int)blockDim.y);
+    }
+}
+PSD_D void psd_gs3_release(int gcoff) {
+    PSD_LDS_DECL;
+    psd_gc* cmd = (psd_gc*)(psd_lds + gcoff);
+    PSD_ONE { cmd->cmd = 0; }
+    PSD_PAIR_BARRIER();
+}
+#define PSD_GS3_ENTER(P)                          \
+    if ((P).gcoff != 0 && PSD_WAVE_ROLE >= 1) {   \
+        psd_gs3_helper((P).gcoff);                \
+        return;                                   \
+    }
+#define PSD_GS3_LEAVE(P) \
+    if ((P).gcoff != 0) psd_gs3_release((P).gcoff)
+#else
+#define PSD_GS3_ENTER(P) ((void)0)
+#define PSD_GS3_LEAVE(P) ((void)0)
+#endif
+
+// wavefront 0's side of a scan run over the positions j0..j1 of a sweep window
+PSD_D void psd_gs3_lead(const psd_gparams& P, const psd_gstate& st, const psd_gwin& w, int j0, int j1, int slot0) {
+    PSD_LDS_DECL;
+    psd_gc C;
+    C.cmd = 1;
+    C.p = st.p; C.W = w.W; C.ld = w.ld; C.bsz = w.bsz; C.bs = w.bs; C.be = w.be;
+    C.j0 = j0; C.j1 = j1; C.slot0 = slot0;
+    C.ifirstm = st.ifirstm; C.ilastm = st.ilastm;
+    C.wboff = (int)((char*)w.b - (char*)psd_lds);
+    C.taboff = P.gtaboff;
+    C.tr = P.tr;
+    C.S = P.S;
+    PSD_SYNC();
+#ifdef PSD_HOSTSIM
+    psd_gs3_run(C, 0, 1);
+#else
+    psd_gc* cmd = (psd_gc*)(psd_lds + P.gcoff);
+    PSD_ONE { *cmd = C; }
+    PSD_PAIR_BARRIER();
+    psd_gs3_run(C, 0, (int)blockDim.y);
+    PSD_ONE { cmd->cmd = 0; }
+#endif
+}
+
 // One window (positions qs..qe of column hj, processed downwards) of stage 2; blockDim = 64 G, L links per wave
 // (psd_ghess_waves / psd_ghess_links).  Same state, lists and descriptor as psd_gq_hess_window.
 PSD_KERNEL_B(64 * PSD_GHESS_MAXWAVES) psd_gq_hess_step(psd_gparams P, int L, int scan) {
@@ -1278,7 +1678,12 @@ PSD_D void psd_gq_sweep_window(const psd_gparams& P, psd_gstate& st, double* lds
         jstart = ifirst + 1;
         slot = 2;
     }
-    for (int j = jstart; j <= ke; ++j) {
+    const bool scan = P.gtaboff != 0 && p >= 2 && p <= 64 && jstart <= ke;
+    if (scan) {  // scan form: both chains of a position before any update (psd_gs3_run)
+        psd_gs3_lead(P, st, w, jstart, ke, slot);
+        slot += 2 * (ke - jstart + 1);
+    }
+    for (int j = jstart; j <= ke && !scan; ++j) {
         double c1, s1, c2, s2;
         if (first && p == 1 && j == ifirst) {  // :955-958
             c1 = st.c1; s1 = st.s1; c2 = st.c2; s2 = st.s2;
@@ -1960,7 +2365,11 @@ PSD_D void psd_gq_step_body(const psd_gparams& P) {
     PSD_ONE { *P.st = st; }
 }
 
-PSD_KERNEL_B(PSD_STEP_NT) psd_gq_step(psd_gparams P) { psd_gq_step_body(P); }
+PSD_KERNEL_B(4 * PSD_STEP_NT) psd_gq_step(psd_gparams P) {
+    PSD_GS3_ENTER(P);
+    psd_gq_step_body(P);
+    PSD_GS3_LEAVE(P);
+}
 
 // cursor b of a multishift train (see psd_rq_cursor_body): starts 2 b ticks behind the leader with its own shift pair
 PSD_D void psd_gq_cursor_body(const psd_gparams& P, int b) {
@@ -2002,18 +2411,20 @@ PSD_D void psd_gq_cursor_body(const psd_gparams& P, int b) {
 }
 
 // all cursors of a tick in one launch, one workgroup each (as psd_rq_step_train)
-PSD_KERNEL_B(PSD_STEP_NT) psd_gq_step_train(psd_gparams P, int p, int cstride) {
+PSD_KERNEL_B(4 * PSD_STEP_NT) psd_gq_step_train(psd_gparams P, int p, int cstride) {
+    PSD_GS3_ENTER(P);
     const int b = PSD_BLOCK_X;
     if (b == 0) {
         psd_gq_step_body(P);
-        return;
+    } else {
+        psd_gparams Q = P;
+        Q.st = P.cst + b;
+        Q.desc = P.desc + b;
+        Q.cnt = P.cnt + (size_t)b * cstride;
+        Q.tr = P.tr + (size_t)b * p * PSD_GTR_CAP;
+        psd_gq_cursor_body(Q, b);
     }
-    psd_gparams Q = P;
-    Q.st = P.cst + b;
-    Q.desc = P.desc + b;
-    Q.cnt = P.cnt + (size_t)b * cstride;
-    Q.tr = P.tr + (size_t)b * p * PSD_GTR_CAP;
-    psd_gq_cursor_body(Q, b);
+    PSD_GS3_LEAVE(P);
 }
 
 // Bulk application of one window's rotation lists, by factor: grid = (tiles, p factors, 3 roles).
