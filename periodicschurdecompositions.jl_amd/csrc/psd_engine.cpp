@@ -3376,6 +3376,8 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
     if (hess_pipe && lds_hess > c->ghess_lds_set) {
         PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_gq_hess_step),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hess));
+        PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_gq_hess_step_scan),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hess));
         c->ghess_lds_set = lds_hess;
     }
 #endif
@@ -3434,8 +3436,10 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
             }
 #endif
             P.tick = (int)launched;
-            if (hess_pipe)
-                PSD_LAUNCH(psd_gq_hess_step, psd_dim3(1), 64 * ((hess_scan && p <= 64) ? 4 : hess_waves), lds_hess, c->stream, P, hess_links, hess_scan);  // (scan form: four wavefronts, one per SIMD)
+            if (hess_pipe && hess_scan && p <= 64)
+                PSD_LAUNCH(psd_gq_hess_step_scan, psd_dim3(1), 256, lds_hess, c->stream, P, hess_links);  // (scan form: four wavefronts, one per SIMD)
+            else if (hess_pipe)
+                PSD_LAUNCH(psd_gq_hess_step, psd_dim3(1), 64 * hess_waves, lds_hess, c->stream, P, hess_links, 0);
             else if (M > 1)
                 PSD_LAUNCH2(psd_gq_step_train, psd_dim3(M), PSD_STEP_NT, gwaves, lds_step, c->stream, P, p, p + 8);
             else

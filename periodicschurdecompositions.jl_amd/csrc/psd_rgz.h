@@ -974,6 +974,14 @@ PSD_HD size_t psd_ghess_lds_bytes(int p, int W) {
 // entry set to zero; A_1: the rotation that closes the lap, on its columns).  K positions = K rounds of (scan, two update
 // phases) instead of K + G beats of L dependent links each.
 // tab: [p][4] = (c, s) of the rotation made at factor l (l = 1: from column hj of A_1), then its pair (scratch).
+// The rendezvous between the chain and the update phases of the scan windows: LDS traffic has to be complete, the
+// rotation records on their way to device memory have not (the next kernel reads them) — __syncthreads() would wait for
+// their acknowledge at every position.
+#ifndef PSD_HOSTSIM
+#define PSD_GH_BARRIER() PSD_PAIR_BARRIER()
+#else
+#define PSD_GH_BARRIER() PSD_SYNC()
+#endif
 PSD_D void psd_ghess_scan_window(const psd_gparams& P, const psd_gstate& st, const psd_gwin& w, double* side, double* tab,
                                  int qe, int K) {
     const int p = st.p;
@@ -1125,7 +1133,7 @@ PSD_D void psd_ghess_scan_window(const psd_gparams& P, const psd_gstate& st, con
             }
         }
 #endif
-        PSD_SYNC();
+        PSD_GH_BARRIER();
         // ---- the two update phases: thread (f, qq) is the qq-th of the tpf threads of factor f + 1
         for (int sub = 0; sub < 2; ++sub) {
             PSD_PAR_FOR(t, NT) {
@@ -1180,7 +1188,7 @@ PSD_D void psd_ghess_scan_window(const psd_gparams& P, const psd_gstate& st, con
                     }
                 }
             }
-            PSD_SYNC();
+            PSD_GH_BARRIER();
         }
     }
 }
@@ -1584,7 +1592,7 @@ PSD_D void psd_gs3_lead(const psd_gparams& P, const psd_gstate& st, const psd_gw
 
 // One window (positions qs..qe of column hj, processed downwards) of stage 2; blockDim = 64 G, L links per wave
 // (psd_ghess_waves / psd_ghess_links).  Same state, lists and descriptor as psd_gq_hess_window.
-PSD_KERNEL_B(64 * PSD_GHESS_MAXWAVES) psd_gq_hess_step(psd_gparams P, int L, int scan) {
+PSD_D void psd_gq_hess_step_body(const psd_gparams& P, int L, int scan) {
     PSD_LDS_DECL;
     psd_gstate st = *P.st;
     PSD_ONE { P.desc->active = 0; P.desc->defer_run = 0; }
@@ -1611,6 +1619,7 @@ PSD_KERNEL_B(64 * PSD_GHESS_MAXWAVES) psd_gq_hess_step(psd_gparams P, int L, int
     PSD_PAR_FOR(m, p) { lcnt[m] = K; }
     PSD_PAR_FOR(t, w.be - w.bs + 1) { side[t] = A1(w.bs + t, hj); }
     PSD_WAVES_FOR(g, G) { psd_wv::psd_gwin_load(P, w, n, p, g, G); }
+    const long long tk1 = psd_clock();
     if (scan && p <= 64) {  // scan form: K rounds of (chain of pairs, two update phases)
         double* tab = (double*)((char*)psd_lds + ((((size_t)((char*)(lcnt + p) - (char*)psd_lds)) + 15) & ~(size_t)15));
         PSD_SYNC();
@@ -1621,9 +1630,13 @@ PSD_KERNEL_B(64 * PSD_GHESS_MAXWAVES) psd_gq_hess_step(psd_gparams P, int L, int
             PSD_SYNC();
         }
     }
+    const long long tk2 = psd_clock();
     PSD_WAVES_FOR(g, G) { psd_wv::psd_gwin_store(P, w, n, p, g, G); }
     PSD_PAR_FOR(t, w.be - w.bs + 1) { A1(w.bs + t, hj) = side[t]; }
     psd_gdesc_write(P, st, lcnt, w.bs, w.be, w.be + 1, n, 1, w.bs - 1, 0, 0, 0, 0, 1, hj + 1);
+    st.cyc[1] += tk1 - tk0;  // state + window load
+    st.cyc[2] += tk2 - tk1;  // the K positions
+    st.cyc[3] += psd_clock() - tk2;  // window store, descriptor
     st.nwindows += 1;
     st.kcur = qs - 1;
     if (st.kcur < hj + 1) {
@@ -1637,6 +1650,10 @@ PSD_KERNEL_B(64 * PSD_GHESS_MAXWAVES) psd_gq_hess_step(psd_gparams P, int L, int
     PSD_SYNC();
     PSD_ONE { *P.st = st; }
 }
+
+PSD_KERNEL_B(64 * PSD_GHESS_MAXWAVES) psd_gq_hess_step(psd_gparams P, int L, int scan) { psd_gq_hess_step_body(P, L, scan); }
+// the scan form runs four wavefronts: its own entry, so that the register budget is that of 256 threads, not of 1024
+PSD_KERNEL_B(256) psd_gq_hess_step_scan(psd_gparams P, int L) { psd_gq_hess_step_body(P, L, 1); }
 
 // rgeneralized.jl:890-1054: one window of the implicit double-shift sweep
 PSD_D void psd_gq_sweep_window(const psd_gparams& P, psd_gstate& st, double* ldsd, int* lcnt) {

@@ -13,7 +13,8 @@ import psd_amd  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
 rep = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-eng = psd_amd.Engine(device=0)
+# PSD_DIAG_LIB=1: the diagnostic build (tick logs, PSD_GDBG stage cycles)
+eng = psd_amd.Engine(device=0, libpath=psd_amd.DIAG_LIB_PATH) if os.environ.get("PSD_DIAG_LIB") else psd_amd.Engine(device=0)
 for _ in range(rep):
     if which == "cfg3":
         n, p = 1024, 64
