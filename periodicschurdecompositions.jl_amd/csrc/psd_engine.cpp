@@ -288,7 +288,10 @@ struct psd_ctx {
     int hess_pipe = 1;              // PSD_H2_PIPE=0: chain launches back to back on one stream; 2: pipe form also beside other contexts
     hipEvent_t evE[2] = {nullptr, nullptr}, evF[2] = {nullptr, nullptr}, evG[2] = {nullptr, nullptr};
     hipEvent_t evC[2] = {nullptr, nullptr};  // a tick's chase launch is done (rows-role deferral: psd_rdefer_edge)
-    hipStream_t stream5 = nullptr;           // the Schur-vector updates when stream2 carries both far parts of the H updates
+    // (the Schur-vector updates of a tick, when stream2 carries both far parts of the H updates, run on stream3: the panel
+    //  stream of the Hessenberg reduction, idle during the iteration and confined to the same compute units as stream2.  A
+    //  fifth stream of its own was measured first: the runtime multiplexes streams onto four hardware queues, the two chain
+    //  streams of the pipe form then shared one, and the reduction took 1.6 s instead of 0.41 s.)
 #endif
     int apply_worklist = 1;   // PSD_APPLY_WL=0: the grid-per-cursor bulk-apply kernels
     int apply_wl_grid = 2048; // workgroups of the work-list bulk apply (PSD_APPLY_WL_GRID)
@@ -1191,7 +1194,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     const bool cdef = mb && c->cdefer && (c->cdefer == 2 || ovl2) && nprob == 1;  // far rows of the column roles likewise (psd_cdefer_edge)
     bool rdef = cdef && (c->rdefer == 2 || (c->rdefer == 1 && n < 1536));  // and the far columns of the rows roles in front of them (psd_rdefer_edge)
 #ifndef PSD_HOSTSIM
-    if (zdef && !c->stream5) rdef = false;
+    if (zdef && !c->stream3) rdef = false;
 #endif
     bool far_pending = false;  // (the far column roles of the previous tick have been launched / are still to run)
     P.cdefer = cdef ? 1 : 0;
@@ -1316,7 +1319,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 // Both far parts of the H updates on stream2 (psd_rdefer_edge, psd_cdefer_edge), in the order rows, columns:
                 // the far columns of this tick's rows roles start as soon as the chases are done (evC) and run beside the
                 // near parts on this stream, the far rows of the column roles follow when those near parts are done (evE);
-                // the NEXT tick's near parts wait for both (evG).  The Schur vectors go to a stream of their own (stream5)
+                // the NEXT tick's near parts wait for both (evG).  The Schur vectors go to a stream of their own (stream3)
                 // so that they do not hold up the far H updates the next tick waits for.  The serial simulation runs both
                 // far parts at the latest point the streams allow, behind the next tick's chases.
                 const int wl_grid = c->apply_wl_grid;
@@ -1344,9 +1347,9 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 PSD_CHECK(launch_apply_wl(c, c->stream2, Pq, n, p, 1, NSL, zlo1, zhi1, 6, W, fgrid));
                 PSD_CHECK(hipEventRecord(c->evG[par], c->stream2));
                 if (zdef) {
-                    PSD_CHECK(hipStreamWaitEvent(c->stream5, c->evC[par], 0));
-                    PSD_CHECK(launch_apply_wl(c, c->stream5, Pq, n, p, 0, NSL, zlo1, zhi1, 4, W, fgrid));
-                    PSD_CHECK(hipEventRecord(c->evF[par], c->stream5));
+                    PSD_CHECK(hipStreamWaitEvent(c->stream3, c->evC[par], 0));
+                    PSD_CHECK(launch_apply_wl(c, c->stream3, Pq, n, p, 0, NSL, zlo1, zhi1, 4, W, fgrid));
+                    PSD_CHECK(hipEventRecord(c->evF[par], c->stream3));
                 } else {
                     PSD_CHECK(hipEventRecord(c->evF[par], c->stream2));
                 }
@@ -1476,7 +1479,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     }
 #ifndef PSD_HOSTSIM
     if (zdef || cdef) PSD_CHECK(hipStreamSynchronize(c->stream2));
-    if (rdef && zdef) PSD_CHECK(hipStreamSynchronize(c->stream5));
+    if (rdef && zdef) PSD_CHECK(hipStreamSynchronize(c->stream3));
 #else
     if (cdef && far_pending) {  // (the last tick's far column roles: its parity is the one the last launch used)
         psd_rparams Pl = P;
@@ -1637,8 +1640,6 @@ int psd_create(psd_ctx** ctx, int device) {
             for (int q = keep; q < ncu; ++q) mask[q >> 5] |= (1u << (q & 31));
             rc = hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)((ncu + 31) / 32), mask);
             if (rc == hipSuccess) c->far_grid = (ncu - keep) * 8;
-            if (rc == hipSuccess && hipExtStreamCreateWithCUMask(&c->stream5, (uint32_t)((ncu + 31) / 32), mask) != hipSuccess)
-                c->stream5 = nullptr;
         }
         if (rc != hipSuccess) rc = hipStreamCreate(&c->stream2);
         if (rc != hipSuccess) {
@@ -1764,7 +1765,7 @@ int psd_destroy(psd_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
-    if (c->stream5) (void)hipStreamDestroy(c->stream5);
+
     if (c->stream4) (void)hipStreamDestroy(c->stream4);
     if (c->stream) (void)hipStreamDestroy(c->stream);
 #endif
