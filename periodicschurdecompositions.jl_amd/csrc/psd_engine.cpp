@@ -285,6 +285,8 @@ struct psd_ctx {
     hipStream_t stream2 = nullptr;  // the far parts of the bulk updates (beside the next tick's chases)
     hipStream_t stream3 = nullptr;  // the panel updates of the Hessenberg reduction (beside its chain)
     hipStream_t stream4 = nullptr;  // every other chain launch of the Hessenberg reduction in pipe mode (hessenberg2_pipe)
+    int hess_pipe_depth = 3;        // chain launches in flight in the pipe form (real reduction): 3 with stream2 — idle during the reduction — as the
+                                    // third chain stream, or 2 (PSD_H2_DEPTH).  Measured at n = 1024, p = 64: 409 -> 399 ms
     int hess_pipe = 1;              // PSD_H2_PIPE=0: chain launches back to back on one stream; 2: pipe form also beside other contexts
     hipEvent_t evE[2] = {nullptr, nullptr}, evF[2] = {nullptr, nullptr}, evG[2] = {nullptr, nullptr};
     hipEvent_t evC[2] = {nullptr, nullptr};  // a tick's chase launch is done (rows-role deferral: psd_rdefer_edge)
@@ -768,6 +770,7 @@ int hessenberg2_pipe(psd_ctx* c, int n, int p, const psd_hess2_args& ha, int K) 
         ~SideStreams() {
             if (c->stream3) (void)hipStreamSynchronize(c->stream3);
             if (c->stream4) (void)hipStreamSynchronize(c->stream4);
+            if (c->stream2) (void)hipStreamSynchronize(c->stream2);
         }
     } side_streams{c};
 
@@ -775,19 +778,23 @@ int hessenberg2_pipe(psd_ctx* c, int n, int p, const psd_hess2_args& ha, int K) 
     const size_t lds = ((size_t)n + 8 + 2 * PSD_H2_NT + 64) * sizeof(double);
     const int Q = (n - 1) * p;
     const int nbatch = Q / K + 1;
-    if ((int)c->h2ev.size() < 26) {
+    if ((int)c->h2ev.size() < 34) {
         const size_t old = c->h2ev.size();
-        c->h2ev.resize(26, nullptr);
+        c->h2ev.resize(34, nullptr);
         for (size_t q = old; q < c->h2ev.size(); ++q) PSD_CHECK(hipEventCreateWithFlags(&c->h2ev[q], hipEventDisableTiming));
     }
     hipEvent_t* evA = c->h2ev.data();       // [8]: chain stream 0 reached the end of a batch
     hipEvent_t* evB = c->h2ev.data() + 8;   // [8]: a batch of panel updates is done
     hipEvent_t* evC = c->h2ev.data() + 16;  // [8]: chain stream 1 reached the end of a batch
     hipEvent_t evJ = c->h2ev[24], evK = c->h2ev[25];
-    hipStream_t S[2] = {c->stream, c->stream4};
+    hipEvent_t* evD = c->h2ev.data() + 26;  // [8]: chain stream 2 reached the end of a batch (three-deep form)
+    // NS chain streams: 2, or 3 with the iteration's second stream (idle here) as the third (c->hess_pipe_depth)
+    const int NS = (c->hess_pipe_depth >= 3 && c->stream2) ? 3 : 2;
+    hipStream_t S[3] = {c->stream, c->stream4, c->stream2};
     PSD_CHECK(hipEventRecord(evJ, c->stream));  // (whatever ran on the main stream before: the memsets, the caller's work)
     PSD_CHECK(hipStreamWaitEvent(c->stream3, evJ, 0));
     PSD_CHECK(hipStreamWaitEvent(c->stream4, evJ, 0));
+    if (NS == 3) PSD_CHECK(hipStreamWaitEvent(c->stream2, evJ, 0));
     hipLaunchKernelGGL((psd_hess2_link<NK, CR>), dim3(nC), dim3(PSD_H2_NT), lds, S[0], ha, n, 0, 1, nC, 0);  // staging
     int nextb = 0;
     const bool nobulk = psd_env_diag("PSD_H2_NOBULK") != nullptr;  // (timing experiment: the chain alone; results are wrong)
@@ -796,6 +803,10 @@ int hessenberg2_pipe(psd_ctx* c, int n, int p, const psd_hess2_args& ha, int K) 
         PSD_CHECK(hipEventRecord(evC[b & 7], S[1]));
         PSD_CHECK(hipStreamWaitEvent(c->stream3, evA[b & 7], 0));
         PSD_CHECK(hipStreamWaitEvent(c->stream3, evC[b & 7], 0));
+        if (NS == 3) {
+            PSD_CHECK(hipEventRecord(evD[b & 7], S[2]));
+            PSD_CHECK(hipStreamWaitEvent(c->stream3, evD[b & 7], 0));
+        }
         if (!nobulk) hipLaunchKernelGGL((psd_hess2_bulk<NK>), dim3(nT + nB, K), dim3(PSD_H2_NT), lds, c->stream3, ha, n, b * K, nT);
         PSD_CHECK(hipEventRecord(evB[b & 7], c->stream3));
         return 0;
@@ -803,12 +814,13 @@ int hessenberg2_pipe(psd_ctx* c, int n, int p, const psd_hess2_args& ha, int K) 
     int idx = 0;
     for (int i = 1; i <= n - 1; ++i)
         for (int j = p; j >= 1; --j, ++idx) {
-            hipStream_t s = S[(idx + 1) & 1];
+            hipStream_t s = S[(idx + 1) % NS];
             // chain#idx reads the matrix of link idx + 1, last updated by B(idx + 1 - p): batch (idx + 1 - p) / K; the launch
             // behind it, on the other stream, reads a matrix of the same batch
             const int need = idx + 1 - p;
             if (need >= 0 && need % K == 0) PSD_CHECK(hipStreamWaitEvent(s, evB[(need / K) & 7], 0));
             if (need >= 1 && (need - 1) % K == 0) PSD_CHECK(hipStreamWaitEvent(s, evB[((need - 1) / K) & 7], 0));
+            if (NS == 3 && need >= 2 && (need - 2) % K == 0) PSD_CHECK(hipStreamWaitEvent(s, evB[((need - 2) / K) & 7], 0));
             hipLaunchKernelGGL((psd_hess2_link<NK, CR>), dim3(nC), dim3(PSD_H2_NT), lds, s, ha, n, i, j, nC, 0);
             if (idx >= nextb * K + K - 1) {
                 PSD_CHECK(batch(nextb));
@@ -818,6 +830,10 @@ int hessenberg2_pipe(psd_ctx* c, int n, int p, const psd_hess2_args& ha, int K) 
     for (; nextb < nbatch; ++nextb) PSD_CHECK(batch(nextb));
     PSD_CHECK(hipEventRecord(evK, S[1]));
     PSD_CHECK(hipStreamWaitEvent(c->stream, evK, 0));
+    if (NS == 3) {
+        PSD_CHECK(hipEventRecord(evJ, S[2]));
+        PSD_CHECK(hipStreamWaitEvent(c->stream, evJ, 0));
+    }
     PSD_CHECK(hipStreamWaitEvent(c->stream, evB[(nbatch - 1) & 7], 0));
     if (psd_env_diag("PSD_H2_BULKBENCH")) {
         // diagnostics: the panel kernel ALONE on the finished matrices (the transformations it applies are the ring's
@@ -1664,6 +1680,7 @@ int psd_create(psd_ctx** ctx, int device) {
         }
         if (hipStreamCreate(&c->stream4) != hipSuccess) c->stream4 = nullptr;
         if (const char* e = psd_env("PSD_H2_PIPE")) c->hess_pipe = atoi(e);
+        if (const char* e = psd_env("PSD_H2_DEPTH")) c->hess_pipe_depth = atoi(e);
     }
 #endif
 #ifndef PSD_HOSTSIM
