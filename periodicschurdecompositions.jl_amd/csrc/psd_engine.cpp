@@ -789,7 +789,11 @@ int hessenberg2_pipe(psd_ctx* c, int n, int p, const psd_hess2_args& ha, int K) 
     hipEvent_t evJ = c->h2ev[24], evK = c->h2ev[25];
     hipEvent_t* evD = c->h2ev.data() + 26;  // [8]: chain stream 2 reached the end of a batch (three-deep form)
     // NS chain streams: 2, or 3 with the iteration's second stream (idle here) as the third (c->hess_pipe_depth)
-    const int NS = (c->hess_pipe_depth >= 3 && c->stream2) ? 3 : 2;
+    // (three only while three launches fit the chip beside each other with room to spare — n <= 1024: 3 x 129 workgroups of
+    //  the 16-column kernel, four to a CU.  The 32-column kernel of larger orders runs two workgroups per CU: a third launch
+    //  would take slots the second still needs, and the first could wait for ever — measured: n = 2048 ran into the bounded
+    //  wait, n = 1536 took 1.67 s instead of 1.41 s)
+    const int NS = (c->hess_pipe_depth >= 3 && c->stream2 && n <= 1024) ? 3 : 2;
     hipStream_t S[3] = {c->stream, c->stream4, c->stream2};
     PSD_CHECK(hipEventRecord(evJ, c->stream));  // (whatever ran on the main stream before: the memsets, the caller's work)
     PSD_CHECK(hipStreamWaitEvent(c->stream3, evJ, 0));
