@@ -98,7 +98,8 @@ int psd_get_hess_pipe(psd_ctx* ctx);
  * units of a slot as the ranks; an inbox is a plain device pointer, across GPUs it would be a peer mapping.  The
  * result does not depend on the number of slices (the reflectors are functions of the vectors handed over: G = 2 and
  * G = 4 agree to the bit) and agrees with slices = 1 to rounding.  1 (default): off.
- * Honoured for p <= 64 and at least two factors per slice; every wait is bounded, a hand-over that never arrives ends
+ * Honoured for p <= 64 and at least two factors per slice, and clamped to what can be resident together (64 x G
+ * workgroups, one per compute unit: G <= 4 on the 256 CUs of one MI355X); every wait is bounded, a hand-over that never arrives ends
  * the call with PSD_INFO_RUNTIME.  DESIGN.md section 7c. */
 int psd_set_slices(psd_ctx* ctx, int slices);
 int psd_get_slices(psd_ctx* ctx);

@@ -272,6 +272,7 @@ struct psd_ctx {
                            // gate by 3.6 % (tests/gpu_fuzz_real.py; worst case 0.80 of the gate with 8) - not kept
     int train_long = 256;  // bulges per train of the multi-block scheduler when slots can be recycled (PSD_TRAIN_LONG; 0: one bulge per slot)
     int band_helper = 1;  // PSD_BAND_HELPER=0: a leader computes the product band of its decisions itself
+    int redge = 0, cedge = 0;  // near / far boundaries of the deferred roles (0: psd_rdefer_edge / psd_cdefer_edge; PSD_RDEFER_EDGE, PSD_CDEFER_EDGE)
     int rdefer = 1;   // far columns of the rows roles on stream2 as well, in front of the far column roles (psd_rdefer_edge); needs cdefer.
                       // 1: for n < 1536 (measured: iteration 358 -> 346 ms at n = 1024, p = 64; 1641 -> 1661 ms at n = 2048: the tick
                       // is bound by the bytes of the bulk updates there, whatever runs beside what), 2: always, 0: never (PSD_RDEFER)
@@ -297,6 +298,7 @@ struct psd_ctx {
 #endif
     int apply_worklist = 1;   // PSD_APPLY_WL=0: the grid-per-cursor bulk-apply kernels
     int apply_wl_grid = 2048; // workgroups of the work-list bulk apply (PSD_APPLY_WL_GRID)
+    int ncu = 0;              // compute units of the device (0: unknown)
     int slices = 1;           // factor-sliced sweep windows of the real engine (psd_set_slices, psd_slice3.h): workgroups per window
     unsigned char* slmem = nullptr;  // command blocks and inboxes of the sliced windows, then the error word of their waits
     int chase3 = 1;           // scan chase of the real periodic QR sweep (psd_chase3.h; PSD_C3=0: the two-wave / one-wave chases)
@@ -1218,12 +1220,17 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
 #endif
     bool far_pending = false;  // (the far column roles of the previous tick have been launched / are still to run)
     P.cdefer = cdef ? 1 : 0;
+    P.redge = c->redge;
+    P.cedge = c->cedge;
     // factor-sliced sweep windows (psd_set_slices; psd_slice3.h): G workgroups per slot, each with the window blocks of
     // its contiguous slice of the period; needs the scan chase, the slot scheduler and at least two factors per slice
     int slG = 1;
 #ifndef PSD_HOSTSIM
     if (c->slices > 1 && mb && scan3 && nprob == 1 && p / c->slices >= 2 && c->slices <= PSD_SL_MAXG) {
         slG = c->slices;
+        // (every workgroup of the launch takes the LDS of a whole CU and the slices of a window wait for one another:
+        //  all PSD_SLOTS x G of them have to be resident together — G <= 4 on the 256 CUs of an MI355X; more is clamped)
+        while (slG > 1 && c->ncu > 0 && PSD_SLOTS * slG > c->ncu) slG /= 2;
         const size_t slbytes = (size_t)PSD_SLOTS * (PSD_SL_CMD_BYTES + PSD_SL_MAXG * PSD_SL_BOX_BYTES) + 64;
         if (!c->slmem) PSD_CHECK(psd_rt_malloc((void**)&c->slmem, slbytes));
         PSD_CHECK(psd_rt_memset(c->slmem, 0, slbytes, c->stream));
@@ -1651,6 +1658,7 @@ int psd_create(psd_ctx** ctx, int device) {
         // is confined to the CUs the chases do not need (CU mask), PSD_OVERLAP_CUS of them stay free for the slots.
         int ncu = 0;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+        c->ncu = ncu;
         int keep = PSD_SLOTS;
         if (const char* e = psd_env_diag("PSD_OVERLAP_CUS")) keep = atoi(e);
         hipError_t rc = hipErrorInvalidValue;
@@ -1696,6 +1704,8 @@ int psd_create(psd_ctx** ctx, int device) {
 #endif
     if (const char* e = psd_env("PSD_CDEFER")) c->cdefer = atoi(e);
     if (const char* e = psd_env("PSD_RDEFER")) c->rdefer = atoi(e);
+    if (const char* e = psd_env("PSD_RDEFER_EDGE")) c->redge = atoi(e);
+    if (const char* e = psd_env("PSD_CDEFER_EDGE")) c->cedge = atoi(e);
     if (const char* e = psd_env("PSD_ORD_PIPE")) c->ord_pipe = atoi(e);
     if (const char* e = psd_env("PSD_FORMQ_BLOCKED")) c->formq_blocked = atoi(e);
     if (const char* e = psd_env("PSD_BAND_HELPER")) c->band_helper = atoi(e);
@@ -2286,6 +2296,7 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
 #ifndef PSD_HOSTSIM
     if (c->slices > 1 && M > 1 && zscan3 && p / c->slices >= 2 && c->slices <= PSD_SL_MAXG) {
         zslG = c->slices;
+        while (zslG > 1 && c->ncu > 0 && M * zslG > c->ncu) zslG /= 2;  // (as iterate_dev: the M x G workgroups must be resident together)
         const size_t slbytes = (size_t)PSD_SLOTS * (PSD_SL_CMD_BYTES + PSD_SL_MAXG * PSD_SL_BOX_BYTES) + 64;
         if (!c->slmem) PSD_CHECK(psd_rt_malloc((void**)&c->slmem, slbytes));
         PSD_CHECK(psd_rt_memset(c->slmem, 0, slbytes, c->stream));

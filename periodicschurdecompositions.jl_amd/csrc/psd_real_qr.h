@@ -233,6 +233,7 @@ struct psd_rparams {
     // 1: the far part of a tick's column roles (rows more than PSD_CDEFER_EDGE above the window, psd_apply_desc::rcut) runs
     // on the second stream beside the NEXT tick's chases (iterate_dev; psd_rq_apply_wl modes 5 / 6)
     int cdefer;
+    int redge, cedge;  // psd_rdefer_edge / psd_cdefer_edge when > 0 (tuning: more of a role's lines in its near part)
 };
 // Deferred column roles.  The column role of a window (owner m's transformations on columns plo..phi of H_{m-1}) reaches
 // from the top of the matrix down to the window.  What the next launch of chases, bands, shift blocks and decisions reads
@@ -1447,13 +1448,13 @@ PSD_D void psd_desc_write(const psd_rparams& P, psd_rstate& st, const int* lcnt,
         d.prob = st.prob;
         d.split = (split && st.wantT) ? 1 : 0;
         {   // first far column of the rows role (psd_rdefer_edge)
-            int cc = phi + 1 + psd_rdefer_edge(st.Wmax);
+            int cc = phi + 1 + ((P.redge > 0) ? P.redge : psd_rdefer_edge(st.Wmax));
             if (cc < lc0) cc = lc0;
             if (cc > lc1 + 1) cc = lc1 + 1;
             d.cut = cc;
         }
         {   // first near row of the column role (psd_cdefer_edge): rows rr0 .. rcut - 1 may run one tick late
-            int rc = plo - psd_cdefer_edge(st.Wmax);
+            int rc = plo - ((P.cedge > 0) ? P.cedge : psd_cdefer_edge(st.Wmax));
             if (rc < rr0) rc = rr0;
             if (rc > rr1 + 1) rc = rr1 + 1;
             d.rcut = rc;

@@ -50,6 +50,30 @@ def test_sliced_windows_real(gpu_engine):
             assert np.array_equal(res[2].Z[j], res[4].Z[j]), (n, p, lr, j)
 
 
+def test_eight_slices_are_clamped_to_what_fits(gpu_engine):
+    """G = 8 on one GPU: 64 x 8 workgroups that each take a compute unit's LDS and wait for one another cannot all be
+    resident on 256 CUs, so the engine runs 4 slices (clamped, not an error and not a hang) — and, the result not depending
+    on the number of slices, gives exactly what G = 4 gives."""
+    import torch
+
+    torch.cuda.init()
+    import psd_amd
+
+    e8 = psd_amd.Engine(device=0)
+    e8.set_slices(8)
+    e4 = psd_amd.Engine(device=0)
+    e4.set_slices(4)
+    for (n, p, lr) in [(200, 16, "R"), (150, 64, "L")]:
+        A = pt.bench_factors(n, p, seed=950 + n + p)
+        p8 = e8.pschur(A, lr)
+        p4 = e4.pschur(A, lr)
+        ok, err = e8.checkpsd(p8, A, thresh=100 * np.sqrt(max(n / 32, 1)))
+        assert ok, (n, p, float(err.max()))
+        assert np.array_equal(p8.values, p4.values)
+        for j in range(p):
+            assert np.array_equal(p8.Ts[j], p4.Ts[j]) and np.array_equal(p8.Z[j], p4.Z[j])
+
+
 def test_slices_argument_checks(gpu_engine):
     import psd_amd
 
