@@ -19,7 +19,7 @@ def _run(eng, A, S, lr):
     return eng.pschur_(W, lr) if S is None else eng.pschur_(W, lr, S=S)
 
 
-@pytest.mark.parametrize("kind,n,p", [("d", 260, 12), ("d", 1024, 8), ("z", 150, 10), ("dg", 120, 6), ("zg", 90, 5)])
+@pytest.mark.parametrize("kind,n,p", [("d", 260, 12), ("d", 1024, 8), ("z", 150, 10), ("z", 512, 16), ("dg", 120, 6), ("zg", 90, 5)])
 def test_two_ranks_one_after_the_other(gpu_engine, kind, n, p):
     eng = gpu_engine
     cplx = kind.startswith("z")
