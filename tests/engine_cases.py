@@ -585,6 +585,34 @@ def case_zordschur_pipelined(make_engine, sizes, gsizes):
         assert np.allclose(res[0].values[fin], res[1].values[fin], rtol=1e-6, atol=1e-8 * abs(res[1].values[fin]).max())
 
 
+def case_ordschur_pipelined_failure(make_engine):
+    """A swap that cannot be done (two equal eigenvalues, rows 40 and 45 of 60) while earlier selected eigenvalues are
+    still travelling: the pipelined driver stops the later blocks, lets the earlier ones arrive and raises what the
+    serial driver raises (ComplexF64: SingularException from the cyclic Sylvester system)."""
+    import psd_amd
+
+    n, p = 60, 2
+    rng = np.random.default_rng(5)
+    T = [np.asfortranarray(np.triu(rng.standard_normal((n, n)))).astype(np.complex128) for _ in range(p)]
+    for j in range(p):
+        T[j][np.diag_indices(n)] = 1.0 + np.arange(n) * 0.1 * (j + 1)
+        T[j][44, 44] = T[j][39, 39]
+    Z = [np.asfortranarray(np.eye(n, dtype=np.complex128)) for _ in range(p)]
+    lam = np.prod([np.diag(t) for t in T], axis=0).astype(complex)
+    sel = np.zeros(n, dtype=bool)
+    sel[[9, 19, 44, 50]] = True
+    raised = []
+    for pipe in ("1", "0"):
+        eng = make_engine({"PSD_ORD_PIPE": pipe})
+        P = psd_amd.PeriodicSchur([np.asfortranarray(t.copy()) for t in T], [np.asfortranarray(z.copy()) for z in Z], lam.copy(), "R", 1)
+        try:
+            eng.ordschur_(P, sel)
+            raised.append(None)
+        except (psd_amd.SingularException, psd_amd.IllConditionedException) as ex:
+            raised.append(type(ex).__name__)
+    assert raised[0] is not None and raised[0] == raised[1], raised
+
+
 def case_rordschur_edge(eng):
     import psd_amd
 

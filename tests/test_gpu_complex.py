@@ -158,6 +158,7 @@ def test_zordschur_pipelined(monkeypatch):
 
     ec.case_zordschur_pipelined(make, [(130, 2, "R", 0.5), (150, 4, "L", 0.3), (300, 16, "R", 0.4), (256, 40, "L", 0.5)],
                                 [(130, 3, "R"), (140, 4, "L"), (200, 12, "R")])
+    ec.case_ordschur_pipelined_failure(make)
 
 
 def test_ordschur_alignments(gpu_engine):
