@@ -167,32 +167,56 @@ PSD_D void psd_gdesc_write(const psd_gparams& P, psd_gstate& st, const int* lcnt
     PSD_SYNC();
 }
 
+// index of entry (a, b) (1-based inside the active block of nn rows, m = nn - 1) among the nine staged entries of a factor
+// (psd_g_qzrots): the trailing triangle first — for nn = 3 it overlaps the leading one, same values either way
+PSD_HD int psd_g_qsidx(int a, int b, int m, int nn) {
+    if (a == nn && b == nn) return 8;
+    if (a == m && b == nn) return 7;
+    if (a == m && b == m) return 6;
+    if (a == 1) return b - 1;
+    if (a == 2) return 1 + b;
+    return 5;
+}
+
 // rgeneralized.jl:1140-1359 `_qzrots` (MB03AF 'Double'): starting rotations of an implicit double-shift sweep
 // on the active block i1..i1+nb-1, from HBM.
+// scr: LDS, 12 p doubles: the entries of the factors the two passes read — the leading 3 x 3 upper triangle and the
+// trailing 2 x 2 upper triangle of the active block — staged by one lane per factor (read one after the other from device
+// memory inside the chains they cost a memory round trip per factor and pass: 59 us per call at p = 32).
 PSD_D void psd_g_qzrots(const psd_gparams& P, int n, int p, int i1, int nb, double& c1o, double& s1o, double& c2o,
-                        double& s2o) {
+                        double& s2o, double* scr) {
     const psd_mat<double> H1 = psd_gfac(P, n, 1);
+    PSD_SYNC();
+    PSD_PAR_FOR(t, p) {
+        const psd_mat<double> Hl = psd_gfac(P, n, t + 1);
+        double* q = scr + 12 * t;
+        const int e = i1 + nb - 1;
+        q[0] = Hl(i1, i1); q[1] = Hl(i1, i1 + 1); q[2] = Hl(i1, i1 + 2);
+        q[3] = Hl(i1 + 1, i1 + 1); q[4] = Hl(i1 + 1, i1 + 2); q[5] = Hl(i1 + 2, i1 + 2);
+        q[6] = Hl(e - 1, e - 1); q[7] = Hl(e - 1, e); q[8] = Hl(e, e);
+    }
+    PSD_SYNC();
     double c1, s1, c2, s2, r, al, be, ga, de;
     psd_givens(H1(i1, i1), H1(i1 + 1, i1), c1, s1, r);
     psd_givens(r, 1.0, c2, s2, r);
     const int i2 = i1 + nb - 1;
     for (int l = p; l >= 2; --l) {
-        const psd_mat<double> Hl = psd_gfac(P, n, l);
+        const double* q = scr + 12 * (l - 1);  // 0..5: (1,1) (1,2) (1,3) (2,2) (2,3) (3,3) of the active block; 6..8: (m,m) (m,nn) (nn,nn)
         if (psd_gsig(P, l)) {
-            al = c2 * (c1 * Hl(i1, i1) + s1 * Hl(i1, i1 + 1));
-            be = s1 * c2 * Hl(i1 + 1, i1 + 1);
-            ga = s2 * Hl(i2, i2);
+            al = c2 * (c1 * q[0] + s1 * q[1]);
+            be = s1 * c2 * q[3];
+            ga = s2 * q[8];
             psd_givens(al, be, c1, s1, r);
             double v;
             psd_givens(r, ga, c2, s2, v);
         } else {
-            al = c1 * s2 * Hl(i1, i1);
-            ga = s1 * Hl(i1, i1);
-            be = s2 * (c1 * Hl(i1, i1 + 1) + s1 * Hl(i1 + 1, i1 + 1));
-            de = c1 * Hl(i1 + 1, i1 + 1) - s1 * Hl(i1, i1 + 1);
+            al = c1 * s2 * q[0];
+            ga = s1 * q[0];
+            be = s2 * (c1 * q[1] + s1 * q[3]);
+            de = c1 * q[3] - s1 * q[1];
             psd_givens(de, ga, c1, s1, r);
             al = c1 * al + s1 * be;
-            be = c2 * Hl(i2, i2);
+            be = c2 * q[8];
             psd_givens(be, al, c2, s2, r);
         }
     }
@@ -219,8 +243,9 @@ PSD_D void psd_g_qzrots(const psd_gparams& P, int n, int p, int i1, int nb, doub
     psd_givens(val2, r, c5, s5, r);
     psd_givens(val3, r, c6, s6, r);
     for (int i = p; i >= 2; --i) {
-        const psd_mat<double> Hi = psd_gfac(P, n, i);
-#define PSD_V(a, b) Hi(i1 - 1 + (a), i1 - 1 + (b))
+        const double* q = scr + 12 * (i - 1);
+        // (the staged entries by name: PSD_V(a, b) with a, b in 1..3 from the leading triangle, m / nn from the trailing one)
+#define PSD_V(a, b) q[psd_g_qsidx((a), (b), m, nn)]
         if (psd_gsig(P, i)) {
             double ss = s3 * s4;
             const double sss = s2 * ss, ssss = s1 * sss;
@@ -2234,7 +2259,7 @@ PSD_D bool psd_gq_check(const psd_gparams& P, psd_gstate& st, double* ldsd, doub
         return false;
     }
     PSD_SYNC();
-    psd_g_qzrots(P, n, p, ifirst, ilast - ifirst + 1, st.c1, st.s1, st.c2, st.s2);
+    psd_g_qzrots(P, n, p, ifirst, ilast - ifirst + 1, st.c1, st.s1, st.c2, st.s2, ldsd);
     PSD_GDBG_STAMP(2);
     st.train_n = 1;
     if ((st.train_want >= 2 || st.train_want == -2) && P.tshift != nullptr && ilast - ifirst + 1 >= 4) {
