@@ -1246,6 +1246,18 @@ PSD_D bool psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
             // (2 nb).  The width with the least modelled time per sweep is taken (narrow windows: more, cheaper ticks and
             // more cursors).
             const int w = i - l + 1;
+            // (round 4: with the scan chase a position costs little and hardly depends on p, so what a tick costs beside
+            //  its positions weighs more the wider the active block is — the bulk updates grow with it.  Measured with fixed
+            //  ratios (tools/r04/run_ff.sh): the best o / c is about 104 at w = 256, 400 at w = 512, 800 .. 3200 at w = 1024
+            //  for p = 16 (iteration 394 -> 353 ms), and makes no difference at p = 64, where the LDS caps the width: o / c
+            //  grows with (w / 256)^2.)
+            double ocw = (double)st.train_oc;
+            if (w > 256) {
+                double f = (double)w / 256.0;
+                f *= f;
+                if (f > 32.0) f = 32.0;
+                ocw *= f;
+            }
             int mt = st.train_want;
             if (mt > PSD_TRAIN_MAX) mt = PSD_TRAIN_MAX;
             int nb = st.Wmax - 4, m = 1;
@@ -1257,7 +1269,7 @@ PSD_D bool psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
                 if (mc < 2) break;
                 const int spc = (gap == 1) ? (nbc + 4) : (2 * nbc);
                 const double cost = (double)((w + nbc - 1) / nbc + ((mc - 1) * spc + nbc - 1) / nbc) *
-                                    (double)(nbc * st.p + st.train_oc) / mc;
+                                    ((double)(nbc * st.p) + ocw) / mc;
                 if (cost < best) {
                     best = cost;
                     nb = nbc;
@@ -1277,7 +1289,7 @@ PSD_D bool psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
                     int mx = 1 + (w - nbc) / spx;
                     if (mx > mt) mx = mt;
                     if (sneed > PSD_TRAIN_MAX - 1 || mx < 2 || w / st.train_wdiv <= sneed + 1) continue;
-                    const double thr = (double)sneed * nbc / (double)(nbc * st.p + st.train_oc);
+                    const double thr = (double)sneed * nbc / ((double)(nbc * st.p) + ocw);
                     if (thr > bestthr) {
                         bestthr = thr;
                         nbl = nbc;
