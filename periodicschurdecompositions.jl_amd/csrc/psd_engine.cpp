@@ -266,7 +266,9 @@ struct psd_ctx {
         hi = lo + base + (shard_rank < rem ? 1 : 0);
     }
     int train_stop = 1;    // a long train stops admitting bulges once one of them leaves the bottom converged (PSD_TRAIN_STOP=0: never)
-    int train_wdiv = 8;    // a long train has at most (range width) / train_wdiv bulges (PSD_TRAIN_WDIV).  4 is 2.5 % (n = 1024, p = 64) to
+    int train_wdiv = 0;    // a long train has at most (range width) / train_wdiv bulges (PSD_TRAIN_WDIV); 0: 6 for periods 12 .. 32 (round 4,
+                           // scan chase: 3 .. 11 % faster there — 1024 x 16: 377 -> 334 ms — with the residuals where they were;
+                           // 5 % slower at p = 64), 8 otherwise.  4 is 2.5 % (n = 1024, p = 64) to
                            // 16 % (n = 512, p = 16) faster on the iteration and was tried as the default at the end of round 3: the
                            // residual grows by 8-9 % on the bench inputs, and 1 of 485 random cases (n = 371, p = 8) left the residual
                            // gate by 3.6 % (tests/gpu_fuzz_real.py; worst case 0.80 of the gate with 8) - not kept
@@ -1277,7 +1279,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     int Mw = M;
     if (mb && c->train_mb_m > Mw && c->train_m >= 32) Mw = (c->train_mb_m > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : c->train_mb_m;
     PSD_LAUNCH(psd_rq_init, psd_dim3(p, nprob), 256, 256 * 8, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, Mw, train_oc,
-               mb ? 1 : 0, mb ? c->cgap : 2, c->train_long, c->train_wdiv);
+               mb ? 1 : 0, mb ? c->cgap : 2, c->train_long, (c->train_wdiv > 0) ? c->train_wdiv : ((p >= 12 && p <= 32) ? 6 : 8));
     const size_t lds_apply = apply_lds_bytes();
     const int tiles = (n + PSD_APPLY_NT - 1) / PSD_APPLY_NT;
     const int batch = 32;
@@ -1711,7 +1713,7 @@ int psd_create(psd_ctx** ctx, int device) {
     if (const char* e = psd_env("PSD_BAND_HELPER")) c->band_helper = atoi(e);
     if (const char* e = psd_env_diag("PSD_TRAIN_LONG")) c->train_long = atoi(e);
     if (const char* e = psd_env_diag("PSD_TRAIN_STOP")) c->train_stop = atoi(e);
-    if (const char* e = psd_env_diag("PSD_TRAIN_WDIV")) c->train_wdiv = atoi(e) > 0 ? atoi(e) : 8;
+    if (const char* e = psd_env_diag("PSD_TRAIN_WDIV")) c->train_wdiv = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = psd_env("PSD_MB")) c->mblock = atoi(e);
     if (const char* e = psd_env_diag("PSD_TRAIN_MB")) c->train_mb_m = atoi(e);
     if (const char* e = psd_env_diag("PSD_APPLY_WL")) c->apply_worklist = atoi(e);

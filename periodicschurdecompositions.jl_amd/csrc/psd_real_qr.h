@@ -1252,7 +1252,10 @@ PSD_D bool psd_rq_shift(const psd_rparams& P, psd_rstate& st, double* work, int*
             //  for p = 16 (iteration 394 -> 353 ms), and makes no difference at p = 64, where the LDS caps the width: o / c
             //  grows with (w / 256)^2.)
             double ocw = (double)st.train_oc;
-            if (w > 256) {
+            // (periods of 12 and more only: short periods keep the schedule their residual margins were measured with — the
+            //  hard inputs of DESIGN section 6, n = 600 .. 700 with p <= 11, sit at 0.71 .. 0.94 of the gate with it and one of
+            //  them at 1.03 with the wider windows)
+            if (w > 256 && st.p >= 12) {
                 double f = (double)w / 256.0;
                 f *= f;
                 if (f > 32.0) f = 32.0;
