@@ -490,7 +490,7 @@ PSD_D void psd_c3_run(const psd_c2& Cin, int, int, int taboff) {
         }
         const int ex = psd_c3_expo(psd_c3_max3(x0, x1, x2));
         // factor j at index j (1..p); index 1 = H_1
-        double U[65][6], zo[65][3], v1[65], v2[65], tau[65], beta[65], bz[65];
+        double U[65][6], zo[65][3], v1[65], v2[65], tau[65], beta[65], bz[65] = {0.0};
         int ecor[65], eu[65];
         for (int j = 2; j <= p; ++j) {
             const double* q = wb + (j - 1) * bsz + (k - bs) * ld + (k - bs);

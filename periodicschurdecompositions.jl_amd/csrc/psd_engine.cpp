@@ -2261,6 +2261,7 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
     P.zcoff = zscan3 ? (int)((size_t)p * W * (W + 1) * sizeof(psd_z)) : 0;
     P.zc3off = zscan3 ? (int)step_lds_scratch_end(p, W, 16, false) : 0;
     const int zwaves = zscan3 ? PSD_ZC3_WAVES : 1;
+    (void)zwaves;  // (the serial simulation launches one simulated wavefront)
     P.zslG = 1;
     P.zslmem = nullptr;
     P.zslerr = nullptr;
@@ -2542,6 +2543,7 @@ int zgiterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
     // (scan form of the stage-2 kernel, the default; PSD_HESS_SCAN=0: the pipeline of beats over the factors of round 2)
     int hess_scan = 1;
     if (const char* e = psd_env("PSD_HESS_SCAN")) hess_scan = atoi(e);
+    (void)hess_scan;
 #ifndef PSD_HOSTSIM
     if (hess_pipe && lds_hess > c->zghess_lds_set) {
         PSD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(psd_zgq_hess_step),
@@ -3378,6 +3380,7 @@ int giterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, const uint8_t
     // wavefronts' command block behind everything the state machine uses
     P.gcoff = P.gtaboff = 0;
     int gwaves = 1;
+    (void)gwaves;
     {
         int gscan = 1;
         if (const char* e = psd_env("PSD_GSCAN")) gscan = atoi(e);

@@ -2297,6 +2297,7 @@ PSD_D void psd_rq_qr_window(const psd_rparams& P, psd_rstate& st, double* ldsd, 
     }
 #else
     const bool sliced = false;
+    (void)sliced;
 #endif
     psd_c3_winio(P, w, n, p0, false);
     const long long tc1 = psd_clock();

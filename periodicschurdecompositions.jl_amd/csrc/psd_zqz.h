@@ -848,6 +848,7 @@ PSD_D void psd_zq_sweep_window(const psd_zparams& P, psd_zstate& st, psd_z* ldsz
     }
 #else
     const bool sliced = false;
+    (void)sliced;
 #endif
     psd_zc3_winio(P, w, n, p0, false);
     const long long tc1 = psd_clock();
