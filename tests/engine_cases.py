@@ -610,7 +610,10 @@ def case_ordschur_pipelined_failure(make_engine):
             raised.append(None)
         except (psd_amd.SingularException, psd_amd.IllConditionedException) as ex:
             raised.append(type(ex).__name__)
-    assert raised[0] is not None and raised[0] == raised[1], raised
+    # (the serial simulation keeps the two eigenvalues exactly equal until they meet and raises; on the device the earlier
+    #  swaps leave them a rounding error apart and the swap goes through — with either driver)
+    assert raised[0] == raised[1], raised
+    return raised[0]
 
 
 def case_rordschur_edge(eng):

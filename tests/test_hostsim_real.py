@@ -100,7 +100,7 @@ def test_zordschur_pipelined(built, monkeypatch):
         return psd_amd.Engine(libpath=lib)
 
     ec.case_zordschur_pipelined(make, [(130, 2, "R", 0.5), (150, 4, "L", 0.3)], [(130, 3, "R"), (140, 4, "L")])
-    ec.case_ordschur_pipelined_failure(make)
+    assert ec.case_ordschur_pipelined_failure(make) is not None  # (exact arithmetic order of the simulation: the swap is refused)
 
 
 def test_rphessenberg(sim_engine):
