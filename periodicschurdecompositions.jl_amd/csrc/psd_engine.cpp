@@ -274,6 +274,7 @@ struct psd_ctx {
                            // gate by 3.6 % (tests/gpu_fuzz_real.py; worst case 0.80 of the gate with 8) - not kept
     int train_long = 256;  // bulges per train of the multi-block scheduler when slots can be recycled (PSD_TRAIN_LONG; 0: one bulge per slot)
     int band_helper = 1;  // PSD_BAND_HELPER=0: a leader computes the product band of its decisions itself
+    int zcdefer = 0;  // ComplexF64 engine: far rows of the column roles on the second stream (PSD_ZCDEFER; see ziterate_dev)
     int redge = 0, cedge = 0;  // near / far boundaries of the deferred roles (0: psd_rdefer_edge / psd_cdefer_edge; PSD_RDEFER_EDGE, PSD_CDEFER_EDGE)
     int rdefer = 1;   // far columns of the rows roles on stream2 as well, in front of the far column roles (psd_rdefer_edge); needs cdefer.
                       // 1: for n < 1536 (measured: iteration 358 -> 346 ms at n = 1024, p = 64; 1641 -> 1661 ms at n = 2048: the tick
@@ -1706,6 +1707,7 @@ int psd_create(psd_ctx** ctx, int device) {
 #endif
     if (const char* e = psd_env("PSD_CDEFER")) c->cdefer = atoi(e);
     if (const char* e = psd_env("PSD_RDEFER")) c->rdefer = atoi(e);
+    if (const char* e = psd_env("PSD_ZCDEFER")) c->zcdefer = atoi(e);
     if (const char* e = psd_env("PSD_RDEFER_EDGE")) c->redge = atoi(e);
     if (const char* e = psd_env("PSD_CDEFER_EDGE")) c->cedge = atoi(e);
     if (const char* e = psd_env("PSD_ORD_PIPE")) c->ord_pipe = atoi(e);
@@ -2258,6 +2260,7 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
     // scan chase (psd_zchase3.h, the default): PSD_ZC3_WAVES wavefronts per chase workgroup, the command block in the
     // reduction scratch behind the window image (idle while a window is chased), the rotation table behind the scratch
     const bool zscan3 = c->chase3 && p >= PSD_ZC3_MINP && p <= PSD_ZC3_MAXP;
+    P.zcdefer = 0;
     P.zcoff = zscan3 ? (int)((size_t)p * W * (W + 1) * sizeof(psd_z)) : 0;
     P.zc3off = zscan3 ? (int)step_lds_scratch_end(p, W, 16, false) : 0;
     const int zwaves = zscan3 ? PSD_ZC3_WAVES : 1;
@@ -2316,6 +2319,13 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
 #else
     const bool zdef = M > 1 && wantZ && c->overlap == 2;
 #endif
+    // far rows of the column roles on the second stream as well (psd_zparams::zcdefer): OFF by default — measured at
+    // configs[2] (n = 1024, p = 64): iteration 2.02 s without, 2.10-2.12 s with it (the tick is bound by the bytes of its
+    // bulk updates; the extra launch and the cross-stream events cost more than the overlap gives).  PSD_ZCDEFER=1 turns
+    // it on (bit-identical results: tests/test_hostsim_complex.py::test_zcolumn_roles_deferred).
+    const bool zcdef = zdef && c->zcdefer != 0 && c->apply_worklist != 0;
+    bool far_pending = false;
+    P.zcdefer = zcdef ? 1 : 0;
     // (the tile holds the rows a window's lists span: at most W + 1, not the 32 the kernel could serve — at p = 64 (W = 12) that is
     //  13.5 KiB instead of 33 KiB per single-wave workgroup, twelve of them per CU instead of four)
     const size_t lds_apply = PSD_ZTR_LDS_BYTES + (size_t)((W + 2 < 32) ? (W + 2) : 32) * (PSD_ZAPPLY_NT + 1) * sizeof(psd_z);
@@ -2361,7 +2371,7 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
 #endif
             P.tick = (int)launched;
             const int par = zdef ? (int)(launched & 1) : 0;
-            psd_zparams Pq = P;
+            psd_zparams Pq = P, Pprev = P;
             if (zdef) {
 #ifndef PSD_HOSTSIM
                 if (launched >= 2) PSD_CHECK(hipStreamWaitEvent(c->stream, c->evF[par], 0));  // (the Z launch that read this parity's lists)
@@ -2369,7 +2379,11 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
                 Pq.desc = P.desc + (size_t)par * PSD_TRAIN_MAX;
                 Pq.cnt = P.cnt + (size_t)par * PSD_TRAIN_MAX * (p + 8);
                 Pq.tr = P.tr + (size_t)par * PSD_TRAIN_MAX * p * PSD_ZTR_CAP;
+                Pprev.desc = P.desc + (size_t)(par ^ 1) * PSD_TRAIN_MAX;
+                Pprev.cnt = P.cnt + (size_t)(par ^ 1) * PSD_TRAIN_MAX * (p + 8);
+                Pprev.tr = P.tr + (size_t)(par ^ 1) * PSD_TRAIN_MAX * p * PSD_ZTR_CAP;
             }
+            (void)Pprev;
             if (M == 1)
                 PSD_LAUNCH2(psd_zq_step, psd_dim3(1), PSD_STEP_NT, zwaves, lds_step, c->stream, P);
             else
@@ -2385,15 +2399,34 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
             } else if (zdef) {
                 // Schur-vector updates one stream over (as iterate_dev: nothing reads Z_m before the iteration ends and only
                 // owner m's lists touch it): they start when the tick's H updates are done and run beside the next tick's
-                // chases; the lists of a tick are double-buffered by parity, the chase that reuses a parity awaits evF
+                // chases; the lists of a tick are double-buffered by parity, the chase that reuses a parity awaits evF.
+                // With zcdef the far rows of the sweep windows' column roles (psd_zapply_desc::rcut) go the same way, in
+                // front of the Z launch: the next tick's rows roles cross them, so those wait for them (evG); the last
+                // window of a sweep keeps its column role whole, so that the check in the next launch finds nothing under
+                // way.  The serial simulation runs them at the latest point the streams
+                // allow, behind the next tick's chases.
+                if (zcdef && far_pending) {
+#ifndef PSD_HOSTSIM
+                    PSD_CHECK(hipStreamWaitEvent(c->stream, c->evG[par ^ 1], 0));
+#else
+                    PSD_CHECK(zapply(c->stream, Pprev, 5));
+#endif
+                    far_pending = false;
+                }
                 PSD_CHECK(zapply(c->stream, Pq, 2));
-                PSD_CHECK(zapply(c->stream, Pq, 1));
+                PSD_CHECK(zapply(c->stream, Pq, zcdef ? 4 : 1));
 #ifndef PSD_HOSTSIM
                 PSD_CHECK(hipEventRecord(c->evE[par], c->stream));
                 PSD_CHECK(hipStreamWaitEvent(c->stream2, c->evE[par], 0));
+                if (zcdef) {
+                    PSD_CHECK(zapply(c->stream2, Pq, 5));
+                    PSD_CHECK(hipEventRecord(c->evG[par], c->stream2));
+                    far_pending = true;
+                }
                 PSD_CHECK(zapply(c->stream2, Pq, 3));
                 PSD_CHECK(hipEventRecord(c->evF[par], c->stream2));
 #else
+                if (zcdef) far_pending = true;
                 PSD_CHECK(zapply(c->stream, Pq, 3));
 #endif
             } else if (c->apply_worklist) {
@@ -2422,6 +2455,17 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
             return PSD_INFO_RUNTIME + 0xfffe;
         }
     }
+#ifdef PSD_HOSTSIM
+    if (zcdef && far_pending) {  // (the last tick's far column roles: its parity is the one the last launch used)
+        psd_zparams Pl = P;
+        const int parl = (int)((launched - 1) & 1);
+        Pl.desc = P.desc + (size_t)parl * PSD_TRAIN_MAX;
+        Pl.cnt = P.cnt + (size_t)parl * PSD_TRAIN_MAX * (p + 8);
+        Pl.tr = P.tr + (size_t)parl * PSD_TRAIN_MAX * p * PSD_ZTR_CAP;
+        PSD_CHECK(zapply(c->stream, Pl, 5));
+        far_pending = false;
+    }
+#endif
 #ifndef PSD_HOSTSIM
     if (zdef) PSD_CHECK(hipStreamSynchronize(c->stream2));  // (the phase pass below scales columns of Z)
     PSD_CHECK(poller.finish(pend));
@@ -3009,6 +3053,7 @@ int zordschur_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, const uint8_t*
     O.z.zlo = 1;  // (ordschur! is not sharded: every Z_m is this context's)
     O.z.zhi = p;
     O.z.zcoff = O.z.zc3off = 0;
+    O.z.zcdefer = 0;
     O.z.zslG = 1;
     O.z.zslmem = nullptr;
     O.z.zslerr = nullptr;

@@ -262,6 +262,7 @@ PSD_D void psd_zord_step_body(const psd_oparams& O) {
                 d.lc1 = n;
                 d.rr0 = 1;
                 d.rr1 = ilo - 1;
+                d.rcut = d.rr0;
                 d.zr0 = 1;
                 d.zr1 = st.wantZ ? n : 0;
                 d.defer_h1 = 0;

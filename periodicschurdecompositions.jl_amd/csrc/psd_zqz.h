@@ -42,6 +42,7 @@ struct psd_zapply_desc {
     int plo, phi;
     int lc0, lc1;   // left role: columns of H_m
     int rr0, rr1;   // right role: rows of H_{m-1}
+    int rcut;       // first near row of the right role (rows rr0 .. rcut - 1 may run one tick late: psd_zparams::zcdefer); rr0: none are far (the last window of a sweep, every other kind of window)
     int zr0, zr1;   // Z role
     int defer_h1;   // 1: right-updates of H_1 are deferred (downward passes); 2: left-updates (upward pass)
     int defer_run;  // set with the last window of such a pass: run psd_zq_defer now (1 right, 2 left)
@@ -54,6 +55,7 @@ struct psd_zstate {
     int phase, info;
     int ilast, ifirst, ifirstm, ilastm, iiter, ziter, jiter, maxit;
     int jlo, kcur, zflag;
+    int settle;  // (unused)
     int ldeflate, jdeflate, ncase2, pend2;
     int nsweeps, nzshift, nsplit, nwindows, nlog, maxlog;
     double c0;
@@ -94,6 +96,9 @@ struct psd_zparams {
     int zslG;
     unsigned char* zslmem;
     int* zslerr;
+    // 1: the far rows of the sweep windows' column roles (more than psd_cdefer_edge above the window) run on the second
+    // stream beside the next tick's chases (as psd_rparams::cdefer of the real engine)
+    int zcdefer;
 };
 
 PSD_HD psd_mat<psd_z> psd_zfac(const psd_zparams& P, int n, int j) {
@@ -310,7 +315,7 @@ PSD_D void psd_zlog(const psd_zparams& P, psd_zstate& st, int kind, int lo, int 
 }
 
 PSD_D void psd_zdesc_write(const psd_zparams& P, psd_zstate& st, const int* lcnt, int plo, int phi, int lc0,
-                           int lc1, int rr0, int rr1, int defer_h1, int defer_run, int djlo, int djhi) {
+                           int lc1, int rr0, int rr1, int defer_h1, int defer_run, int djlo, int djhi, bool nofar = true) {
     PSD_SYNC();
     const bool over = psd_list_overflow(lcnt, st.p, PSD_ZTR_CAP);
     if (over) {  // never apply truncated lists
@@ -327,6 +332,17 @@ PSD_D void psd_zdesc_write(const psd_zparams& P, psd_zstate& st, const int* lcnt
         d.lc1 = lc1;
         d.rr0 = rr0;
         d.rr1 = rr1;
+        {   // Plain sweep windows only, and not the last window of a sweep: the passes that defer a side of H_1 keep
+            // their column roles whole, and the check behind a sweep's (a train's) last windows — it may read or rewrite
+            // whole rows and columns: Case II, the norm of H_1 — runs in the very next launch, with nothing under way.
+            int rc = rr0;
+            if (P.zcdefer && !nofar && defer_h1 == 0 && defer_run == 0) {
+                rc = plo - psd_cdefer_edge(st.Wmax);
+                if (rc < rr0) rc = rr0;
+                if (rc > rr1 + 1) rc = rr1 + 1;
+            }
+            d.rcut = rc;
+        }
         d.zr0 = 1;
         d.zr1 = st.wantZ ? st.n : 0;
         d.defer_h1 = defer_h1;
@@ -926,7 +942,7 @@ PSD_D void psd_zq_sweep_window(const psd_zparams& P, psd_zstate& st, psd_z* ldsz
     st.cyc[1] += tc1 - tc0;
     st.cyc[2] += tc2 - tc1;
     st.cyc[3] += psd_clock() - tc2;
-    psd_zdesc_write(P, st, lcnt, ks, ke + 1, w.be + 1, ilastm, ifirstm, w.bs - 1, 0, 0, 0, 0);
+    psd_zdesc_write(P, st, lcnt, ks, ke + 1, w.be + 1, ilastm, ifirstm, w.bs - 1, 0, 0, 0, 0, ke >= ilast - 1);
     st.nwindows += 1;
     st.kcur = ke + 1;
     if (ke >= ilast - 1)
@@ -1270,7 +1286,8 @@ PSD_D int psd_ztr_stage(const psd_ztr* gtr, int cnt, psd_ztr* ltr, int* flags) {
     return !flags[0] ? 1 : (!flags[1] ? -1 : 0);
 }
 
-PSD_D void psd_zq_apply_item(const psd_zparams& P, int n, int p, int role, int bx, int m) {
+// part (right role only): 0 all its rows, 1 the near rows (rcut .. rr1), 2 the far rows (rr0 .. rcut - 1)
+PSD_D void psd_zq_apply_item(const psd_zparams& P, int n, int p, int role, int bx, int m, int part = 0) {
     PSD_LDS_DECL;
     const psd_zapply_desc d = *P.desc;
     if (!d.active) return;
@@ -1353,8 +1370,10 @@ PSD_D void psd_zq_apply_item(const psd_zparams& P, int n, int p, int role, int b
         const int jm = (role == 1) ? ((m == 1) ? p : (m - 1)) : m;
         if (role == 1 && d.defer_h1 == 1 && jm == 1) return;  // H_1's right side is deferred (downward passes)
         if (role == 2 && (m < P.zlo || m > P.zhi)) return;  // (another rank's Schur vectors)
-        const int lo = (role == 1) ? d.rr0 : d.zr0;
-        const int hi = (role == 1) ? d.rr1 : d.zr1;
+        int lo = (role == 1) ? d.rr0 : d.zr0;
+        int hi = (role == 1) ? d.rr1 : d.zr1;
+        if (role == 1 && part == 1 && lo < d.rcut) lo = d.rcut;
+        if (role == 1 && part == 2 && hi > d.rcut - 1) hi = d.rcut - 1;
         const int r0 = lo + bx * T;
         if (r0 > hi) return;
         const int nr = (hi - r0 + 1 < T) ? (hi - r0 + 1) : T;
@@ -1431,13 +1450,17 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply_wl(psd_zparams P, int n, int p, int cst
     int* ioff = (int*)(psd_lds + tbl);  // [M + 1]
     int* nt = ioff + (M + 1);           // [M]
     const int T = PSD_ZAPPLY_NT;
-    const int role = (pass == 1) ? 1 : ((pass == 2) ? 0 : 2);
+    // (pass 4 / 5: the near / far rows of the column roles, psd_zparams::zcdefer)
+    const int role = (pass == 1 || pass == 4 || pass == 5) ? 1 : ((pass == 2) ? 0 : 2);
+    const int part = (pass == 4) ? 1 : ((pass == 5) ? 2 : 0);
     PSD_PAR_FOR(b, M) {
         const psd_zapply_desc d = P.desc[b];
         int q = 0;
         if (d.active) {
-            const int lo = (role == 0) ? d.lc0 : ((role == 1) ? d.rr0 : d.zr0);
-            const int hi = (role == 0) ? d.lc1 : ((role == 1) ? d.rr1 : d.zr1);
+            int lo = (role == 0) ? d.lc0 : ((role == 1) ? d.rr0 : d.zr0);
+            int hi = (role == 0) ? d.lc1 : ((role == 1) ? d.rr1 : d.zr1);
+            if (part == 1 && lo < d.rcut) lo = d.rcut;
+            if (part == 2 && hi > d.rcut - 1) hi = d.rcut - 1;
             if (hi >= lo) q = (hi - lo + T) / T;
         }
         nt[b] = q;
@@ -1470,7 +1493,7 @@ PSD_KERNEL_B(PSD_ZAPPLY_NT) psd_zq_apply_wl(psd_zparams P, int n, int p, int cst
         Q.desc = P.desc + b;
         Q.cnt = P.cnt + (size_t)b * cstride;
         Q.tr = P.tr + (size_t)b * p * PSD_ZTR_CAP;
-        psd_zq_apply_item(Q, n, p, role, bx, m);
+        psd_zq_apply_item(Q, n, p, role, bx, m, part);
         PSD_SYNC();  // (the list and the tile in LDS are reused by the next item)
     }
 }
@@ -1533,7 +1556,7 @@ PSD_KERNEL psd_zq_init(psd_zparams P, int n, int p, int wantT, int wantZ, int W,
         psd_zstate st;
         st.n = n; st.p = p; st.wantT = wantT; st.wantZ = wantZ; st.W = st.Wmax = W; st.train_oc = train_oc;
         st.phase = PSD_ZPH_CHECK; st.info = 0;
-        st.ilast = n; st.ifirst = -1; st.ifirstm = 1; st.ilastm = n; st.iiter = 1;
+        st.ilast = n; st.ifirst = -1; st.ifirstm = 1; st.ilastm = n; st.iiter = 1; st.settle = -4;
         // generalized.jl:199: p >= log2(floatmin)/log2(eps) = 19.65
         st.ziter = (p >= 20) ? -1 : 0;
         st.jiter = 0; st.maxit = maxitfac * n;
