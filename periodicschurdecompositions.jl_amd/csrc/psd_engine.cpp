@@ -274,6 +274,7 @@ struct psd_ctx {
                            // gate by 3.6 % (tests/gpu_fuzz_real.py; worst case 0.80 of the gate with 8) - not kept
     int train_long = 256;  // bulges per train of the multi-block scheduler when slots can be recycled (PSD_TRAIN_LONG; 0: one bulge per slot)
     int band_helper = 1;  // PSD_BAND_HELPER=0: a leader computes the product band of its decisions itself
+    int zstream = 3;  // rows-deferral form: the Schur-vector updates on stream3 (beside the far H updates) or behind them on stream2 (PSD_ZSTREAM)
     int zcdefer = 0;  // ComplexF64 engine: far rows of the column roles on the second stream (PSD_ZCDEFER; see ziterate_dev)
     int redge = 0, cedge = 0;  // near / far boundaries of the deferred roles (0: psd_rdefer_edge / psd_cdefer_edge; PSD_RDEFER_EDGE, PSD_CDEFER_EDGE)
     int rdefer = 1;   // far columns of the rows roles on stream2 as well, in front of the far column roles (psd_rdefer_edge); needs cdefer.
@@ -1377,9 +1378,10 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 PSD_CHECK(launch_apply_wl(c, c->stream2, Pq, n, p, 1, NSL, zlo1, zhi1, 6, W, fgrid));
                 PSD_CHECK(hipEventRecord(c->evG[par], c->stream2));
                 if (zdef) {
-                    PSD_CHECK(hipStreamWaitEvent(c->stream3, c->evC[par], 0));
-                    PSD_CHECK(launch_apply_wl(c, c->stream3, Pq, n, p, 0, NSL, zlo1, zhi1, 4, W, fgrid));
-                    PSD_CHECK(hipEventRecord(c->evF[par], c->stream3));
+                    hipStream_t zs = (c->zstream == 2) ? c->stream2 : c->stream3;  // (PSD_ZSTREAM=2: behind the far H updates on stream2)
+                    if (zs != c->stream2) PSD_CHECK(hipStreamWaitEvent(zs, c->evC[par], 0));
+                    PSD_CHECK(launch_apply_wl(c, zs, Pq, n, p, 0, NSL, zlo1, zhi1, 4, W, fgrid));
+                    PSD_CHECK(hipEventRecord(c->evF[par], zs));
                 } else {
                     PSD_CHECK(hipEventRecord(c->evF[par], c->stream2));
                 }
@@ -1708,6 +1710,7 @@ int psd_create(psd_ctx** ctx, int device) {
     if (const char* e = psd_env("PSD_CDEFER")) c->cdefer = atoi(e);
     if (const char* e = psd_env("PSD_RDEFER")) c->rdefer = atoi(e);
     if (const char* e = psd_env("PSD_ZCDEFER")) c->zcdefer = atoi(e);
+    if (const char* e = psd_env("PSD_ZSTREAM")) c->zstream = atoi(e);
     if (const char* e = psd_env("PSD_RDEFER_EDGE")) c->redge = atoi(e);
     if (const char* e = psd_env("PSD_CDEFER_EDGE")) c->cedge = atoi(e);
     if (const char* e = psd_env("PSD_ORD_PIPE")) c->ord_pipe = atoi(e);
