@@ -1125,6 +1125,17 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
                 int* pinfo_out = nullptr) {
     const int W = choose_window(p, 8, true);
     if (W == 0) return PSD_INFO_NOTIMPL;
+#ifndef PSD_HOSTSIM
+    // Every way out (a failed runtime call or the runaway cap in the middle of the launch sequence included) first waits
+    // for the side streams: their launches read this call's lists and write the caller's factors and Schur vectors.
+    struct BulkStreams {
+        psd_ctx* c;
+        ~BulkStreams() {
+            if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+            if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+        }
+    } bulk_streams{c};
+#endif
     psd_rparams P;
     P.H = dH;
     P.Z = wantZ ? dZ : nullptr;
@@ -2241,6 +2252,14 @@ int ziterate_dev(psd_ctx* c, int n, int p, psd_z* dH, psd_z* dZ, int wantT, int 
                  psd_stats* stats, int maxlog) {
     const int W = choose_window(p, 16);
     if (W == 0) return PSD_INFO_NOTIMPL;
+#ifndef PSD_HOSTSIM
+    struct BulkStream {  // (as iterate_dev: no way out leaves a launch of the second stream behind)
+        psd_ctx* c;
+        ~BulkStream() {
+            if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+        }
+    } bulk_stream{c};
+#endif
     psd_zparams P;
     P.H = dH;
     {
