@@ -268,7 +268,8 @@ struct psd_ctx {
     int train_stop = 1;    // a long train stops admitting bulges once one of them leaves the bottom converged (PSD_TRAIN_STOP=0: never)
     int train_wdiv = 0;    // a long train has at most (range width) / train_wdiv bulges (PSD_TRAIN_WDIV); 0: 6 for periods 12 .. 32 (round 4,
                            // scan chase: 3 .. 11 % faster there — 1024 x 16: 377 -> 334 ms — with the residuals where they were;
-                           // 5 % slower at p = 64), 8 otherwise.  4 is 2.5 % (n = 1024, p = 64) to
+                           // 5 % slower at p = 64); 16 for periods below 12 at n >= 512 (fewer bulges per train: the residual of
+                           // large orders with short periods sits close to the gate); 8 otherwise.  4 is 2.5 % (n = 1024, p = 64) to
                            // 16 % (n = 512, p = 16) faster on the iteration and was tried as the default at the end of round 3: the
                            // residual grows by 8-9 % on the bench inputs, and 1 of 485 random cases (n = 371, p = 8) left the residual
                            // gate by 3.6 % (tests/gpu_fuzz_real.py; worst case 0.80 of the gate with 8) - not kept
@@ -1292,7 +1293,7 @@ int iterate_dev(psd_ctx* c, int n, int p, double* dH, double* dZ, int wantT, int
     int Mw = M;
     if (mb && c->train_mb_m > Mw && c->train_m >= 32) Mw = (c->train_mb_m > PSD_TRAIN_MAX) ? PSD_TRAIN_MAX : c->train_mb_m;
     PSD_LAUNCH(psd_rq_init, psd_dim3(p, nprob), 256, 256 * 8, c->stream, P, n, p, wantT, wantZ, W, maxitfac, maxlog, Mw, train_oc,
-               mb ? 1 : 0, mb ? c->cgap : 2, c->train_long, (c->train_wdiv > 0) ? c->train_wdiv : ((p >= 12 && p <= 32) ? 6 : 8));
+               mb ? 1 : 0, mb ? c->cgap : 2, c->train_long, (c->train_wdiv > 0) ? c->train_wdiv : ((p >= 12 && p <= 32) ? 6 : ((p < 12 && n >= 512) ? 16 : 8)));
     const size_t lds_apply = apply_lds_bytes();
     const int tiles = (n + PSD_APPLY_NT - 1) / PSD_APPLY_NT;
     const int batch = 32;
