@@ -50,6 +50,12 @@ ctx() = something(_ctx[], (_ctx[] = Ctx()))
 engine_version() = unsafe_string(ccall((:psd_version, libpsd), Cstring, ()))
 "bulges per multishift train (0 or 1: the reference's one-shift-one-sweep iteration, sweep for sweep)"
 set_train!(m::Integer) = ccall((:psd_set_train, libpsd), Cint, (Ptr{Cvoid}, Cint), ctx().ptr, m)
+"period shard of the Schur vectors (one context per GPU, one process each): rank `r` of `w` forms and updates only the Z_j of its slice"
+set_shard!(r::Integer, w::Integer) = ccall((:psd_set_shard, libpsd), Cint, (Ptr{Cvoid}, Cint, Cint), ctx().ptr, r, w)
+"factor-sliced sweep windows: G workgroups per window, each with the blocks of its slice of the period (clamped to what fits one GPU)"
+set_slices!(G::Integer) = ccall((:psd_set_slices, libpsd), Cint, (Ptr{Cvoid}, Cint), ctx().ptr, G)
+"1 if this context's Hessenberg reductions take the pipe form (fixed when the context was created)"
+hess_pipe() = ccall((:psd_get_hess_pipe, libpsd), Cint, (Ptr{Cvoid},), ctx().ptr)
 
 # info -> the exception the reference throws at the same place
 function _throw(info::Integer)
